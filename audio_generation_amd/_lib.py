@@ -1,0 +1,82 @@
+"""ctypes binding of ``libagx.so`` (the C ABI declared in ``include/agx.h``).
+
+The product path has no other implementation: if the shared library is missing
+or fails to load, importing an op raises -- there is no eager/PyTorch or CPU
+fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64,
+                    c_size_t, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libagx.so")
+
+# constants mirrored from include/agx.h
+CONV_CAUSAL, CONV_TRANSPOSED, CONV_UPSAMPLE, CONV_SAME = 0, 1, 2, 3
+IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA = 0, 1, 2
+EPI_LEAKY_PRE, EPI_RESIDUAL, EPI_LEAKY_POST = 1, 2, 4
+
+
+class ConvDesc(Structure):
+    """``agx_conv_desc`` (include/agx.h)."""
+    _fields_ = [("kind", c_int32), ("batch", c_int32), ("c_in", c_int32), ("c_out", c_int32),
+                ("l_in", c_int32), ("kernel", c_int32), ("stride", c_int32), ("dilation", c_int32),
+                ("epilogue", c_int32), ("slope", c_float), ("impl", c_int32)]
+
+
+# every symbol include/agx.h declares: name -> (restype, argtypes)
+_PD = POINTER(ConvDesc)
+SIGNATURES = {
+    "agx_version": (c_int, []),
+    "agx_last_error": (c_char_p, []),
+    "agx_conv_out_len": (c_int64, [_PD]),
+    "agx_conv_packed_floats": (c_int64, [_PD]),
+    "agx_conv_pack": (c_int, [_PD, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "agx_conv_forward": (c_int, [_PD, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "agx_conv_kernel_name": (c_int, [_PD, c_char_p, c_size_t]),
+    "agx_resblock_workspace_bytes": (c_size_t, [_PD]),
+    "agx_resblock_forward": (c_int, [_PD, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_int32, c_void_p, c_size_t, c_void_p]),
+    "agx_rvq_packed_floats": (c_int64, [c_int32, c_int32, c_int32]),
+    "agx_rvq_pack": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "agx_rvq_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "agx_rvq_forward": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
+                                c_int32, c_int32, c_int32, c_int32, c_int32,
+                                c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
+                                c_void_p, c_size_t, c_void_p]),
+    "agx_rvq_dequantize": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p,
+                                   c_int64, c_int64, c_int32, c_void_p]),
+}
+
+_lib = None
+
+
+class AgxError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load libagx.so once; raise loudly when it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AgxError(
+            f"{LIB_PATH} not found: build it with `python -m audio_generation_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI and the header drifted apart
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().agx_last_error()
+        raise AgxError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,49 @@
+// Shared host-side helpers of libagx (error state, launch checks, lowered conv plan).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "agx.h"
+
+namespace agx {
+
+// Thread-local last-error message (the only mutable global state of the library).
+void set_error(const char *fmt, ...);
+int fail(int code, const char *fmt, ...);
+const char *last_error();
+
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return AGX_OK;
+}
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Every layer kind of agx_conv_desc lowers to one "polyphase convolution":
+//   y[b, co, q*t + p] = epi( bias[co] + sum_{ci, j<J} Wp[ci*J + j][co*q + p] * x[b, ci, t*s + j*d - P] )
+// for t in [0, Lt), p in [0, q), output positions >= Lout dropped and input
+// positions outside [0, Lvalid) read as zero.
+struct ConvPlan {
+    int B, Cin, Cout, Lin;
+    int Lt;      // base positions
+    int q;       // output phases per base position
+    int J;       // taps per phase
+    int s, d;    // input step per base position / per tap
+    int P;       // left offset
+    int Lout;    // output length
+    int Lvalid;  // input positions >= Lvalid are zero (crop by a negative right pad)
+    int M;       // q * Cout  (rows of the implicit GEMM)
+    int epilogue;
+    float slope;
+};
+
+// Lower a descriptor; returns AGX_OK or an error (message set).
+int lower_conv(const agx_conv_desc *d, ConvPlan *p);
+
+}  // namespace agx

@@ -1,0 +1,89 @@
+// C-ABI entry points of the convolution family: shape checks + kernel dispatch.
+#include "common.hpp"
+
+namespace agx {
+int launch_conv_direct(const ConvPlan &p, const float *x, const float *wp, const float *bias,
+                       const float *res, float *y, hipStream_t st);
+int launch_conv_mfma(const ConvPlan &p, const float *x, const float *wp, const float *bias,
+                     const float *res, float *y, hipStream_t st);
+bool conv_mfma_supported(const ConvPlan &p);
+const char *conv_mfma_variant(const ConvPlan &p);
+const char *conv_direct_variant(const ConvPlan &p);
+int launch_resblock_fused(const ConvPlan &p, const float *x, const float *w1, const float *b1,
+                          const float *w2, const float *b2, float *y, int post_act, hipStream_t st);
+bool resblock_fused_supported(const ConvPlan &p);
+
+static int run_conv(const ConvPlan &p, int impl, const float *x, const float *wp, const float *bias,
+                    const float *res, float *y, hipStream_t st) {
+    if (impl == AGX_IMPL_AUTO) impl = conv_mfma_supported(p) ? AGX_IMPL_MFMA : AGX_IMPL_DIRECT;
+    if (impl == AGX_IMPL_MFMA) return launch_conv_mfma(p, x, wp, bias, res, y, st);
+    if (impl == AGX_IMPL_DIRECT) return launch_conv_direct(p, x, wp, bias, res, y, st);
+    return fail(AGX_ERR_BAD_SHAPE, "conv: unknown impl %d", impl);
+}
+}  // namespace agx
+
+extern "C" {
+
+int agx_conv_forward(const agx_conv_desc *d, const float *x, const float *packed, const float *bias,
+                     const float *res, float *y, void *stream) {
+    using namespace agx;
+    ConvPlan p;
+    int rc = lower_conv(d, &p);
+    if (rc != AGX_OK) return rc;
+    if (!x || !packed || !y) return fail(AGX_ERR_NULL_POINTER, "agx_conv_forward: NULL pointer");
+    if ((p.epilogue & AGX_EPI_RESIDUAL) && !res)
+        return fail(AGX_ERR_NULL_POINTER, "agx_conv_forward: residual epilogue without res");
+    return run_conv(p, d->impl, x, packed, bias, res, y, static_cast<hipStream_t>(stream));
+}
+
+int agx_conv_kernel_name(const agx_conv_desc *d, char *buf, size_t buf_len) {
+    using namespace agx;
+    ConvPlan p;
+    int rc = lower_conv(d, &p);
+    if (rc != AGX_OK) return rc;
+    if (!buf || buf_len == 0) return fail(AGX_ERR_NULL_POINTER, "agx_conv_kernel_name: NULL buffer");
+    int impl = d->impl;
+    if (impl == AGX_IMPL_AUTO) impl = conv_mfma_supported(p) ? AGX_IMPL_MFMA : AGX_IMPL_DIRECT;
+    snprintf(buf, buf_len, "%s", impl == AGX_IMPL_MFMA ? conv_mfma_variant(p) : conv_direct_variant(p));
+    return AGX_OK;
+}
+
+size_t agx_resblock_workspace_bytes(const agx_conv_desc *d) {
+    if (!d || d->batch <= 0 || d->c_out <= 0 || d->l_in <= 0) return 0;
+    return size_t(d->batch) * d->c_out * d->l_in * sizeof(float);
+}
+
+int agx_resblock_forward(const agx_conv_desc *d, const float *x, const float *packed1,
+                         const float *bias1, const float *packed2, const float *bias2, float *y,
+                         int32_t post_act, void *workspace, size_t workspace_bytes, void *stream) {
+    using namespace agx;
+    if (!d) return fail(AGX_ERR_NULL_POINTER, "agx_resblock_forward: NULL descriptor");
+    if (d->kind != AGX_CONV_CAUSAL || d->stride != 1 || d->c_in != d->c_out)
+        return fail(AGX_ERR_BAD_SHAPE, "resblock: needs a stride-1 causal conv with c_in == c_out");
+    if (!x || !packed1 || !packed2 || !y) return fail(AGX_ERR_NULL_POINTER, "agx_resblock_forward: NULL pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    agx_conv_desc d1 = *d;
+    d1.epilogue = AGX_EPI_LEAKY_PRE;
+    ConvPlan p1;
+    int rc = lower_conv(&d1, &p1);
+    if (rc != AGX_OK) return rc;
+    if (d->impl != AGX_IMPL_DIRECT && resblock_fused_supported(p1))
+        return launch_resblock_fused(p1, x, packed1, bias1, packed2, bias2, y, post_act, st);
+    // two launches: h = leaky(conv1(x)+b1) -> workspace;  y = [leaky](x + conv2(h) + b2)
+    if (!workspace || workspace_bytes < agx_resblock_workspace_bytes(d))
+        return fail(AGX_ERR_WORKSPACE, "resblock: workspace too small (%zu < %zu)", workspace_bytes,
+                    agx_resblock_workspace_bytes(d));
+    float *h = static_cast<float *>(workspace);
+    rc = run_conv(p1, d->impl, x, packed1, bias1, nullptr, h, st);
+    if (rc != AGX_OK) return rc;
+    agx_conv_desc d2 = *d;
+    d2.kernel = 1;
+    d2.dilation = 1;
+    d2.epilogue = AGX_EPI_RESIDUAL | (post_act ? AGX_EPI_LEAKY_POST : 0);
+    ConvPlan p2;
+    rc = lower_conv(&d2, &p2);
+    if (rc != AGX_OK) return rc;
+    return run_conv(p2, d->impl, h, packed2, bias2, x, y, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,162 @@
+// fp32-input MFMA implicit-GEMM polyphase convolution for gfx950.
+//
+// GEMM view of   y[b, co, q*t+p] = sum_{ci,j} Wp[ci*J+j][co*q+p] * x[b, ci, t*s + j*d - P]:
+//   M = q*Cout rows (A = packed weights, K-major so a wave's 32 rows are one
+//       128-byte line), N = base positions t of one batch item (B = the input
+//       tile staged in LDS, time contiguous so the 32 columns of a fragment are
+//       32 consecutive LDS dwords), K = Cin*J.
+// v_mfma_f32_32x32x2_f32 is an exact binary32 FMA chain in k order at the f32
+// vector peak rate (MI355X_MICROARCH: 64 FLOP/clk/SIMD), so results match an
+// fp32 reference to rounding order only -- no reduced precision anywhere.
+//
+// Work decomposition: 256 threads = 4 waves arranged WM x WN; each wave owns
+// MW x NW accumulator tiles of 32x32.  The channel loop stages CC input
+// channels x (tile + halo) per step; A fragments stream from L2 straight into
+// registers (every workgroup reads the same few MB of weights), B fragments
+// are one ds_read_b32 each.  The f32 MFMA takes 64 cycles per issue, so operand
+// delivery is far off the critical path; the tile shapes below are chosen for
+// grid size and halo re-read, not LDS bandwidth.
+//
+// Replaces: F.pad + F.conv1d (networks/vae.py:34-37), conv_transpose1d + crop
+// (vae.py:61-64), interpolate + conv1d (vae.py:86-89) and the elementwise
+// LeakyReLU / residual add around them (vae.py:113-117, 130-141, 186-198).
+#include "common.hpp"
+
+namespace agx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int MW, int NW, int WM, int WN, int CC>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvPlan p, int span,
+                                                        const float *__restrict__ x,
+                                                        const float *__restrict__ wp,
+                                                        const float *__restrict__ bias,
+                                                        const float *__restrict__ res,
+                                                        float *__restrict__ y) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [CC][span]
+    constexpr int BM = 32 * MW * WM, BN = 32 * NW * WN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int t0 = blockIdx.x * BN;
+    const int m0 = blockIdx.y * BM + wm * (32 * MW);
+    const int n0 = wn * (32 * NW);
+    const int b = blockIdx.z;
+    const int in0 = t0 * p.s - p.P;
+
+    f32x16 acc[MW][NW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
+
+    // per-lane A row offsets (clamped: rows >= M are computed but never stored)
+    int arow[MW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i) arow[i] = min(m0 + i * 32 + li, p.M - 1);
+    // per-lane B column offsets inside the staged tile
+    int bcol[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) bcol[k] = (n0 + k * 32 + li) * p.s + lh * span;
+
+    const float *xb = x + size_t(b) * p.Cin * p.Lin;
+    const size_t JM = size_t(p.J) * p.M;
+
+    for (int c0 = 0; c0 < p.Cin; c0 += CC) {
+        __syncthreads();
+        for (int c = wave; c < CC; c += 4) {
+            const float *src = xb + size_t(c0 + c) * p.Lin;
+            float *dst = xs + c * span;
+            for (int i = lane; i < span; i += 64) {
+                const int pos = in0 + i;
+                dst[i] = (pos >= 0 && pos < p.Lvalid) ? src[pos] : 0.f;
+            }
+        }
+        __syncthreads();
+        for (int j = 0; j < p.J; ++j) {
+            const float *wj = wp + (size_t(c0 + lh) * p.J + j) * p.M;
+            const float *xj = xs + j * p.d;
+#pragma unroll
+            for (int ks = 0; ks < CC / 2; ++ks) {
+                float a[MW], bf[NW];
+#pragma unroll
+                for (int i = 0; i < MW; ++i) a[i] = wj[size_t(2 * ks) * JM + arow[i]];
+#pragma unroll
+                for (int k = 0; k < NW; ++k) bf[k] = xj[(2 * ks) * span + bcol[k]];
+#pragma unroll
+                for (int i = 0; i < MW; ++i)
+#pragma unroll
+                    for (int k = 0; k < NW; ++k)
+                        acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bf[k], acc[i][k], 0, 0, 0);
+            }
+        }
+    }
+
+    // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int t = t0 + n0 + k * 32 + li;
+            if (t >= p.Lt) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= p.M) continue;
+                const int co = m / p.q, ph = m - co * p.q;
+                const int u = t * p.q + ph;
+                if (u >= p.Lout) continue;
+                float v = acc[i][k][r] + (bias ? bias[co] : 0.f);
+                if (p.epilogue & AGX_EPI_LEAKY_PRE) v = v > 0.f ? v : v * p.slope;
+                const size_t o = (size_t(b) * p.Cout + co) * p.Lout + u;
+                if (p.epilogue & AGX_EPI_RESIDUAL) v += res[o];
+                if (p.epilogue & AGX_EPI_LEAKY_POST) v = v > 0.f ? v : v * p.slope;
+                y[o] = v;
+            }
+        }
+    }
+}
+
+template <int MW, int NW, int WM, int WN, int CC>
+static int launch_variant(const ConvPlan &p, const float *x, const float *wp, const float *bias,
+                          const float *res, float *y, hipStream_t st) {
+    constexpr int BM = 32 * MW * WM, BN = 32 * NW * WN;
+    const int span = (BN - 1) * p.s + (p.J - 1) * p.d + 1;
+    const size_t lds = size_t(CC) * span * sizeof(float);
+    if (lds > 160 * 1024) return fail(AGX_ERR_UNSUPPORTED, "conv_mfma: tile needs %zu B of LDS", lds);
+    auto kern = conv_mfma_kernel<MW, NW, WM, WN, CC>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    dim3 grid(ceil_div(p.Lt, BN), ceil_div(p.M, BM), p.B), block(256);
+    if (grid.y > 65535 || grid.z > 65535) return fail(AGX_ERR_BAD_SHAPE, "conv_mfma: grid too large");
+    hipLaunchKernelGGL(kern, grid, block, lds, st, p, span, x, wp, bias, res, y);
+    return check_launch("conv_mfma");
+}
+
+bool conv_mfma_supported(const ConvPlan &p) { return p.Cin % 16 == 0 && p.M >= 32; }
+
+const char *conv_mfma_variant(const ConvPlan &p) {
+    if (p.M >= 128) return "conv_mfma<2,2,2,2,16>";
+    if (p.M >= 64) return "conv_mfma<2,2,1,4,16>";
+    return "conv_mfma<1,4,1,4,16>";
+}
+
+int launch_conv_mfma(const ConvPlan &p, const float *x, const float *wp, const float *bias,
+                     const float *res, float *y, hipStream_t st) {
+    if (!conv_mfma_supported(p))
+        return fail(AGX_ERR_UNSUPPORTED, "conv_mfma: needs Cin %% 16 == 0 and q*Cout >= 32 (Cin=%d M=%d)",
+                    p.Cin, p.M);
+    if (p.M >= 128) return launch_variant<2, 2, 2, 2, 16>(p, x, wp, bias, res, y, st);
+    if (p.M >= 64) return launch_variant<2, 2, 1, 4, 16>(p, x, wp, bias, res, y, st);
+    return launch_variant<1, 4, 1, 4, 16>(p, x, wp, bias, res, y, st);
+}
+
+}  // namespace agx

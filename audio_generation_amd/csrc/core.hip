@@ -1,0 +1,133 @@
+// libagx core: error state, descriptor lowering, shape queries.
+#include <cmath>
+#include <cstring>
+
+#include "common.hpp"
+
+namespace agx {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+const char *last_error() { return g_err; }
+
+int lower_conv(const agx_conv_desc *d, ConvPlan *p) {
+    if (!d) return fail(AGX_ERR_NULL_POINTER, "conv descriptor is NULL");
+    if (d->batch <= 0 || d->c_in <= 0 || d->c_out <= 0 || d->l_in <= 0 || d->kernel <= 0 ||
+        d->stride <= 0 || d->dilation <= 0)
+        return fail(AGX_ERR_BAD_SHAPE,
+                    "conv: non-positive dimension (B=%d Cin=%d Cout=%d L=%d K=%d s=%d d=%d)", d->batch,
+                    d->c_in, d->c_out, d->l_in, d->kernel, d->stride, d->dilation);
+    const int K = d->kernel, s = d->stride, dil = d->dilation, L = d->l_in;
+    p->B = d->batch;
+    p->Cin = d->c_in;
+    p->Cout = d->c_out;
+    p->Lin = L;
+    p->Lvalid = L;
+    p->epilogue = d->epilogue;
+    p->slope = d->slope;
+    switch (d->kind) {
+        case AGX_CONV_CAUSAL: {
+            // vae.py:32   pad = dilation*(K-1) - stride + 1
+            // vae.py:39-43 extra right pad from the UNdilated kernel size
+            const int P = dil * (K - 1) - s + 1;
+            const double nxt = double(L - K + P) / double(s) + 1.0;
+            const int target = (int(std::ceil(nxt)) - 1) * s + K - P;
+            const int E = target - L;
+            const int padded = L + P + E;
+            const int span = dil * (K - 1) + 1;
+            if (padded < span) return fail(AGX_ERR_BAD_SHAPE, "conv: input too short (L=%d)", L);
+            p->q = 1;
+            p->J = K;
+            p->s = s;
+            p->d = dil;
+            p->P = P;
+            p->Lt = (padded - span) / s + 1;
+            p->Lout = p->Lt;
+            if (E < 0) p->Lvalid = L + E;  // F.pad with a negative pad crops
+            break;
+        }
+        case AGX_CONV_SAME: {
+            if (s != 1) return fail(AGX_ERR_BAD_SHAPE, "same-conv needs stride 1");
+            p->q = 1;
+            p->J = K;
+            p->s = 1;
+            p->d = dil;
+            p->P = (dil * (K - 1)) / 2;  // torch: left = total // 2
+            p->Lt = L;
+            p->Lout = L;
+            break;
+        }
+        case AGX_CONV_UPSAMPLE: {
+            if (dil != 1) return fail(AGX_ERR_BAD_SHAPE, "upsample-conv needs dilation 1");
+            // nearest x s, then 'same' conv: polyphase over the low-rate signal
+            const int pl = (K - 1) / 2;
+            auto fdiv = [](int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); };
+            const int jmin = fdiv(-pl, s);
+            const int jmax = fdiv(s - 1 + K - 1 - pl, s);
+            p->q = s;
+            p->J = jmax - jmin + 1;
+            p->s = 1;
+            p->d = 1;
+            p->P = -jmin;
+            p->Lt = L;
+            p->Lout = L * s;
+            break;
+        }
+        case AGX_CONV_TRANSPOSED: {
+            if (dil != 1) return fail(AGX_ERR_BAD_SHAPE, "transposed conv needs dilation 1");
+            if (K < s) return fail(AGX_ERR_UNSUPPORTED, "transposed conv with K < stride");
+            p->q = s;
+            p->J = (K + s - 1) / s;
+            p->s = 1;
+            p->d = 1;
+            p->P = p->J - 1;
+            p->Lt = L;
+            p->Lout = L * s;  // (L-1)s + K, minus the K - s crop of vae.py:58,63-64
+            break;
+        }
+        default:
+            return fail(AGX_ERR_BAD_SHAPE, "conv: unknown kind %d", d->kind);
+    }
+    p->M = p->q * p->Cout;
+    return AGX_OK;
+}
+
+}  // namespace agx
+
+extern "C" {
+
+int agx_version(void) { return AGX_VERSION; }
+
+const char *agx_last_error(void) { return agx::last_error(); }
+
+int64_t agx_conv_out_len(const agx_conv_desc *d) {
+    agx::ConvPlan p;
+    int rc = agx::lower_conv(d, &p);
+    return rc == AGX_OK ? int64_t(p.Lout) : int64_t(rc);
+}
+
+int64_t agx_conv_packed_floats(const agx_conv_desc *d) {
+    agx::ConvPlan p;
+    int rc = agx::lower_conv(d, &p);
+    if (rc != AGX_OK) return rc;
+    // + dim0 floats of scratch at the tail for the weight-norm scales
+    const int dim0 = (d->kind == AGX_CONV_TRANSPOSED) ? d->c_in : d->c_out;
+    return int64_t(p.Cin) * p.J * p.M + dim0;
+}
+
+}  // extern "C"

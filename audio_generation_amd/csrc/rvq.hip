@@ -1,0 +1,450 @@
+// Residual vector quantiser for gfx950: one launch for all residual stages.
+//
+// Stands in for the external `som_quantizer.ResidualQuantizer` the reference
+// calls at networks/vae.py:315-318 (source absent from the reference tree; the
+// arithmetic reproduced bit-for-bit is the one fixed in oracle/rvq_exact.c).
+//
+// One workgroup (4 waves) owns 32 frames for the whole stage loop.  The
+// residual tile R[d][frame] and the running output O[d][frame] live in LDS
+// (2 x 66 KB at D = 512), so latents are read once and x_q / indices written
+// once.  Per stage:
+//   A. scores s[k] = |c_k|^2 - 2 r.c_k for all K codewords with the fp32-input
+//      MFMA (rows = codewords streamed from the transposed codebook image in L2,
+//      columns = the 32 frames from LDS), per-frame minimum by in-lane min over
+//      the accumulator registers + one lane shuffle + a 4-entry LDS exchange;
+//   B. every codeword whose score is within a rigorous fp32 error margin of the
+//      minimum is a candidate; a frame with one candidate is decided, the rest
+//      are decided by the defining binary64 distance (sequential, unfused);
+//   C. r -= c, out += c, index written, squared residual accumulated.
+#include "common.hpp"
+
+namespace agx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int FT = 32;    // frames per workgroup
+constexpr int RS = 33;    // LDS row stride of R / O (conflict-free in both access patterns)
+constexpr int CAND = 8;   // candidate slots per frame
+
+__host__ __device__ inline int64_t rvq_stage_floats(int k, int dim) {
+    return int64_t(dim) * k + k + 4;  // CbT (D,K) | c2 (K) | cmax2 + pad
+}
+
+// ------------------------------------------------------------------------- pack
+__global__ __launch_bounds__(256) void rvq_pack_kernel(const float *__restrict__ cb, int n_q, int k,
+                                                       int dim, float *__restrict__ packed) {
+    const int q = blockIdx.y;
+    const int code = blockIdx.x * 256 + threadIdx.x;
+    float *img = packed + q * rvq_stage_floats(k, dim);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // cmax2 slot is filled by rvq_cmax_kernel
+    }
+    if (code >= k) return;
+    const float *row = cb + (size_t(q) * k + code) * dim;
+    float acc = 0.f;
+    for (int d = 0; d < dim; ++d) {
+        const float v = row[d];
+        img[size_t(d) * k + code] = v;
+        acc = fmaf(v, v, acc);
+    }
+    img[size_t(dim) * k + code] = acc;
+}
+
+__global__ __launch_bounds__(256) void rvq_cmax_kernel(int k, int dim, float *__restrict__ packed) {
+    float *img = packed + blockIdx.x * rvq_stage_floats(k, dim);
+    const float *c2 = img + size_t(dim) * k;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < k; i += 256) m = fmaxf(m, c2[i]);
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float *tail = img + size_t(dim) * k + k;
+        tail[0] = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+        tail[1] = tail[2] = tail[3] = 0.f;
+    }
+}
+
+// ---------------------------------------------------------------- exact distance
+// The DEFINING arithmetic (oracle/rvq_exact.c): binary64, d ascending, one
+// subtract + one multiply + one add per term, never fused.
+#pragma clang fp contract(off)
+__device__ __noinline__ double exact_dist_lds(const float *r_col /* stride RS */,
+                                              const float *__restrict__ c, int dim) {
+    double acc = 0.0;
+    for (int d = 0; d < dim; ++d) {
+        const double diff = double(r_col[d * RS]) - double(c[d]);
+        const double sq = diff * diff;
+        acc = acc + sq;
+    }
+    return acc;
+}
+#pragma clang fp contract(fast)
+
+// ------------------------------------------------------------------------ forward
+struct RvqArgs {
+    const float *x;
+    int64_t x_sb, x_st, x_sd;
+    const float *cb;      // (Q,K,D)
+    const float *packed;  // stage images
+    int B, T, D, K, Q;
+    float *xq;
+    int64_t q_sb, q_st, q_sd;
+    int64_t *index;  // (B*T, Q)
+    double *sq_err;  // (Q)
+};
+
+template <int MT>
+__global__ __launch_bounds__(256) void rvq_forward_kernel(RvqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Dp = (a.D + 1) & ~1;
+    float *R = smem;                 // [Dp][RS]
+    float *O = R + Dp * RS;          // [Dp][RS]
+    float *wmin = O + Dp * RS;       // [4][FT]
+    float *rn2 = wmin + 4 * FT;      // [FT]
+    int *cnt = reinterpret_cast<int *>(rn2 + FT);         // [FT]
+    int *state = cnt + FT;                                 // [FT] 0 decided / 1 exact among cands / 2 full
+    int *best = state + FT;                                // [FT]
+    int *ccode = best + FT;                                // [FT][CAND]
+    float *cscore = reinterpret_cast<float *>(ccode + FT * CAND);  // [FT][CAND]
+    double *cdist = reinterpret_cast<double *>(cscore + FT * CAND);  // [FT][CAND] (8-byte aligned: offsets are even)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int64_t N = int64_t(a.B) * a.T;
+    const int64_t n0 = int64_t(blockIdx.x) * FT;
+    const int D = a.D, K = a.K;
+
+    // ---- stage the latents: R[d][f] = x[n0+f][d], O = 0; pick the coalesced order ----
+    for (int e = tid; e < Dp * RS; e += 256) O[e] = 0.f;
+    if (a.x_st == 1 || a.x_sd != 1) {  // time-contiguous ("b c l"): frames fastest
+        for (int e = tid; e < Dp * FT; e += 256) {
+            const int d = e >> 5, f = e & 31;
+            const int64_t n = n0 + f;
+            float v = 0.f;
+            if (d < D && n < N) {
+                const int64_t b = n / a.T, t = n - b * a.T;
+                v = a.x[b * a.x_sb + t * a.x_st + d * a.x_sd];
+            }
+            R[d * RS + f] = v;
+        }
+    } else {  // channel-contiguous ("b l c"): d fastest
+        for (int f = wave; f < FT; f += 4) {
+            const int64_t n = n0 + f;
+            const int64_t b = n < N ? n / a.T : 0, t = n < N ? n - b * a.T : 0;
+            const float *src = a.x + b * a.x_sb + t * a.x_st;
+            for (int d = lane; d < Dp; d += 64) R[d * RS + f] = (d < D && n < N) ? src[d] : 0.f;
+        }
+    }
+    __syncthreads();
+    // ||r||^2 per frame (wave w owns frames w, w+4, ...)
+    for (int f = wave; f < FT; f += 4) {
+        float part = 0.f;
+        for (int d = lane; d < D; d += 64) {
+            const float v = R[d * RS + f];
+            part = fmaf(v, v, part);
+        }
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+        if (lane == 0) rn2[f] = part;
+    }
+    __syncthreads();
+
+    const float err_unit = float(D + 8) * 5.9604645e-8f * 1.25f;  // (D+8) * 2^-24 * 1.25
+    const int n_chunks = (K + 128 * MT - 1) / (128 * MT);
+
+    for (int q = 0; q < a.Q; ++q) {
+        const float *img = a.packed + q * rvq_stage_floats(K, D);
+        const float *c2 = img + size_t(D) * K;
+        const float cmax2 = c2[K];
+        const float *cbq = a.cb + size_t(q) * K * D;
+
+        if (tid < FT) cnt[tid] = 0;
+        __syncthreads();
+        // margin = 2 * error bound of a computed score of this frame (see rvq.hip header, B.)
+        const float margin = 2.02f * err_unit * (cmax2 + 2.f * sqrtf(rn2[li] * cmax2));
+        float running = INFINITY;
+
+        for (int ch = 0; ch < n_chunks; ++ch) {
+            const int code0 = ch * (128 * MT) + wave * (32 * MT);
+            f32x16 acc[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            int acol[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acol[i] = min(code0 + i * 32 + li, K - 1);
+
+            // ---- A: scores.  A[i=code][k=d], B[k=d][j=frame] ----
+            const float *rb = R + lh * RS + li;
+#pragma unroll 4
+            for (int d0 = 0; d0 < Dp; d0 += 2) {
+                const int dd = d0 + lh;
+                const float *arow = img + size_t(min(dd, D - 1)) * K;
+                const float bsel = (dd < D) ? 1.f : 0.f;  // odd D: the pad row of R is zero, A must be finite
+                const float bf = rb[d0 * RS] * bsel;
+                float av[MT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) av[i] = arow[acol[i]];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bf, acc[i], 0, 0, 0);
+            }
+            // scores in place; rows of register r: (r&3) + 8*(r>>2) + 4*lh
+            float m = INFINITY;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int code = code0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float s = (code < K) ? (c2[min(code, K - 1)] - 2.f * acc[i][r]) : INFINITY;
+                    acc[i][r] = s;
+                    m = fminf(m, s);
+                }
+            m = fminf(m, __shfl_xor(m, 32));
+            if (lh == 0) wmin[wave * FT + li] = m;
+            __syncthreads();
+            const float cm = fminf(fminf(wmin[li], wmin[FT + li]), fminf(wmin[2 * FT + li], wmin[3 * FT + li]));
+            running = fminf(running, cm);
+            const float thr = running + margin;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float s = acc[i][r];
+                    if (s <= thr) {
+                        const int code = code0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const int slot = atomicAdd(&cnt[li], 1);
+                        if (slot < CAND) {
+                            ccode[li * CAND + slot] = code;
+                            cscore[li * CAND + slot] = s;
+                        }
+                    }
+                }
+            __syncthreads();
+        }
+
+        // ---- B: decide ----
+        if (tid < FT) {  // wave 0, lane == li == frame
+            const int f = tid;
+            const int n = cnt[f];
+            if (n > CAND) {
+                state[f] = 2;
+            } else {
+                const float thr = running + margin;
+                int kept = 0;
+                for (int c = 0; c < n; ++c) {
+                    const float s = cscore[f * CAND + c];
+                    const int code = ccode[f * CAND + c];
+                    if (s <= thr) {
+                        ccode[f * CAND + kept] = code;
+                        ++kept;
+                    }
+                }
+                cnt[f] = kept;
+                if (kept == 0) {  // only reachable with NaN scores: stay in bounds
+                    best[f] = 0;
+                    state[f] = 0;
+                } else if (kept == 1) {
+                    best[f] = ccode[f * CAND];
+                    state[f] = 0;
+                } else {
+                    state[f] = 1;
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const int f = tid >> 3, c = tid & 7;
+            if (state[f] == 1 && c < cnt[f])
+                cdist[f * CAND + c] = exact_dist_lds(R + f, cbq + size_t(ccode[f * CAND + c]) * D, D);
+        }
+        __syncthreads();
+        if (tid < FT && state[tid] == 1) {
+            const int f = tid;
+            double bd = cdist[f * CAND];
+            int bc = ccode[f * CAND];
+            for (int c = 1; c < cnt[f]; ++c) {
+                const double dc = cdist[f * CAND + c];
+                const int code = ccode[f * CAND + c];
+                if (dc < bd || (dc == bd && code < bc)) {
+                    bd = dc;
+                    bc = code;
+                }
+            }
+            best[f] = bc;
+        }
+        __syncthreads();
+        // candidate overflow (degenerate codebooks): full defining search, whole block per frame
+        for (int f = 0; f < FT; ++f) {
+            if (state[f] != 2) continue;  // uniform across the block (LDS value)
+            double bd = INFINITY;
+            int bc = 0x7fffffff;
+            for (int code = tid; code < K; code += 256) {
+                const double dc = exact_dist_lds(R + f, cbq + size_t(code) * D, D);
+                if (dc < bd || (dc == bd && code < bc)) {
+                    bd = dc;
+                    bc = code;
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                const double od = __shfl_xor(bd, off);
+                const int oc = __shfl_xor(bc, off);
+                if (od < bd || (od == bd && oc < bc)) {
+                    bd = od;
+                    bc = oc;
+                }
+            }
+            __syncthreads();  // cdist / ccode row 0 are free to reuse as exchange
+            if (lane == 0) {
+                cdist[wave] = bd;
+                ccode[wave] = bc;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < 4; ++w)
+                    if (cdist[w] < bd || (cdist[w] == bd && ccode[w] < bc)) {
+                        bd = cdist[w];
+                        bc = ccode[w];
+                    }
+                best[f] = bc;
+            }
+            __syncthreads();
+        }
+
+        // ---- C: r -= c, out += c, index, squared residual ----
+        for (int f = wave; f < FT; f += 4) {
+            const int idx = best[f];
+            const float *c = cbq + size_t(idx) * D;
+            float part = 0.f;
+            for (int d = lane; d < D; d += 64) {
+                const float cv = c[d];
+                const float rv = R[d * RS + f] - cv;
+                R[d * RS + f] = rv;
+                O[d * RS + f] = O[d * RS + f] + cv;
+                part = fmaf(rv, rv, part);
+            }
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            if (lane == 0) {
+                rn2[f] = part;
+                if (n0 + f < N) a.index[(n0 + f) * a.Q + q] = idx;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int f = 0; f < FT; ++f)
+                if (n0 + f < N) s += double(rn2[f]);
+            atomicAdd(&a.sq_err[q], s);
+        }
+    }
+
+    // ---- write x_q ----
+    if (a.q_st == 1 || a.q_sd != 1) {
+        for (int e = tid; e < D * FT; e += 256) {
+            const int d = e >> 5, f = e & 31;
+            const int64_t n = n0 + f;
+            if (n < N) {
+                const int64_t b = n / a.T, t = n - b * a.T;
+                a.xq[b * a.q_sb + t * a.q_st + d * a.q_sd] = O[d * RS + f];
+            }
+        }
+    } else {
+        for (int f = wave; f < FT; f += 4) {
+            const int64_t n = n0 + f;
+            if (n >= N) continue;
+            const int64_t b = n / a.T, t = n - b * a.T;
+            float *dst = a.xq + b * a.q_sb + t * a.q_st;
+            for (int d = lane; d < D; d += 64) dst[d] = O[d * RS + f];
+        }
+    }
+}
+
+static size_t rvq_lds_bytes(int dim) {
+    const int Dp = (dim + 1) & ~1;
+    size_t floats = size_t(2) * Dp * RS + 4 * FT + FT /*rn2*/ + 3 * FT /*cnt,state,best*/ +
+                    FT * CAND /*ccode*/ + FT * CAND /*cscore*/;
+    floats = (floats + 1) & ~size_t(1);
+    return floats * 4 + size_t(FT) * CAND * 8;
+}
+
+// ------------------------------------------------------------------------ dequantize
+__global__ __launch_bounds__(256) void rvq_dequant_kernel(const float *__restrict__ cb,
+                                                          const int64_t *__restrict__ idx, int64_t n,
+                                                          int k, int dim, float *__restrict__ out,
+                                                          int64_t o_sn, int64_t o_sd, int accumulate) {
+    const int64_t row = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    int64_t i = idx[row];
+    i = i < 0 ? 0 : (i >= k ? k - 1 : i);
+    const float *c = cb + i * dim;
+    float *o = out + row * o_sn;
+    for (int d = threadIdx.x & 63; d < dim; d += 64) {
+        const float v = c[d];
+        o[d * o_sd] = accumulate ? o[d * o_sd] + v : v;
+    }
+}
+
+}  // namespace agx
+
+extern "C" {
+
+int64_t agx_rvq_packed_floats(int32_t n_q, int32_t k, int32_t dim) {
+    if (n_q <= 0 || k <= 0 || dim <= 0) return AGX_ERR_BAD_SHAPE;
+    return int64_t(n_q) * agx::rvq_stage_floats(k, dim);
+}
+
+int agx_rvq_pack(const float *codebooks, int32_t n_q, int32_t k, int32_t dim, float *packed, void *stream) {
+    using namespace agx;
+    if (n_q <= 0 || k <= 0 || dim <= 0) return fail(AGX_ERR_BAD_SHAPE, "rvq_pack: bad shape Q=%d K=%d D=%d", n_q, k, dim);
+    if (!codebooks || !packed) return fail(AGX_ERR_NULL_POINTER, "rvq_pack: NULL pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(rvq_pack_kernel, dim3(ceil_div(k, 256), n_q), dim3(256), 0, st, codebooks, n_q, k, dim, packed);
+    hipLaunchKernelGGL(rvq_cmax_kernel, dim3(n_q), dim3(256), 0, st, k, dim, packed);
+    return check_launch("agx_rvq_pack");
+}
+
+size_t agx_rvq_workspace_bytes(int32_t, int32_t, int32_t, int32_t, int32_t) { return 0; }
+
+int agx_rvq_forward(const float *x, int64_t x_sb, int64_t x_st, int64_t x_sd, const float *codebooks,
+                    const float *packed, int32_t batch, int32_t t, int32_t dim, int32_t k, int32_t q_used,
+                    float *xq, int64_t q_sb, int64_t q_st, int64_t q_sd, int64_t *index, double *sq_err,
+                    void *workspace, size_t workspace_bytes, void *stream) {
+    using namespace agx;
+    (void)workspace;
+    (void)workspace_bytes;
+    if (batch <= 0 || t <= 0 || dim <= 0 || k <= 0 || q_used < 0)
+        return fail(AGX_ERR_BAD_SHAPE, "rvq_forward: bad shape B=%d T=%d D=%d K=%d Q=%d", batch, t, dim, k, q_used);
+    if (!x || !codebooks || !packed || !xq || (q_used > 0 && (!index || !sq_err)))
+        return fail(AGX_ERR_NULL_POINTER, "rvq_forward: NULL pointer");
+    const size_t lds = rvq_lds_bytes(dim);
+    if (lds > 160 * 1024) return fail(AGX_ERR_UNSUPPORTED, "rvq_forward: D=%d needs %zu B of LDS", dim, lds);
+    RvqArgs a{x, x_sb, x_st, x_sd, codebooks, packed, batch, t, dim, k, q_used, xq, q_sb, q_st, q_sd, index, sq_err};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t n = int64_t(batch) * t;
+    dim3 grid((unsigned)ceil_div64(n, FT)), block(256);
+    auto launch = [&](auto kern) -> int {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(kern, grid, block, lds, st, a);
+        return check_launch("rvq_forward");
+    };
+    if (k > 512) return launch(rvq_forward_kernel<8>);
+    if (k > 256) return launch(rvq_forward_kernel<4>);
+    if (k > 128) return launch(rvq_forward_kernel<2>);
+    return launch(rvq_forward_kernel<1>);
+}
+
+int agx_rvq_dequantize(const float *codebook, const int64_t *idx, int64_t n, int32_t k, int32_t dim,
+                       float *out, int64_t o_sn, int64_t o_sd, int32_t accumulate, void *stream) {
+    using namespace agx;
+    if (n <= 0 || k <= 0 || dim <= 0) return fail(AGX_ERR_BAD_SHAPE, "rvq_dequantize: bad shape");
+    if (!codebook || !idx || !out) return fail(AGX_ERR_NULL_POINTER, "rvq_dequantize: NULL pointer");
+    hipLaunchKernelGGL(rvq_dequant_kernel, dim3((unsigned)ceil_div64(n, 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), codebook, idx, n, k, dim, out, o_sn, o_sd, accumulate);
+    return check_launch("rvq_dequantize");
+}
+
+}  // extern "C"

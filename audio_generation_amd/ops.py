@@ -1,0 +1,177 @@
+"""Tensor-level wrappers over the C ABI: allocate outputs with torch, pass raw
+device pointers + the current HIP stream to ``libagx``.  PyTorch is plumbing
+here (memory, streams); all arithmetic happens in the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (CONV_CAUSAL, CONV_SAME, CONV_TRANSPOSED, CONV_UPSAMPLE, EPI_LEAKY_POST,
+                   EPI_LEAKY_PRE, EPI_RESIDUAL, IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA, AgxError, ConvDesc)
+
+Tensor = torch.Tensor
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(*tensors: Optional[Tensor]) -> None:
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise AgxError("audio_generation_amd runs on the MI355X only: got a tensor on "
+                           f"'{t.device}'.  There is no CPU / eager fallback.")
+        if t.dtype not in (torch.float32, torch.int64, torch.float64):
+            raise AgxError(f"unsupported dtype {t.dtype}")
+
+
+def _f32c(t: Tensor) -> Tensor:
+    if t.dtype != torch.float32:
+        raise AgxError(f"expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# --------------------------------------------------------------------------- conv
+def conv_desc(kind: int, batch: int, c_in: int, c_out: int, l_in: int, kernel: int, stride: int = 1,
+              dilation: int = 1, epilogue: int = 0, slope: float = 0.1, impl: int = IMPL_AUTO) -> ConvDesc:
+    return ConvDesc(kind, batch, c_in, c_out, l_in, kernel, stride, dilation, epilogue, slope, impl)
+
+
+def conv_out_len(desc: ConvDesc) -> int:
+    n = _lib.load().agx_conv_out_len(ctypes.byref(desc))
+    if n < 0:
+        _lib.check(int(n), "agx_conv_out_len")
+    return int(n)
+
+
+def conv_pack(desc: ConvDesc, v: Tensor, g: Optional[Tensor] = None) -> Tensor:
+    """Weight-norm fold + repack (``agx_conv_pack``).  Returns the packed image."""
+    lib = _lib.load()
+    _need_gpu(v, g)
+    n = lib.agx_conv_packed_floats(ctypes.byref(desc))
+    if n < 0:
+        _lib.check(int(n), "agx_conv_packed_floats")
+    v = _f32c(v)
+    g = None if g is None else _f32c(g)
+    packed = torch.empty(int(n), dtype=torch.float32, device=v.device)
+    _lib.check(lib.agx_conv_pack(ctypes.byref(desc), _ptr(v), _ptr(g), _ptr(packed), _stream()),
+               "agx_conv_pack")
+    return packed
+
+
+def conv_forward(desc: ConvDesc, x: Tensor, packed: Tensor, bias: Optional[Tensor],
+                 res: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    lib = _lib.load()
+    _need_gpu(x, packed, bias, res)
+    x = _f32c(x)
+    if tuple(x.shape) != (desc.batch, desc.c_in, desc.l_in):
+        raise AgxError(f"conv_forward: x is {tuple(x.shape)}, descriptor says "
+                       f"{(desc.batch, desc.c_in, desc.l_in)}")
+    l_out = conv_out_len(desc)
+    y = out if out is not None else torch.empty((desc.batch, desc.c_out, l_out), dtype=torch.float32,
+                                                 device=x.device)
+    if res is not None:
+        res = _f32c(res)
+        if res.shape != y.shape:
+            raise AgxError(f"conv_forward: residual is {tuple(res.shape)}, output is {tuple(y.shape)}")
+    if bias is not None:
+        bias = _f32c(bias)
+    _lib.check(lib.agx_conv_forward(ctypes.byref(desc), _ptr(x), _ptr(packed), _ptr(bias), _ptr(res),
+                                    _ptr(y), _stream()), "agx_conv_forward")
+    return y
+
+
+def resblock_forward(desc: ConvDesc, x: Tensor, packed1: Tensor, bias1: Optional[Tensor],
+                     packed2: Tensor, bias2: Optional[Tensor], post_act: bool = True) -> Tensor:
+    lib = _lib.load()
+    _need_gpu(x, packed1, packed2, bias1, bias2)
+    x = _f32c(x)
+    if tuple(x.shape) != (desc.batch, desc.c_in, desc.l_in):
+        raise AgxError(f"resblock_forward: x is {tuple(x.shape)}, descriptor says "
+                       f"{(desc.batch, desc.c_in, desc.l_in)}")
+    y = torch.empty_like(x)
+    ws_bytes = int(lib.agx_resblock_workspace_bytes(ctypes.byref(desc)))
+    ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=x.device)
+    _lib.check(lib.agx_resblock_forward(ctypes.byref(desc), _ptr(x), _ptr(packed1), _ptr(bias1),
+                                        _ptr(packed2), _ptr(bias2), _ptr(y), int(bool(post_act)),
+                                        _ptr(ws), ws_bytes, _stream()), "agx_resblock_forward")
+    return y
+
+
+# ---------------------------------------------------------------------------- rvq
+def rvq_pack(codebooks: Tensor) -> Tensor:
+    lib = _lib.load()
+    _need_gpu(codebooks)
+    codebooks = _f32c(codebooks)
+    q, k, d = codebooks.shape
+    n = lib.agx_rvq_packed_floats(q, k, d)
+    if n < 0:
+        _lib.check(int(n), "agx_rvq_packed_floats")
+    packed = torch.empty(int(n), dtype=torch.float32, device=codebooks.device)
+    _lib.check(lib.agx_rvq_pack(_ptr(codebooks), q, k, d, _ptr(packed), _stream()), "agx_rvq_pack")
+    return packed
+
+
+def rvq_forward(x: Tensor, codebooks: Tensor, packed: Tensor, q_used: int,
+                layout: str = "b l c") -> Tuple[Tensor, Tensor, Tensor]:
+    """x: (B,T,D) for layout "b l c" or (B,D,T) for "b c l" (any strides).
+    Returns (x_q in the same layout/shape, index (B,T,q_used) int64, sq_err (q_used) f64)."""
+    lib = _lib.load()
+    _need_gpu(x, codebooks, packed)
+    if x.dtype != torch.float32:
+        raise AgxError(f"rvq_forward: expected float32, got {x.dtype}")
+    codebooks = _f32c(codebooks)
+    q_total, k, d = codebooks.shape
+    if not 0 <= q_used <= q_total:
+        raise AgxError(f"rvq_forward: q_used={q_used} outside [0, {q_total}]")
+    if layout == "b l c":
+        b, t, dim = x.shape
+        sb, st, sd = x.stride()
+    elif layout == "b c l":
+        b, dim, t = x.shape
+        sb, sd, st = x.stride()
+    else:
+        raise AgxError(f"rvq_forward: unknown layout {layout!r}")
+    if dim != d:
+        raise AgxError(f"rvq_forward: frame dim {dim} != codebook dim {d}")
+    xq = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    if layout == "b l c":
+        qb, qt, qd = xq.stride()
+    else:
+        qb, qd, qt = xq.stride()
+    index = torch.empty((b, t, q_used), dtype=torch.int64, device=x.device)
+    sq_err = torch.zeros(max(q_used, 1), dtype=torch.float64, device=x.device)
+    _lib.check(lib.agx_rvq_forward(_ptr(x), sb, st, sd, _ptr(codebooks), _ptr(packed), b, t, d, k, q_used,
+                                   _ptr(xq), qb, qt, qd, _ptr(index), _ptr(sq_err), None, 0, _stream()),
+               "agx_rvq_forward")
+    if q_used == 0:
+        xq.zero_()
+    return xq, index, sq_err[:q_used]
+
+
+def rvq_dequantize(codebook: Tensor, idx: Tensor, out: Optional[Tensor] = None,
+                   accumulate: bool = False) -> Tensor:
+    """``codebook[idx]``: idx (...,) int64 -> (..., D)."""
+    lib = _lib.load()
+    _need_gpu(codebook, idx)
+    codebook = _f32c(codebook)
+    k, d = codebook.shape
+    idx_c = idx.contiguous().to(torch.int64)
+    n = idx_c.numel()
+    if out is None:
+        out = torch.empty((*idx.shape, d), dtype=torch.float32, device=codebook.device)
+        accumulate = False
+    flat = out.view(n, d)
+    _lib.check(lib.agx_rvq_dequantize(_ptr(codebook), _ptr(idx_c), n, k, d, _ptr(flat), flat.stride(0),
+                                      flat.stride(1), int(accumulate), _stream()), "agx_rvq_dequantize")
+    return out

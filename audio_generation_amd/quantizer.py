@@ -1,0 +1,150 @@
+"""Drop-in residual vector quantiser executed by ``agx_rvq_forward``.
+
+Stands where the reference imports ``ResidualQuantizer`` / ``tuple_checker`` from
+the external ``som_quantizer`` module (``networks/vae.py:6``; source absent from
+the reference tree -- **parity unpinned**, see ``oracle/rvq_exact.c``).  The
+surface below is exactly what the reference's callers touch:
+
+* ctor kwargs of ``vae.py:245-251``;
+* ``__call__(x[b l c], codebook_n, update_codebook=, prioritize_early=)`` ->
+  ``(x_q, index, commit_loss)`` (``vae.py:315-318``);
+* ``.num_quantizers`` (``training.py:183,496``), ``.use_som`` (``utils.py:239``),
+  ``.quantizers[i].dequantize(idx)`` (``vae.py:333``),
+  ``.quantizers[0].som.height/.width`` (``utils.py:244-245``),
+  ``.get_stale_clusters()`` (``training.py:435,461``; ``utils.py:176-181``),
+  ``.update_cutoff(new_cutoff=, ratio=)`` (``vae.py:351``), ``.parameters()``
+  (``training.py:516``).
+
+The forward search is the HIP kernel; the codebook *update* rules of the
+external module (EMA / SOM neighbourhoods) are unknown and training-only, so
+``update_codebook=True`` applies a plain EMA k-means update (build-defined,
+torch bookkeeping, not on the measured path).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from ._lib import AgxError
+from .vae import tuple_checker  # re-exported like the external module does (vae.py:6)
+
+Tensor = torch.Tensor
+__all__ = ["ResidualQuantizer", "tuple_checker"]
+
+
+def _near_square(n: int):
+    """Factor n into (h, w) as square as possible (utils.py:13-27 semantics)."""
+    h = int(n ** 0.5)
+    while h > 1 and n % h:
+        h -= 1
+    return max(h, 1), n // max(h, 1)
+
+
+class _SomGrid:
+    def __init__(self, k: int):
+        self.height, self.width = _near_square(k)
+
+
+class _Stage(nn.Module):
+    """View of one residual stage (``quantizer.quantizers[i]``)."""
+
+    def __init__(self, parent: "ResidualQuantizer", i: int):
+        super().__init__()
+        object.__setattr__(self, "_parent", parent)  # not a submodule: avoids a reference cycle in state_dict
+        self.i = i
+        self.som = _SomGrid(parent.codebook_size)
+
+    @property
+    def codebook(self) -> Tensor:
+        return self._parent.codebooks[self.i]
+
+    def dequantize(self, idx: Tensor) -> Tensor:
+        """``(..,) int -> (.., D)`` gather (call site vae.py:333)."""
+        return ops.rvq_dequantize(self._parent.codebooks.detach()[self.i], idx)
+
+
+class ResidualQuantizer(nn.Module):
+    def __init__(self, num_quantizers=8, dim=512, quantizer_class="ema", codebook_sizes=1024,
+                 vq_cutoff_freq=1, use_som=True, som_kernel_type="hard", ema_decay=0.99):
+        super().__init__()
+        sizes = tuple_checker(codebook_sizes, num_quantizers)
+        if len(set(int(s) for s in sizes)) != 1:
+            raise NotImplementedError("the HIP search kernel needs one codebook size for all stages")
+        self.num_quantizers = int(num_quantizers)
+        self.dim = int(dim)
+        self.codebook_size = int(sizes[0])
+        self.quantizer_class = quantizer_class
+        self.vq_cutoff_freq = vq_cutoff_freq
+        self.use_som = use_som
+        self.som_kernel_type = som_kernel_type
+        self.ema_decay = ema_decay
+        init = torch.randn(self.num_quantizers, self.codebook_size, self.dim)
+        if quantizer_class == "base":          # learnable codebook (config/training.yml: vq_type "base")
+            self.codebooks = nn.Parameter(init)
+        else:                                   # "ema": statistics-updated, not a parameter
+            self.register_buffer("codebooks", init)
+        self.register_buffer("cluster_frequency", torch.ones(self.num_quantizers, self.codebook_size))
+        self.register_buffer("ema_sum", init.clone())
+        self.quantizers = nn.ModuleList([_Stage(self, i) for i in range(self.num_quantizers)])
+        self._packed: Optional[Tensor] = None
+        self._packed_key = None
+
+    # ------------------------------------------------------------------ kernels
+    def _packed_codebooks(self) -> Tensor:
+        cb = self.codebooks
+        key = (cb.data_ptr(), cb._version)
+        if self._packed is None or self._packed_key != key:
+            self._packed = ops.rvq_pack(cb.detach())
+            self._packed_key = key
+        return self._packed
+
+    def _q_used(self, codebook_n) -> int:
+        return self.num_quantizers if codebook_n is None else max(0, min(int(codebook_n), self.num_quantizers))
+
+    def _quantize(self, x: Tensor, layout: str, codebook_n, update_codebook: bool):
+        q_used = self._q_used(codebook_n)
+        xq, index, sq_err = ops.rvq_forward(x, self.codebooks.detach(), self._packed_codebooks(), q_used, layout)
+        commit = (sq_err.sum() / float(x.numel())).to(torch.float32)
+        if update_codebook and self.training:
+            frames = x if layout == "b l c" else x.transpose(1, 2)
+            self._ema_update(frames.reshape(-1, self.dim), index.reshape(-1, q_used))
+        return xq, index, commit
+
+    def quantize_bcl(self, x: Tensor, codebook_n=None, update_codebook=False, prioritize_early=False):
+        """Native entry used by ``CausalVQAE.encode``: (B,D,T) in, (B,D,T) out."""
+        return self._quantize(x, "b c l", codebook_n, update_codebook)
+
+    def forward(self, x: Tensor, codebook_n=None, update_codebook=False, prioritize_early=False):
+        """Reference call contract (vae.py:315-318): (B,T,D) -> (x_q, index, commit_loss)."""
+        return self._quantize(x, "b l c", codebook_n, update_codebook)
+
+    # --------------------------------------------------------- training bookkeeping
+    @torch.no_grad()
+    def _ema_update(self, frames: Tensor, index: Tensor) -> None:
+        """Plain EMA k-means update per stage (build-defined; see module docstring)."""
+        residual = frames.clone()
+        cb = self.codebooks.data
+        for q in range(index.shape[1]):
+            idx = index[:, q]
+            counts = torch.bincount(idx, minlength=self.codebook_size).to(cb.dtype)
+            sums = torch.zeros_like(cb[q]).index_add_(0, idx, residual)
+            self.cluster_frequency[q].mul_(self.ema_decay).add_(counts, alpha=1 - self.ema_decay)
+            if self.quantizer_class != "base":
+                self.ema_sum[q].mul_(self.ema_decay).add_(sums, alpha=1 - self.ema_decay)
+                denom = self.cluster_frequency[q].clamp_min(1e-5).unsqueeze(1)
+                cb[q].copy_(self.ema_sum[q] / denom)
+            residual = residual - cb[q][idx]
+        self.codebooks._version  # noqa: B018  (in-place copy_ above bumps the version -> repack)
+
+    def get_stale_clusters(self) -> List[int]:
+        """Number of codewords per stage whose EMA usage fell below the cutoff."""
+        return [int((self.cluster_frequency[q] < self.vq_cutoff_freq).sum()) for q in range(self.num_quantizers)]
+
+    def update_cutoff(self, new_cutoff=None, ratio=None):
+        if new_cutoff is not None:
+            self.vq_cutoff_freq = new_cutoff
+        if ratio is not None:
+            self.vq_cutoff_freq = self.vq_cutoff_freq * ratio

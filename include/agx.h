@@ -1,0 +1,157 @@
+/* agx.h -- flat C ABI of the MI355X-native neural-audio-codec forward path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI of its own: its hot
+ * path is a chain of ATen calls made from torch.nn.Modules.  Each entry point
+ * below replaces the ATen call sequence of one reference function (cited per
+ * declaration, paths relative to the reference tree); INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into memory the caller owns; the library
+ *     never allocates, frees or retains a pointer past the call;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *     launches are asynchronous on it and the library never synchronises;
+ *   - return value 0 = success, negative = error (AGX_ERR_*); the message of the
+ *     last error of the calling thread is returned by agx_last_error();
+ *   - tensors are contiguous fp32, "NCL" (batch, channel, time) unless said
+ *     otherwise; indices are int64 to match torch.argmin.
+ */
+#ifndef AGX_H
+#define AGX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AGX_VERSION 100 /* 0.1.0 */
+
+#define AGX_OK 0
+#define AGX_ERR_BAD_SHAPE (-1)
+#define AGX_ERR_NULL_POINTER (-2)
+#define AGX_ERR_WORKSPACE (-3)
+#define AGX_ERR_LAUNCH (-4)
+#define AGX_ERR_UNSUPPORTED (-5)
+
+int agx_version(void);
+const char *agx_last_error(void);
+
+/* ------------------------------------------------------------------------- *
+ * Convolutions                                                               *
+ * ------------------------------------------------------------------------- */
+
+/* Which reference layer a convolution descriptor stands for. */
+#define AGX_CONV_CAUSAL 0   /* CausalConv1d,          networks/vae.py:14-43  */
+#define AGX_CONV_TRANSPOSED 1 /* CausalConvT1d,       networks/vae.py:45-64  */
+#define AGX_CONV_UPSAMPLE 2 /* CausalUpsampleConv1d,  networks/vae.py:66-89  */
+#define AGX_CONV_SAME 3     /* Conv1d(padding="same"), networks/wavelets.py:193-201 */
+
+/* Which kernel family executes it (AGX_IMPL_AUTO picks by shape). */
+#define AGX_IMPL_AUTO 0
+#define AGX_IMPL_DIRECT 1 /* fp32 VALU, any shape                            */
+#define AGX_IMPL_MFMA 2   /* fp32-input MFMA implicit GEMM (exact fp32 FMA chain) */
+
+/* Epilogue flags (fused into the conv kernel; all optional). */
+#define AGX_EPI_LEAKY_PRE 1  /* LeakyReLU(slope) on (acc + bias)   vae.py:99,125,156 */
+#define AGX_EPI_RESIDUAL 2   /* += res[b,co,t]                     vae.py:117        */
+#define AGX_EPI_LEAKY_POST 4 /* LeakyReLU(slope) after the add     vae.py:131-134    */
+
+typedef struct agx_conv_desc {
+    int32_t kind;      /* AGX_CONV_*                                              */
+    int32_t batch;     /* B                                                       */
+    int32_t c_in;      /* input channels                                          */
+    int32_t c_out;     /* output channels                                         */
+    int32_t l_in;      /* input length                                            */
+    int32_t kernel;    /* K (reference kernel_size)                               */
+    int32_t stride;    /* conv stride (CAUSAL) or up-factor (TRANSPOSED/UPSAMPLE) */
+    int32_t dilation;  /* CAUSAL only, else 1                                     */
+    int32_t epilogue;  /* OR of AGX_EPI_*                                         */
+    float slope;       /* LeakyReLU negative slope (reference: 0.1)               */
+    int32_t impl;      /* AGX_IMPL_*                                              */
+} agx_conv_desc;
+
+/* Output length of the layer exactly as the reference computes it
+ * (vae.py:32-43 incl. _calc_extra_pad; vae.py:58-64; vae.py:86-89).  <0 on error. */
+int64_t agx_conv_out_len(const agx_conv_desc *d);
+
+/* Number of floats of the packed weight image of this layer. */
+int64_t agx_conv_packed_floats(const agx_conv_desc *d);
+
+/* Fold weight-norm and repack one conv layer's weight for the kernels.
+ *   v : the reference parameter `weight_v` (or the plain `weight` when g == NULL),
+ *       torch layout: (c_out, c_in, K) for CAUSAL/UPSAMPLE/SAME, (c_in, c_out, K)
+ *       for TRANSPOSED;
+ *   g : `weight_g` (dim0,1,1) or NULL.  w = g * v / ||v||, norm over all dims but
+ *       0 -- utils.py:34-42 (torch.nn.utils.weight_norm, dim=0);
+ *   packed : agx_conv_packed_floats(d) floats.  UPSAMPLE layers are stored as the
+ *       `stride` polyphase 3-tap filters of the nearest-upsample + conv pair. */
+int agx_conv_pack(const agx_conv_desc *d, const float *v, const float *g, float *packed,
+                  void *stream);
+
+/* y = epilogue(conv(x) + bias).  x (B,c_in,l_in); y,res (B,c_out,l_out);
+ * bias (c_out) or NULL; res only read when AGX_EPI_RESIDUAL is set.
+ * Replaces F.pad + conv1d (vae.py:34-37), conv_transpose1d + crop (vae.py:61-64),
+ * interpolate + conv1d (vae.py:86-89). */
+int agx_conv_forward(const agx_conv_desc *d, const float *x, const float *packed,
+                     const float *bias, const float *res, float *y, void *stream);
+
+/* Name of the kernel family/tile variant agx_conv_forward would launch for this
+ * descriptor (e.g. "conv_mfma<2,2,2,2,16>"), for profilers and bench.py; matches
+ * the template arguments in the rocprofv3 kernel names.  Returns AGX_OK. */
+int agx_conv_kernel_name(const agx_conv_desc *d, char *buf, size_t buf_len);
+
+/* Fused CausalResidualBlock1d + trailing activation (vae.py:113-117 wrapped by
+ * the Sequential(..., activation) of vae.py:130-135 / 193-198):
+ *   y = leaky( x + conv_k1( leaky( conv_kK,dil(x) + b1 ) ) + b2 )
+ * d describes conv1 (kind CAUSAL, stride 1, c_in == c_out; its epilogue field is
+ * ignored); packed1/packed2 are the packed images of conv1 and of the k=1 conv2.
+ * post_act = 0 skips the trailing activation.  Shapes without a single-kernel
+ * implementation run as two fused-epilogue conv launches through `workspace`
+ * (agx_resblock_workspace_bytes(d) bytes; the hidden activation). */
+size_t agx_resblock_workspace_bytes(const agx_conv_desc *d);
+int agx_resblock_forward(const agx_conv_desc *d, const float *x, const float *packed1,
+                         const float *bias1, const float *packed2, const float *bias2,
+                         float *y, int32_t post_act, void *workspace, size_t workspace_bytes,
+                         void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Residual vector quantiser (external `som_quantizer.ResidualQuantizer`;      *
+ * call sites vae.py:245-251, 315-318, 333)                                   *
+ * ------------------------------------------------------------------------- */
+
+/* Packed codebook image: per stage the transposed codebook (D,K), the squared
+ * norms (K) and max norm; floats needed for Q stages. */
+int64_t agx_rvq_packed_floats(int32_t n_q, int32_t k, int32_t dim);
+int agx_rvq_pack(const float *codebooks /* (Q,K,D) */, int32_t n_q, int32_t k, int32_t dim,
+                 float *packed, void *stream);
+
+/* Nearest-codeword search over q_used residual stages.
+ *   x, xq   : frames, element (b,t,d) at  b*stride_b + t*stride_t + d*stride_d
+ *             (so both "b l c" and "b c l" tensors are accepted without a copy);
+ *   index   : (B,T,q_used) int64, contiguous (utils.py:249);
+ *   sq_err  : q_used doubles, += sum over all elements of the squared residual
+ *             left after each stage (caller zeroes it; commit loss =
+ *             sum(sq_err)/(B*T*D));
+ *   workspace: agx_rvq_workspace_bytes() bytes.
+ * The arg-min is exact: binary32 MFMA scores select candidates, ties and near
+ * ties are decided by the defining binary64 arithmetic (oracle/rvq_exact.c). */
+size_t agx_rvq_workspace_bytes(int32_t batch, int32_t t, int32_t dim, int32_t k, int32_t q_used);
+int agx_rvq_forward(const float *x, int64_t x_sb, int64_t x_st, int64_t x_sd,
+                    const float *codebooks /* (Q,K,D) */, const float *packed,
+                    int32_t batch, int32_t t, int32_t dim, int32_t k, int32_t q_used,
+                    float *xq, int64_t q_sb, int64_t q_st, int64_t q_sd,
+                    int64_t *index, double *sq_err, void *workspace, size_t workspace_bytes,
+                    void *stream);
+
+/* quantizers[i].dequantize(idx) (vae.py:333): out[n,:] (+)= codebook[idx[n],:].
+ * out element (n,d) at n*stride_n + d*stride_d. */
+int agx_rvq_dequantize(const float *codebook /* (K,D) */, const int64_t *idx, int64_t n,
+                       int32_t k, int32_t dim, float *out, int64_t o_sn, int64_t o_sd,
+                       int32_t accumulate, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGX_H */

@@ -1,0 +1,112 @@
+"""CPU-side checks of the C-ABI library and the host logic (no kernel is launched)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from audio_generation_amd import _lib, ops
+from audio_generation_amd.vae import CausalVQAE
+from oracle import codec
+from tests.helpers import load_meta, load_npz, sub_sd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from audio_generation_amd import build
+    build.build()
+    return _lib.load()
+
+
+def _declared_symbols():
+    names = set()
+    for fn in os.listdir(os.path.join(ROOT, "include")):
+        if fn.endswith(".h"):
+            text = open(os.path.join(ROOT, "include", fn)).read()
+            text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+            names |= set(re.findall(r"\b(agx_[a-z0-9_]+)\s*\(", text))
+    return names
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    declared = _declared_symbols()
+    assert declared, "no declarations found in include/*.h"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/agx.h but not exported by libagx.so"
+    assert lib.agx_version() == 100
+
+
+def test_out_len_matches_reference_padding_rule(lib):
+    # CAUSAL: vae.py:32-43; checked against the oracle's restatement (itself pinned by goldens)
+    for (k, s, d) in [(7, 1, 1), (7, 1, 3), (7, 1, 9), (5, 2, 1), (9, 4, 1), (11, 5, 1), (17, 8, 1), (3, 1, 1),
+                      (1, 1, 1), (5, 3, 2), (1, 2, 1)]:
+        for length in (17, 50, 51, 53, 61, 64, 225, 1600, 72000):
+            left, right = codec.causal_pads(length, k, s, d)
+            want = (length + left + right - d * (k - 1) - 1) // s + 1
+            desc = ops.conv_desc(_lib.CONV_CAUSAL, 1, 4, 4, length, k, s, d)
+            assert ops.conv_out_len(desc) == want, (k, s, d, length)
+    for s in (1, 2, 4, 5, 8):
+        assert ops.conv_out_len(ops.conv_desc(_lib.CONV_UPSAMPLE, 1, 4, 4, 225, 2 * s + 1, s)) == 225 * s
+        assert ops.conv_out_len(ops.conv_desc(_lib.CONV_TRANSPOSED, 1, 4, 4, 225, 2 * s + 1, s)) == 225 * s
+    assert ops.conv_out_len(ops.conv_desc(_lib.CONV_SAME, 1, 4, 4, 77, 3, 1)) == 77
+    # 72000 -> 225 known answer (vae.py:354)
+    length = 72000
+    for s in (2, 4, 5, 8):
+        length = ops.conv_out_len(ops.conv_desc(_lib.CONV_CAUSAL, 1, 4, 4, length, 2 * s + 1, s))
+    assert length == 225
+
+
+def test_bad_descriptors_report_errors(lib):
+    bad = ops.conv_desc(_lib.CONV_CAUSAL, 1, 0, 4, 10, 3)
+    assert lib.agx_conv_out_len(ctypes.byref(bad)) == -1
+    assert b"non-positive" in lib.agx_last_error()
+    with pytest.raises(_lib.AgxError):
+        ops.conv_out_len(ops.conv_desc(99, 1, 4, 4, 10, 3))
+    with pytest.raises(_lib.AgxError):
+        ops.conv_out_len(ops.conv_desc(_lib.CONV_TRANSPOSED, 1, 4, 4, 10, 3, 5))  # K < stride
+    assert lib.agx_rvq_packed_floats(0, 4, 4) < 0
+    assert lib.agx_rvq_packed_floats(8, 1024, 512) == 8 * (512 * 1024 + 1024 + 4)
+
+
+def test_no_cpu_fallback():
+    with pytest.raises(_lib.AgxError, match="MI355X only"):
+        ops.conv_pack(ops.conv_desc(_lib.CONV_CAUSAL, 1, 4, 4, 16, 3), torch.zeros(4, 4, 3))
+    model = CausalVQAE(in_channels=1, n_blocks=2, strides=(2, 2), first_block_channels=4, codebook_dim=8,
+                       num_quantizers=1, codebook_size=8, input_format="n c l", wavelet_decoders=False)
+    with pytest.raises(_lib.AgxError):
+        model(torch.zeros(1, 1, 64))
+
+
+def test_state_dict_layout_is_the_references():
+    g6 = load_meta()["g6"]
+    model = CausalVQAE(in_channels=1, n_blocks=4, strides=(2, 4, 5, 8), num_quantizers=8, codebook_size=1024,
+                       codebook_dim=512, input_format="n c l", wavelet_decoders=False)
+    keys = {k for k in model.state_dict() if not k.startswith("quantizer.")}
+    assert keys == set(g6["state_dict_keys"])
+    assert sum(p.numel() for p in model.encoders.parameters()) == g6["params_encoders"]
+    assert sum(p.numel() for p in model.decoders.parameters()) == g6["params_decoders"]
+    assert model.scale_factor == 320 and model.num_quantizers == 8 and model.codebook_size == [1024] * 8
+    # a reference checkpoint loads as is (conv stacks; the quantiser's keys are external)
+    g1, meta = load_npz("g1_tiny_vqae.npz"), load_meta()["g1"]["kwargs"]
+    tiny = CausalVQAE(**{**meta, "strides": tuple(meta["strides"])})
+    missing, unexpected = tiny.load_state_dict(sub_sd(g1, "sd/"), strict=False)
+    assert unexpected == [] and all(k.startswith("quantizer.") for k in missing)
+
+
+def test_quantizer_surface():
+    from audio_generation_amd.quantizer import ResidualQuantizer, tuple_checker
+    q = ResidualQuantizer(num_quantizers=3, dim=8, quantizer_class="base", codebook_sizes=12)
+    assert q.num_quantizers == 3 and len(q.quantizers) == 3 and q.use_som
+    assert (q.quantizers[0].som.height, q.quantizers[0].som.width) == (3, 4)
+    assert len(list(q.parameters())) == 1 and q.get_stale_clusters() == [0, 0, 0]
+    q.update_cutoff(new_cutoff=2.0)
+    assert q.get_stale_clusters() == [12, 12, 12]
+    q.update_cutoff(ratio=0.25)
+    assert q.vq_cutoff_freq == 0.5
+    assert tuple_checker(3, 2) == [3, 3]
+    ema = ResidualQuantizer(num_quantizers=2, dim=4, quantizer_class="ema", codebook_sizes=4)
+    assert len(list(ema.parameters())) == 0 and "codebooks" in ema.state_dict()
