@@ -141,22 +141,57 @@ static int launch_variant(const ConvPlan &p, const float *x, const float *wp, co
     return check_launch("conv_mfma");
 }
 
-bool conv_mfma_supported(const ConvPlan &p) { return p.Cin % 16 == 0 && p.M >= 32; }
+// ---- tile variant table -----------------------------------------------------------
+// Preference order per M class; a variant is eligible when its input tile fits LDS.
+// <= 72 KB keeps two workgroups resident per CU, which is what hides the staging phase.
+struct Variant {
+    int mw, nw, wm, wn, cc;
+    const char *name;
+    int (*launch)(const ConvPlan &, const float *, const float *, const float *, const float *, float *,
+                  hipStream_t);
+};
+
+#define AGX_VARIANT(MW, NW, WM, WN, CC) \
+    { MW, NW, WM, WN, CC, "conv_mfma<" #MW "," #NW "," #WM "," #WN "," #CC ">", launch_variant<MW, NW, WM, WN, CC> }
+
+static const Variant kWide[] = {AGX_VARIANT(2, 2, 2, 2, 16), AGX_VARIANT(2, 2, 2, 2, 8)};
+static const Variant kMid[] = {AGX_VARIANT(2, 2, 1, 4, 16), AGX_VARIANT(2, 2, 1, 4, 8), AGX_VARIANT(2, 1, 1, 4, 16),
+                               AGX_VARIANT(2, 1, 1, 4, 8)};
+static const Variant kNarrow[] = {AGX_VARIANT(1, 4, 1, 4, 16), AGX_VARIANT(1, 4, 1, 4, 8), AGX_VARIANT(1, 1, 1, 4, 16),
+                                  AGX_VARIANT(1, 1, 1, 4, 8)};
+
+static size_t variant_lds(const Variant &v, const ConvPlan &p) {
+    const int bn = 32 * v.nw * v.wn;
+    const size_t span = size_t(bn - 1) * p.s + size_t(p.J - 1) * p.d + 1;
+    return size_t(v.cc) * span * sizeof(float);
+}
+
+static const Variant *select_variant(const ConvPlan &p) {
+    if (p.Cin % 16 != 0 || p.M < 32) return nullptr;
+    const Variant *list = p.M >= 128 ? kWide : (p.M >= 64 ? kMid : kNarrow);
+    const int n = p.M >= 128 ? 2 : 4;
+    for (int i = 0; i < n; ++i)
+        if (variant_lds(list[i], p) <= 72 * 1024) return &list[i];
+    for (int i = 0; i < n; ++i)
+        if (variant_lds(list[i], p) <= 160 * 1024) return &list[i];
+    return nullptr;
+}
+
+bool conv_mfma_supported(const ConvPlan &p) { return select_variant(p) != nullptr; }
 
 const char *conv_mfma_variant(const ConvPlan &p) {
-    if (p.M >= 128) return "conv_mfma<2,2,2,2,16>";
-    if (p.M >= 64) return "conv_mfma<2,2,1,4,16>";
-    return "conv_mfma<1,4,1,4,16>";
+    const Variant *v = select_variant(p);
+    return v ? v->name : "conv_mfma<unsupported>";
 }
 
 int launch_conv_mfma(const ConvPlan &p, const float *x, const float *wp, const float *bias,
                      const float *res, float *y, hipStream_t st) {
-    if (!conv_mfma_supported(p))
-        return fail(AGX_ERR_UNSUPPORTED, "conv_mfma: needs Cin %% 16 == 0 and q*Cout >= 32 (Cin=%d M=%d)",
-                    p.Cin, p.M);
-    if (p.M >= 128) return launch_variant<2, 2, 2, 2, 16>(p, x, wp, bias, res, y, st);
-    if (p.M >= 64) return launch_variant<2, 2, 1, 4, 16>(p, x, wp, bias, res, y, st);
-    return launch_variant<1, 4, 1, 4, 16>(p, x, wp, bias, res, y, st);
+    const Variant *v = select_variant(p);
+    if (!v)
+        return fail(AGX_ERR_UNSUPPORTED,
+                    "conv_mfma: needs Cin %% 16 == 0, q*Cout >= 32 and an input tile that fits LDS (Cin=%d M=%d s=%d J=%d d=%d)",
+                    p.Cin, p.M, p.s, p.J, p.d);
+    return v->launch(p, x, wp, bias, res, y, st);
 }
 
 }  // namespace agx

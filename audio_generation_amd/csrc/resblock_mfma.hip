@@ -1,13 +1,194 @@
-// Fused residual block (single kernel) -- see agx_resblock_forward in agx.h.
+// Fused causal residual block for gfx950 -- one launch, one read and one write
+// of the activation tensor:
+//
+//     y = leaky( x + W2 . leaky( W1 (*)_dil x + b1 ) + b2 )
+//
+// (networks/vae.py:113-117 plus the activation that follows the block in the
+// enclosing Sequential, vae.py:130-135 / 193-198.)
+//
+// A wave owns ALL C channels of its 32*NW time columns.  GEMM1 (the dilated
+// k-tap conv) is the implicit GEMM of conv_mfma.hip.  Its 32x32 accumulator has
+// the time column on the lane and the channel in the registers, which is exactly
+// the B-operand shape of v_mfma_f32_32x32x2_f32 for a product that sums over
+// the accumulator's ROW index: register s of lane half h holds hidden channel
+// (s&3) + 8*(s>>2) + 4*h, so GEMM2 (the k=1 conv) feeds the activated
+// accumulator registers straight back as B operands, k-step s <-> register s,
+// with the A fragment W2[co][that channel].  The hidden activation never leaves
+// the register file: no LDS round trip, no second kernel, and the memory-bound
+// k=1 conv of the unfused path disappears.
 #include "common.hpp"
 
 namespace agx {
 
-bool resblock_fused_supported(const ConvPlan &) { return false; }
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-int launch_resblock_fused(const ConvPlan &, const float *, const float *, const float *, const float *,
-                          const float *, float *, int, hipStream_t) {
-    return fail(AGX_ERR_UNSUPPORTED, "resblock: no fused kernel for this shape");
+template <int MW, int NW, int CC>
+__global__ __launch_bounds__(256) void resblock_mfma_kernel(ConvPlan p, int span, int post_act,
+                                                            const float *__restrict__ x,
+                                                            const float *__restrict__ w1,
+                                                            const float *__restrict__ b1,
+                                                            const float *__restrict__ w2,
+                                                            const float *__restrict__ b2,
+                                                            float *__restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [CC][span]
+    constexpr int C = 32 * MW, BN = 32 * NW * 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int t0 = blockIdx.x * BN;
+    const int n0 = wave * (32 * NW);
+    const int b = blockIdx.y;
+    const int in0 = t0 - p.P;  // stride 1
+
+    f32x16 acc[MW][NW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
+
+    int bcol[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) bcol[k] = n0 + k * 32 + li + lh * span;
+
+    const float *xb = x + size_t(b) * C * p.Lin;
+    const size_t JM = size_t(p.J) * C;
+
+    // ---- GEMM1: h = W1 (*) x ------------------------------------------------------
+    for (int c0 = 0; c0 < C; c0 += CC) {
+        __syncthreads();
+        for (int c = wave; c < CC; c += 4) {
+            const float *src = xb + size_t(c0 + c) * p.Lin;
+            float *dst = xs + c * span;
+            for (int i = lane; i < span; i += 64) {
+                const int pos = in0 + i;
+                dst[i] = (pos >= 0 && pos < p.Lvalid) ? src[pos] : 0.f;
+            }
+        }
+        __syncthreads();
+        for (int j = 0; j < p.J; ++j) {
+            const float *wj = w1 + (size_t(c0 + lh) * p.J + j) * C + li;
+            const float *xj = xs + j * p.d;
+#pragma unroll
+            for (int ks = 0; ks < CC / 2; ++ks) {
+                float a[MW], bf[NW];
+#pragma unroll
+                for (int i = 0; i < MW; ++i) a[i] = wj[size_t(2 * ks) * JM + i * 32];
+#pragma unroll
+                for (int k = 0; k < NW; ++k) bf[k] = xj[(2 * ks) * span + bcol[k]];
+#pragma unroll
+                for (int i = 0; i < MW; ++i)
+#pragma unroll
+                    for (int k = 0; k < NW; ++k)
+                        acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bf[k], acc[i][k], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- hidden activation, in registers --------------------------------------------
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float bv = b1 ? b1[i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] : 0.f;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) {
+                const float v = acc[i][k][r] + bv;
+                acc[i][k][r] = v > 0.f ? v : v * p.slope;
+            }
+        }
+
+    // ---- GEMM2: out = W2 . h, B operand = the accumulator registers -------------------
+    f32x16 out[MW][NW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[i][k][r] = 0.f;
+
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {       // hidden-channel subtile
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {   // k-step == accumulator register
+            const int kch = i * 32 + (s & 3) + 8 * (s >> 2) + 4 * lh;
+            const float *w2k = w2 + size_t(kch) * C + li;
+            float a[MW];
+#pragma unroll
+            for (int io = 0; io < MW; ++io) a[io] = w2k[io * 32];
+#pragma unroll
+            for (int io = 0; io < MW; ++io)
+#pragma unroll
+                for (int k = 0; k < NW; ++k)
+                    out[io][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[io], acc[i][k][s], out[io][k], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: + b2 + x, trailing activation ----------------------------------------
+    float *yb = y + size_t(b) * C * p.Lin;
+#pragma unroll
+    for (int io = 0; io < MW; ++io)
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int t = t0 + n0 + k * 32 + li;
+            if (t >= p.Lin) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = io * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const size_t o = size_t(co) * p.Lin + t;
+                float v = out[io][k][r] + (b2 ? b2[co] : 0.f) + xb[o];
+                if (post_act) v = v > 0.f ? v : v * p.slope;
+                yb[o] = v;
+            }
+        }
+}
+
+template <int MW, int NW, int CC>
+static int launch_rb(const ConvPlan &p, const float *x, const float *w1, const float *b1, const float *w2,
+                     const float *b2, float *y, int post_act, hipStream_t st) {
+    constexpr int BN = 32 * NW * 4;
+    const int span = (BN - 1) + (p.J - 1) * p.d + 1;
+    const size_t lds = size_t(CC) * span * sizeof(float);
+    auto kern = resblock_mfma_kernel<MW, NW, CC>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    dim3 grid(ceil_div(p.Lin, BN), p.B), block(256);
+    if (grid.y > 65535) return fail(AGX_ERR_BAD_SHAPE, "resblock: batch too large for one launch");
+    hipLaunchKernelGGL(kern, grid, block, lds, st, p, span, post_act, x, w1, b1, w2, b2, y);
+    return check_launch("resblock_mfma");
+}
+
+bool resblock_fused_supported(const ConvPlan &p) {
+    if (p.Cin != p.Cout || p.s != 1 || p.q != 1 || p.Lvalid != p.Lin || p.Lt != p.Lin) return false;
+    if (p.Cin != 32 && p.Cin != 64 && p.Cin != 128 && p.Cin != 256) return false;
+    const int bn = p.Cin == 32 ? 512 : (p.Cin == 64 ? 256 : 128);
+    const size_t span = size_t(bn - 1) + size_t(p.J - 1) * p.d + 1;
+    return 16 * span * sizeof(float) <= 160 * 1024;
+}
+
+const char *resblock_variant(const ConvPlan &p) {
+    switch (p.Cin) {
+        case 32: return "resblock_mfma<1,4,16>";
+        case 64: return "resblock_mfma<2,2,16>";
+        case 128: return "resblock_mfma<4,1,16>";
+        default: return "resblock_mfma<8,1,16>";
+    }
+}
+
+int launch_resblock_fused(const ConvPlan &p, const float *x, const float *w1, const float *b1,
+                          const float *w2, const float *b2, float *y, int post_act, hipStream_t st) {
+    if (!resblock_fused_supported(p)) return fail(AGX_ERR_UNSUPPORTED, "resblock: no fused kernel for C=%d", p.Cin);
+    switch (p.Cin) {
+        case 32: return launch_rb<1, 4, 16>(p, x, w1, b1, w2, b2, y, post_act, st);
+        case 64: return launch_rb<2, 2, 16>(p, x, w1, b1, w2, b2, y, post_act, st);
+        case 128: return launch_rb<4, 1, 16>(p, x, w1, b1, w2, b2, y, post_act, st);
+        default: return launch_rb<8, 1, 16>(p, x, w1, b1, w2, b2, y, post_act, st);
+    }
 }
 
 }  // namespace agx

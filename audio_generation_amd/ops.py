@@ -15,6 +15,22 @@ from ._lib import (CONV_CAUSAL, CONV_SAME, CONV_TRANSPOSED, CONV_UPSAMPLE, EPI_L
 
 Tensor = torch.Tensor
 
+# Optional launch observer (bench.py / profiling): an object with
+# ``begin(kind, info) -> token`` and ``end(token)`` called around every C-ABI
+# compute call.  None (the default) costs one global lookup per call.
+_observer = None
+
+
+def set_observer(obs) -> None:
+    global _observer
+    _observer = obs
+
+
+def conv_kernel_name(desc: "ConvDesc") -> str:
+    buf = ctypes.create_string_buffer(96)
+    _lib.check(_lib.load().agx_conv_kernel_name(ctypes.byref(desc), buf, len(buf)), "agx_conv_kernel_name")
+    return buf.value.decode()
+
 
 def _ptr(t: Optional[Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
@@ -86,8 +102,11 @@ def conv_forward(desc: ConvDesc, x: Tensor, packed: Tensor, bias: Optional[Tenso
             raise AgxError(f"conv_forward: residual is {tuple(res.shape)}, output is {tuple(y.shape)}")
     if bias is not None:
         bias = _f32c(bias)
+    tok = _observer.begin("conv", desc) if _observer is not None else None
     _lib.check(lib.agx_conv_forward(ctypes.byref(desc), _ptr(x), _ptr(packed), _ptr(bias), _ptr(res),
                                     _ptr(y), _stream()), "agx_conv_forward")
+    if tok is not None:
+        _observer.end(tok)
     return y
 
 
@@ -102,9 +121,12 @@ def resblock_forward(desc: ConvDesc, x: Tensor, packed1: Tensor, bias1: Optional
     y = torch.empty_like(x)
     ws_bytes = int(lib.agx_resblock_workspace_bytes(ctypes.byref(desc)))
     ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=x.device)
+    tok = _observer.begin("resblock", desc) if _observer is not None else None
     _lib.check(lib.agx_resblock_forward(ctypes.byref(desc), _ptr(x), _ptr(packed1), _ptr(bias1),
                                         _ptr(packed2), _ptr(bias2), _ptr(y), int(bool(post_act)),
                                         _ptr(ws), ws_bytes, _stream()), "agx_resblock_forward")
+    if tok is not None:
+        _observer.end(tok)
     return y
 
 
@@ -151,9 +173,12 @@ def rvq_forward(x: Tensor, codebooks: Tensor, packed: Tensor, q_used: int,
         qb, qd, qt = xq.stride()
     index = torch.empty((b, t, q_used), dtype=torch.int64, device=x.device)
     sq_err = torch.zeros(max(q_used, 1), dtype=torch.float64, device=x.device)
+    tok = _observer.begin("rvq", (b, t, d, k, q_used)) if _observer is not None else None
     _lib.check(lib.agx_rvq_forward(_ptr(x), sb, st, sd, _ptr(codebooks), _ptr(packed), b, t, d, k, q_used,
                                    _ptr(xq), qb, qt, qd, _ptr(index), _ptr(sq_err), None, 0, _stream()),
                "agx_rvq_forward")
+    if tok is not None:
+        _observer.end(tok)
     if q_used == 0:
         xq.zero_()
     return xq, index, sq_err[:q_used]

@@ -153,6 +153,9 @@ class CausalUpsampleConv1d(_ConvBase):
 
 class CausalResidualBlock1d(nn.Module):
     """networks/vae.py:91-117: ``x + conv_k1(act(conv_k7,dil(x)))``."""
+    # profiling aid: issue the two convs as separate C-ABI calls (same kernels) so a
+    # launch observer can time them one by one
+    split_launches = False
 
     def __init__(self, in_channels, out_channels, kernel_size=7, dilation=1, bias=True,
                  activation=None, dropout=0.0, depthwise=False):
@@ -173,7 +176,7 @@ class CausalResidualBlock1d(nn.Module):
         ``Sequential`` when ``post_slope`` is given) through ``agx_resblock_forward``."""
         slope = _leaky_slope(self.activation)
         c1, c2 = self.conv1.conv, self.conv2.conv
-        if slope is None or (post_slope is not None and post_slope != slope):
+        if self.split_launches or slope is None or (post_slope is not None and post_slope != slope):
             # exotic activation mix: two convs with separate epilogues
             h = self.conv1.run(x, EPI_LEAKY_PRE if slope is not None else 0, slope or 0.0)
             epi = ops.EPI_RESIDUAL | (EPI_LEAKY_POST if post_slope is not None else 0)

@@ -1,0 +1,290 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 24 kHz samples/s through encode -> RVQ -> decode.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (the driver launches N > 1 through torch.distributed.run;
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment).  A "step"
+is one forward of the "Soundstream default" codec (BASELINE.json configs[1]:
+8 x 1024 x 512 RVQ, strides 2,4,5,8, fp32) over one batch of 32 synthetic
+72 000-sample clips resident in HBM; the batch dimension shards over ranks with
+no data-path collective (weak scaling: 32 clips per GPU).  Rank 0 prints ONE
+JSON line.
+
+Besides the contract fields the line carries
+  roofline     -- the dominant kernel (by time) of the forward: achieved vs peak,
+                  per-launch durations measured with HIP events on the launch stream;
+  cpu_baseline -- the CPU oracle (torch fp32 conv stacks + the exact RVQ) timed on
+                  this box's host cores on a bounded sample of the same workload;
+  parity       -- GPU vs oracle on that sample (index equality on identical
+                  latents, waveform RMS), so every bench line is also a parity check.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA peak
+PEAK_HBM_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E spec (measured copy ceiling ~6300)
+CLIP = 72000               # utils.py:149 collator clip length = 3 s @ 24 kHz
+BATCH_PER_GPU = 32
+MODEL_KW = dict(in_channels=1, n_blocks=4, strides=(2, 4, 5, 8), num_quantizers=8, codebook_size=1024,
+                codebook_dim=512, input_format="n c l", wavelet_decoders=False)
+
+
+# ----------------------------------------------------------------------- work model
+def conv_work(desc):
+    """(executed MACs, reference-counted MACs, layer-boundary bytes) of one conv launch.
+
+    executed  = what the polyphase form needs: B * Cin * J * (q*Cout) * Lt
+    reference = the (2s+1)-tap count on the upsampled signal the reference executes
+    bytes     = read the unpadded input once + write the output once (SURVEY 8d byte model)
+    """
+    from audio_generation_amd import _lib, ops
+    b, cin, cout, lin, k, s = desc.batch, desc.c_in, desc.c_out, desc.l_in, desc.kernel, desc.stride
+    lout = ops.conv_out_len(desc)
+    if desc.kind == _lib.CONV_UPSAMPLE:
+        pl = (k - 1) // 2
+        jmin, jmax = (-pl) // s, (s - 1 + k - 1 - pl) // s
+        executed = b * cin * (jmax - jmin + 1) * s * cout * lin
+        reference = b * cin * cout * k * lout
+    elif desc.kind == _lib.CONV_TRANSPOSED:
+        executed = b * cin * (-(-k // s)) * s * cout * lin
+        reference = b * cin * cout * k * lin
+    else:
+        executed = reference = b * cin * cout * k * lout
+    nbytes = 4 * b * (cin * lin + cout * lout)
+    if desc.epilogue & _lib.EPI_RESIDUAL:
+        nbytes += 4 * b * cout * lout
+    return executed, reference, nbytes
+
+
+class LaunchTimer:
+    """ops observer: HIP events (torch.cuda.Event on the launch stream) around every C-ABI call."""
+
+    def __init__(self):
+        self.records = []
+
+    def begin(self, kind, info):
+        from audio_generation_amd import ops
+        if kind == "rvq":
+            b, t, d, k, q = info
+            name, work = "rvq_forward", (b * t * q * k * d, b * t * q * k * d, 4 * b * t * d * 2 + 8 * b * t * q)
+        else:
+            name, work = ops.conv_kernel_name(info), conv_work(info)
+            if kind == "resblock":
+                name = "resblock[" + name + "]"
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return (name, work, e0, e1)
+
+    def end(self, tok):
+        tok[3].record()
+        self.records.append(tok)
+
+    def summary(self, steps):
+        torch.cuda.synchronize()
+        per = {}
+        for name, (ex, ref, nb), e0, e1 in self.records:
+            r = per.setdefault(name, dict(ms=0.0, launches=0, macs=0, ref_macs=0, bytes=0))
+            r["ms"] += e0.elapsed_time(e1)
+            r["launches"] += 1
+            r["macs"] += ex
+            r["ref_macs"] += ref
+            r["bytes"] += nb
+        for r in per.values():
+            r["avg_us"] = 1e3 * r["ms"] / r["launches"]
+            r["tflops"] = 2e-9 * r["macs"] / r["ms"] if r["ms"] > 0 else 0.0
+            r["gbps"] = 1e-6 * r["bytes"] / r["ms"] if r["ms"] > 0 else 0.0
+            r["launches_per_step"] = r["launches"] / steps
+            r["ms_per_step"] = r["ms"] / steps
+        return per
+
+
+# ----------------------------------------------------------------------------- main
+def make_inputs(batch, rank):
+    gen = torch.Generator().manual_seed(1234 + rank)
+    return (0.1 * torch.randn(batch, 1, CLIP, generator=gen)).clamp(-1, 1)
+
+
+def build_model(dev):
+    from audio_generation_amd.vae import CausalVQAE
+    torch.manual_seed(0)
+    model = CausalVQAE(**MODEL_KW).eval()
+    return model.to(dev)
+
+
+def calibrate_codebooks(model, x_small):
+    """codebooks = randn * sigma(encoder output) so the arg-min is non-degenerate."""
+    with torch.no_grad():
+        z = model._run_encoders(x_small)
+        sigma = float(z.std())
+        gen = torch.Generator().manual_seed(7)
+        cb = torch.randn(model.quantizer.codebooks.shape, generator=gen) * sigma
+        model.quantizer.codebooks.copy_(cb.to(z.device))
+    return sigma
+
+
+def cpu_baseline_and_parity(model, x_cpu, y_gpu, idx_gpu, z_gpu, n_items):
+    """Time the oracle on host cores on the first ``n_items`` clips and check the GPU result."""
+    from oracle import codec, rvq
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    spec = codec.CodecSpec(in_channels=1, n_blocks=4, strides=(2, 4, 5, 8), codebook_dim=512,
+                           wavelet_decoders=False, input_format="n c l")
+    cbs = sd["quantizer.codebooks"]
+    xs = x_cpu[:n_items]
+
+    def run():
+        with torch.no_grad():
+            z = codec.encode_latents(xs, sd, spec)
+            zq, idx, _ = rvq.residual_quantize(z, cbs, score_dtype=torch.float32)
+            return z, zq, idx, codec.decode_latents(zq, sd, spec)
+
+    run()  # warm-up (thread pools, page faults)
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        z, zq, idx, y = run()
+        times.append(time.perf_counter() - t0)
+    sec = sorted(times)[0]
+    # parity: (a) oracle RVQ on the GPU's latents must give the GPU's indices exactly;
+    #         (b) waveform RMS vs the oracle decode of those codes; (c) independent path agreement
+    with torch.no_grad():
+        zq_g, idx_g, _ = rvq.residual_quantize(z_gpu[:n_items].cpu().transpose(1, 2).contiguous(), cbs)
+        y_g = codec.decode_latents(zq_g, sd, spec)
+    parity = {
+        "index_bit_exact_on_same_latents": bool(torch.equal(idx_g, idx_gpu[:n_items].cpu())),
+        "waveform_rms_vs_oracle": float((y_gpu[:n_items].cpu().double() - y_g.double()).pow(2).mean().sqrt()),
+        "independent_path_index_agreement": float((idx == idx_gpu[:n_items].cpu()).float().mean()),
+        "independent_path_waveform_rms": float((y_gpu[:n_items].cpu().double() - y.double()).pow(2).mean().sqrt()),
+        "latent_rms_vs_oracle": float((z_gpu[:n_items].cpu().transpose(1, 2).double() - z.double()).pow(2).mean().sqrt()),
+    }
+    base = {"value": n_items * CLIP / sec, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{n_items} clips x {CLIP} samples (same inputs/weights as the GPU run), "
+                      f"oracle conv stacks (torch fp32 CPU, {cores} threads) + exact RVQ, best of 2 after 1 warm-up"}
+    return base, parity
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-per-gpu", type=int, default=BATCH_PER_GPU)
+    ap.add_argument("--cpu-items", type=int, default=4, help="clips in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from audio_generation_amd import dist as agx_dist
+    from audio_generation_amd import ops
+    from audio_generation_amd.vae import CausalResidualBlock1d
+
+    rank, local_rank, world = agx_dist.env_world()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N > 1 through `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    agx_dist.init("nccl")
+
+    bsz = args.batch_per_gpu
+    model = build_model(dev)
+    x_cpu = make_inputs(bsz, rank)
+    x = x_cpu.to(dev)                       # inputs resident in HBM before the timed region
+    sigma = calibrate_codebooks(model, x[:2])
+
+    def step():
+        with torch.no_grad():
+            return model(x)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    agx_dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    agx_dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = agx_dist.max_over_ranks(time.perf_counter() - t0, device=dev)
+    y, commit, index = out
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    total_samples = world * bsz * CLIP * args.steps
+    result = {
+        "metric": "24kHz samples/s encode->RVQ->decode", "value": total_samples / elapsed, "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "Soundstream default: 8-codebook RVQ (1024 x 512), strides [2,4,5,8], 24 kHz, "
+                               f"batch {bsz}/GPU x {CLIP} samples, fp32, eval forward (encode->RVQ->decode)",
+                   "batch_per_gpu": bsz, "global_batch": bsz * world, "clip_samples": CLIP,
+                   "parallelism": f"batch-sharded x{world}, no data-path collective",
+                   "codebook_sigma": sigma},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # instrumented pass (outside the timed region): per-launch HIP-event durations
+        timer = LaunchTimer()
+        CausalResidualBlock1d.split_launches = True
+        ops.set_observer(timer)
+        prof_steps = max(2, min(5, args.steps))
+        for _ in range(prof_steps):
+            step()
+        ops.set_observer(None)
+        CausalResidualBlock1d.split_launches = False
+        per = timer.summary(prof_steps)
+        dom_name, dom = max(per.items(), key=lambda kv: kv[1]["ms"])
+        mfma_bound = dom_name.startswith(("conv_mfma", "rvq", "resblock"))
+        exec_flops = 2.0 * sum(r["macs"] for r in per.values()) / prof_steps
+        ref_flops = 2.0 * sum(r["ref_macs"] for r in per.values()) / prof_steps
+        enc_bytes = 4864.0  # layer-boundary bytes per input sample, encoder
+        if mfma_bound:
+            roof = {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                    "frac": dom["tflops"] / PEAK_FP32_TFLOPS, "traffic": None}
+        else:
+            roof = {"bound": "hbm", "achieved": dom["gbps"], "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                    "frac": dom["gbps"] / PEAK_HBM_GBPS, "traffic": None}
+        roof.update({"kernel": dom_name, "avg_launch_us": dom["avg_us"],
+                     "launches_per_step": dom["launches_per_step"],
+                     "share_of_step": dom["ms_per_step"] / ms_per_step,
+                     "flops_counted": "executed (polyphase) MACs x 2; reference-counted total alongside",
+                     "whole_forward_tflops_executed": 1e-9 * exec_flops / ms_per_step,
+                     "whole_forward_tflops_reference_count": 1e-9 * ref_flops / ms_per_step,
+                     "whole_forward_frac_of_fp32_peak": 1e-9 * exec_flops / ms_per_step / PEAK_FP32_TFLOPS,
+                     "layer_boundary_hbm_frac_encoder_model": (bsz * CLIP / (1e-3 * ms_per_step)) * enc_bytes / 1e9 / PEAK_HBM_GBPS,
+                     "kernels": {k: {"ms_per_step": round(v["ms_per_step"], 4), "avg_us": round(v["avg_us"], 2),
+                                     "launches_per_step": v["launches_per_step"], "tflops": round(v["tflops"], 2),
+                                     "gbps": round(v["gbps"], 1)} for k, v in sorted(per.items())}})
+        result["roofline"] = roof
+
+    if rank == 0 and world == 1 and args.cpu_items > 0:
+        with torch.no_grad():
+            z_gpu = model._run_encoders(x)
+        base, parity = cpu_baseline_and_parity(model, x_cpu, y, index, z_gpu, min(args.cpu_items, bsz))
+        result["cpu_baseline"] = base
+        result["parity"] = parity
+        result["speedup_vs_cpu_baseline"] = result["value"] / base["value"]
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
