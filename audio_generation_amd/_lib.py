@@ -38,6 +38,7 @@ SIGNATURES = {
     "agx_conv_forward": (c_int, [_PD, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "agx_conv_kernel_name": (c_int, [_PD, c_char_p, c_size_t]),
     "agx_resblock_workspace_bytes": (c_size_t, [_PD]),
+    "agx_resblock_kernel_name": (c_int, [_PD, c_char_p, c_size_t]),
     "agx_resblock_forward": (c_int, [_PD, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int32, c_void_p, c_size_t, c_void_p]),
     "agx_rvq_packed_floats": (c_int64, [c_int32, c_int32, c_int32]),

@@ -12,6 +12,7 @@ const char *conv_direct_variant(const ConvPlan &p);
 int launch_resblock_fused(const ConvPlan &p, const float *x, const float *w1, const float *b1,
                           const float *w2, const float *b2, float *y, int post_act, hipStream_t st);
 bool resblock_fused_supported(const ConvPlan &p);
+const char *resblock_variant(const ConvPlan &p);
 
 static int run_conv(const ConvPlan &p, int impl, const float *x, const float *wp, const float *bias,
                     const float *res, float *y, hipStream_t st) {
@@ -51,6 +52,24 @@ int agx_conv_kernel_name(const agx_conv_desc *d, char *buf, size_t buf_len) {
 size_t agx_resblock_workspace_bytes(const agx_conv_desc *d) {
     if (!d || d->batch <= 0 || d->c_out <= 0 || d->l_in <= 0) return 0;
     return size_t(d->batch) * d->c_out * d->l_in * sizeof(float);
+}
+
+int agx_resblock_kernel_name(const agx_conv_desc *d, char *buf, size_t buf_len) {
+    using namespace agx;
+    if (!d || !buf || buf_len == 0) return fail(AGX_ERR_NULL_POINTER, "agx_resblock_kernel_name: NULL pointer");
+    agx_conv_desc d1 = *d;
+    d1.epilogue = AGX_EPI_LEAKY_PRE;
+    ConvPlan p;
+    int rc = lower_conv(&d1, &p);
+    if (rc != AGX_OK) return rc;
+    if (d->impl != AGX_IMPL_DIRECT && resblock_fused_supported(p)) {
+        snprintf(buf, buf_len, "%s", resblock_variant(p));
+    } else {
+        int impl = d->impl;
+        if (impl == AGX_IMPL_AUTO) impl = conv_mfma_supported(p) ? AGX_IMPL_MFMA : AGX_IMPL_DIRECT;
+        snprintf(buf, buf_len, "2x:%s", impl == AGX_IMPL_MFMA ? conv_mfma_variant(p) : conv_direct_variant(p));
+    }
+    return AGX_OK;
 }
 
 int agx_resblock_forward(const agx_conv_desc *d, const float *x, const float *packed1,

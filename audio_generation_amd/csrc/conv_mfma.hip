@@ -20,21 +20,19 @@
 // Replaces: F.pad + F.conv1d (networks/vae.py:34-37), conv_transpose1d + crop
 // (vae.py:61-64), interpolate + conv1d (vae.py:86-89) and the elementwise
 // LeakyReLU / residual add around them (vae.py:113-117, 130-141, 186-198).
-#include "common.hpp"
+#include "mfma_tile.hpp"
 
 namespace agx {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
 template <int MW, int NW, int WM, int WN, int CC>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvPlan p, int span,
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
                                                         const float *__restrict__ x,
                                                         const float *__restrict__ wp,
                                                         const float *__restrict__ bias,
                                                         const float *__restrict__ res,
                                                         float *__restrict__ y) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    extern __shared__ __attribute__((aligned(16))) float xs[];  // [CC][span]
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [2][CC][span]
     constexpr int BM = 32 * MW * WM, BN = 32 * NW * WN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -63,58 +61,46 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvPlan p, int span,
     for (int k = 0; k < NW; ++k) bcol[k] = (n0 + k * 32 + li) * p.s + lh * span;
 
     const float *xb = x + size_t(b) * p.Cin * p.Lin;
-    const size_t JM = size_t(p.J) * p.M;
+    conv_gemm<MW, NW, CC>(acc, xs, xb, wp, p, p.M, span, in0, arow, bcol, wave, lane);
 
-    for (int c0 = 0; c0 < p.Cin; c0 += CC) {
-        __syncthreads();
-        for (int c = wave; c < CC; c += 4) {
-            const float *src = xb + size_t(c0 + c) * p.Lin;
-            float *dst = xs + c * span;
-            for (int i = lane; i < span; i += 64) {
-                const int pos = in0 + i;
-                dst[i] = (pos >= 0 && pos < p.Lvalid) ? src[pos] : 0.f;
-            }
-        }
-        __syncthreads();
-        for (int j = 0; j < p.J; ++j) {
-            const float *wj = wp + (size_t(c0 + lh) * p.J + j) * p.M;
-            const float *xj = xs + j * p.d;
-#pragma unroll
-            for (int ks = 0; ks < CC / 2; ++ks) {
-                float a[MW], bf[NW];
-#pragma unroll
-                for (int i = 0; i < MW; ++i) a[i] = wj[size_t(2 * ks) * JM + arow[i]];
-#pragma unroll
-                for (int k = 0; k < NW; ++k) bf[k] = xj[(2 * ks) * span + bcol[k]];
-#pragma unroll
-                for (int i = 0; i < MW; ++i)
-#pragma unroll
-                    for (int k = 0; k < NW; ++k)
-                        acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bf[k], acc[i][k], 0, 0, 0);
-            }
-        }
-    }
-
-    // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // ---- epilogue.  All loads (bias, residual) are issued on clamped addresses before
+    // any use so they overlap; only the stores are predicated.
+    const bool has_res = (p.epilogue & AGX_EPI_RESIDUAL) != 0;
+    const bool pre = (p.epilogue & AGX_EPI_LEAKY_PRE) != 0, post = (p.epilogue & AGX_EPI_LEAKY_POST) != 0;
 #pragma unroll
     for (int i = 0; i < MW; ++i) {
+        int co[16], ph[16];
+        float bv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = min(m0 + i * 32 + acc_row(r, lh), p.M - 1);
+            co[r] = (p.q == 1) ? m : m / p.q;
+            ph[r] = m - co[r] * p.q;
+            bv[r] = bias ? bias[co[r]] : 0.f;
+        }
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
             const int t = t0 + n0 + k * 32 + li;
-            if (t >= p.Lt) continue;
+            const int tc = min(t, p.Lt - 1);
+            size_t off[16];
+            float rv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= p.M) continue;
-                const int co = m / p.q, ph = m - co * p.q;
-                const int u = t * p.q + ph;
-                if (u >= p.Lout) continue;
-                float v = acc[i][k][r] + (bias ? bias[co] : 0.f);
-                if (p.epilogue & AGX_EPI_LEAKY_PRE) v = v > 0.f ? v : v * p.slope;
-                const size_t o = (size_t(b) * p.Cout + co) * p.Lout + u;
-                if (p.epilogue & AGX_EPI_RESIDUAL) v += res[o];
-                if (p.epilogue & AGX_EPI_LEAKY_POST) v = v > 0.f ? v : v * p.slope;
-                y[o] = v;
+                const int u = min(tc * p.q + ph[r], p.Lout - 1);
+                off[r] = (size_t(b) * p.Cout + co[r]) * p.Lout + u;
+            }
+            if (has_res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = res[off[r]];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][k][r] + bv[r];
+                if (pre) v = leaky(v, p.slope);
+                if (has_res) v += rv[r];
+                if (post) v = leaky(v, p.slope);
+                const bool ok = t < p.Lt && (m0 + i * 32 + acc_row(r, lh)) < p.M && (t * p.q + ph[r]) < p.Lout;
+                if (ok) y[off[r]] = v;
             }
         }
     }
@@ -125,7 +111,7 @@ static int launch_variant(const ConvPlan &p, const float *x, const float *wp, co
                           const float *res, float *y, hipStream_t st) {
     constexpr int BM = 32 * MW * WM, BN = 32 * NW * WN;
     const int span = (BN - 1) * p.s + (p.J - 1) * p.d + 1;
-    const size_t lds = size_t(CC) * span * sizeof(float);
+    const size_t lds = size_t(2) * CC * span * sizeof(float);  // double-buffered input tile
     if (lds > 160 * 1024) return fail(AGX_ERR_UNSUPPORTED, "conv_mfma: tile needs %zu B of LDS", lds);
     auto kern = conv_mfma_kernel<MW, NW, WM, WN, CC>;
     static bool attr_set = false;
@@ -154,26 +140,31 @@ struct Variant {
 #define AGX_VARIANT(MW, NW, WM, WN, CC) \
     { MW, NW, WM, WN, CC, "conv_mfma<" #MW "," #NW "," #WM "," #WN "," #CC ">", launch_variant<MW, NW, WM, WN, CC> }
 
-static const Variant kWide[] = {AGX_VARIANT(2, 2, 2, 2, 16), AGX_VARIANT(2, 2, 2, 2, 8)};
+static const Variant kWide[] = {AGX_VARIANT(2, 2, 2, 2, 16), AGX_VARIANT(2, 2, 2, 2, 8), AGX_VARIANT(2, 2, 2, 2, 32)};
 static const Variant kMid[] = {AGX_VARIANT(2, 2, 1, 4, 16), AGX_VARIANT(2, 2, 1, 4, 8), AGX_VARIANT(2, 1, 1, 4, 16),
-                               AGX_VARIANT(2, 1, 1, 4, 8)};
+                               AGX_VARIANT(2, 1, 1, 4, 8),  AGX_VARIANT(2, 2, 1, 4, 32)};
 static const Variant kNarrow[] = {AGX_VARIANT(1, 4, 1, 4, 16), AGX_VARIANT(1, 4, 1, 4, 8), AGX_VARIANT(1, 1, 1, 4, 16),
-                                  AGX_VARIANT(1, 1, 1, 4, 8)};
+                                  AGX_VARIANT(1, 1, 1, 4, 8),  AGX_VARIANT(1, 4, 1, 4, 32)};
 
 static size_t variant_lds(const Variant &v, const ConvPlan &p) {
     const int bn = 32 * v.nw * v.wn;
     const size_t span = size_t(bn - 1) * p.s + size_t(p.J - 1) * p.d + 1;
-    return size_t(v.cc) * span * sizeof(float);
+    return size_t(2) * v.cc * span * sizeof(float);
 }
 
 static const Variant *select_variant(const ConvPlan &p) {
     if (p.Cin % 16 != 0 || p.M < 32) return nullptr;
     const Variant *list = p.M >= 128 ? kWide : (p.M >= 64 ? kMid : kNarrow);
-    const int n = p.M >= 128 ? 2 : 4;
+    const int n = p.M >= 128 ? 3 : 5;
+    // few taps per channel (k=1 / k=3 / polyphase): a 32-channel chunk halves the number of
+    // barrier + DMA hand-overs per MFMA
+    if (p.J <= 4 && p.Cin % 32 == 0)
+        for (int i = 0; i < n; ++i)
+            if (list[i].cc == 32 && variant_lds(list[i], p) <= 72 * 1024) return &list[i];
     for (int i = 0; i < n; ++i)
-        if (variant_lds(list[i], p) <= 72 * 1024) return &list[i];
+        if (list[i].cc != 32 && variant_lds(list[i], p) <= 72 * 1024) return &list[i];
     for (int i = 0; i < n; ++i)
-        if (variant_lds(list[i], p) <= 160 * 1024) return &list[i];
+        if (list[i].cc != 32 && variant_lds(list[i], p) <= 160 * 1024) return &list[i];
     return nullptr;
 }
 

@@ -1,0 +1,151 @@
+// Device-side building blocks shared by the fp32-MFMA convolution kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+
+namespace agx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Row of accumulator register r in lane half lh (C/D layout of v_mfma_f32_32x32x2_f32:
+// column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)).
+__device__ __forceinline__ constexpr int acc_row(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
+
+__device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// Stage CC channel rows of the input, positions [in0, in0 + span), into LDS
+// (xs[c * span + i]); positions outside [0, Lvalid) read as zero.  Loads are
+// issued unconditionally on clamped addresses so that RPW * U of them are in
+// flight per wave before the first LDS write (a conditional load makes hipcc
+// wait for every element separately).
+template <int CC, int U = 2>
+__device__ __forceinline__ void stage_rows(float *__restrict__ xs, const float *__restrict__ xb, int Lin,
+                                           int Lvalid, int in0, int span, int wave, int lane) {
+    constexpr int RPW = CC / 4;  // rows per wave (4 waves)
+    for (int i0 = lane; i0 < span; i0 += 64 * U) {
+        float v[RPW][U];
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const float *src = xb + size_t(wave + 4 * rr) * Lin;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int pos = in0 + i0 + u * 64;
+                const float t = src[min(max(pos, 0), Lvalid - 1)];
+                v[rr][u] = (pos >= 0 && pos < Lvalid) ? t : 0.f;
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * 64;
+                if (i < span) xs[(wave + 4 * rr) * span + i] = v[rr][u];
+            }
+    }
+}
+
+// A fragments (weights) of one (channel chunk, tap) phase: a[ks][i] =
+// Wp[(c0 + 2*ks + lh) * J + j][arow[i]]; Wp is K-major with row length M.
+template <int MW, int CC>
+__device__ __forceinline__ void load_a_phase(float (&a)[CC / 2][MW], const float *__restrict__ wp, int c0,
+                                             int j, int J, int M, int lh, const int (&arow)[MW]) {
+    // uniform (scalar) base + one per-lane offset per row block: lets hipcc use the
+    // saddr + voffset form instead of a 64-bit VGPR address per load
+    const float *wj = wp + (size_t(c0) * J + j) * M;
+    const int step = 2 * J * M;
+    const int lane_row = lh * J * M;
+#pragma unroll
+    for (int ks = 0; ks < CC / 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < MW; ++i) a[ks][i] = (wj + ks * step)[lane_row + arow[i]];
+}
+
+// Asynchronous global -> LDS copy of one dword per lane (LDS-DMA): the LDS
+// destination is wave-uniform base + lane * 4, the global source is per lane,
+// EXEC-masked lanes write nothing.  No VGPR is involved, so a whole input chunk
+// can be in flight while the MFMAs of the previous chunk run.
+__device__ __forceinline__ void glds_dword(const float *gsrc_lane, float *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc_lane,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 4, 0, 0);
+}
+
+// Issue the LDS-DMA of CC channel rows, positions [in0, in0 + span), into buf
+// (row stride span).  Out-of-range positions are never written: the caller
+// zero-fills both buffers once and they stay zero (the in-range set does not
+// depend on the channel chunk).
+template <int CC>
+__device__ __forceinline__ void issue_rows_dma(float *__restrict__ buf, const float *__restrict__ xb, int Lin,
+                                               int Lvalid, int in0, int span, int wave, int lane) {
+#pragma unroll
+    for (int rr = 0; rr < CC / 4; ++rr) {
+        const int c = wave + 4 * rr;
+        const float *src = xb + size_t(c) * Lin + in0 + lane;
+        float *dst = buf + c * span;
+        for (int i0 = 0; i0 < span; i0 += 64) {
+            const int i = i0 + lane, pos = in0 + i;
+            if (i < span && pos >= 0 && pos < Lvalid) glds_dword(src + i0, dst + i0);
+        }
+    }
+}
+
+// The implicit-GEMM main loop over all (channel chunk, tap) phases.
+//   acc[i][k] += sum_{c, j} Wp[c*J + j][arow[i]] * x[c][bcol0[k] + j*d]   (x via the LDS tile)
+//
+// Pipeline: the input chunk c+1 streams into the second LDS buffer by LDS-DMA
+// while the MFMAs of chunk c run (one barrier per chunk); A fragments (weights,
+// L2-resident) are prefetched one (chunk, tap) phase ahead into registers; B
+// fragments are single ds_read_b32, batched per phase.  xs holds 2 * CC * span floats.
+template <int MW, int NW, int CC>
+__device__ __forceinline__ void conv_gemm(f32x16 (&acc)[MW][NW], float *__restrict__ xs,
+                                          const float *__restrict__ xb, const float *__restrict__ wp,
+                                          const ConvPlan &p, int M, int span, int in0,
+                                          const int (&arow)[MW], const int (&bcol)[NW], int wave, int lane) {
+    const int lh = lane >> 5;
+    const int tid = wave * 64 + lane;
+    float *buf0 = xs, *buf1 = xs + CC * span;
+    for (int e = tid; e < 2 * CC * span; e += 256) xs[e] = 0.f;
+    float a_cur[CC / 2][MW], a_nxt[CC / 2][MW];
+    load_a_phase<MW, CC>(a_cur, wp, 0, 0, p.J, M, lh, arow);
+    __syncthreads();
+    issue_rows_dma<CC>(buf0, xb, p.Lin, p.Lvalid, in0, span, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int it = 0;
+    for (int c0 = 0; c0 < p.Cin; c0 += CC, ++it) {
+        float *cur = (it & 1) ? buf1 : buf0;
+        float *nxt = (it & 1) ? buf0 : buf1;
+        if (c0 + CC < p.Cin)
+            issue_rows_dma<CC>(nxt, xb + size_t(c0 + CC) * p.Lin, p.Lin, p.Lvalid, in0, span, wave, lane);
+        for (int j = 0; j < p.J; ++j) {
+            int nj = j + 1, nc0 = c0;
+            if (nj == p.J) {
+                nj = 0;
+                nc0 += CC;
+            }
+            if (nc0 < p.Cin) load_a_phase<MW, CC>(a_nxt, wp, nc0, nj, p.J, M, lh, arow);
+            const float *xj = cur + j * p.d;
+            float bf[CC / 2][NW];
+#pragma unroll
+            for (int ks = 0; ks < CC / 2; ++ks)
+#pragma unroll
+                for (int k = 0; k < NW; ++k) bf[ks][k] = xj[(2 * ks) * span + bcol[k]];
+#pragma unroll
+            for (int ks = 0; ks < CC / 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < MW; ++i)
+#pragma unroll
+                    for (int k = 0; k < NW; ++k)
+                        acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ks][i], bf[ks][k], acc[i][k], 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < CC / 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < MW; ++i) a_cur[ks][i] = a_nxt[ks][i];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of the next chunk has landed
+        __syncthreads();                                   // everyone's has, and everyone is done reading cur
+    }
+}
+
+}  // namespace agx

@@ -16,21 +16,19 @@
 // with the A fragment W2[co][that channel].  The hidden activation never leaves
 // the register file: no LDS round trip, no second kernel, and the memory-bound
 // k=1 conv of the unfused path disappears.
-#include "common.hpp"
+#include "mfma_tile.hpp"
 
 namespace agx {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
 template <int MW, int NW, int CC>
-__global__ __launch_bounds__(256) void resblock_mfma_kernel(ConvPlan p, int span, int post_act,
+__global__ __launch_bounds__(256, (MW <= 4 ? 2 : 1)) void resblock_mfma_kernel(ConvPlan p, int span, int post_act,
                                                             const float *__restrict__ x,
                                                             const float *__restrict__ w1,
                                                             const float *__restrict__ b1,
                                                             const float *__restrict__ w2,
                                                             const float *__restrict__ b2,
                                                             float *__restrict__ y) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];  // [CC][span]
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [2][CC][span]
     constexpr int C = 32 * MW, BN = 32 * NW * 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -47,43 +45,16 @@ __global__ __launch_bounds__(256) void resblock_mfma_kernel(ConvPlan p, int span
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
 
-    int bcol[NW];
+    int arow[MW], bcol[NW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i) arow[i] = i * 32 + li;
 #pragma unroll
     for (int k = 0; k < NW; ++k) bcol[k] = n0 + k * 32 + li + lh * span;
 
     const float *xb = x + size_t(b) * C * p.Lin;
-    const size_t JM = size_t(p.J) * C;
 
     // ---- GEMM1: h = W1 (*) x ------------------------------------------------------
-    for (int c0 = 0; c0 < C; c0 += CC) {
-        __syncthreads();
-        for (int c = wave; c < CC; c += 4) {
-            const float *src = xb + size_t(c0 + c) * p.Lin;
-            float *dst = xs + c * span;
-            for (int i = lane; i < span; i += 64) {
-                const int pos = in0 + i;
-                dst[i] = (pos >= 0 && pos < p.Lvalid) ? src[pos] : 0.f;
-            }
-        }
-        __syncthreads();
-        for (int j = 0; j < p.J; ++j) {
-            const float *wj = w1 + (size_t(c0 + lh) * p.J + j) * C + li;
-            const float *xj = xs + j * p.d;
-#pragma unroll
-            for (int ks = 0; ks < CC / 2; ++ks) {
-                float a[MW], bf[NW];
-#pragma unroll
-                for (int i = 0; i < MW; ++i) a[i] = wj[size_t(2 * ks) * JM + i * 32];
-#pragma unroll
-                for (int k = 0; k < NW; ++k) bf[k] = xj[(2 * ks) * span + bcol[k]];
-#pragma unroll
-                for (int i = 0; i < MW; ++i)
-#pragma unroll
-                    for (int k = 0; k < NW; ++k)
-                        acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bf[k], acc[i][k], 0, 0, 0);
-            }
-        }
-    }
+    conv_gemm<MW, NW, CC>(acc, xs, xb, w1, p, C, span, in0, arow, bcol, wave, lane);
 
     // ---- hidden activation, in registers --------------------------------------------
 #pragma unroll
@@ -124,23 +95,28 @@ __global__ __launch_bounds__(256) void resblock_mfma_kernel(ConvPlan p, int span
         }
     }
 
-    // ---- epilogue: + b2 + x, trailing activation ----------------------------------------
+    // ---- epilogue: + b2 + x, trailing activation (loads hoisted, stores predicated) ----
     float *yb = y + size_t(b) * C * p.Lin;
 #pragma unroll
-    for (int io = 0; io < MW; ++io)
+    for (int io = 0; io < MW; ++io) {
+        float bv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bv[r] = b2 ? b2[io * 32 + acc_row(r, lh)] : 0.f;
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
             const int t = t0 + n0 + k * 32 + li;
-            if (t >= p.Lin) continue;
+            const int tc = min(t, p.Lin - 1);
+            float xv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xv[r] = xb[size_t(io * 32 + acc_row(r, lh)) * p.Lin + tc];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = io * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const size_t o = size_t(co) * p.Lin + t;
-                float v = out[io][k][r] + (b2 ? b2[co] : 0.f) + xb[o];
-                if (post_act) v = v > 0.f ? v : v * p.slope;
-                yb[o] = v;
+                float v = out[io][k][r] + bv[r] + xv[r];
+                if (post_act) v = leaky(v, p.slope);
+                if (t < p.Lin) yb[size_t(io * 32 + acc_row(r, lh)) * p.Lin + t] = v;
             }
         }
+    }
 }
 
 template <int MW, int NW, int CC>
@@ -148,7 +124,7 @@ static int launch_rb(const ConvPlan &p, const float *x, const float *w1, const f
                      const float *b2, float *y, int post_act, hipStream_t st) {
     constexpr int BN = 32 * NW * 4;
     const int span = (BN - 1) + (p.J - 1) * p.d + 1;
-    const size_t lds = size_t(CC) * span * sizeof(float);
+    const size_t lds = size_t(2) * CC * span * sizeof(float);  // double-buffered input tile
     auto kern = resblock_mfma_kernel<MW, NW, CC>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -168,7 +144,7 @@ bool resblock_fused_supported(const ConvPlan &p) {
     if (p.Cin != 32 && p.Cin != 64 && p.Cin != 128 && p.Cin != 256) return false;
     const int bn = p.Cin == 32 ? 512 : (p.Cin == 64 ? 256 : 128);
     const size_t span = size_t(bn - 1) + size_t(p.J - 1) * p.d + 1;
-    return 16 * span * sizeof(float) <= 160 * 1024;
+    return 2 * 16 * span * sizeof(float) <= 160 * 1024;
 }
 
 const char *resblock_variant(const ConvPlan &p) {

@@ -32,6 +32,12 @@ def conv_kernel_name(desc: "ConvDesc") -> str:
     return buf.value.decode()
 
 
+def resblock_kernel_name(desc: "ConvDesc") -> str:
+    buf = ctypes.create_string_buffer(96)
+    _lib.check(_lib.load().agx_resblock_kernel_name(ctypes.byref(desc), buf, len(buf)), "agx_resblock_kernel_name")
+    return buf.value.decode()
+
+
 def _ptr(t: Optional[Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 

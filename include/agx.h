@@ -111,6 +111,9 @@ int agx_conv_kernel_name(const agx_conv_desc *d, char *buf, size_t buf_len);
  * implementation run as two fused-epilogue conv launches through `workspace`
  * (agx_resblock_workspace_bytes(d) bytes; the hidden activation). */
 size_t agx_resblock_workspace_bytes(const agx_conv_desc *d);
+/* Kernel name agx_resblock_forward would launch ("resblock_mfma<..>" when fused,
+ * "2x:<conv kernel>" for the two-launch form). */
+int agx_resblock_kernel_name(const agx_conv_desc *d, char *buf, size_t buf_len);
 int agx_resblock_forward(const agx_conv_desc *d, const float *x, const float *packed1,
                          const float *bias1, const float *packed2, const float *bias2,
                          float *y, int32_t post_act, void *workspace, size_t workspace_bytes,

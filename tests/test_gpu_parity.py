@@ -139,6 +139,15 @@ def test_residual_and_epilogues():
             y_act = m.run(x.to(DEV), 0.1)
         assert max_abs(y_plain.cpu(), want) < 3e-5, (c, d)
         assert max_abs(y_act.cpu(), codec.leaky(want)) < 3e-5, (c, d)
+        # the two-launch form (conv + conv with fused epilogues) must agree with the single-kernel form
+        try:
+            CausalResidualBlock1d.split_launches = True
+            with torch.no_grad():
+                y_split = m.run(x.to(DEV), 0.1)
+        finally:
+            CausalResidualBlock1d.split_launches = False
+        assert max_abs(y_split.cpu(), codec.leaky(want)) < 3e-5, (c, d)
+        assert max_abs(y_split, y_act) < 3e-5, (c, d)
 
 
 # ------------------------------------------------------------------------------- RVQ
