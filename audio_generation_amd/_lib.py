@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libagx.so")
 # constants mirrored from include/agx.h
 CONV_CAUSAL, CONV_TRANSPOSED, CONV_UPSAMPLE, CONV_SAME = 0, 1, 2, 3
 IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA = 0, 1, 2
-EPI_LEAKY_PRE, EPI_RESIDUAL, EPI_LEAKY_POST = 1, 2, 4
+EPI_LEAKY_PRE, EPI_RESIDUAL, EPI_LEAKY_POST, EPI_GELU_PRE = 1, 2, 4, 8
 
 
 class ConvDesc(Structure):
@@ -50,6 +50,14 @@ SIGNATURES = {
                                 c_void_p, c_size_t, c_void_p]),
     "agx_rvq_dequantize": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p,
                                    c_int64, c_int64, c_int32, c_void_p]),
+    "agx_layernorm_ct": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float,
+                                 c_void_p]),
+    "agx_attention_alibi": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float,
+                                    c_void_p]),
+    "agx_multires_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                                     c_int32, c_int32, c_void_p]),
+    "agx_wavelet_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32,
+                                 c_int32, c_int32, c_void_p]),
 }
 
 _lib = None

@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvPlan p, int ci_til
         if (u >= p.Lout) continue;
         float v = acc[r] + (bias ? bias[co] : 0.f);
         if (p.epilogue & AGX_EPI_LEAKY_PRE) v = v > 0.f ? v : v * p.slope;
+        if (p.epilogue & AGX_EPI_GELU_PRE) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
         const size_t o = (size_t(b) * p.Cout + co) * p.Lout + u;
         if (p.epilogue & AGX_EPI_RESIDUAL) v += res[o];
         if (p.epilogue & AGX_EPI_LEAKY_POST) v = v > 0.f ? v : v * p.slope;

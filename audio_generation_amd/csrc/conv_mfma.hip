@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
     // any use so they overlap; only the stores are predicated.
     const bool has_res = (p.epilogue & AGX_EPI_RESIDUAL) != 0;
     const bool pre = (p.epilogue & AGX_EPI_LEAKY_PRE) != 0, post = (p.epilogue & AGX_EPI_LEAKY_POST) != 0;
+    const bool gelu = (p.epilogue & AGX_EPI_GELU_PRE) != 0;
 #pragma unroll
     for (int i = 0; i < MW; ++i) {
         int co[16], ph[16];
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
             for (int r = 0; r < 16; ++r) {
                 float v = acc[i][k][r] + bv[r];
                 if (pre) v = leaky(v, p.slope);
+                if (gelu) v = gelu_erf(v);
                 if (has_res) v += rv[r];
                 if (post) v = leaky(v, p.slope);
                 const bool ok = t < p.Lt && (m0 + i * 32 + acc_row(r, lh)) < p.M && (t * p.q + ph[r]) < p.Lout;

@@ -15,6 +15,9 @@ __device__ __forceinline__ constexpr int acc_row(int r, int lh) { return (r & 3)
 
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+// torch.nn.GELU() default (approximate='none'): 0.5 x (1 + erf(x / sqrt 2))
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+
 // Stage CC channel rows of the input, positions [in0, in0 + span), into LDS
 // (xs[c * span + i]); positions outside [0, Lvalid) read as zero.  Loads are
 // issued unconditionally on clamped addresses so that RPW * U of them are in

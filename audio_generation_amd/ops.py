@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 from ._lib import (CONV_CAUSAL, CONV_SAME, CONV_TRANSPOSED, CONV_UPSAMPLE, EPI_LEAKY_POST,
-                   EPI_LEAKY_PRE, EPI_RESIDUAL, IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA, AgxError, ConvDesc)
+                   EPI_GELU_PRE, EPI_LEAKY_PRE, EPI_RESIDUAL, IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA, AgxError, ConvDesc)
 
 Tensor = torch.Tensor
 
@@ -206,3 +206,65 @@ def rvq_dequantize(codebook: Tensor, idx: Tensor, out: Optional[Tensor] = None,
     _lib.check(lib.agx_rvq_dequantize(_ptr(codebook), _ptr(idx_c), n, k, d, _ptr(flat), flat.stride(0),
                                       flat.stride(1), int(accumulate), _stream()), "agx_rvq_dequantize")
     return out
+
+
+# ------------------------------------------------------------------ attention block
+def layernorm_ct(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], eps: float = 1e-5) -> Tensor:
+    """LayerNorm over the channel dim of a (B, C, T) tensor."""
+    lib = _lib.load()
+    _need_gpu(x, weight, bias)
+    x = _f32c(x)
+    b, c, t = x.shape
+    y = torch.empty_like(x)
+    tok = _observer.begin("other", ("layernorm_ct", 8 * x.numel())) if _observer is not None else None
+    _lib.check(lib.agx_layernorm_ct(_ptr(x), _ptr(None if weight is None else _f32c(weight)),
+                                    _ptr(None if bias is None else _f32c(bias)), _ptr(y), b, c, t, float(eps),
+                                    _stream()), "agx_layernorm_ct")
+    if tok is not None:
+        _observer.end(tok)
+    return y
+
+
+def attention_alibi(qkv: Tensor, slopes: Tensor, heads: int, head_dim: int, scale_div: float) -> Tensor:
+    """softmax(QK^T/scale_div + ALiBi) V on a (B, 3*H*Dh, T) tensor -> (B, H*Dh, T)."""
+    lib = _lib.load()
+    _need_gpu(qkv, slopes)
+    qkv = _f32c(qkv)
+    b, c3, t = qkv.shape
+    if c3 != 3 * heads * head_dim:
+        raise AgxError(f"attention_alibi: qkv has {c3} channels, expected {3 * heads * head_dim}")
+    out = torch.empty((b, heads * head_dim, t), dtype=torch.float32, device=qkv.device)
+    tok = _observer.begin("other", ("attention_alibi", 4 * (qkv.numel() + out.numel()))) if _observer is not None else None
+    _lib.check(lib.agx_attention_alibi(_ptr(qkv), _ptr(_f32c(slopes)), _ptr(out), b, heads, head_dim, t,
+                                       float(scale_div), _stream()), "agx_attention_alibi")
+    if tok is not None:
+        _observer.end(tok)
+    return out
+
+
+# ------------------------------------------------------------------ wavelet layers
+def multires_forward(x: Tensor, h0: Tensor, h1: Tensor, w: Tensor, depth: int) -> Tensor:
+    lib = _lib.load()
+    _need_gpu(x, h0, h1, w)
+    x = _f32c(x)
+    b, c, length = x.shape
+    k = h0.shape[-1]
+    if tuple(h0.shape) != (c, 1, k) or tuple(h1.shape) != (c, 1, k) or tuple(w.shape) != (c, depth + 2):
+        raise AgxError("multires_forward: parameter shapes do not match (C,1,K) / (C,depth+2)")
+    y = torch.empty_like(x)
+    _lib.check(lib.agx_multires_forward(_ptr(x), _ptr(_f32c(h0)), _ptr(_f32c(h1)), _ptr(_f32c(w)), _ptr(y),
+                                        b, c, length, k, depth, _stream()), "agx_multires_forward")
+    return y
+
+
+def wavelet_fold(h: Tensor, space: Tensor, sigma: Tensor, scale: int) -> Tensor:
+    lib = _lib.load()
+    _need_gpu(h, space, sigma)
+    h = _f32c(h)
+    b, c, length = h.shape
+    space = _f32c(space.reshape(-1))
+    sigma = _f32c(sigma.reshape(-1))
+    y = torch.empty((b, c, length * scale), dtype=torch.float32, device=h.device)
+    _lib.check(lib.agx_wavelet_fold(_ptr(h), _ptr(space), _ptr(sigma), sigma.numel(), _ptr(y), b, c, length,
+                                    space.numel(), scale, _stream()), "agx_wavelet_fold")
+    return y

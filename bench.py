@@ -79,6 +79,8 @@ class LaunchTimer:
         if kind == "rvq":
             b, t, d, k, q = info
             name, work = "rvq_forward", (b * t * q * k * d, b * t * q * k * d, 4 * b * t * d * 2 + 8 * b * t * q)
+        elif kind == "other":
+            name, work = info[0], (0, 0, info[1])
         elif kind == "resblock":
             name = ops.resblock_kernel_name(info)
             e1_, r1_, _ = conv_work(info)

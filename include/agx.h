@@ -57,6 +57,7 @@ const char *agx_last_error(void);
 #define AGX_EPI_LEAKY_PRE 1  /* LeakyReLU(slope) on (acc + bias)   vae.py:99,125,156 */
 #define AGX_EPI_RESIDUAL 2   /* += res[b,co,t]                     vae.py:117        */
 #define AGX_EPI_LEAKY_POST 4 /* LeakyReLU(slope) after the add     vae.py:131-134    */
+#define AGX_EPI_GELU_PRE 8   /* exact (erf) GELU on (acc + bias)   transformers.py:216, wavelets.py:96 */
 
 typedef struct agx_conv_desc {
     int32_t kind;      /* AGX_CONV_*                                              */
@@ -153,6 +154,46 @@ int agx_rvq_forward(const float *x, int64_t x_sb, int64_t x_st, int64_t x_sd,
 int agx_rvq_dequantize(const float *codebook /* (K,D) */, const int64_t *idx, int64_t n,
                        int32_t k, int32_t dim, float *out, int64_t o_sn, int64_t o_sd,
                        int32_t accumulate, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Attention bottleneck (networks/transformers.py:7-279), channel-major layout *
+ * ------------------------------------------------------------------------- *
+ * The block runs on (B, C, T) tensors -- the layout the encoder produces -- so
+ * every Linear is an agx_conv_forward with kernel 1 (AGX_EPI_GELU_PRE /
+ * AGX_EPI_RESIDUAL fuse the FFN activation and both residual adds). */
+
+/* torch.nn.LayerNorm over the channel dim of a (B, C, T) tensor
+ * (transformers.py:159 and :214): y = (x - mean) / sqrt(var + eps) * w + b. */
+int agx_layernorm_ct(const float *x, const float *weight, const float *bias, float *y,
+                     int32_t batch, int32_t channels, int32_t t, float eps, void *stream);
+
+/* softmax(Q K^T / scale_div + M) V per (batch, head) with the ALiBi bias
+ * M[h,i,j] = -slopes[h] * |i - j| computed in the kernel (transformers.py:175-188;
+ * Alibi :38-39, 62-75).  qkv is (B, 3*H*Dh, T): q rows [0,H*Dh), k rows
+ * [H*Dh, 2*H*Dh), v rows [2*H*Dh, 3*H*Dh), head-major inside each.  out is
+ * (B, H*Dh, T).  fp32-input MFMA for both contractions.  T <= 256, Dh <= 128. */
+int agx_attention_alibi(const float *qkv, const float *slopes, float *out, int32_t batch,
+                        int32_t heads, int32_t head_dim, int32_t t, float scale_div, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Wavelet / multiresolution layers (networks/wavelets.py)                     *
+ * ------------------------------------------------------------------------- */
+
+/* CausalMultiresConv1d.forward (wavelets.py:79-96): depth-level cascade of two
+ * depthwise causal filters h0/h1 (C,1,K) with dilation 1,2,4,..., per-channel
+ * mixing w (C, depth+2), exact GELU.  x, y (B, C, L).  One launch. */
+int agx_multires_forward(const float *x, const float *h0, const float *h1, const float *w, float *y,
+                         int32_t batch, int32_t channels, int32_t length, int32_t kernel,
+                         int32_t depth, void *stream);
+
+/* The fold in the middle of WaveletLayer.forward (wavelets.py:221-231):
+ * every input step emits an n_points-long wavelet cos(t)exp(-t^2/sigma_c) * h laid
+ * end to end, the output is the sliding-window sum (window n_points, hop
+ * n_points/scale) plus the reference's raw-sample tail.  h (B, C, L) ->
+ * y (B, C, L*scale).  sigma has `sigma_len` entries (C, or 1 when shared). */
+int agx_wavelet_fold(const float *h, const float *space, const float *sigma, int32_t sigma_len,
+                     float *y, int32_t batch, int32_t channels, int32_t length, int32_t n_points,
+                     int32_t scale, void *stream);
 
 #ifdef __cplusplus
 }
