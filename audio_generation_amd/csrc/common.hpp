@@ -43,6 +43,18 @@ struct ConvPlan {
     float slope;
 };
 
+// Packed weight image ("group-K-major"): channels in groups of 16,
+//   Wp[((ci / 16) * J + j) * M + m][ci % 16]
+// so that (a) a lane's A operands for consecutive k-steps are contiguous (one 16-byte
+// load feeds 4 MFMAs) and (b) one (16-channel group, tap) slab is a contiguous M*64 B block.
+constexpr int kWG = 16;  // channels per weight group
+__host__ __device__ inline int64_t packed_weight_floats(int Cin, int J, int M) {
+    return int64_t((Cin + kWG - 1) / kWG) * J * M * kWG;
+}
+__host__ __device__ inline size_t packed_weight_index(int ci, int j, int m, int J, int M) {
+    return (size_t(ci / kWG) * J + j) * M * kWG + size_t(m) * kWG + (ci % kWG);
+}
+
 // Lower a descriptor; returns AGX_OK or an error (message set).
 int lower_conv(const agx_conv_desc *d, ConvPlan *p);
 

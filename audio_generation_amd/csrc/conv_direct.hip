@@ -42,14 +42,13 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvPlan p, int ci_til
         __syncthreads();
         for (int c = 0; c < nc; ++c) {
             const float *xr = xs + c * span + tid * p.s;
-            const float *wr = wp + size_t(c0 + c) * p.J * p.M;
             for (int j = 0; j < p.J; ++j) {
                 const float xv = xr[j * p.d];
-                const float *wj = wr + size_t(j) * p.M;
+                const float *wj = wp + packed_weight_index(c0 + c, j, 0, p.J, p.M);
 #pragma unroll
                 for (int r = 0; r < CO_T; ++r) {
                     const int m = min(m0 + r, p.M - 1);  // wave-uniform -> scalar load
-                    acc[r] = fmaf(wj[m], xv, acc[r]);
+                    acc[r] = fmaf(wj[size_t(m) * kWG], xv, acc[r]);
                 }
             }
         }

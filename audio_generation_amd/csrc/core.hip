@@ -127,7 +127,7 @@ int64_t agx_conv_packed_floats(const agx_conv_desc *d) {
     if (rc != AGX_OK) return rc;
     // + dim0 floats of scratch at the tail for the weight-norm scales
     const int dim0 = (d->kind == AGX_CONV_TRANSPOSED) ? d->c_in : d->c_out;
-    return int64_t(p.Cin) * p.J * p.M + dim0;
+    return agx::packed_weight_floats(p.Cin, p.J, p.M) + dim0;
 }
 
 }  // extern "C"

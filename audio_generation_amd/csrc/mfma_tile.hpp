@@ -49,20 +49,33 @@ __device__ __forceinline__ void stage_rows(float *__restrict__ xs, const float *
     }
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// k-step mapping inside a CC-channel chunk: MFMA step ks multiplies channel
+// c0 + ks (lane half 0) and channel c0 + CC/2 + ks (lane half 1), so a lane's
+// operands for consecutive steps are consecutive channels = contiguous floats of
+// the packed image (common.hpp): one 16-byte load feeds 4 MFMAs.
+//
 // A fragments (weights) of one (channel chunk, tap) phase: a[ks][i] =
-// Wp[(c0 + 2*ks + lh) * J + j][arow[i]]; Wp is K-major with row length M.
+// W[row arow[i]][channel c0 + lh*CC/2 + ks][tap j].
 template <int MW, int CC>
 __device__ __forceinline__ void load_a_phase(float (&a)[CC / 2][MW], const float *__restrict__ wp, int c0,
                                              int j, int J, int M, int lh, const int (&arow)[MW]) {
-    // uniform (scalar) base + one per-lane offset per row block: lets hipcc use the
-    // saddr + voffset form instead of a 64-bit VGPR address per load
-    const float *wj = wp + (size_t(c0) * J + j) * M;
-    const int step = 2 * J * M;
-    const int lane_row = lh * J * M;
+    const int ch0 = c0 + lh * (CC / 2);  // first channel of this lane half
+    const float *slab = wp + (size_t(ch0 / kWG) * J + j) * M * kWG + (ch0 % kWG);
 #pragma unroll
-    for (int ks = 0; ks < CC / 2; ++ks)
+    for (int i = 0; i < MW; ++i) {
+        const float *row = slab + size_t(arow[i]) * kWG;
 #pragma unroll
-        for (int i = 0; i < MW; ++i) a[ks][i] = (wj + ks * step)[lane_row + arow[i]];
+        for (int v = 0; v < CC / 8; ++v) {
+            // CC = 32: the half spans a whole 16-channel group = 4 vectors; CC = 16: 2; CC = 8: 1
+            const f32x4 q = *reinterpret_cast<const f32x4 *>(row + 4 * v);
+            a[4 * v + 0][i] = q[0];
+            a[4 * v + 1][i] = q[1];
+            a[4 * v + 2][i] = q[2];
+            a[4 * v + 3][i] = q[3];
+        }
+    }
 }
 
 // Asynchronous global -> LDS copy of one dword per lane (LDS-DMA): the LDS
@@ -100,7 +113,10 @@ __device__ __forceinline__ void issue_rows_dma(float *__restrict__ buf, const fl
 // while the MFMAs of chunk c run (one barrier per chunk); A fragments (weights,
 // L2-resident) are prefetched one (chunk, tap) phase ahead into registers; B
 // fragments are single ds_read_b32, batched per phase.  xs holds 2 * CC * span floats.
-template <int MW, int NW, int CC>
+// ABL (ablation, timing-only diagnostic builds; 0 in every shipped launch):
+//   bit 0: skip the per-chunk input DMA, bit 1: skip the weight prefetch loads,
+//   bit 2: skip the per-chunk barrier.  Results are wrong by construction.
+template <int MW, int NW, int CC, int ABL = 0>
 __device__ __forceinline__ void conv_gemm(f32x16 (&acc)[MW][NW], float *__restrict__ xs,
                                           const float *__restrict__ xb, const float *__restrict__ wp,
                                           const ConvPlan &p, int M, int span, int in0,
@@ -119,21 +135,33 @@ __device__ __forceinline__ void conv_gemm(f32x16 (&acc)[MW][NW], float *__restri
     for (int c0 = 0; c0 < p.Cin; c0 += CC, ++it) {
         float *cur = (it & 1) ? buf1 : buf0;
         float *nxt = (it & 1) ? buf0 : buf1;
-        if (c0 + CC < p.Cin)
-            issue_rows_dma<CC>(nxt, xb + size_t(c0 + CC) * p.Lin, p.Lin, p.Lvalid, in0, span, wave, lane);
         for (int j = 0; j < p.J; ++j) {
             int nj = j + 1, nc0 = c0;
             if (nj == p.J) {
                 nj = 0;
                 nc0 += CC;
             }
-            if (nc0 < p.Cin) load_a_phase<MW, CC>(a_nxt, wp, nc0, nj, p.J, M, lh, arow);
+            if (!(ABL & 2) && nc0 < p.Cin) load_a_phase<MW, CC>(a_nxt, wp, nc0, nj, p.J, M, lh, arow);
+            if (ABL & 2) {
+#pragma unroll
+                for (int ks = 0; ks < CC / 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < MW; ++i) a_nxt[ks][i] = a_cur[ks][i] * 1.0001f;
+            }
+            // The next chunk's DMA goes out behind this phase's weight prefetch: vmcnt retires in
+            // order, and hipcc waits vmcnt(0) at the top of the next phase for the prefetched
+            // weights, so the DMA gets a full phase of MFMAs to land instead of none.
+            if (!(ABL & 1) && j == 0 && c0 + CC < p.Cin)
+                issue_rows_dma<CC>(nxt, xb + size_t(c0 + CC) * p.Lin, p.Lin, p.Lvalid, in0, span, wave, lane);
+            // pin the prefetch at the head of the phase: without the barrier hipcc sinks these
+            // loads to the end of the phase and waits vmcnt(0) for them at the top of the next one
+            __builtin_amdgcn_sched_barrier(0);
             const float *xj = cur + j * p.d;
             float bf[CC / 2][NW];
 #pragma unroll
             for (int ks = 0; ks < CC / 2; ++ks)
 #pragma unroll
-                for (int k = 0; k < NW; ++k) bf[ks][k] = xj[(2 * ks) * span + bcol[k]];
+                for (int k = 0; k < NW; ++k) bf[ks][k] = xj[ks * span + bcol[k]];
 #pragma unroll
             for (int ks = 0; ks < CC / 2; ++ks)
 #pragma unroll
@@ -141,13 +169,14 @@ __device__ __forceinline__ void conv_gemm(f32x16 (&acc)[MW][NW], float *__restri
 #pragma unroll
                     for (int k = 0; k < NW; ++k)
                         acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ks][i], bf[ks][k], acc[i][k], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < CC / 2; ++ks)
 #pragma unroll
                 for (int i = 0; i < MW; ++i) a_cur[ks][i] = a_nxt[ks][i];
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of the next chunk has landed
-        __syncthreads();                                   // everyone's has, and everyone is done reading cur
+        if (!(ABL & 4)) __syncthreads();                   // everyone's has, and everyone is done reading cur
     }
 }
 

@@ -32,18 +32,24 @@ __global__ void fill_ones_kernel(float *p, int n) {
 
 __device__ __forceinline__ int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
-// packed[(ci*J + j) * M + co*q + ph]
+// packed[((ci/16)*J + j) * M + co*q + ph][ci%16]  (common.hpp: packed_weight_index)
 __global__ __launch_bounds__(256) void pack_kernel(const float *__restrict__ v,
                                                    const float *__restrict__ scale,
                                                    float *__restrict__ packed, int kind, int Cin,
                                                    int Cout, int K, int q, int J, int P, int up) {
     const int M = q * Cout;
-    const int64_t total = int64_t(Cin) * J * M;
+    const int64_t total = packed_weight_floats(Cin, J, M);
     const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (e >= total) return;
-    const int m = int(e % M);
-    const int kk = int(e / M);
-    const int ci = kk / J, j = kk % J;
+    // e = ((g * J + j) * M + m) * 16 + c16
+    const int c16 = int(e % kWG);
+    const int m = int((e / kWG) % M);
+    const int gj = int(e / (int64_t(kWG) * M));
+    const int j = gj % J, ci = (gj / J) * kWG + c16;
+    if (ci >= Cin) {  // zero padding of the last channel group
+        packed[e] = 0.f;
+        return;
+    }
     const int co = m / q, ph = m % q;
     float out = 0.f;
     if (kind == AGX_CONV_CAUSAL || kind == AGX_CONV_SAME) {
@@ -74,7 +80,7 @@ extern "C" int agx_conv_pack(const agx_conv_desc *d, const float *v, const float
     const bool transposed = d->kind == AGX_CONV_TRANSPOSED;
     const int dim0 = transposed ? d->c_in : d->c_out;
     const int inner = (transposed ? d->c_out : d->c_in) * d->kernel;
-    const int64_t n_w = int64_t(p.Cin) * p.J * p.M;
+    const int64_t n_w = packed_weight_floats(p.Cin, p.J, p.M);
     float *scale = packed + n_w;  // tail scratch reserved by agx_conv_packed_floats
     if (g)
         hipLaunchKernelGGL(wn_scale_kernel, dim3(dim0), dim3(256), 0, st, v, g, scale, inner);

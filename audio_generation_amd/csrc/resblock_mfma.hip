@@ -16,11 +16,13 @@
 // with the A fragment W2[co][that channel].  The hidden activation never leaves
 // the register file: no LDS round trip, no second kernel, and the memory-bound
 // k=1 conv of the unfused path disappears.
+#include <cstdlib>
+
 #include "mfma_tile.hpp"
 
 namespace agx {
 
-template <int MW, int NW, int CC>
+template <int MW, int NW, int CC, int ABL = 0>
 __global__ __launch_bounds__(256, (MW <= 4 ? 2 : 1)) void resblock_mfma_kernel(ConvPlan p, int span, int post_act,
                                                             const float *__restrict__ x,
                                                             const float *__restrict__ w1,
@@ -49,12 +51,12 @@ __global__ __launch_bounds__(256, (MW <= 4 ? 2 : 1)) void resblock_mfma_kernel(C
 #pragma unroll
     for (int i = 0; i < MW; ++i) arow[i] = i * 32 + li;
 #pragma unroll
-    for (int k = 0; k < NW; ++k) bcol[k] = n0 + k * 32 + li + lh * span;
+    for (int k = 0; k < NW; ++k) bcol[k] = n0 + k * 32 + li + lh * (CC / 2) * span;
 
     const float *xb = x + size_t(b) * C * p.Lin;
 
     // ---- GEMM1: h = W1 (*) x ------------------------------------------------------
-    conv_gemm<MW, NW, CC>(acc, xs, xb, w1, p, C, span, in0, arow, bcol, wave, lane);
+    conv_gemm<MW, NW, CC, ABL>(acc, xs, xb, w1, p, C, span, in0, arow, bcol, wave, lane);
 
     // ---- hidden activation, in registers --------------------------------------------
 #pragma unroll
@@ -81,17 +83,20 @@ __global__ __launch_bounds__(256, (MW <= 4 ? 2 : 1)) void resblock_mfma_kernel(C
 #pragma unroll
     for (int i = 0; i < MW; ++i) {       // hidden-channel subtile
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {   // k-step == accumulator register
-            const int kch = i * 32 + (s & 3) + 8 * (s >> 2) + 4 * lh;
-            const float *w2k = w2 + size_t(kch) * C + li;
-            float a[MW];
+        for (int g = 0; g < 4; ++g) {    // register group: k-steps 4g..4g+3 <-> 4 consecutive hidden channels
+            const int kch = i * 32 + 8 * g + 4 * lh;  // == i*32 + acc_row(4g, lh)
+            const float *w2k = w2 + size_t(kch / kWG) * C * kWG + (kch % kWG) + size_t(li) * kWG;
+            f32x4 a[MW];
 #pragma unroll
-            for (int io = 0; io < MW; ++io) a[io] = w2k[io * 32];
+            for (int io = 0; io < MW; ++io) a[io] = *reinterpret_cast<const f32x4 *>(w2k + size_t(io) * 32 * kWG);
 #pragma unroll
-            for (int io = 0; io < MW; ++io)
+            for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-                for (int k = 0; k < NW; ++k)
-                    out[io][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[io], acc[i][k][s], out[io][k], 0, 0, 0);
+                for (int io = 0; io < MW; ++io)
+#pragma unroll
+                    for (int k = 0; k < NW; ++k)
+                        out[io][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[io][s4], acc[i][k][4 * g + s4],
+                                                                          out[io][k], 0, 0, 0);
         }
     }
 
@@ -119,13 +124,13 @@ __global__ __launch_bounds__(256, (MW <= 4 ? 2 : 1)) void resblock_mfma_kernel(C
     }
 }
 
-template <int MW, int NW, int CC>
+template <int MW, int NW, int CC, int ABL = 0>
 static int launch_rb(const ConvPlan &p, const float *x, const float *w1, const float *b1, const float *w2,
                      const float *b2, float *y, int post_act, hipStream_t st) {
     constexpr int BN = 32 * NW * 4;
     const int span = (BN - 1) + (p.J - 1) * p.d + 1;
     const size_t lds = size_t(2) * CC * span * sizeof(float);  // double-buffered input tile
-    auto kern = resblock_mfma_kernel<MW, NW, CC>;
+    auto kern = resblock_mfma_kernel<MW, NW, CC, ABL>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -162,7 +167,17 @@ int launch_resblock_fused(const ConvPlan &p, const float *x, const float *w1, co
     switch (p.Cin) {
         case 32: return launch_rb<1, 4, 16>(p, x, w1, b1, w2, b2, y, post_act, st);
         case 64: return launch_rb<2, 2, 16>(p, x, w1, b1, w2, b2, y, post_act, st);
-        case 128: return launch_rb<4, 1, 16>(p, x, w1, b1, w2, b2, y, post_act, st);
+        case 128: {
+            // diagnostic: AGX_ABLATE=<bits> selects a timing-only ablation build of this one shape
+            static const int abl = getenv("AGX_ABLATE") ? atoi(getenv("AGX_ABLATE")) : 0;
+            switch (abl) {
+                case 1: return launch_rb<4, 1, 16, 1>(p, x, w1, b1, w2, b2, y, post_act, st);
+                case 2: return launch_rb<4, 1, 16, 2>(p, x, w1, b1, w2, b2, y, post_act, st);
+                case 3: return launch_rb<4, 1, 16, 3>(p, x, w1, b1, w2, b2, y, post_act, st);
+                case 7: return launch_rb<4, 1, 16, 7>(p, x, w1, b1, w2, b2, y, post_act, st);
+                default: return launch_rb<4, 1, 16>(p, x, w1, b1, w2, b2, y, post_act, st);
+            }
+        }
         default: return launch_rb<8, 1, 16>(p, x, w1, b1, w2, b2, y, post_act, st);
     }
 }

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc counter_collection.csv files per kernel.
+
+usage: pmc_summary.py <dir with pass sub-dirs> [min_us]
+Prints, per kernel name (template args kept), the mean per-dispatch duration and
+the per-dispatch mean of every counter found in any pass; FETCH_SIZE is doubled
+as MI355X_MICROARCH.md §HBM prescribes for wide coalesced reads (reported both ways).
+"""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r"\(.*$", "", name)
+    return name.replace("void agx::", "").replace("agx::", "")
+
+
+def main():
+    root = sys.argv[1]
+    min_us = float(sys.argv[2]) if len(sys.argv) > 2 else 50.0
+    agg = defaultdict(lambda: defaultdict(list))
+    dur = defaultdict(list)
+    for f in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
+        seen = set()
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            if us < min_us:
+                continue
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            key = (f, r["Dispatch_Id"])
+            if key not in seen:
+                seen.add(key)
+                dur[k].append(us)
+    for k in sorted(agg, key=lambda k: -sum(dur[k])):
+        c = {n: sum(v) / len(v) for n, v in agg[k].items()}
+        print(f"\n== {k}  dispatches>={min_us:.0f}us: {len(dur[k]) // max(1, len(glob.glob(os.path.join(root, '*'))) // 2)}  "
+              f"mean {sum(dur[k]) / len(dur[k]):.1f} us (profiled)")
+        for n in sorted(c):
+            print(f"   {n:28s} {c[n]:16.0f}")
+        if "SQ_WAVE_CYCLES" in c and c["SQ_WAVE_CYCLES"]:
+            w = c["SQ_WAVE_CYCLES"]
+            print("   -- shares of SQ_WAVE_CYCLES: " + ", ".join(
+                f"{n[3:]} {100 * c[n] / w:.1f}%" for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+                                                         "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_LDS",
+                                                         "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_MISC") if n in c))
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c:
+            print(f"   -- MFMA busy / SQ busy cycles: {c['SQ_VALU_MFMA_BUSY_CYCLES'] / c['SQ_BUSY_CYCLES']:.3f}")
+        if "FETCH_SIZE" in c or "WRITE_SIZE" in c:
+            fk, wk = c.get("FETCH_SIZE", 0.0), c.get("WRITE_SIZE", 0.0)
+            print(f"   -- HBM traffic per dispatch: fetch {fk / 1024:.1f} MiB raw ({2 * fk / 1024:.1f} MiB gfx950-corrected), "
+                  f"write {wk / 1024:.1f} MiB")
+
+
+if __name__ == "__main__":
+    main()
