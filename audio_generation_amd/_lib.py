@@ -32,6 +32,8 @@ _PD = POINTER(ConvDesc)
 SIGNATURES = {
     "agx_version": (c_int, []),
     "agx_last_error": (c_char_p, []),
+    "agx_set_tuning": (c_int, [c_char_p, c_int32]),
+    "agx_get_tuning": (c_int, [c_char_p]),
     "agx_conv_out_len": (c_int64, [_PD]),
     "agx_conv_packed_floats": (c_int64, [_PD]),
     "agx_conv_pack": (c_int, [_PD, c_void_p, c_void_p, c_void_p, c_void_p]),

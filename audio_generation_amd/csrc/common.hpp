@@ -16,6 +16,13 @@ void set_error(const char *fmt, ...);
 int fail(int code, const char *fmt, ...);
 const char *last_error();
 
+// diagnostic knobs (agx_set_tuning)
+struct Tuning {
+    int resblock_res_lds = 0;  // A/B on MI355X: neutral at C<=64, -9 % at C=128 (tools/ab_bench.py)
+    int ablate = 0;
+};
+Tuning &tuning();
+
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));

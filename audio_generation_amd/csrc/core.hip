@@ -25,6 +25,11 @@ int fail(int code, const char *fmt, ...) {
 
 const char *last_error() { return g_err; }
 
+Tuning &tuning() {
+    static Tuning t;
+    return t;
+}
+
 int lower_conv(const agx_conv_desc *d, ConvPlan *p) {
     if (!d) return fail(AGX_ERR_NULL_POINTER, "conv descriptor is NULL");
     if (d->batch <= 0 || d->c_in <= 0 || d->c_out <= 0 || d->l_in <= 0 || d->kernel <= 0 ||
@@ -114,6 +119,21 @@ extern "C" {
 int agx_version(void) { return AGX_VERSION; }
 
 const char *agx_last_error(void) { return agx::last_error(); }
+
+int agx_set_tuning(const char *name, int32_t value) {
+    if (!name) return agx::fail(AGX_ERR_NULL_POINTER, "agx_set_tuning: NULL name");
+    if (!strcmp(name, "resblock_res_lds")) agx::tuning().resblock_res_lds = value;
+    else if (!strcmp(name, "ablate")) agx::tuning().ablate = value;
+    else return agx::fail(AGX_ERR_BAD_SHAPE, "agx_set_tuning: unknown knob '%s'", name);
+    return AGX_OK;
+}
+
+int agx_get_tuning(const char *name) {
+    if (!name) return agx::fail(AGX_ERR_NULL_POINTER, "agx_get_tuning: NULL name");
+    if (!strcmp(name, "resblock_res_lds")) return agx::tuning().resblock_res_lds;
+    if (!strcmp(name, "ablate")) return agx::tuning().ablate;
+    return agx::fail(AGX_ERR_BAD_SHAPE, "agx_get_tuning: unknown knob '%s'", name);
+}
 
 int64_t agx_conv_out_len(const agx_conv_desc *d) {
     agx::ConvPlan p;

@@ -116,11 +116,18 @@ __device__ __forceinline__ void issue_rows_dma(float *__restrict__ buf, const fl
 // ABL (ablation, timing-only diagnostic builds; 0 in every shipped launch):
 //   bit 0: skip the per-chunk input DMA, bit 1: skip the weight prefetch loads,
 //   bit 2: skip the per-chunk barrier.  Results are wrong by construction.
-template <int MW, int NW, int CC, int ABL = 0>
+struct NoChunkHook {
+    __device__ __forceinline__ void operator()(int, const float *) const {}
+};
+
+// on_chunk(c0, cur) is called once per channel chunk while its LDS tile `cur` is valid
+// (used by the fused residual block to pick the residual operand out of the staged input).
+template <int MW, int NW, int CC, int ABL = 0, typename Hook = NoChunkHook>
 __device__ __forceinline__ void conv_gemm(f32x16 (&acc)[MW][NW], float *__restrict__ xs,
                                           const float *__restrict__ xb, const float *__restrict__ wp,
                                           const ConvPlan &p, int M, int span, int in0,
-                                          const int (&arow)[MW], const int (&bcol)[NW], int wave, int lane) {
+                                          const int (&arow)[MW], const int (&bcol)[NW], int wave, int lane,
+                                          Hook on_chunk = Hook()) {
     const int lh = lane >> 5;
     const int tid = wave * 64 + lane;
     float *buf0 = xs, *buf1 = xs + CC * span;
@@ -135,6 +142,7 @@ __device__ __forceinline__ void conv_gemm(f32x16 (&acc)[MW][NW], float *__restri
     for (int c0 = 0; c0 < p.Cin; c0 += CC, ++it) {
         float *cur = (it & 1) ? buf1 : buf0;
         float *nxt = (it & 1) ? buf0 : buf1;
+        on_chunk(c0, cur);
         for (int j = 0; j < p.J; ++j) {
             int nj = j + 1, nc0 = c0;
             if (nj == p.J) {

@@ -22,7 +22,24 @@
 
 namespace agx {
 
-template <int MW, int NW, int CC, int ABL = 0>
+// Residual operand for accumulator registers of channel chunk IC, read from the
+// staged LDS tile (the same bytes GEMM1 consumes) instead of a second pass over HBM.
+// Chunk IC covers channels [IC*16, IC*16+16) = subtile IC/2, registers 8*(IC&1) .. +7.
+template <int IC, int MW, int NW>
+__device__ __forceinline__ void grab_residual(f32x16 (&xres)[MW][NW], const float *cur, int span,
+                                              const int (&rcol)[NW], int lh) {
+    if constexpr (IC * 16 < 32 * MW) {
+        constexpr int i = (IC * 16) / 32, r0 = 8 * (IC & 1);
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int chl = (rr & 3) + 8 * (rr >> 2) + 4 * lh;  // acc_row(r0 + rr, lh) - 16*(IC&1)
+#pragma unroll
+            for (int k = 0; k < NW; ++k) xres[i][k][r0 + rr] = cur[chl * span + rcol[k]];
+        }
+    }
+}
+
+template <int MW, int NW, int CC, int ABL = 0, bool RESL = true>
 __global__ __launch_bounds__(256, (MW <= 4 ? 2 : 1)) void resblock_mfma_kernel(ConvPlan p, int span, int post_act,
                                                             const float *__restrict__ x,
                                                             const float *__restrict__ w1,
@@ -56,7 +73,28 @@ __global__ __launch_bounds__(256, (MW <= 4 ? 2 : 1)) void resblock_mfma_kernel(C
     const float *xb = x + size_t(b) * C * p.Lin;
 
     // ---- GEMM1: h = W1 (*) x ------------------------------------------------------
-    conv_gemm<MW, NW, CC, ABL>(acc, xs, xb, w1, p, C, span, in0, arow, bcol, wave, lane);
+    // RES_LDS: keep the residual operand x[co][t] (this lane's output elements) in registers,
+    // picked from each staged chunk; costs 16*MW*NW VGPRs, so only while 2 waves/SIMD still fit.
+    constexpr bool RES_LDS = RESL && (MW <= 4) && CC == 16;
+    f32x16 xres[RES_LDS ? MW : 1][NW];
+    int rcol[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) rcol[k] = n0 + k * 32 + li + p.P;
+    auto hook = [&](int c0, const float *cur) {
+        if constexpr (RES_LDS) {
+            switch (c0 / 16) {
+                case 0: grab_residual<0, MW, NW>(xres, cur, span, rcol, lh); break;
+                case 1: grab_residual<1, MW, NW>(xres, cur, span, rcol, lh); break;
+                case 2: grab_residual<2, MW, NW>(xres, cur, span, rcol, lh); break;
+                case 3: grab_residual<3, MW, NW>(xres, cur, span, rcol, lh); break;
+                case 4: grab_residual<4, MW, NW>(xres, cur, span, rcol, lh); break;
+                case 5: grab_residual<5, MW, NW>(xres, cur, span, rcol, lh); break;
+                case 6: grab_residual<6, MW, NW>(xres, cur, span, rcol, lh); break;
+                default: grab_residual<7, MW, NW>(xres, cur, span, rcol, lh); break;
+            }
+        }
+    };
+    conv_gemm<MW, NW, CC, ABL>(acc, xs, xb, w1, p, C, span, in0, arow, bcol, wave, lane, hook);
 
     // ---- hidden activation, in registers --------------------------------------------
 #pragma unroll
@@ -112,8 +150,13 @@ __global__ __launch_bounds__(256, (MW <= 4 ? 2 : 1)) void resblock_mfma_kernel(C
             const int t = t0 + n0 + k * 32 + li;
             const int tc = min(t, p.Lin - 1);
             float xv[16];
+            if constexpr (RES_LDS) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) xv[r] = xb[size_t(io * 32 + acc_row(r, lh)) * p.Lin + tc];
+                for (int r = 0; r < 16; ++r) xv[r] = xres[io][k][r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xv[r] = xb[size_t(io * 32 + acc_row(r, lh)) * p.Lin + tc];
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = out[io][k][r] + bv[r] + xv[r];
@@ -124,13 +167,13 @@ __global__ __launch_bounds__(256, (MW <= 4 ? 2 : 1)) void resblock_mfma_kernel(C
     }
 }
 
-template <int MW, int NW, int CC, int ABL = 0>
+template <int MW, int NW, int CC, int ABL = 0, bool RESL = true>
 static int launch_rb(const ConvPlan &p, const float *x, const float *w1, const float *b1, const float *w2,
                      const float *b2, float *y, int post_act, hipStream_t st) {
     constexpr int BN = 32 * NW * 4;
     const int span = (BN - 1) + (p.J - 1) * p.d + 1;
     const size_t lds = size_t(2) * CC * span * sizeof(float);  // double-buffered input tile
-    auto kern = resblock_mfma_kernel<MW, NW, CC, ABL>;
+    auto kern = resblock_mfma_kernel<MW, NW, CC, ABL, RESL>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -164,22 +207,24 @@ const char *resblock_variant(const ConvPlan &p) {
 int launch_resblock_fused(const ConvPlan &p, const float *x, const float *w1, const float *b1,
                           const float *w2, const float *b2, float *y, int post_act, hipStream_t st) {
     if (!resblock_fused_supported(p)) return fail(AGX_ERR_UNSUPPORTED, "resblock: no fused kernel for C=%d", p.Cin);
+    const bool resl = tuning().resblock_res_lds != 0;
+#define AGX_RB(MW, NW, ABL)                                                                   \
+    (resl ? launch_rb<MW, NW, 16, ABL, true>(p, x, w1, b1, w2, b2, y, post_act, st)          \
+          : launch_rb<MW, NW, 16, ABL, false>(p, x, w1, b1, w2, b2, y, post_act, st))
     switch (p.Cin) {
-        case 32: return launch_rb<1, 4, 16>(p, x, w1, b1, w2, b2, y, post_act, st);
-        case 64: return launch_rb<2, 2, 16>(p, x, w1, b1, w2, b2, y, post_act, st);
-        case 128: {
-            // diagnostic: AGX_ABLATE=<bits> selects a timing-only ablation build of this one shape
-            static const int abl = getenv("AGX_ABLATE") ? atoi(getenv("AGX_ABLATE")) : 0;
-            switch (abl) {
-                case 1: return launch_rb<4, 1, 16, 1>(p, x, w1, b1, w2, b2, y, post_act, st);
-                case 2: return launch_rb<4, 1, 16, 2>(p, x, w1, b1, w2, b2, y, post_act, st);
-                case 3: return launch_rb<4, 1, 16, 3>(p, x, w1, b1, w2, b2, y, post_act, st);
-                case 7: return launch_rb<4, 1, 16, 7>(p, x, w1, b1, w2, b2, y, post_act, st);
-                default: return launch_rb<4, 1, 16>(p, x, w1, b1, w2, b2, y, post_act, st);
+        case 32: return AGX_RB(1, 4, 0);
+        case 64: return AGX_RB(2, 2, 0);
+        case 128:
+            switch (tuning().ablate) {  // timing-only diagnostic builds of this one shape
+                case 1: return AGX_RB(4, 1, 1);
+                case 2: return AGX_RB(4, 1, 2);
+                case 3: return AGX_RB(4, 1, 3);
+                case 7: return AGX_RB(4, 1, 7);
+                default: return AGX_RB(4, 1, 0);
             }
-        }
-        default: return launch_rb<8, 1, 16>(p, x, w1, b1, w2, b2, y, post_act, st);
+        default: return launch_rb<8, 1, 16, 0, false>(p, x, w1, b1, w2, b2, y, post_act, st);
     }
+#undef AGX_RB
 }
 
 }  // namespace agx

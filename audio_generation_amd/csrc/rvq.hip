@@ -21,14 +21,17 @@
 namespace agx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int FT = 32;    // frames per workgroup
+constexpr int NWV = 8;    // waves per workgroup (2 per SIMD: one computes while the other waits on L2)
+constexpr int NT = 64 * NWV;
 constexpr int RS = 33;    // LDS row stride of R / O (conflict-free in both access patterns)
 constexpr int CAND = 8;   // candidate slots per frame
 
-__host__ __device__ inline int64_t rvq_stage_floats(int k, int dim) {
-    return int64_t(dim) * k + k + 4;  // CbT (D,K) | c2 (K) | cmax2 + pad
-}
+__host__ __device__ inline int rvq_dp(int dim) { return (dim + 7) & ~7; }  // D rounded up to the 8-deep k block
+// stage image: CbG[Dp/4][K][4] (4 consecutive dims of one codeword adjacent, zero padded) | c2 (K) | cmax2 + pad
+__host__ __device__ inline int64_t rvq_stage_floats(int k, int dim) { return int64_t(rvq_dp(dim)) * k + k + 4; }
 
 // ------------------------------------------------------------------------- pack
 __global__ __launch_bounds__(256) void rvq_pack_kernel(const float *__restrict__ cb, int n_q, int k,
@@ -36,23 +39,21 @@ __global__ __launch_bounds__(256) void rvq_pack_kernel(const float *__restrict__
     const int q = blockIdx.y;
     const int code = blockIdx.x * 256 + threadIdx.x;
     float *img = packed + q * rvq_stage_floats(k, dim);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        // cmax2 slot is filled by rvq_cmax_kernel
-    }
     if (code >= k) return;
     const float *row = cb + (size_t(q) * k + code) * dim;
+    const int dp = rvq_dp(dim);
     float acc = 0.f;
-    for (int d = 0; d < dim; ++d) {
-        const float v = row[d];
-        img[size_t(d) * k + code] = v;
+    for (int d = 0; d < dp; ++d) {
+        const float v = d < dim ? row[d] : 0.f;
+        img[(size_t(d >> 2) * k + code) * 4 + (d & 3)] = v;
         acc = fmaf(v, v, acc);
     }
-    img[size_t(dim) * k + code] = acc;
+    img[size_t(dp) * k + code] = acc;
 }
 
 __global__ __launch_bounds__(256) void rvq_cmax_kernel(int k, int dim, float *__restrict__ packed) {
     float *img = packed + blockIdx.x * rvq_stage_floats(k, dim);
-    const float *c2 = img + size_t(dim) * k;
+    const float *c2 = img + size_t(rvq_dp(dim)) * k;
     float m = 0.f;
     for (int i = threadIdx.x; i < k; i += 256) m = fmaxf(m, c2[i]);
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void rvq_cmax_kernel(int k, int dim, float *__
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
-        float *tail = img + size_t(dim) * k + k;
+        float *tail = img + size_t(rvq_dp(dim)) * k + k;
         tail[0] = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
         tail[1] = tail[2] = tail[3] = 0.f;
     }
@@ -96,13 +97,13 @@ struct RvqArgs {
 };
 
 template <int MT>
-__global__ __launch_bounds__(256) void rvq_forward_kernel(RvqArgs a) {
+__global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int Dp = (a.D + 1) & ~1;
+    const int Dp = rvq_dp(a.D);
     float *R = smem;                 // [Dp][RS]
     float *O = R + Dp * RS;          // [Dp][RS]
-    float *wmin = O + Dp * RS;       // [4][FT]
-    float *rn2 = wmin + 4 * FT;      // [FT]
+    float *wmin = O + Dp * RS;       // [NWV][FT]
+    float *rn2 = wmin + NWV * FT;    // [FT]
     int *cnt = reinterpret_cast<int *>(rn2 + FT);         // [FT]
     int *state = cnt + FT;                                 // [FT] 0 decided / 1 exact among cands / 2 full
     int *best = state + FT;                                // [FT]
@@ -117,9 +118,9 @@ __global__ __launch_bounds__(256) void rvq_forward_kernel(RvqArgs a) {
     const int D = a.D, K = a.K;
 
     // ---- stage the latents: R[d][f] = x[n0+f][d], O = 0; pick the coalesced order ----
-    for (int e = tid; e < Dp * RS; e += 256) O[e] = 0.f;
+    for (int e = tid; e < Dp * RS; e += NT) O[e] = 0.f;
     if (a.x_st == 1 || a.x_sd != 1) {  // time-contiguous ("b c l"): frames fastest
-        for (int e = tid; e < Dp * FT; e += 256) {
+        for (int e = tid; e < Dp * FT; e += NT) {
             const int d = e >> 5, f = e & 31;
             const int64_t n = n0 + f;
             float v = 0.f;
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void rvq_forward_kernel(RvqArgs a) {
             R[d * RS + f] = v;
         }
     } else {  // channel-contiguous ("b l c"): d fastest
-        for (int f = wave; f < FT; f += 4) {
+        for (int f = wave; f < FT; f += NWV) {
             const int64_t n = n0 + f;
             const int64_t b = n < N ? n / a.T : 0, t = n < N ? n - b * a.T : 0;
             const float *src = a.x + b * a.x_sb + t * a.x_st;
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void rvq_forward_kernel(RvqArgs a) {
     }
     __syncthreads();
     // ||r||^2 per frame (wave w owns frames w, w+4, ...)
-    for (int f = wave; f < FT; f += 4) {
+    for (int f = wave; f < FT; f += NWV) {
         float part = 0.f;
         for (int d = lane; d < D; d += 64) {
             const float v = R[d * RS + f];
@@ -151,11 +152,12 @@ __global__ __launch_bounds__(256) void rvq_forward_kernel(RvqArgs a) {
     __syncthreads();
 
     const float err_unit = float(D + 8) * 5.9604645e-8f * 1.25f;  // (D+8) * 2^-24 * 1.25
-    const int n_chunks = (K + 128 * MT - 1) / (128 * MT);
+    constexpr int CHUNK = NWV * 32 * MT;  // codewords scored per pass
+    const int n_chunks = (K + CHUNK - 1) / CHUNK;
 
     for (int q = 0; q < a.Q; ++q) {
         const float *img = a.packed + q * rvq_stage_floats(K, D);
-        const float *c2 = img + size_t(D) * K;
+        const float *c2 = img + size_t(Dp) * K;
         const float cmax2 = c2[K];
         const float *cbq = a.cb + size_t(q) * K * D;
 
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(256) void rvq_forward_kernel(RvqArgs a) {
         float running = INFINITY;
 
         for (int ch = 0; ch < n_chunks; ++ch) {
-            const int code0 = ch * (128 * MT) + wave * (32 * MT);
+            const int code0 = ch * CHUNK + wave * (32 * MT);
             f32x16 acc[MT];
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -176,20 +178,33 @@ __global__ __launch_bounds__(256) void rvq_forward_kernel(RvqArgs a) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) acol[i] = min(code0 + i * 32 + li, K - 1);
 
-            // ---- A: scores.  A[i=code][k=d], B[k=d][j=frame] ----
-            const float *rb = R + lh * RS + li;
-#pragma unroll 4
-            for (int d0 = 0; d0 < Dp; d0 += 2) {
-                const int dd = d0 + lh;
-                const float *arow = img + size_t(min(dd, D - 1)) * K;
-                const float bsel = (dd < D) ? 1.f : 0.f;  // odd D: the pad row of R is zero, A must be finite
-                const float bf = rb[d0 * RS] * bsel;
-                float av[MT];
+            // ---- A: scores.  A[i=code][k=d], B[k=d][j=frame].  Within an 8-deep block of d, MFMA
+            // step ks pairs d0+ks (lane half 0) with d0+4+ks (half 1): a lane's 4 A operands are
+            // 4 consecutive dims of its codeword = one 16-byte load of the CbG image, prefetched
+            // one block ahead; B operands are conflict-free ds_read_b32 of the residual tile.
+            const float *rb = R + (4 * lh) * RS + li;
+            const float *ab = img + size_t(lh) * K * 4;
+            f32x4 a_cur[MT], a_nxt[MT];
 #pragma unroll
-                for (int i = 0; i < MT; ++i) av[i] = arow[acol[i]];
+            for (int i = 0; i < MT; ++i) a_cur[i] = *reinterpret_cast<const f32x4 *>(ab + size_t(acol[i]) * 4);
+            for (int d8 = 0; d8 < Dp; d8 += 8) {
+                if (d8 + 8 < Dp) {
+                    const float *an = ab + size_t((d8 + 8) >> 2) * K * 4;
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bf, acc[i], 0, 0, 0);
+                    for (int i = 0; i < MT; ++i) a_nxt[i] = *reinterpret_cast<const f32x4 *>(an + size_t(acol[i]) * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                float bf[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) bf[ks] = rb[(d8 + ks) * RS];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i][ks], bf[ks], acc[i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) a_cur[i] = a_nxt[i];
             }
             // scores in place; rows of register r: (r&3) + 8*(r>>2) + 4*lh
             float m = INFINITY;
@@ -205,7 +220,9 @@ __global__ __launch_bounds__(256) void rvq_forward_kernel(RvqArgs a) {
             m = fminf(m, __shfl_xor(m, 32));
             if (lh == 0) wmin[wave * FT + li] = m;
             __syncthreads();
-            const float cm = fminf(fminf(wmin[li], wmin[FT + li]), fminf(wmin[2 * FT + li], wmin[3 * FT + li]));
+            float cm = wmin[li];
+#pragma unroll
+            for (int w = 1; w < NWV; ++w) cm = fminf(cm, wmin[w * FT + li]);
             running = fminf(running, cm);
             const float thr = running + margin;
 #pragma unroll
@@ -255,7 +272,7 @@ __global__ __launch_bounds__(256) void rvq_forward_kernel(RvqArgs a) {
             }
         }
         __syncthreads();
-        {
+        if (tid < FT * CAND) {
             const int f = tid >> 3, c = tid & 7;
             if (state[f] == 1 && c < cnt[f])
                 cdist[f * CAND + c] = exact_dist_lds(R + f, cbq + size_t(ccode[f * CAND + c]) * D, D);
@@ -281,7 +298,7 @@ __global__ __launch_bounds__(256) void rvq_forward_kernel(RvqArgs a) {
             if (state[f] != 2) continue;  // uniform across the block (LDS value)
             double bd = INFINITY;
             int bc = 0x7fffffff;
-            for (int code = tid; code < K; code += 256) {
+            for (int code = tid; code < K; code += NT) {
                 const double dc = exact_dist_lds(R + f, cbq + size_t(code) * D, D);
                 if (dc < bd || (dc == bd && code < bc)) {
                     bd = dc;
@@ -303,7 +320,7 @@ __global__ __launch_bounds__(256) void rvq_forward_kernel(RvqArgs a) {
             }
             __syncthreads();
             if (tid == 0) {
-                for (int w = 1; w < 4; ++w)
+                for (int w = 1; w < NWV; ++w)
                     if (cdist[w] < bd || (cdist[w] == bd && ccode[w] < bc)) {
                         bd = cdist[w];
                         bc = ccode[w];
@@ -314,7 +331,7 @@ __global__ __launch_bounds__(256) void rvq_forward_kernel(RvqArgs a) {
         }
 
         // ---- C: r -= c, out += c, index, squared residual ----
-        for (int f = wave; f < FT; f += 4) {
+        for (int f = wave; f < FT; f += NWV) {
             const int idx = best[f];
             const float *c = cbq + size_t(idx) * D;
             float part = 0.f;
@@ -342,7 +359,7 @@ __global__ __launch_bounds__(256) void rvq_forward_kernel(RvqArgs a) {
 
     // ---- write x_q ----
     if (a.q_st == 1 || a.q_sd != 1) {
-        for (int e = tid; e < D * FT; e += 256) {
+        for (int e = tid; e < D * FT; e += NT) {
             const int d = e >> 5, f = e & 31;
             const int64_t n = n0 + f;
             if (n < N) {
@@ -351,7 +368,7 @@ __global__ __launch_bounds__(256) void rvq_forward_kernel(RvqArgs a) {
             }
         }
     } else {
-        for (int f = wave; f < FT; f += 4) {
+        for (int f = wave; f < FT; f += NWV) {
             const int64_t n = n0 + f;
             if (n >= N) continue;
             const int64_t b = n / a.T, t = n - b * a.T;
@@ -362,8 +379,8 @@ __global__ __launch_bounds__(256) void rvq_forward_kernel(RvqArgs a) {
 }
 
 static size_t rvq_lds_bytes(int dim) {
-    const int Dp = (dim + 1) & ~1;
-    size_t floats = size_t(2) * Dp * RS + 4 * FT + FT /*rn2*/ + 3 * FT /*cnt,state,best*/ +
+    const int Dp = rvq_dp(dim);
+    size_t floats = size_t(2) * Dp * RS + NWV * FT + FT /*rn2*/ + 3 * FT /*cnt,state,best*/ +
                     FT * CAND /*ccode*/ + FT * CAND /*cscore*/;
     floats = (floats + 1) & ~size_t(1);
     return floats * 4 + size_t(FT) * CAND * 8;
@@ -423,7 +440,7 @@ int agx_rvq_forward(const float *x, int64_t x_sb, int64_t x_st, int64_t x_sd, co
     RvqArgs a{x, x_sb, x_st, x_sd, codebooks, packed, batch, t, dim, k, q_used, xq, q_sb, q_st, q_sd, index, sq_err};
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t n = int64_t(batch) * t;
-    dim3 grid((unsigned)ceil_div64(n, FT)), block(256);
+    dim3 grid((unsigned)ceil_div64(n, FT)), block(NT);
     auto launch = [&](auto kern) -> int {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -431,9 +448,9 @@ int agx_rvq_forward(const float *x, int64_t x_sb, int64_t x_st, int64_t x_sd, co
         hipLaunchKernelGGL(kern, grid, block, lds, st, a);
         return check_launch("rvq_forward");
     };
-    if (k > 512) return launch(rvq_forward_kernel<8>);
-    if (k > 256) return launch(rvq_forward_kernel<4>);
-    if (k > 128) return launch(rvq_forward_kernel<2>);
+    // codewords per pass = 8 waves x MT x 32
+    if (k > 512) return launch(rvq_forward_kernel<4>);
+    if (k > 256) return launch(rvq_forward_kernel<2>);
     return launch(rvq_forward_kernel<1>);
 }
 
