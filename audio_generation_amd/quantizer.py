@@ -139,6 +139,23 @@ class ResidualQuantizer(nn.Module):
             residual = residual - cb[q][idx]
         self.codebooks._version  # noqa: B018  (in-place copy_ above bumps the version -> repack)
 
+    @torch.no_grad()
+    def init_from_latents(self, z: Tensor, seed: int = 7, decay: float = 0.6) -> float:
+        """Data-driven codebook initialisation (what k-means-style VQ training starts from;
+        also how the synthetic benchmark makes the arg-min non-degenerate):
+        stage 0 = randomly chosen latent frames + small noise, stage q = randn * sigma * decay^q
+        with sigma the per-element std of the frames around their mean.  z is (B, D, T)."""
+        frames = z.transpose(1, 2).reshape(-1, self.dim)
+        gen = torch.Generator().manual_seed(seed)
+        sigma = float((frames - frames.mean(dim=0, keepdim=True)).std())
+        pick = torch.randint(0, frames.shape[0], (self.codebook_size,), generator=gen).to(frames.device)
+        noise = torch.randn(self.num_quantizers, self.codebook_size, self.dim, generator=gen).to(frames.device)
+        cb = self.codebooks.data
+        cb[0].copy_(frames[pick] + 0.1 * sigma * noise[0])
+        for q in range(1, self.num_quantizers):
+            cb[q].copy_(noise[q] * (sigma * decay ** q))
+        return sigma
+
     def get_stale_clusters(self) -> List[int]:
         """Number of codewords per stage whose EMA usage fell below the cutoff."""
         return [int((self.cluster_frequency[q] < self.vq_cutoff_freq).sum()) for q in range(self.num_quantizers)]

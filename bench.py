@@ -130,14 +130,10 @@ def build_model(dev):
 
 
 def calibrate_codebooks(model, x_small):
-    """codebooks = randn * sigma(encoder output) so the arg-min is non-degenerate."""
+    """Codebooks at the scale and location of the encoder output so that the arg-min is
+    non-degenerate: stage 0 = latent frames + noise, later stages shrinking randn."""
     with torch.no_grad():
-        z = model._run_encoders(x_small)
-        sigma = float(z.std())
-        gen = torch.Generator().manual_seed(7)
-        cb = torch.randn(model.quantizer.codebooks.shape, generator=gen) * sigma
-        model.quantizer.codebooks.copy_(cb.to(z.device))
-    return sigma
+        return model.quantizer.init_from_latents(model._run_encoders(x_small), seed=7)
 
 
 def cpu_baseline_and_parity(model, x_cpu, y_gpu, idx_gpu, z_gpu, n_items):
@@ -212,7 +208,7 @@ def main():
     model = build_model(dev)
     x_cpu = make_inputs(bsz, rank)
     x = x_cpu.to(dev)                       # inputs resident in HBM before the timed region
-    sigma = calibrate_codebooks(model, x[:2])
+    sigma = calibrate_codebooks(model, x[:8])
 
     def eager_step():
         with torch.no_grad():
