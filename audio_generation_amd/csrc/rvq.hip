@@ -30,10 +30,32 @@ constexpr int RS = 33;    // LDS row stride of R / O (conflict-free in both acce
 constexpr int CAND = 8;   // candidate slots per frame
 
 __host__ __device__ inline int rvq_dp(int dim) { return (dim + 7) & ~7; }  // D rounded up to the 8-deep k block
-// stage image: CbG[Dp/4][K][4] (4 consecutive dims of one codeword adjacent, zero padded) | c2 (K) | cmax2 + pad
-__host__ __device__ inline int64_t rvq_stage_floats(int k, int dim) { return int64_t(rvq_dp(dim)) * k + k + 4; }
+// stage image, all on CENTRED codewords c' = fl(c - mu), mu = the stage's mean codeword:
+//   CbG[Dp/4][K][4] (4 consecutive dims of one codeword adjacent, zero padded) | c2 = |c'|^2 (K) | cn = |c'| (K)
+//   | cmax2 + pad(3) | mu (Dp)
+// Distances are translation invariant, and scoring |c'|^2 - 2 r'.c' with r' = fl(r - mu) keeps the fp32
+// error bound proportional to the SPREAD of the data instead of its offset from the origin: without the
+// centring, latents that share a large common component (any encoder with a bias) put most codewords
+// inside the error margin of the minimum.
+__host__ __device__ inline int64_t rvq_stage_floats(int k, int dim) {
+    return int64_t(rvq_dp(dim)) * k + 2 * int64_t(k) + 4 + rvq_dp(dim);
+}
 
 // ------------------------------------------------------------------------- pack
+// mu[d] = mean_k c[k][d]  (thread per d; fp32 sequential over k)
+__global__ __launch_bounds__(256) void rvq_mean_kernel(const float *__restrict__ cb, int k, int dim,
+                                                       float *__restrict__ packed) {
+    const int q = blockIdx.y;
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    const int dp = rvq_dp(dim);
+    if (d >= dp) return;
+    float *mu = packed + q * rvq_stage_floats(k, dim) + size_t(dp) * k + 2 * size_t(k) + 4;
+    float acc = 0.f;
+    if (d < dim)
+        for (int c = 0; c < k; ++c) acc += cb[(size_t(q) * k + c) * dim + d];
+    mu[d] = d < dim ? acc / float(k) : 0.f;
+}
+
 __global__ __launch_bounds__(256) void rvq_pack_kernel(const float *__restrict__ cb, int n_q, int k,
                                                        int dim, float *__restrict__ packed) {
     const int q = blockIdx.y;
@@ -42,13 +64,15 @@ __global__ __launch_bounds__(256) void rvq_pack_kernel(const float *__restrict__
     if (code >= k) return;
     const float *row = cb + (size_t(q) * k + code) * dim;
     const int dp = rvq_dp(dim);
+    const float *mu = img + size_t(dp) * k + 2 * size_t(k) + 4;
     float acc = 0.f;
     for (int d = 0; d < dp; ++d) {
-        const float v = d < dim ? row[d] : 0.f;
+        const float v = d < dim ? row[d] - mu[d] : 0.f;
         img[(size_t(d >> 2) * k + code) * 4 + (d & 3)] = v;
         acc = fmaf(v, v, acc);
     }
     img[size_t(dp) * k + code] = acc;
+    img[size_t(dp) * k + k + code] = sqrtf(acc);
 }
 
 __global__ __launch_bounds__(256) void rvq_cmax_kernel(int k, int dim, float *__restrict__ packed) {
@@ -61,7 +85,7 @@ __global__ __launch_bounds__(256) void rvq_cmax_kernel(int k, int dim, float *__
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
-        float *tail = img + size_t(rvq_dp(dim)) * k + k;
+        float *tail = img + size_t(rvq_dp(dim)) * k + 2 * size_t(k);
         tail[0] = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
         tail[1] = tail[2] = tail[3] = 0.f;
     }
@@ -71,15 +95,45 @@ __global__ __launch_bounds__(256) void rvq_cmax_kernel(int k, int dim, float *__
 // The DEFINING arithmetic (oracle/rvq_exact.c): binary64, d ascending, one
 // subtract + one multiply + one add per term, never fused.
 #pragma clang fp contract(off)
-__device__ __noinline__ double exact_dist_lds(const float *r_col /* stride RS */,
-                                              const float *__restrict__ c, int dim) {
-    double acc = 0.0;
-    for (int d = 0; d < dim; ++d) {
-        const double diff = double(r_col[d * RS]) - double(c[d]);
-        const double sq = diff * diff;
-        acc = acc + sq;
+// Whole-wave evaluation, same arithmetic and SAME summation order: lane L owns the
+// contiguous dims [L*blk, (L+1)*blk) (coalesced codeword load), forms its squares,
+// and the running sum is handed from lane to lane in d order.  Returns the
+// distance in every lane.
+__device__ __forceinline__ double exact_dist_wave(const float *r_col /* LDS, stride RS */,
+                                               const float *__restrict__ c, int dim, int lane) {
+    constexpr int BLK_MAX = 8;  // dims per lane held in registers: D <= 512
+    const int blk = (dim + 63) >> 6;
+    const int d0 = lane * blk;
+    if (blk > BLK_MAX) {  // wider frames (wave-uniform): plain sequential evaluation, every lane redundantly
+        double acc = 0.0;
+        for (int d = 0; d < dim; ++d) {
+            const double diff = double(r_col[d * RS]) - double(c[d]);
+            const double sq = diff * diff;
+            acc = acc + sq;
+        }
+        return acc;
     }
-    return acc;
+    // all lanes form their squares in parallel (loads issued together, no dependence on the chain) ...
+    double sq[BLK_MAX];
+#pragma unroll
+    for (int j = 0; j < BLK_MAX; ++j) {
+        const int d = d0 + j;
+        const bool ok = j < blk && d < dim;
+        const double diff = double(ok ? r_col[d * RS] : 0.f) - double(ok ? c[d] : 0.f);
+        sq[j] = diff * diff;
+    }
+    // ... then the running sum walks the lanes in d order: acc = (..((0 + sq_0) + sq_1) + ..)
+    double acc = 0.0;
+    for (int owner = 0; owner * blk < dim; ++owner) {  // wave-uniform bounds
+        const double carry = owner == 0 ? 0.0 : __shfl(acc, owner - 1);
+        if (lane == owner) {
+            acc = carry;
+#pragma unroll
+            for (int j = 0; j < BLK_MAX; ++j)
+                if (j < blk && d0 + j < dim) acc = acc + sq[j];
+        }
+    }
+    return __shfl(acc, (dim - 1) / blk);
 }
 #pragma clang fp contract(fast)
 
@@ -103,8 +157,9 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
     float *R = smem;                 // [Dp][RS]
     float *O = R + Dp * RS;          // [Dp][RS]
     float *wmin = O + Dp * RS;       // [NWV][FT]
-    float *rn2 = wmin + NWV * FT;    // [FT]
-    int *cnt = reinterpret_cast<int *>(rn2 + FT);         // [FT]
+    float *rn2 = wmin + NWV * FT;    // [FT]   ||r - mu||^2 of the current stage
+    float *mus = rn2 + FT;           // [Dp]   the current stage's mean codeword
+    int *cnt = reinterpret_cast<int *>(mus + Dp);         // [FT]
     int *state = cnt + FT;                                 // [FT] 0 decided / 1 exact among cands / 2 full
     int *best = state + FT;                                // [FT]
     int *ccode = best + FT;                                // [FT][CAND]
@@ -139,18 +194,6 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
         }
     }
     __syncthreads();
-    // ||r||^2 per frame (wave w owns frames w, w+4, ...)
-    for (int f = wave; f < FT; f += NWV) {
-        float part = 0.f;
-        for (int d = lane; d < D; d += 64) {
-            const float v = R[d * RS + f];
-            part = fmaf(v, v, part);
-        }
-        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-        if (lane == 0) rn2[f] = part;
-    }
-    __syncthreads();
-
     const float err_unit = float(D + 8) * 5.9604645e-8f * 1.25f;  // (D+8) * 2^-24 * 1.25
     constexpr int CHUNK = NWV * 32 * MT;  // codewords scored per pass
     const int n_chunks = (K + CHUNK - 1) / CHUNK;
@@ -158,13 +201,31 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
     for (int q = 0; q < a.Q; ++q) {
         const float *img = a.packed + q * rvq_stage_floats(K, D);
         const float *c2 = img + size_t(Dp) * K;
-        const float cmax2 = c2[K];
+        const float *cn = c2 + K;
         const float *cbq = a.cb + size_t(q) * K * D;
 
         if (tid < FT) cnt[tid] = 0;
+        const float *mu_g = c2 + 2 * size_t(K) + 4;
+        for (int d = tid; d < Dp; d += NT) mus[d] = mu_g[d];
         __syncthreads();
-        // margin = 2 * error bound of a computed score of this frame (see rvq.hip header, B.)
-        const float margin = 2.02f * err_unit * (cmax2 + 2.f * sqrtf(rn2[li] * cmax2));
+        // ||r - mu||^2 per frame (wave w owns frames w, w+NWV, ...)
+        for (int f = wave; f < FT; f += NWV) {
+            float part = 0.f;
+            for (int d = lane; d < D; d += 64) {
+                const float v = R[d * RS + f] - mus[d];
+                part = fmaf(v, v, part);
+            }
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            if (lane == 0) rn2[f] = part;
+        }
+        __syncthreads();
+        // Error bound of one computed score: |s_k + |r'|^2 - |r - c_k|^2| <= E_k = eu (|r'| + |c'_k|)^2
+        // (fp32 MFMA chain and |c'|^2: (D+2) u (c'^2 + 2 r'c'); the two centring roundings: 2 u (r'+c')^2).
+        // Per CODEWORD, not per codebook: one far-away outlier codeword must not widen the margin of
+        // the near ones.  k is a candidate iff its lower bound s_k - E_k does not exceed
+        // U = min_j (s_j + E_j), the smallest upper bound -- the true arg-min always qualifies.
+        const float rnorm = sqrtf(rn2[li]);
+        const float eu = 1.01f * err_unit;
         float running = INFINITY;
 
         for (int ch = 0; ch < n_chunks; ++ch) {
@@ -196,7 +257,7 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 float bf[4];
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) bf[ks] = rb[(d8 + ks) * RS];
+                for (int ks = 0; ks < 4; ++ks) bf[ks] = rb[(d8 + ks) * RS] - mus[d8 + 4 * lh + ks];
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -206,17 +267,24 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) a_cur[i] = a_nxt[i];
             }
-            // scores in place; rows of register r: (r&3) + 8*(r>>2) + 4*lh
+            // lower bounds in place; rows of register r: (r&3) + 8*(r>>2) + 4*lh.  One subtile at a
+            // time (the sched_barrier keeps hipcc from hoisting all 2*16*MT table loads at once,
+            // which spills at 2 waves/SIMD).
             float m = INFINITY;
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+            for (int i = 0; i < MT; ++i) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int code = code0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const float s = (code < K) ? (c2[min(code, K - 1)] - 2.f * acc[i][r]) : INFINITY;
-                    acc[i][r] = s;
-                    m = fminf(m, s);
+                    const int cc = min(code, K - 1);
+                    const float s = (code < K) ? (c2[cc] - 2.f * acc[i][r]) : INFINITY;
+                    const float rc = rnorm + cn[cc];
+                    const float e = eu * rc * rc;
+                    acc[i][r] = s - e;          // keep the lower bound
+                    m = fminf(m, s + e);        // reduce the upper bound
                 }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             m = fminf(m, __shfl_xor(m, 32));
             if (lh == 0) wmin[wave * FT + li] = m;
             __syncthreads();
@@ -224,7 +292,7 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
 #pragma unroll
             for (int w = 1; w < NWV; ++w) cm = fminf(cm, wmin[w * FT + li]);
             running = fminf(running, cm);
-            const float thr = running + margin;
+            const float thr = running;
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -249,7 +317,7 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
             if (n > CAND) {
                 state[f] = 2;
             } else {
-                const float thr = running + margin;
+                const float thr = running;
                 int kept = 0;
                 for (int c = 0; c < n; ++c) {
                     const float s = cscore[f * CAND + c];
@@ -272,10 +340,12 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
             }
         }
         __syncthreads();
-        if (tid < FT * CAND) {
-            const int f = tid >> 3, c = tid & 7;
-            if (state[f] == 1 && c < cnt[f])
-                cdist[f * CAND + c] = exact_dist_lds(R + f, cbq + size_t(ccode[f * CAND + c]) * D, D);
+        for (int fc = wave; fc < FT * CAND; fc += NWV) {  // one (frame, candidate) pair per wave at a time
+            const int f = fc >> 3, c = fc & 7;
+            if (state[f] == 1 && c < cnt[f]) {             // wave-uniform (LDS values)
+                const double dist = exact_dist_wave(R + f, cbq + size_t(ccode[fc]) * D, D, lane);
+                if (lane == 0) cdist[fc] = dist;
+            }
         }
         __syncthreads();
         if (tid < FT && state[tid] == 1) {
@@ -298,19 +368,11 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
             if (state[f] != 2) continue;  // uniform across the block (LDS value)
             double bd = INFINITY;
             int bc = 0x7fffffff;
-            for (int code = tid; code < K; code += NT) {
-                const double dc = exact_dist_lds(R + f, cbq + size_t(code) * D, D);
+            for (int code = wave; code < K; code += NWV) {  // every lane of the wave gets the same distance
+                const double dc = exact_dist_wave(R + f, cbq + size_t(code) * D, D, lane);
                 if (dc < bd || (dc == bd && code < bc)) {
                     bd = dc;
                     bc = code;
-                }
-            }
-            for (int off = 32; off > 0; off >>= 1) {
-                const double od = __shfl_xor(bd, off);
-                const int oc = __shfl_xor(bc, off);
-                if (od < bd || (od == bd && oc < bc)) {
-                    bd = od;
-                    bc = oc;
                 }
             }
             __syncthreads();  // cdist / ccode row 0 are free to reuse as exchange
@@ -344,7 +406,7 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
             }
             for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
             if (lane == 0) {
-                rn2[f] = part;
+                wmin[f] = part;  // squared residual of this frame (wmin row 0 is free between score passes)
                 if (n0 + f < N) a.index[(n0 + f) * a.Q + q] = idx;
             }
         }
@@ -352,7 +414,7 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
         if (tid == 0) {
             double s = 0.0;
             for (int f = 0; f < FT; ++f)
-                if (n0 + f < N) s += double(rn2[f]);
+                if (n0 + f < N) s += double(wmin[f]);
             atomicAdd(&a.sq_err[q], s);
         }
     }
@@ -380,7 +442,7 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
 
 static size_t rvq_lds_bytes(int dim) {
     const int Dp = rvq_dp(dim);
-    size_t floats = size_t(2) * Dp * RS + NWV * FT + FT /*rn2*/ + 3 * FT /*cnt,state,best*/ +
+    size_t floats = size_t(2) * Dp * RS + NWV * FT + FT /*rn2*/ + Dp /*mus*/ + 3 * FT /*cnt,state,best*/ +
                     FT * CAND /*ccode*/ + FT * CAND /*cscore*/;
     floats = (floats + 1) & ~size_t(1);
     return floats * 4 + size_t(FT) * CAND * 8;
@@ -417,6 +479,7 @@ int agx_rvq_pack(const float *codebooks, int32_t n_q, int32_t k, int32_t dim, fl
     if (n_q <= 0 || k <= 0 || dim <= 0) return fail(AGX_ERR_BAD_SHAPE, "rvq_pack: bad shape Q=%d K=%d D=%d", n_q, k, dim);
     if (!codebooks || !packed) return fail(AGX_ERR_NULL_POINTER, "rvq_pack: NULL pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(rvq_mean_kernel, dim3(ceil_div(rvq_dp(dim), 256), n_q), dim3(256), 0, st, codebooks, k, dim, packed);
     hipLaunchKernelGGL(rvq_pack_kernel, dim3(ceil_div(k, 256), n_q), dim3(256), 0, st, codebooks, n_q, k, dim, packed);
     hipLaunchKernelGGL(rvq_cmax_kernel, dim3(n_q), dim3(256), 0, st, k, dim, packed);
     return check_launch("agx_rvq_pack");
@@ -448,8 +511,8 @@ int agx_rvq_forward(const float *x, int64_t x_sb, int64_t x_st, int64_t x_sd, co
         hipLaunchKernelGGL(kern, grid, block, lds, st, a);
         return check_launch("rvq_forward");
     };
-    // codewords per pass = 8 waves x MT x 32
-    if (k > 512) return launch(rvq_forward_kernel<4>);
+    // codewords per pass = 8 waves x MT x 32.  MT = 4 (one pass for K = 1024) spills at the 256-VGPR cap
+    // of 2 waves/SIMD, so K > 512 runs as passes of 512 codewords with the running-bound candidate rule.
     if (k > 256) return launch(rvq_forward_kernel<2>);
     return launch(rvq_forward_kernel<1>);
 }

@@ -269,6 +269,16 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": dom["gbps"], "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                     "frac": dom["gbps"] / PEAK_HBM_GBPS, "traffic": None}
+        # HBM bytes per launch of that kernel from the committed PMC passes (tools/pmc_summary.py)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
+            key = dom_name.replace("2x:", "")
+            if key in pmc:
+                roof["traffic"] = pmc[key]["bytes_per_launch"]
+                roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, per launch)"
+                roof["algorithmic_bytes_per_launch"] = dom["bytes"] / dom["launches"]
+        except (OSError, ValueError, KeyError):
+            pass
         roof.update({"kernel": dom_name, "avg_launch_us": dom["avg_us"],
                      "launches_per_step": dom["launches_per_step"],
                      "share_of_step": dom["ms_per_step"] / ms_per_step,

@@ -77,14 +77,19 @@ def fast_search(frames: np.ndarray, codebook: np.ndarray, score_dtype=torch.floa
     n, dim = frames.shape
     r = torch.from_numpy(frames).to(score_dtype)
     c = torch.from_numpy(codebook).to(score_dtype)
+    # distances are translation invariant: centre on the mean codeword so the rounding error of
+    # the scores scales with the spread of the data, not with its offset from the origin
+    mu = c.mean(dim=0, keepdim=True)
+    r, c = r - mu, c - mu
     c2 = (c * c).sum(dim=1)
     scores = c2.unsqueeze(0) - 2.0 * (r @ c.t())
     eps = 1e-12 if score_dtype == torch.float64 else 6e-8
-    cmax = c2.max().sqrt()
+    # per-codeword error bound E[n,k] = (dim+8) eps (|r'_n| + |c'_k|)^2 ; candidate iff its lower
+    # bound does not exceed the smallest upper bound (same rule as the HIP kernel)
     rn = (r * r).sum(dim=1).sqrt()
-    margin = 2.0 * (dim + 2) * eps * (cmax * cmax + 2.0 * rn * cmax) + 1e-300
-    smin = scores.min(dim=1).values
-    mask = scores <= (smin + margin).unsqueeze(1)
+    err = 1.3 * (dim + 8) * eps * (rn.unsqueeze(1) + c2.sqrt().unsqueeze(0)) ** 2
+    upper = (scores + err).min(dim=1).values
+    mask = (scores - err) <= upper.unsqueeze(1)
     n_cand = mask.sum(dim=1).to(torch.int32)
     max_cand = int(n_cand.max())
     # first max_cand True positions per row (stable order = ascending k)

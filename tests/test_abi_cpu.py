@@ -69,7 +69,7 @@ def test_bad_descriptors_report_errors(lib):
     with pytest.raises(_lib.AgxError):
         ops.conv_out_len(ops.conv_desc(_lib.CONV_TRANSPOSED, 1, 4, 4, 10, 3, 5))  # K < stride
     assert lib.agx_rvq_packed_floats(0, 4, 4) < 0
-    assert lib.agx_rvq_packed_floats(8, 1024, 512) == 8 * (512 * 1024 + 1024 + 4)
+    assert lib.agx_rvq_packed_floats(8, 1024, 512) == 8 * (512 * 1024 + 2 * 1024 + 4 + 512)
 
 
 def test_no_cpu_fallback():

@@ -208,6 +208,32 @@ def test_rvq_small_scale_latents():
     _rvq_case(2, 100, 512, 1024, 8, seed=12, scale=0.02)
 
 
+def test_rvq_latents_with_large_common_offset():
+    """Encoder outputs share a big bias component; codewords close to actual frames.  The score
+    kernel centres on the stage's mean codeword so its fp32 margin stays tight: still bit-exact,
+    and the single-launch kernel must not fall into the full fp64 search for every frame."""
+    gen = torch.Generator().manual_seed(21)
+    b, t, d, k, q = 4, 225, 512, 1024, 4
+    mean = 3.0 * torch.randn(d, generator=gen)
+    x = mean + 0.02 * torch.randn(b, t, d, generator=gen)
+    frames = x.reshape(-1, d)
+    cbs = torch.randn(q, k, d, generator=gen) * 0.01
+    cbs[0] = frames[torch.randint(0, frames.shape[0], (k,), generator=gen)] + 0.002 * torch.randn(k, d, generator=gen)
+    want_q, want_i, _ = rvq.residual_quantize(x, cbs)
+    xd, cd = x.to(DEV), cbs.to(DEV)
+    packed = ops.rvq_pack(cd)
+    xq, idx, _ = ops.rvq_forward(xd, cd, packed, q)
+    assert torch.equal(idx.cpu(), want_i) and torch.equal(xq.cpu(), want_q)
+    assert want_i[..., 0].unique().numel() > 200
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        ops.rvq_forward(xd, cd, packed, q)
+    e1.record()
+    torch.cuda.synchronize()
+    assert e0.elapsed_time(e1) / 3 < 2.0, "RVQ fell off the fast path (ms per launch)"
+
+
 def test_dequantize_gather():
     cb = torch.randn(50, 24)
     idx = torch.randint(0, 50, (3, 7))
