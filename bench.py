@@ -272,8 +272,9 @@ def main():
         # HBM bytes per launch of that kernel from the committed PMC passes (tools/pmc_summary.py)
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
-            key = dom_name.replace("2x:", "")
-            if key in pmc:
+            stem = dom_name.replace("2x:", "").rstrip(">")   # PMC names carry extra template arguments
+            key = next((k for k in pmc if k == stem + ">" or k.startswith(stem + ",")), None)
+            if key is not None:
                 roof["traffic"] = pmc[key]["bytes_per_launch"]
                 roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, per launch)"
                 roof["algorithmic_bytes_per_launch"] = dom["bytes"] / dom["launches"]

@@ -28,10 +28,17 @@ def main():
     dur = defaultdict(list)
     for f in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
         seen = set()
-        for r in csv.DictReader(open(f)):
+        rows = list(csv.DictReader(open(f)))
+        # full-batch launches only: a pass also contains the smaller calibration / warm-up launches of
+        # the same kernels; keep dispatches within 2x of the kernel's longest one in this pass
+        longest = defaultdict(float)
+        for r in rows:
+            longest[short(r["Kernel_Name"])] = max(longest[short(r["Kernel_Name"])],
+                                                   (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        for r in rows:
             k = short(r["Kernel_Name"])
             us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-            if us < min_us:
+            if us < min_us or us < 0.5 * longest[k]:
                 continue
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             key = (f, r["Dispatch_Id"])
