@@ -18,8 +18,8 @@ const char *last_error();
 
 // diagnostic knobs (agx_set_tuning)
 struct Tuning {
-    int resblock_res_lds = 0;  // A/B on MI355X: neutral at C<=64, -9 % at C=128 (tools/ab_bench.py)
-    int ablate = 0;
+    int rb_cc = 16;   // channels per LDS chunk of the fused residual block (16 or 32)
+    int rb_wgs = 0;   // 1..3: cap resident workgroups per CU of the fused residual block (0 = natural)
 };
 Tuning &tuning();
 

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
     // per-lane B column offsets inside the staged tile
     int bcol[NW];
 #pragma unroll
-    for (int k = 0; k < NW; ++k) bcol[k] = (n0 + k * 32 + li) * p.s + lh * (CC / 2) * span;
+    for (int k = 0; k < NW; ++k) bcol[k] = (n0 + k * 32 + li) * p.s + lh * ((CC < 16 ? CC : 16) / 2) * span;
 
     const float *xb = x + size_t(b) * p.Cin * p.Lin;
     conv_gemm<MW, NW, CC>(acc, xs, xb, wp, p, p.M, span, in0, arow, bcol, wave, lane);

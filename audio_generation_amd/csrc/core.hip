@@ -122,16 +122,16 @@ const char *agx_last_error(void) { return agx::last_error(); }
 
 int agx_set_tuning(const char *name, int32_t value) {
     if (!name) return agx::fail(AGX_ERR_NULL_POINTER, "agx_set_tuning: NULL name");
-    if (!strcmp(name, "resblock_res_lds")) agx::tuning().resblock_res_lds = value;
-    else if (!strcmp(name, "ablate")) agx::tuning().ablate = value;
+    if (!strcmp(name, "rb_cc")) agx::tuning().rb_cc = value;
+    else if (!strcmp(name, "rb_wgs")) agx::tuning().rb_wgs = value;
     else return agx::fail(AGX_ERR_BAD_SHAPE, "agx_set_tuning: unknown knob '%s'", name);
     return AGX_OK;
 }
 
 int agx_get_tuning(const char *name) {
     if (!name) return agx::fail(AGX_ERR_NULL_POINTER, "agx_get_tuning: NULL name");
-    if (!strcmp(name, "resblock_res_lds")) return agx::tuning().resblock_res_lds;
-    if (!strcmp(name, "ablate")) return agx::tuning().ablate;
+    if (!strcmp(name, "rb_cc")) return agx::tuning().rb_cc;
+    if (!strcmp(name, "rb_wgs")) return agx::tuning().rb_wgs;
     return agx::fail(AGX_ERR_BAD_SHAPE, "agx_get_tuning: unknown knob '%s'", name);
 }
 

@@ -7,6 +7,27 @@
 
 namespace agx {
 
+// In-kernel stamps for the diagnostic probe build only (tools/rb_probe.hip defines AGX_STAMPS);
+// a no-op in libagx.
+#ifdef AGX_STAMPS
+__device__ unsigned long long g_stamps[1 << 16];
+#define AGX_STAMP(slot)                                                                          \
+    do {                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)                              \
+            g_stamps[blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime();                   \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+    } while (0)
+#define AGX_STAMP_ADD(slot, t0)                                                                  \
+    do {                                                                                         \
+        if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)                              \
+            g_stamps[blockIdx.x * 16 + (slot)] += __builtin_amdgcn_s_memtime() - (t0);           \
+    } while (0)
+#else
+#define AGX_STAMP(slot) ((void)0)
+#define AGX_STAMP_ADD(slot, t0) ((void)0)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Row of accumulator register r in lane half lh (C/D layout of v_mfma_f32_32x32x2_f32:
@@ -113,79 +134,99 @@ __device__ __forceinline__ void issue_rows_dma(float *__restrict__ buf, const fl
 // while the MFMAs of chunk c run (one barrier per chunk); A fragments (weights,
 // L2-resident) are prefetched one (chunk, tap) phase ahead into registers; B
 // fragments are single ds_read_b32, batched per phase.  xs holds 2 * CC * span floats.
-// ABL (ablation, timing-only diagnostic builds; 0 in every shipped launch):
-//   bit 0: skip the per-chunk input DMA, bit 1: skip the weight prefetch loads,
-//   bit 2: skip the per-chunk barrier.  Results are wrong by construction.
-struct NoChunkHook {
-    __device__ __forceinline__ void operator()(int, const float *) const {}
-};
+template <int NW, int CC>
+__device__ __forceinline__ void load_b_phase(float (&bf)[CC / 2][NW], const float *xj, int span,
+                                             const int (&bcol)[NW]) {
+#pragma unroll
+    for (int ks = 0; ks < CC / 2; ++ks)
+#pragma unroll
+        for (int k = 0; k < NW; ++k) bf[ks][k] = xj[ks * span + bcol[k]];
+}
 
-// on_chunk(c0, cur) is called once per channel chunk while its LDS tile `cur` is valid
-// (used by the fused residual block to pick the residual operand out of the staged input).
-template <int MW, int NW, int CC, int ABL = 0, typename Hook = NoChunkHook>
+// CC = channels per LDS chunk (one DMA hand-over + barrier per chunk); the register pipeline
+// works in phases of PC = min(CC, 16) channels x one tap (operand arrays sized for PC).
+template <int MW, int NW, int CC>
 __device__ __forceinline__ void conv_gemm(f32x16 (&acc)[MW][NW], float *__restrict__ xs,
                                           const float *__restrict__ xb, const float *__restrict__ wp,
                                           const ConvPlan &p, int M, int span, int in0,
-                                          const int (&arow)[MW], const int (&bcol)[NW], int wave, int lane,
-                                          Hook on_chunk = Hook()) {
+                                          const int (&arow)[MW], const int (&bcol)[NW], int wave, int lane) {
+    constexpr int PC = CC < 16 ? CC : 16;
+    constexpr int NH = CC / PC;  // register phases groups per chunk
     const int lh = lane >> 5;
     const int tid = wave * 64 + lane;
     float *buf0 = xs, *buf1 = xs + CC * span;
     for (int e = tid; e < 2 * CC * span; e += 256) xs[e] = 0.f;
-    float a_cur[CC / 2][MW], a_nxt[CC / 2][MW];
-    load_a_phase<MW, CC>(a_cur, wp, 0, 0, p.J, M, lh, arow);
+    float a_cur[PC / 2][MW], a_nxt[PC / 2][MW];
+    float b_cur[PC / 2][NW], b_nxt[PC / 2][NW];
+    load_a_phase<MW, PC>(a_cur, wp, 0, 0, p.J, M, lh, arow);
     __syncthreads();
     issue_rows_dma<CC>(buf0, xb, p.Lin, p.Lvalid, in0, span, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    AGX_STAMP(1);
     int it = 0;
     for (int c0 = 0; c0 < p.Cin; c0 += CC, ++it) {
         float *cur = (it & 1) ? buf1 : buf0;
         float *nxt = (it & 1) ? buf0 : buf1;
-        on_chunk(c0, cur);
-        for (int j = 0; j < p.J; ++j) {
-            int nj = j + 1, nc0 = c0;
-            if (nj == p.J) {
-                nj = 0;
-                nc0 += CC;
+        // first phase of the chunk: its B fragments can only be read now (the tile just landed)
+        load_b_phase<NW, PC>(b_cur, cur, span, bcol);
+        // retire these reads HERE (explicit lgkmcnt(0)): otherwise the loop header inherits them as
+        // pending and hipcc puts its s_waitcnt in front of every phase's MFMAs instead of in front of
+        // the end-of-phase register copies
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        for (int h = 0; h < NH; ++h) {
+            for (int j = 0; j < p.J; ++j) {
+                // next phase: (h, j+1) | (h+1, 0) | (next chunk, 0, 0)
+                int nj = j + 1, nh = h, nc0 = c0;
+                if (nj == p.J) {
+                    nj = 0;
+                    if (++nh == NH) {
+                        nh = 0;
+                        nc0 += CC;
+                    }
+                }
+                // Operands of the NEXT phase are requested before this phase's MFMAs issue, so neither
+                // the L2 latency of the weights nor the LDS latency of the input sits in front of an
+                // MFMA (a bare MFMA loop with its ds_read directly ahead of it loses 13-22 %:
+                // tools/mfma_peak.hip).
+                // (branch-free on purpose: behind a conditional load hipcc puts a full s_waitcnt in front
+                // of the MFMAs; after the very last phase the prefetch just re-reads phase 0)
+                const bool last = nc0 >= p.Cin;
+                load_a_phase<MW, PC>(a_nxt, wp, last ? 0 : nc0 + nh * PC, last ? 0 : nj, p.J, M, lh, arow);
+                // The next chunk's DMA goes out behind this phase's weight prefetch: vmcnt retires in
+                // order and hipcc waits vmcnt(0) for the prefetched weights at the top of the next
+                // phase, so the DMA gets a full phase of MFMAs to land instead of none.
+                if (h == 0 && j == 0 && c0 + CC < p.Cin)
+                    issue_rows_dma<CC>(nxt, xb + size_t(c0 + CC) * p.Lin, p.Lin, p.Lvalid, in0, span, wave, lane);
+                // next phase in this chunk; across a chunk boundary the value is discarded (b_cur is
+                // re-read after the barrier), so any in-range address will do
+                load_b_phase<NW, PC>(b_nxt, cur + (nc0 == c0 ? nh * PC * span + nj * p.d : 0), span, bcol);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < PC / 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < MW; ++i)
+#pragma unroll
+                        for (int k = 0; k < NW; ++k)
+                            acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ks][i], b_cur[ks][k], acc[i][k], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < PC / 2; ++ks) {
+#pragma unroll
+                    for (int i = 0; i < MW; ++i) a_cur[ks][i] = a_nxt[ks][i];
+#pragma unroll
+                    for (int k = 0; k < NW; ++k) b_cur[ks][k] = b_nxt[ks][k];
+                }
             }
-            if (!(ABL & 2) && nc0 < p.Cin) load_a_phase<MW, CC>(a_nxt, wp, nc0, nj, p.J, M, lh, arow);
-            if (ABL & 2) {
-#pragma unroll
-                for (int ks = 0; ks < CC / 2; ++ks)
-#pragma unroll
-                    for (int i = 0; i < MW; ++i) a_nxt[ks][i] = a_cur[ks][i] * 1.0001f;
-            }
-            // The next chunk's DMA goes out behind this phase's weight prefetch: vmcnt retires in
-            // order, and hipcc waits vmcnt(0) at the top of the next phase for the prefetched
-            // weights, so the DMA gets a full phase of MFMAs to land instead of none.
-            if (!(ABL & 1) && j == 0 && c0 + CC < p.Cin)
-                issue_rows_dma<CC>(nxt, xb + size_t(c0 + CC) * p.Lin, p.Lin, p.Lvalid, in0, span, wave, lane);
-            // pin the prefetch at the head of the phase: without the barrier hipcc sinks these
-            // loads to the end of the phase and waits vmcnt(0) for them at the top of the next one
-            __builtin_amdgcn_sched_barrier(0);
-            const float *xj = cur + j * p.d;
-            float bf[CC / 2][NW];
-#pragma unroll
-            for (int ks = 0; ks < CC / 2; ++ks)
-#pragma unroll
-                for (int k = 0; k < NW; ++k) bf[ks][k] = xj[ks * span + bcol[k]];
-#pragma unroll
-            for (int ks = 0; ks < CC / 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < MW; ++i)
-#pragma unroll
-                    for (int k = 0; k < NW; ++k)
-                        acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ks][i], bf[ks][k], acc[i][k], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ks = 0; ks < CC / 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < MW; ++i) a_cur[ks][i] = a_nxt[ks][i];
         }
+#ifdef AGX_STAMPS
+        const unsigned long long tw = __builtin_amdgcn_s_memtime();
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA of the next chunk has landed
-        if (!(ABL & 4)) __syncthreads();                   // everyone's has, and everyone is done reading cur
+        __syncthreads();                                   // everyone's has, and everyone is done reading cur
+        AGX_STAMP_ADD(8, tw);
     }
+    AGX_STAMP(2);
 }
 
 }  // namespace agx

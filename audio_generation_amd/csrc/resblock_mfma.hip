@@ -16,30 +16,11 @@
 // with the A fragment W2[co][that channel].  The hidden activation never leaves
 // the register file: no LDS round trip, no second kernel, and the memory-bound
 // k=1 conv of the unfused path disappears.
-#include <cstdlib>
-
 #include "mfma_tile.hpp"
 
 namespace agx {
 
-// Residual operand for accumulator registers of channel chunk IC, read from the
-// staged LDS tile (the same bytes GEMM1 consumes) instead of a second pass over HBM.
-// Chunk IC covers channels [IC*16, IC*16+16) = subtile IC/2, registers 8*(IC&1) .. +7.
-template <int IC, int MW, int NW>
-__device__ __forceinline__ void grab_residual(f32x16 (&xres)[MW][NW], const float *cur, int span,
-                                              const int (&rcol)[NW], int lh) {
-    if constexpr (IC * 16 < 32 * MW) {
-        constexpr int i = (IC * 16) / 32, r0 = 8 * (IC & 1);
-#pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-            const int chl = (rr & 3) + 8 * (rr >> 2) + 4 * lh;  // acc_row(r0 + rr, lh) - 16*(IC&1)
-#pragma unroll
-            for (int k = 0; k < NW; ++k) xres[i][k][r0 + rr] = cur[chl * span + rcol[k]];
-        }
-    }
-}
-
-template <int MW, int NW, int CC, int ABL = 0, bool RESL = true>
+template <int MW, int NW, int CC>
 __global__ __launch_bounds__(256, (MW <= 4 ? 2 : 1)) void resblock_mfma_kernel(ConvPlan p, int span, int post_act,
                                                             const float *__restrict__ x,
                                                             const float *__restrict__ w1,
@@ -56,6 +37,7 @@ __global__ __launch_bounds__(256, (MW <= 4 ? 2 : 1)) void resblock_mfma_kernel(C
     const int b = blockIdx.y;
     const int in0 = t0 - p.P;  // stride 1
 
+    AGX_STAMP(0);
     f32x16 acc[MW][NW];
 #pragma unroll
     for (int i = 0; i < MW; ++i)
@@ -68,33 +50,12 @@ __global__ __launch_bounds__(256, (MW <= 4 ? 2 : 1)) void resblock_mfma_kernel(C
 #pragma unroll
     for (int i = 0; i < MW; ++i) arow[i] = i * 32 + li;
 #pragma unroll
-    for (int k = 0; k < NW; ++k) bcol[k] = n0 + k * 32 + li + lh * (CC / 2) * span;
+    for (int k = 0; k < NW; ++k) bcol[k] = n0 + k * 32 + li + lh * ((CC < 16 ? CC : 16) / 2) * span;
 
     const float *xb = x + size_t(b) * C * p.Lin;
 
     // ---- GEMM1: h = W1 (*) x ------------------------------------------------------
-    // RES_LDS: keep the residual operand x[co][t] (this lane's output elements) in registers,
-    // picked from each staged chunk; costs 16*MW*NW VGPRs, so only while 2 waves/SIMD still fit.
-    constexpr bool RES_LDS = RESL && (MW <= 4) && CC == 16;
-    f32x16 xres[RES_LDS ? MW : 1][NW];
-    int rcol[NW];
-#pragma unroll
-    for (int k = 0; k < NW; ++k) rcol[k] = n0 + k * 32 + li + p.P;
-    auto hook = [&](int c0, const float *cur) {
-        if constexpr (RES_LDS) {
-            switch (c0 / 16) {
-                case 0: grab_residual<0, MW, NW>(xres, cur, span, rcol, lh); break;
-                case 1: grab_residual<1, MW, NW>(xres, cur, span, rcol, lh); break;
-                case 2: grab_residual<2, MW, NW>(xres, cur, span, rcol, lh); break;
-                case 3: grab_residual<3, MW, NW>(xres, cur, span, rcol, lh); break;
-                case 4: grab_residual<4, MW, NW>(xres, cur, span, rcol, lh); break;
-                case 5: grab_residual<5, MW, NW>(xres, cur, span, rcol, lh); break;
-                case 6: grab_residual<6, MW, NW>(xres, cur, span, rcol, lh); break;
-                default: grab_residual<7, MW, NW>(xres, cur, span, rcol, lh); break;
-            }
-        }
-    };
-    conv_gemm<MW, NW, CC, ABL>(acc, xs, xb, w1, p, C, span, in0, arow, bcol, wave, lane, hook);
+    conv_gemm<MW, NW, CC>(acc, xs, xb, w1, p, C, span, in0, arow, bcol, wave, lane);
 
     // ---- hidden activation, in registers --------------------------------------------
 #pragma unroll
@@ -109,6 +70,7 @@ __global__ __launch_bounds__(256, (MW <= 4 ? 2 : 1)) void resblock_mfma_kernel(C
             }
         }
 
+    AGX_STAMP(3);
     // ---- GEMM2: out = W2 . h, B operand = the accumulator registers -------------------
     f32x16 out[MW][NW];
 #pragma unroll
@@ -138,6 +100,7 @@ __global__ __launch_bounds__(256, (MW <= 4 ? 2 : 1)) void resblock_mfma_kernel(C
         }
     }
 
+    AGX_STAMP(4);
     // ---- epilogue: + b2 + x, trailing activation (loads hoisted, stores predicated) ----
     float *yb = y + size_t(b) * C * p.Lin;
 #pragma unroll
@@ -149,14 +112,12 @@ __global__ __launch_bounds__(256, (MW <= 4 ? 2 : 1)) void resblock_mfma_kernel(C
         for (int k = 0; k < NW; ++k) {
             const int t = t0 + n0 + k * 32 + li;
             const int tc = min(t, p.Lin - 1);
+            // residual operand: re-read from global (L2 / Infinity Cache).  Picking it out of the
+            // staged LDS tile instead was measured neutral at C <= 64 and 9 % slower at C = 128;
+            // prefetching it ahead of GEMM2 spills at 2 waves/SIMD and was 1-10 % slower.
             float xv[16];
-            if constexpr (RES_LDS) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) xv[r] = xres[io][k][r];
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) xv[r] = xb[size_t(io * 32 + acc_row(r, lh)) * p.Lin + tc];
-            }
+            for (int r = 0; r < 16; ++r) xv[r] = xb[size_t(io * 32 + acc_row(r, lh)) * p.Lin + tc];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = out[io][k][r] + bv[r] + xv[r];
@@ -165,15 +126,19 @@ __global__ __launch_bounds__(256, (MW <= 4 ? 2 : 1)) void resblock_mfma_kernel(C
             }
         }
     }
+    AGX_STAMP(5);
 }
 
-template <int MW, int NW, int CC, int ABL = 0, bool RESL = true>
+template <int MW, int NW, int CC>
 static int launch_rb(const ConvPlan &p, const float *x, const float *w1, const float *b1, const float *w2,
                      const float *b2, float *y, int post_act, hipStream_t st) {
     constexpr int BN = 32 * NW * 4;
     const int span = (BN - 1) + (p.J - 1) * p.d + 1;
-    const size_t lds = size_t(2) * CC * span * sizeof(float);  // double-buffered input tile
-    auto kern = resblock_mfma_kernel<MW, NW, CC, ABL, RESL>;
+    size_t lds = size_t(2) * CC * span * sizeof(float);  // double-buffered input tile
+    if (lds > 160 * 1024) return fail(AGX_ERR_UNSUPPORTED, "resblock: tile needs %zu B of LDS", lds);
+    const int wgs = tuning().rb_wgs;  // diagnostic: cap workgroups per CU by requesting more LDS
+    if (wgs >= 1 && wgs <= 3 && lds < size_t(160 * 1024) / wgs) lds = size_t(160 * 1024) / wgs;
+    auto kern = resblock_mfma_kernel<MW, NW, CC>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -187,19 +152,26 @@ static int launch_rb(const ConvPlan &p, const float *x, const float *w1, const f
     return check_launch("resblock_mfma");
 }
 
+static int rb_bn(int c) { return c == 32 ? 512 : (c == 64 ? 256 : 128); }
+
 bool resblock_fused_supported(const ConvPlan &p) {
     if (p.Cin != p.Cout || p.s != 1 || p.q != 1 || p.Lvalid != p.Lin || p.Lt != p.Lin) return false;
     if (p.Cin != 32 && p.Cin != 64 && p.Cin != 128 && p.Cin != 256) return false;
-    const int bn = p.Cin == 32 ? 512 : (p.Cin == 64 ? 256 : 128);
-    const size_t span = size_t(bn - 1) + size_t(p.J - 1) * p.d + 1;
+    const size_t span = size_t(rb_bn(p.Cin) - 1) + size_t(p.J - 1) * p.d + 1;
     return 2 * 16 * span * sizeof(float) <= 160 * 1024;
 }
 
+static bool rb_use_cc32(const ConvPlan &p) {
+    const size_t span = size_t(rb_bn(p.Cin) - 1) + size_t(p.J - 1) * p.d + 1;
+    return tuning().rb_cc == 32 && 2 * 32 * span * sizeof(float) <= 160 * 1024;
+}
+
 const char *resblock_variant(const ConvPlan &p) {
+    const bool c32 = rb_use_cc32(p);
     switch (p.Cin) {
-        case 32: return "resblock_mfma<1,4,16>";
-        case 64: return "resblock_mfma<2,2,16>";
-        case 128: return "resblock_mfma<4,1,16>";
+        case 32: return c32 ? "resblock_mfma<1,4,32>" : "resblock_mfma<1,4,16>";
+        case 64: return c32 ? "resblock_mfma<2,2,32>" : "resblock_mfma<2,2,16>";
+        case 128: return c32 ? "resblock_mfma<4,1,32>" : "resblock_mfma<4,1,16>";
         default: return "resblock_mfma<8,1,16>";
     }
 }
@@ -207,22 +179,15 @@ const char *resblock_variant(const ConvPlan &p) {
 int launch_resblock_fused(const ConvPlan &p, const float *x, const float *w1, const float *b1,
                           const float *w2, const float *b2, float *y, int post_act, hipStream_t st) {
     if (!resblock_fused_supported(p)) return fail(AGX_ERR_UNSUPPORTED, "resblock: no fused kernel for C=%d", p.Cin);
-    const bool resl = tuning().resblock_res_lds != 0;
-#define AGX_RB(MW, NW, ABL)                                                                   \
-    (resl ? launch_rb<MW, NW, 16, ABL, true>(p, x, w1, b1, w2, b2, y, post_act, st)          \
-          : launch_rb<MW, NW, 16, ABL, false>(p, x, w1, b1, w2, b2, y, post_act, st))
+    const bool c32 = rb_use_cc32(p);
+#define AGX_RB(MW, NW)                                                          \
+    (c32 ? launch_rb<MW, NW, 32>(p, x, w1, b1, w2, b2, y, post_act, st)        \
+         : launch_rb<MW, NW, 16>(p, x, w1, b1, w2, b2, y, post_act, st))
     switch (p.Cin) {
-        case 32: return AGX_RB(1, 4, 0);
-        case 64: return AGX_RB(2, 2, 0);
-        case 128:
-            switch (tuning().ablate) {  // timing-only diagnostic builds of this one shape
-                case 1: return AGX_RB(4, 1, 1);
-                case 2: return AGX_RB(4, 1, 2);
-                case 3: return AGX_RB(4, 1, 3);
-                case 7: return AGX_RB(4, 1, 7);
-                default: return AGX_RB(4, 1, 0);
-            }
-        default: return launch_rb<8, 1, 16, 0, false>(p, x, w1, b1, w2, b2, y, post_act, st);
+        case 32: return AGX_RB(1, 4);
+        case 64: return AGX_RB(2, 2);
+        case 128: return AGX_RB(4, 1);
+        default: return launch_rb<8, 1, 16>(p, x, w1, b1, w2, b2, y, post_act, st);
     }
 #undef AGX_RB
 }

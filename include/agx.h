@@ -40,8 +40,8 @@ const char *agx_last_error(void);
 
 /* Diagnostic tuning knobs (A/B experiments from one process; defaults are the
  * shipped configuration).  Unknown names return AGX_ERR_BAD_SHAPE.
- *   "resblock_res_lds" 1/0  residual operand from the staged LDS tile / re-read from HBM
- *   "ablate"           bits timing-only ablation of the C=128 residual block (0 = off)      */
+ *   "rb_cc"  16 | 32   channels per LDS chunk of the fused residual block
+ *   "rb_wgs" 0 | 1..3  cap on resident workgroups per CU of the fused residual block (0 = natural) */
 int agx_set_tuning(const char *name, int32_t value);
 int agx_get_tuning(const char *name);
 
