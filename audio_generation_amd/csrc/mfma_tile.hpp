@@ -155,7 +155,19 @@ __device__ __forceinline__ void conv_gemm(f32x16 (&acc)[MW][NW], float *__restri
     const int lh = lane >> 5;
     const int tid = wave * 64 + lane;
     float *buf0 = xs, *buf1 = xs + CC * span;
-    for (int e = tid; e < 2 * CC * span; e += 256) xs[e] = 0.f;
+    // Zero only the positions the DMA will never write (outside [0, Lvalid)): interior tiles have
+    // none, so the fill is skipped there instead of costing 2*CC*span/256 LDS stores per thread.
+    {
+        const int lo = min(max(-in0, 0), span);                 // first in-range tile position
+        const int hi = max(min(p.Lvalid - in0, span), lo);      // one past the last
+        if (lo > 0 || hi < span) {
+            const int nz = lo + (span - hi);                    // out-of-range positions per row
+            for (int e = tid; e < 2 * CC * nz; e += 256) {
+                const int row = e / nz, i = e - row * nz;
+                xs[row * span + (i < lo ? i : hi + (i - lo))] = 0.f;
+            }
+        }
+    }
     float a_cur[PC / 2][MW], a_nxt[PC / 2][MW];
     float b_cur[PC / 2][NW], b_nxt[PC / 2][NW];
     load_a_phase<MW, PC>(a_cur, wp, 0, 0, p.J, M, lh, arow);

@@ -101,28 +101,40 @@ __global__ __launch_bounds__(256, (MW <= 4 ? 2 : 1)) void resblock_mfma_kernel(C
     }
 
     AGX_STAMP(4);
-    // ---- epilogue: + b2 + x, trailing activation (loads hoisted, stores predicated) ----
+    // ---- epilogue: + b2 + x, trailing activation.  ALL residual loads go out first (the GEMM1
+    // accumulators are dead, so their registers hold the 16*MW*NW operands): one exposed memory
+    // latency per workgroup instead of one per 32x32 block.
     float *yb = y + size_t(b) * C * p.Lin;
+    constexpr int EG = MW <= 2 ? MW : 2;  // row blocks per load batch (register budget at 2 waves/SIMD)
 #pragma unroll
-    for (int io = 0; io < MW; ++io) {
-        float bv[16];
+    for (int g0 = 0; g0 < MW; g0 += EG) {
+        float xv[EG][NW][16];
+        __builtin_amdgcn_sched_barrier(0);  // keep each batch of loads where it is written
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bv[r] = b2 ? b2[io * 32 + acc_row(r, lh)] : 0.f;
+        for (int ig = 0; ig < EG; ++ig)
 #pragma unroll
-        for (int k = 0; k < NW; ++k) {
-            const int t = t0 + n0 + k * 32 + li;
-            const int tc = min(t, p.Lin - 1);
-            // residual operand: re-read from global (L2 / Infinity Cache).  Picking it out of the
-            // staged LDS tile instead was measured neutral at C <= 64 and 9 % slower at C = 128;
-            // prefetching it ahead of GEMM2 spills at 2 waves/SIMD and was 1-10 % slower.
-            float xv[16];
+            for (int k = 0; k < NW; ++k) {
+                const int tc = min(t0 + n0 + k * 32 + li, p.Lin - 1);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) xv[r] = xb[size_t(io * 32 + acc_row(r, lh)) * p.Lin + tc];
+                for (int r = 0; r < 16; ++r)
+                    xv[ig][k][r] = xb[((g0 + ig) * 32 + acc_row(r, lh)) * p.Lin + tc];
+            }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = out[io][k][r] + bv[r] + xv[r];
-                if (post_act) v = leaky(v, p.slope);
-                if (t < p.Lin) yb[size_t(io * 32 + acc_row(r, lh)) * p.Lin + t] = v;
+        for (int ig = 0; ig < EG; ++ig) {
+            const int io = g0 + ig;
+            float bv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bv[r] = b2 ? b2[io * 32 + acc_row(r, lh)] : 0.f;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) {
+                const int t = t0 + n0 + k * 32 + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = out[io][k][r] + bv[r] + xv[ig][k][r];
+                    if (post_act) v = leaky(v, p.slope);
+                    if (t < p.Lin) yb[(io * 32 + acc_row(r, lh)) * p.Lin + t] = v;
+                }
             }
         }
     }

@@ -200,9 +200,16 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch N > 1 through `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    agx_dist.init("nccl")
+    # one GPU per rank.  AGX_DIST_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than
+    # ranks (ranks then share devices and the barrier / MAX-reduce run on CPU tensors).
+    backend = os.environ.get("AGX_DIST_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and world > n_dev:
+        raise SystemExit(f"{world} ranks but {n_dev} GPUs visible")
+    torch.cuda.set_device(local_rank % n_dev)
+    dev = torch.device("cuda", local_rank % n_dev)
+    agx_dist.init(backend)
+    red_dev = dev if backend == "nccl" else "cpu"
 
     bsz = args.batch_per_gpu
     model = build_model(dev)
@@ -232,7 +239,7 @@ def main():
     torch.cuda.synchronize()
     agx_dist.barrier()
     torch.cuda.synchronize()
-    elapsed = agx_dist.max_over_ranks(time.perf_counter() - t0, device=dev)
+    elapsed = agx_dist.max_over_ranks(time.perf_counter() - t0, device=red_dev)
     y, commit, index = out
 
     ms_per_step = 1e3 * elapsed / args.steps
