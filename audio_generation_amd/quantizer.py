@@ -106,8 +106,21 @@ class ResidualQuantizer(nn.Module):
 
     def _quantize(self, x: Tensor, layout: str, codebook_n, update_codebook: bool):
         q_used = self._q_used(codebook_n)
-        xq, index, sq_err = ops.rvq_forward(x, self.codebooks.detach(), self._packed_codebooks(), q_used, layout)
-        commit = (sq_err.sum() / float(x.numel())).to(torch.float32)
+        xq, index, sq_err = ops.rvq_forward(x.detach(), self.codebooks.detach(), self._packed_codebooks(), q_used,
+                                            layout)
+        if torch.is_grad_enabled() and x.requires_grad:
+            # training semantics (build-defined, the external module's are unknown): straight-through
+            # estimator for x_q, and a commitment loss that is differentiable in the encoder output --
+            # sum over stages of mean((x - sum_{p<=q} c_p)^2) with the selected codewords detached.
+            partial, commit = None, x.new_zeros(())
+            for q in range(q_used):
+                c = ops.rvq_dequantize(self.codebooks.detach()[q], index[..., q])          # (B,T,D)
+                c = c if layout == "b l c" else c.transpose(1, 2)
+                partial = c if partial is None else partial + c
+                commit = commit + ((x - partial) ** 2).mean()
+            xq = x + (xq - x).detach()
+        else:
+            commit = (sq_err.sum() / float(x.numel())).to(torch.float32)
         if update_codebook and self.training:
             frames = x if layout == "b l c" else x.transpose(1, 2)
             self._ema_update(frames.reshape(-1, self.dim), index.reshape(-1, q_used))
@@ -154,6 +167,9 @@ class ResidualQuantizer(nn.Module):
         cb[0].copy_(frames[pick] + 0.1 * sigma * noise[0])
         for q in range(1, self.num_quantizers):
             cb[q].copy_(noise[q] * (sigma * decay ** q))
+        # keep the EMA statistics consistent with the new codewords (codebook = ema_sum / frequency)
+        self.cluster_frequency.fill_(1.0)
+        self.ema_sum.copy_(cb)
         return sigma
 
     def get_stale_clusters(self) -> List[int]:

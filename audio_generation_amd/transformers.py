@@ -19,9 +19,11 @@ from __future__ import annotations
 from typing import Optional
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from . import ops
+from .autograd_bridge import hip_forward_aten_backward, needs_grad
 from ._lib import CONV_CAUSAL, EPI_GELU_PRE, EPI_RESIDUAL, AgxError
 
 Tensor = torch.Tensor
@@ -176,13 +178,32 @@ class Transformer(nn.Module):
                            FeedForward(dim, dim, dropout=dropout)])
             for _ in range(depth)])
 
-    def run_bct(self, x: Tensor) -> Tensor:
-        """Channel-major (B, dim, T) in and out: 7 launches per layer, both
-        residual adds fused into the W_o / FFN-out conv epilogues."""
+    def _hip_bct(self, x: Tensor) -> Tensor:
         for attention, ff in self.layers:
             x = attention.run_bct(x, residual=x)
             x = ff.run_bct(x, residual=x)
         return x
+
+    def _aten_bct(self, x: Tensor) -> Tensor:
+        """ATen restatement for the interim backward bridge only (autograd_bridge.py)."""
+        x = x.transpose(1, 2)
+        for attention, ff in self.layers:
+            b, t, _ = x.shape
+            xn = attention.norm(x)
+            q, k, v = (lin(xn).reshape(b, t, attention.n_heads, attention.dim_head).transpose(1, 2)
+                       for lin in (attention.W_q, attention.W_k, attention.W_v))
+            s = q @ k.transpose(-1, -2) / (attention.dim_head ** 0.5) + attention.alibi_obj.get_M(crop=(t, t))
+            o = (s.softmax(dim=-1) @ v).transpose(1, 2).reshape(b, t, attention.inner_dim)
+            x = x + attention.W_o(o)
+            x = x + ff.net(x)
+        return x.transpose(1, 2)
+
+    def run_bct(self, x: Tensor) -> Tensor:
+        """Channel-major (B, dim, T) in and out: 7 launches per layer, both residual adds fused into
+        the W_o / FFN-out conv epilogues.  With autograd on, the backward is bridged through ATen."""
+        if needs_grad(x, self):
+            return hip_forward_aten_backward(self._hip_bct, self._aten_bct, x, list(self.parameters()))
+        return self._hip_bct(x)
 
     def forward(self, x: Tensor, y=None) -> Tensor:
         if y is not None:

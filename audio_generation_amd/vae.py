@@ -9,7 +9,9 @@ called: every layer runs as a hand-written HIP kernel behind the C ABI of
 ``forward`` walks it and issues fused launches (residual block = one call,
 activation / padding / crop / upsample folded into the conv kernels).
 
-Forward only for now: backward kernels are SURVEY 8(f1).
+Differentiation: the forward always runs on libagx; when autograd needs a
+gradient the backward is bridged through an ATen restatement of the same stack
+(``autograd_bridge.py`` -- interim until the backward kernels of SURVEY 8(f1)).
 """
 from __future__ import annotations
 
@@ -17,9 +19,11 @@ import math
 from typing import List, Optional, Sequence
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from . import ops
+from .autograd_bridge import hip_forward_aten_backward, needs_grad
 from ._lib import (CONV_CAUSAL, CONV_TRANSPOSED, CONV_UPSAMPLE, EPI_LEAKY_POST, EPI_LEAKY_PRE,
                    IMPL_AUTO, AgxError)
 
@@ -81,6 +85,14 @@ class _ConvParams(nn.Module):
         self._packed: Optional[Tensor] = None
         self._packed_key = None
 
+    def aten_weight(self) -> Tensor:
+        """Plain weight as a differentiable function of the parameters (backward bridge only)."""
+        if hasattr(self, "weight_v"):
+            v, g = self.weight_v, self.weight_g
+            norm = v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, 1, 1)
+            return v * (g / norm)
+        return self.weight
+
     def packed(self, kind: int) -> Tensor:
         """Packed (weight-norm folded) image, rebuilt when the parameters change
         (optimizer step, ``load_state_dict``, ``.to(device)``)."""
@@ -115,9 +127,20 @@ class _ConvBase(nn.Module):
         return self.run(x)
 
 
+def _act_aten(x: Tensor, slope: Optional[float]) -> Tensor:
+    return x if slope is None else F.leaky_relu(x, slope)
+
+
 class CausalConv1d(_ConvBase):
     """networks/vae.py:14-43."""
     kind = CONV_CAUSAL
+
+    def _aten(self, x: Tensor) -> Tensor:  # backward bridge only (autograd_bridge.py)
+        c = self.conv
+        k, s, d = c.kernel_size[0], c.stride[0], c.dilation[0]
+        nxt = (x.shape[-1] - k + self.pad) / s + 1
+        extra = (math.ceil(nxt) - 1) * s + k - self.pad - x.shape[-1]
+        return F.conv1d(F.pad(x, (self.pad, extra)), c.aten_weight(), c.bias, stride=s, dilation=d)
 
     def __init__(self, in_channels, out_channels, kernel_size, dilation=1, stride=1, bias=True,
                  groups=1, norm="weight"):
@@ -138,6 +161,10 @@ class CausalConvT1d(_ConvBase):
         self.conv = _ConvParams(in_channels, out_channels, kernel_size, stride, 1, bias, True, norm)
         self.right_pad = kernel_size - stride
 
+    def _aten(self, x: Tensor) -> Tensor:  # backward bridge only
+        y = F.conv_transpose1d(x, self.conv.aten_weight(), self.conv.bias, stride=self.conv.stride[0])
+        return y[..., : y.shape[-1] - self.right_pad]
+
 
 class CausalUpsampleConv1d(_ConvBase):
     """networks/vae.py:66-89 (nearest upsample + ``padding="same"`` conv; not
@@ -149,6 +176,10 @@ class CausalUpsampleConv1d(_ConvBase):
         super().__init__()
         self.scale_factor = stride
         self.conv = _ConvParams(in_channels, out_channels, kernel_size, stride, 1, bias, False, norm)
+
+    def _aten(self, x: Tensor) -> Tensor:  # backward bridge only
+        up = x.repeat_interleave(self.scale_factor, dim=-1)
+        return F.conv1d(up, self.conv.aten_weight(), self.conv.bias, padding="same")
 
 
 class CausalResidualBlock1d(nn.Module):
@@ -188,6 +219,9 @@ class CausalResidualBlock1d(nn.Module):
         return ops.resblock_forward(desc, x, c1.packed(CONV_CAUSAL), b1, c2.packed(CONV_CAUSAL), b2,
                                     post_act=post_slope is not None)
 
+    def _aten(self, x: Tensor) -> Tensor:  # backward bridge only
+        return x + self.conv2._aten(_act_aten(self.conv1._aten(x), _leaky_slope(self.activation)))
+
     def forward(self, x: Tensor) -> Tensor:
         return self.run(x, None)
 
@@ -212,6 +246,11 @@ class CausalEncoderBlock(nn.Module):
     def forward(self, x: Tensor) -> Tensor:
         for seq in self.layers:
             x = _run_fused_pair(seq[0], seq[1], x)
+        return x
+
+    def _aten(self, x: Tensor) -> Tensor:  # backward bridge only
+        for seq in self.layers:
+            x = _act_aten(seq[0]._aten(x), _leaky_slope(seq[1]))
         return x
 
 
@@ -244,6 +283,12 @@ class CausalDecoderBlock(nn.Module):
         x = _run_fused_pair(self.in_conv[0], self.in_conv[1], x)
         for seq in self.layers:
             x = _run_fused_pair(seq[0], seq[1], x)
+        return x
+
+    def _aten(self, x: Tensor) -> Tensor:  # backward bridge only
+        x = _act_aten(self.in_conv[0]._aten(x), _leaky_slope(self.in_conv[1]))
+        for seq in self.layers:
+            x = _act_aten(seq[0]._aten(x), _leaky_slope(seq[1]))
         return x
 
 
@@ -316,7 +361,7 @@ class CausalVQAE(nn.Module):
     def rearrange_out(self, x: Tensor) -> Tensor:
         return x.transpose(1, 2).contiguous() if self.input_format == "b l c" else x
 
-    def _run_encoders(self, x: Tensor) -> Tensor:
+    def _encoders_hip(self, x: Tensor) -> Tensor:
         first = self.encoders[0]
         if not isinstance(first[0], nn.Identity):
             raise NotImplementedError("only norm=Identity (the reference default) has a HIP path")
@@ -325,10 +370,35 @@ class CausalVQAE(nn.Module):
             x = enc(x)
         return x
 
-    def _run_decoders(self, x: Tensor) -> Tensor:
+    def _decoders_hip(self, x: Tensor) -> Tensor:
         for dec in self.decoders:
             x = dec(x)
         return x
+
+    def _encoders_aten(self, x: Tensor) -> Tensor:  # backward bridge only
+        x = self.encoders[0][1]._aten(x)
+        for enc in list(self.encoders)[1:]:
+            x = enc._aten(x)
+        return x
+
+    def _decoders_aten(self, x: Tensor) -> Tensor:  # backward bridge only
+        for dec in self.decoders:
+            x = dec._aten(x)
+        return x
+
+    def _run_encoders(self, x: Tensor) -> Tensor:
+        """Encoder stack: libagx forward; when a gradient is needed the backward is bridged
+        through ATen (autograd_bridge.py -- interim until SURVEY 8(f1))."""
+        if needs_grad(x, self.encoders):
+            return hip_forward_aten_backward(self._encoders_hip, self._encoders_aten, x,
+                                             list(self.encoders.parameters()))
+        return self._encoders_hip(x)
+
+    def _run_decoders(self, x: Tensor) -> Tensor:
+        if needs_grad(x, self.decoders):
+            return hip_forward_aten_backward(self._decoders_hip, self._decoders_aten, x,
+                                             list(self.decoders.parameters()))
+        return self._decoders_hip(x)
 
     def encode(self, x, update_codebook=False, codebook_n=None, prioritize_early=False):
         """vae.py:307-322 -> (x_q (B,C,T), commit_loss, index (B,T,Q))."""

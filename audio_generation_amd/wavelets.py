@@ -18,6 +18,7 @@ from math import sqrt
 from typing import Optional
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from . import ops
@@ -114,6 +115,17 @@ class WaveletLayer(nn.Module):
             scale = scale.repeat(hidden_channels).reshape(1, hidden_channels, 1, 1)
         self.wavelet_scale = nn.Parameter(scale)
         self.register_buffer("cos_kernel", torch.cos(self.space))
+
+    def _aten(self, x: Tensor) -> Tensor:
+        """ATen restatement for the interim backward bridge only (autograd_bridge.py)."""
+        h = F.conv1d(x, self.conv_in.weight, self.conv_in.bias, padding="same").unsqueeze(-1)
+        y = (torch.cos(self.space) * torch.exp(-(self.space ** 2) / self.wavelet_scale) * h).flatten(2)
+        expected = y.shape[-1] // self.fold_dim
+        out = y.unfold(-1, self.n_points, self.fold_dim).sum(dim=-1)
+        short = out.shape[-1] - expected
+        if short < 0:
+            out = torch.cat([out, y[..., short:]], dim=-1)
+        return F.conv1d(out, self.conv_out.weight, self.conv_out.bias, padding="same")
 
     def run_fused(self, x: Tensor, post_slope: Optional[float] = None) -> Tensor:
         h = self.conv_in.run(x, CONV_SAME)

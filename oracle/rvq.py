@@ -136,6 +136,21 @@ def residual_quantize(x: Tensor, codebooks: Tensor, codebook_n: Optional[int] = 
             torch.tensor(commit, dtype=torch.float32))
 
 
+def residual_quantize_train(x: Tensor, codebooks: Tensor, codebook_n: Optional[int] = None
+                            ) -> Tuple[Tensor, Tensor, Tensor]:
+    """Training-mode semantics of the build's quantiser (build-defined; the external module's
+    are unknown): straight-through estimator ``x + (x_q - x).detach()`` and the commitment
+    loss ``sum_q mean((x - sum_{p<=q} c_p)^2)`` with the selected codewords detached, so the
+    loss is differentiable in the encoder output.  Differentiable torch ops on CPU."""
+    xq, index, _ = residual_quantize(x.detach(), codebooks, codebook_n)
+    partial, commit = None, x.new_zeros(())
+    for q in range(index.shape[-1]):
+        c = codebooks.detach()[q][index[..., q]]
+        partial = c if partial is None else partial + c
+        commit = commit + ((x - partial) ** 2).mean()
+    return x + (xq - x).detach(), index, commit
+
+
 def dequantize(codebook: Tensor, idx: Tensor) -> Tensor:
     """``quantizers[i].dequantize(idx)`` (call site vae.py:333): plain gather,
     (..,) int -> (.., D)."""
