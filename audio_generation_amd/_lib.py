@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libagx.so")
 # constants mirrored from include/agx.h
 CONV_CAUSAL, CONV_TRANSPOSED, CONV_UPSAMPLE, CONV_SAME = 0, 1, 2, 3
 IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA = 0, 1, 2
-EPI_LEAKY_PRE, EPI_RESIDUAL, EPI_LEAKY_POST, EPI_GELU_PRE = 1, 2, 4, 8
+EPI_LEAKY_PRE, EPI_RESIDUAL, EPI_LEAKY_POST, EPI_GELU_PRE, EPI_MASK = 1, 2, 4, 8, 16
 
 
 class ConvDesc(Structure):
@@ -38,6 +38,9 @@ SIGNATURES = {
     "agx_conv_packed_floats": (c_int64, [_PD]),
     "agx_conv_pack": (c_int, [_PD, c_void_p, c_void_p, c_void_p, c_void_p]),
     "agx_conv_forward": (c_int, [_PD, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "agx_conv_bwd_packed_floats": (c_int64, [_PD]),
+    "agx_conv_pack_bwd": (c_int, [_PD, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "agx_conv_bwd_data": (c_int, [_PD, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     "agx_conv_kernel_name": (c_int, [_PD, c_char_p, c_size_t]),
     "agx_resblock_workspace_bytes": (c_size_t, [_PD]),
     "agx_resblock_kernel_name": (c_int, [_PD, c_char_p, c_size_t]),

@@ -48,6 +48,8 @@ struct ConvPlan {
     int M;       // q * Cout  (rows of the implicit GEMM)
     int epilogue;
     float slope;
+    int oshift;         // output index = q*t + p - oshift (backward-data of strided convs), 0 otherwise
+    const float *mask;  // AGX_EPI_MASK: v *= (mask[o] > 0 ? 1 : slope)  (LeakyReLU gradient), else unused
 };
 
 // Packed weight image ("group-K-major"): channels in groups of 16,
@@ -64,5 +66,8 @@ __host__ __device__ inline size_t packed_weight_index(int ci, int j, int m, int 
 
 // Lower a descriptor; returns AGX_OK or an error (message set).
 int lower_conv(const agx_conv_desc *d, ConvPlan *p);
+// Plan of the backward-data op of layer `d` (gradient w.r.t. the layer input, given the gradient
+// w.r.t. its output): the same polyphase form with input/output channels swapped.
+int lower_conv_bwd_data(const agx_conv_desc *d, ConvPlan *p);
 
 }  // namespace agx

@@ -60,14 +60,15 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvPlan p, int ci_til
         const int m = m0 + r;
         if (m >= p.M) break;
         const int co = m / p.q, ph = m - co * p.q;
-        const int u = t * p.q + ph;
-        if (u >= p.Lout) continue;
+        const int u = t * p.q + ph - p.oshift;
+        if (u < 0 || u >= p.Lout) continue;
         float v = acc[r] + (bias ? bias[co] : 0.f);
         if (p.epilogue & AGX_EPI_LEAKY_PRE) v = v > 0.f ? v : v * p.slope;
         if (p.epilogue & AGX_EPI_GELU_PRE) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
         const size_t o = (size_t(b) * p.Cout + co) * p.Lout + u;
         if (p.epilogue & AGX_EPI_RESIDUAL) v += res[o];
         if (p.epilogue & AGX_EPI_LEAKY_POST) v = v > 0.f ? v : v * p.slope;
+        if (p.epilogue & AGX_EPI_MASK) v = p.mask[o] > 0.f ? v : v * p.slope;
         y[o] = v;
     }
 }

@@ -63,9 +63,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
     const float *xb = x + size_t(b) * p.Cin * p.Lin;
     conv_gemm<MW, NW, CC>(acc, xs, xb, wp, p, p.M, span, in0, arow, bcol, wave, lane);
 
-    // ---- epilogue.  All loads (bias, residual) are issued on clamped addresses before
+    // ---- epilogue.  All loads (bias, residual, mask) are issued on clamped addresses before
     // any use so they overlap; only the stores are predicated.
-    const bool has_res = (p.epilogue & AGX_EPI_RESIDUAL) != 0;
+    const bool has_res = (p.epilogue & AGX_EPI_RESIDUAL) != 0, has_mask = (p.epilogue & AGX_EPI_MASK) != 0;
     const bool pre = (p.epilogue & AGX_EPI_LEAKY_PRE) != 0, post = (p.epilogue & AGX_EPI_LEAKY_POST) != 0;
     const bool gelu = (p.epilogue & AGX_EPI_GELU_PRE) != 0;
 #pragma unroll
@@ -84,15 +84,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
             const int t = t0 + n0 + k * 32 + li;
             const int tc = min(t, p.Lt - 1);
             size_t off[16];
-            float rv[16];
+            float rv[16], mv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int u = min(tc * p.q + ph[r], p.Lout - 1);
+                const int u = min(max(tc * p.q + ph[r] - p.oshift, 0), p.Lout - 1);
                 off[r] = (size_t(b) * p.Cout + co[r]) * p.Lout + u;
             }
             if (has_res) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) rv[r] = res[off[r]];
+            }
+            if (has_mask) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mv[r] = p.mask[off[r]];
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -101,7 +105,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
                 if (gelu) v = gelu_erf(v);
                 if (has_res) v += rv[r];
                 if (post) v = leaky(v, p.slope);
-                const bool ok = t < p.Lt && (m0 + i * 32 + acc_row(r, lh)) < p.M && (t * p.q + ph[r]) < p.Lout;
+                if (has_mask) v = mv[r] > 0.f ? v : v * p.slope;
+                const int u = t * p.q + ph[r] - p.oshift;
+                const bool ok = t < p.Lt && (m0 + i * 32 + acc_row(r, lh)) < p.M && u >= 0 && u < p.Lout;
                 if (ok) y[off[r]] = v;
             }
         }

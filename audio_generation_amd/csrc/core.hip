@@ -109,6 +109,58 @@ int lower_conv(const agx_conv_desc *d, ConvPlan *p) {
             return fail(AGX_ERR_BAD_SHAPE, "conv: unknown kind %d", d->kind);
     }
     p->M = p->q * p->Cout;
+    p->oshift = 0;
+    p->mask = nullptr;
+    return AGX_OK;
+}
+
+// d(out)/d(in) of the forward plan  y[co, q t + p] = sum Wp[ci,j][co,p] x[ci, t s + j d - P]:
+//   * s == 1 (stride-1 causal / same convs): correlation with the flipped kernel,
+//       dx[ci, i] = sum_{co,j'} W[co,ci,J-1-j'] dy[co, i + j' d - ((J-1) d - P)]
+//   * s > 1, q == 1 (strided down conv, d == 1): i + P = s t' + p'  =>  dx[s t' + p' - P] =
+//       sum_m W[., p' + s m] dy[t' - m]   -- the transposed-conv phase form with an output shift of P
+//   * q > 1 (polyphase upsample / transposed forward, s == d == 1): a strided conv over dy,
+//       dx[ci, i] = sum_{co,k} Wp[p = k % q][ci][j = J-1 - k / q][co] dy[co, q i + k - q (J-1-P)]
+int lower_conv_bwd_data(const agx_conv_desc *d, ConvPlan *b) {
+    ConvPlan f;
+    int rc = lower_conv(d, &f);
+    if (rc != AGX_OK) return rc;
+    if (f.Lvalid != f.Lin) return fail(AGX_ERR_UNSUPPORTED, "bwd_data: cropped inputs (negative right pad) not supported");
+    *b = f;
+    b->Cin = f.Cout;
+    b->Cout = f.Cin;
+    b->Lin = f.Lout;   // the op reads dy
+    b->Lvalid = f.Lout;
+    b->Lout = f.Lin;   // and writes dx
+    b->epilogue = 0;
+    b->mask = nullptr;
+    b->oshift = 0;
+    if (f.q == 1 && f.s == 1) {
+        b->q = 1;
+        b->J = f.J;
+        b->s = 1;
+        b->d = f.d;
+        b->P = (f.J - 1) * f.d - f.P;
+        b->Lt = f.Lin;
+    } else if (f.q == 1) {
+        if (f.d != 1) return fail(AGX_ERR_UNSUPPORTED, "bwd_data: strided conv with dilation > 1");
+        b->q = f.s;
+        b->J = (f.J + f.s - 1) / f.s;
+        b->s = 1;
+        b->d = 1;
+        b->P = b->J - 1;
+        b->oshift = f.P;
+        b->Lt = (f.Lin + f.P + f.s - 1) / f.s;  // t' up to the last i + P
+        if (f.P < 0) return fail(AGX_ERR_UNSUPPORTED, "bwd_data: negative left pad");
+    } else {
+        b->q = 1;
+        b->J = f.q * f.J;
+        b->s = f.q;
+        b->d = 1;
+        b->P = f.q * (f.J - 1 - f.P);
+        b->Lt = f.Lin;
+    }
+    b->M = b->q * b->Cout;
     return AGX_OK;
 }
 

@@ -32,6 +32,25 @@ __global__ void fill_ones_kernel(float *p, int n) {
 
 __device__ __forceinline__ int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
+// Folded forward weight of the polyphase form: coefficient of x[ci, t*s + j*d - P] in y[co, q*t + ph].
+__device__ __forceinline__ float fwd_weight(const float *__restrict__ v, const float *__restrict__ scale,
+                                            int kind, int Cin, int Cout, int K, int J, int P, int up, int ci,
+                                            int j, int co, int ph) {
+    if (kind == AGX_CONV_CAUSAL || kind == AGX_CONV_SAME) return v[(size_t(co) * Cin + ci) * K + j] * scale[co];
+    if (kind == AGX_CONV_UPSAMPLE) {
+        // taps k of the high-rate 'same' conv that land on low-rate offset j - P
+        const int pl = (K - 1) / 2;
+        const float sc = scale[co];
+        float out = 0.f;
+        for (int k = 0; k < K; ++k)
+            if (floordiv(ph + k - pl, up) == j - P) out += v[(size_t(co) * Cin + ci) * K + k] * sc;
+        return out;
+    }
+    // AGX_CONV_TRANSPOSED: weight (Cin, Cout, K), norm over dim 0 = Cin
+    const int k = ph + up * (J - 1 - j);
+    return k < K ? v[(size_t(ci) * Cout + co) * K + k] * scale[ci] : 0.f;
+}
+
 // packed[((ci/16)*J + j) * M + co*q + ph][ci%16]  (common.hpp: packed_weight_index)
 __global__ __launch_bounds__(256) void pack_kernel(const float *__restrict__ v,
                                                    const float *__restrict__ scale,
@@ -50,24 +69,80 @@ __global__ __launch_bounds__(256) void pack_kernel(const float *__restrict__ v,
         packed[e] = 0.f;
         return;
     }
-    const int co = m / q, ph = m % q;
+    packed[e] = fwd_weight(v, scale, kind, Cin, Cout, K, J, P, up, ci, j, m / q, m % q);
+}
+
+// Packed image of the BACKWARD-DATA op (core.hip: lower_conv_bwd_data).  (Cin, Cout, K, q, J, P, s) are
+// the FORWARD plan's; the image has fwd-Cout "input" channels and M_b = q_b * fwd-Cin rows.
+__global__ __launch_bounds__(256) void pack_bwd_kernel(const float *__restrict__ v,
+                                                       const float *__restrict__ scale,
+                                                       float *__restrict__ packed, int kind, int Cin,
+                                                       int Cout, int K, int q, int J, int P, int s, int up,
+                                                       int Jb, int qb) {
+    const int Mb = qb * Cin;
+    const int64_t total = packed_weight_floats(Cout, Jb, Mb);
+    const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int c16 = int(e % kWG);
+    const int m = int((e / kWG) % Mb);
+    const int gj = int(e / (int64_t(kWG) * Mb));
+    const int jb = gj % Jb, co = (gj / Jb) * kWG + c16;  // bwd input channel = fwd output channel
+    if (co >= Cout) {
+        packed[e] = 0.f;
+        return;
+    }
+    const int ci = m / qb, phb = m % qb;  // bwd output channel = fwd input channel
     float out = 0.f;
-    if (kind == AGX_CONV_CAUSAL || kind == AGX_CONV_SAME) {
-        out = v[(size_t(co) * Cin + ci) * K + j] * scale[co];
-    } else if (kind == AGX_CONV_UPSAMPLE) {
-        // taps k of the high-rate 'same' conv that land on low-rate offset j - P
-        const int pl = (K - 1) / 2;
-        const float sc = scale[co];
-        for (int k = 0; k < K; ++k)
-            if (floordiv(ph + k - pl, up) == j - P) out += v[(size_t(co) * Cin + ci) * K + k] * sc;
-    } else {  // AGX_CONV_TRANSPOSED: weight (Cin, Cout, K), norm over dim 0 = Cin
-        const int k = ph + up * (J - 1 - j);
-        if (k < K) out = v[(size_t(ci) * Cout + co) * K + k] * scale[ci];
+    if (q == 1 && s == 1) {
+        out = fwd_weight(v, scale, kind, Cin, Cout, K, J, P, up, ci, J - 1 - jb, co, 0);
+    } else if (q == 1) {  // strided conv: tap p' + s*m, m = Jb-1-jb
+        const int k = phb + s * (Jb - 1 - jb);
+        if (k < J) out = fwd_weight(v, scale, kind, Cin, Cout, K, J, P, up, ci, k, co, 0);
+    } else {              // polyphase forward: k = jb, p = k % q, j = J-1 - k / q
+        out = fwd_weight(v, scale, kind, Cin, Cout, K, J, P, up, ci, J - 1 - jb / q, co, jb % q);
     }
     packed[e] = out;
 }
 
 }  // namespace agx
+
+static int pack_scales(const agx_conv_desc *d, const float *v, const float *g, float *scale, hipStream_t st) {
+    using namespace agx;
+    const bool transposed = d->kind == AGX_CONV_TRANSPOSED;
+    const int dim0 = transposed ? d->c_in : d->c_out;
+    const int inner = (transposed ? d->c_out : d->c_in) * d->kernel;
+    if (g)
+        hipLaunchKernelGGL(wn_scale_kernel, dim3(dim0), dim3(256), 0, st, v, g, scale, inner);
+    else
+        hipLaunchKernelGGL(fill_ones_kernel, dim3(ceil_div(dim0, 256)), dim3(256), 0, st, scale, dim0);
+    return dim0;
+}
+
+extern "C" int64_t agx_conv_bwd_packed_floats(const agx_conv_desc *d) {
+    agx::ConvPlan b;
+    int rc = agx::lower_conv_bwd_data(d, &b);
+    if (rc != AGX_OK) return rc;
+    const int dim0 = (d->kind == AGX_CONV_TRANSPOSED) ? d->c_in : d->c_out;
+    return agx::packed_weight_floats(b.Cin, b.J, b.M) + dim0;
+}
+
+extern "C" int agx_conv_pack_bwd(const agx_conv_desc *d, const float *v, const float *g, float *packed,
+                                 void *stream) {
+    using namespace agx;
+    ConvPlan f, b;
+    int rc = lower_conv(d, &f);
+    if (rc != AGX_OK) return rc;
+    rc = lower_conv_bwd_data(d, &b);
+    if (rc != AGX_OK) return rc;
+    if (!v || !packed) return fail(AGX_ERR_NULL_POINTER, "agx_conv_pack_bwd: NULL pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t n_w = packed_weight_floats(b.Cin, b.J, b.M);
+    float *scale = packed + n_w;
+    pack_scales(d, v, g, scale, st);
+    hipLaunchKernelGGL(pack_bwd_kernel, dim3((unsigned)ceil_div64(n_w, 256)), dim3(256), 0, st, v, scale, packed,
+                       d->kind, f.Cin, f.Cout, d->kernel, f.q, f.J, f.P, f.s, d->stride, b.J, b.q);
+    return check_launch("agx_conv_pack_bwd");
+}
 
 extern "C" int agx_conv_pack(const agx_conv_desc *d, const float *v, const float *g, float *packed,
                              void *stream) {

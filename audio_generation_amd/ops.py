@@ -116,6 +116,41 @@ def conv_forward(desc: ConvDesc, x: Tensor, packed: Tensor, bias: Optional[Tenso
     return y
 
 
+def conv_pack_bwd(desc: ConvDesc, v: Tensor, g: Optional[Tensor] = None) -> Tensor:
+    """Packed image of the layer's backward-data op (``agx_conv_pack_bwd``)."""
+    lib = _lib.load()
+    _need_gpu(v, g)
+    n = lib.agx_conv_bwd_packed_floats(ctypes.byref(desc))
+    if n < 0:
+        _lib.check(int(n), "agx_conv_bwd_packed_floats")
+    v = _f32c(v)
+    g = None if g is None else _f32c(g)
+    packed = torch.empty(int(n), dtype=torch.float32, device=v.device)
+    _lib.check(lib.agx_conv_pack_bwd(ctypes.byref(desc), _ptr(v), _ptr(g), _ptr(packed), _stream()),
+               "agx_conv_pack_bwd")
+    return packed
+
+
+def conv_bwd_data(desc: ConvDesc, dy: Tensor, packed_bwd: Tensor, add: Optional[Tensor] = None,
+                  mask: Optional[Tensor] = None, slope: float = 0.1) -> Tensor:
+    """Gradient w.r.t. the input of the layer ``desc`` describes (forward descriptor)."""
+    lib = _lib.load()
+    _need_gpu(dy, packed_bwd, add, mask)
+    dy = _f32c(dy)
+    l_out = conv_out_len(desc)
+    if tuple(dy.shape) != (desc.batch, desc.c_out, l_out):
+        raise AgxError(f"conv_bwd_data: dy is {tuple(dy.shape)}, expected {(desc.batch, desc.c_out, l_out)}")
+    dx = torch.empty((desc.batch, desc.c_in, desc.l_in), dtype=torch.float32, device=dy.device)
+    for t, nm in ((add, "add"), (mask, "mask")):
+        if t is not None and tuple(t.shape) != tuple(dx.shape):
+            raise AgxError(f"conv_bwd_data: {nm} is {tuple(t.shape)}, dx is {tuple(dx.shape)}")
+    add = None if add is None else _f32c(add)
+    mask = None if mask is None else _f32c(mask)
+    _lib.check(lib.agx_conv_bwd_data(ctypes.byref(desc), _ptr(dy), _ptr(packed_bwd), _ptr(add), _ptr(mask),
+                                     float(slope), _ptr(dx), _stream()), "agx_conv_bwd_data")
+    return dx
+
+
 def resblock_forward(desc: ConvDesc, x: Tensor, packed1: Tensor, bias1: Optional[Tensor],
                      packed2: Tensor, bias2: Optional[Tensor], post_act: bool = True) -> Tensor:
     lib = _lib.load()

@@ -65,6 +65,7 @@ int agx_get_tuning(const char *name);
 #define AGX_EPI_RESIDUAL 2   /* += res[b,co,t]                     vae.py:117        */
 #define AGX_EPI_LEAKY_POST 4 /* LeakyReLU(slope) after the add     vae.py:131-134    */
 #define AGX_EPI_GELU_PRE 8   /* exact (erf) GELU on (acc + bias)   transformers.py:216, wavelets.py:96 */
+#define AGX_EPI_MASK 16      /* backward only: v *= (mask[o] > 0 ? 1 : slope), the LeakyReLU gradient     */
 
 typedef struct agx_conv_desc {
     int32_t kind;      /* AGX_CONV_*                                              */
@@ -104,6 +105,23 @@ int agx_conv_pack(const agx_conv_desc *d, const float *v, const float *g, float 
  * interpolate + conv1d (vae.py:86-89). */
 int agx_conv_forward(const agx_conv_desc *d, const float *x, const float *packed,
                      const float *bias, const float *res, float *y, void *stream);
+
+/* ---- backward of a conv layer (training.py:380 loss.backward()) ------------
+ * The gradient w.r.t. the layer INPUT is the same polyphase convolution with the channel roles
+ * swapped and the taps re-indexed (stride-1 convs: flipped kernel; strided convs: transposed-conv
+ * phase form; polyphase up-convs: a strided conv), so it runs on the forward kernels with its own
+ * packed image:
+ *   dx = [mask-gradient]( [add] + conv_bwd(dy) )
+ * d is the FORWARD descriptor of the layer (its epilogue field is ignored).
+ *   dy   (B, c_out, l_out)  gradient w.r.t. the layer's linear output (pre-activation)
+ *   add  (B, c_in, l_in) or NULL: accumulated first (residual branch of vae.py:117)
+ *   mask (B, c_in, l_in) or NULL: the layer input as saved by the forward (= the previous layer's
+ *        post-LeakyReLU output); the result is multiplied by its activation gradient (1 or slope)
+ *   dx   (B, c_in, l_in) */
+int64_t agx_conv_bwd_packed_floats(const agx_conv_desc *d);
+int agx_conv_pack_bwd(const agx_conv_desc *d, const float *v, const float *g, float *packed, void *stream);
+int agx_conv_bwd_data(const agx_conv_desc *d, const float *dy, const float *packed_bwd, const float *add,
+                      const float *mask, float slope, float *dx, void *stream);
 
 /* Name of the kernel family/tile variant agx_conv_forward would launch for this
  * descriptor (e.g. "conv_mfma<2,2,2,2,16>"), for profilers and bench.py; matches

@@ -1,0 +1,63 @@
+"""Native backward kernels against the CPU oracle's autograd."""
+import pytest
+import torch
+
+from audio_generation_amd import _lib, ops
+from oracle import codec
+from tests.helpers import max_abs
+from tests.test_gpu_parity import KIND, SHAPES
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _oracle_conv(kind, x, w, bias, s, d):
+    if kind == "conv":
+        return codec.causal_conv1d(x, w, bias, stride=s, dilation=d)
+    if kind == "convt":
+        return codec.causal_conv_t1d(x, w, bias, stride=s)
+    return codec.upsample_conv1d(x, w, bias, s)
+
+
+@pytest.mark.parametrize("impl", ["direct", "mfma"])
+def test_backward_data_matches_autograd(impl):
+    gen = torch.Generator().manual_seed(31)
+    checked = 0
+    for (kind, cin, cout, k, s, d, b, length) in SHAPES:
+        # the backward op has the channel roles swapped: MFMA tiles need fwd-Cout % 16 == 0 and >= 32 rows
+        rows = cin * (s if kind == "conv" and s > 1 else 1)
+        if impl == "mfma" and (cout % 16 != 0 or rows < 32):
+            continue
+        wshape = (cin, cout, k) if kind == "convt" else (cout, cin, k)
+        v = torch.randn(wshape, generator=gen) / (cin * k) ** 0.5
+        g = torch.rand((wshape[0], 1, 1), generator=gen) + 0.5
+        x = torch.randn(b, cin, length, generator=gen, requires_grad=True)
+        y = _oracle_conv(kind, x, codec.fold_weight_norm(g, v), None, s, d)
+        dy = torch.randn(y.shape, generator=gen)
+        (want,) = torch.autograd.grad(y, x, dy)
+        desc = ops.conv_desc(KIND[kind], b, cin, cout, length, k, s, d, 0, 0.1,
+                             _lib.IMPL_DIRECT if impl == "direct" else _lib.IMPL_MFMA)
+        packed = ops.conv_pack_bwd(desc, v.to(DEV), g.to(DEV))
+        dx = ops.conv_bwd_data(desc, dy.to(DEV), packed)
+        assert tuple(dx.shape) == tuple(want.shape)
+        err = max_abs(dx.cpu(), want)
+        assert err < 3e-5 * max(1.0, float(want.abs().max())), (impl, kind, cin, cout, k, s, d, err)
+        checked += 1
+    assert checked >= (len(SHAPES) if impl == "direct" else 12)
+
+
+def test_backward_data_residual_and_activation_gradient():
+    """dx = leaky'(saved input) * (add + conv_bwd(dy)) -- the fused form the residual block needs."""
+    gen = torch.Generator().manual_seed(32)
+    b, c, length, k, d = 2, 32, 400, 7, 3
+    v = torch.randn(c, c, k, generator=gen) / (c * k) ** 0.5
+    g = torch.rand(c, 1, 1, generator=gen) + 0.5
+    pre = torch.randn(b, c, length, generator=gen, requires_grad=True)   # previous layer's pre-activation
+    x = codec.leaky(pre)                                                 # what the forward saved
+    y = x + codec.causal_conv1d(x, codec.fold_weight_norm(g, v), None, dilation=d)
+    dy = torch.randn(y.shape, generator=gen)
+    (want,) = torch.autograd.grad(y, pre, dy)
+    desc = ops.conv_desc(_lib.CONV_CAUSAL, b, c, c, length, k, 1, d)
+    packed = ops.conv_pack_bwd(desc, v.to(DEV), g.to(DEV))
+    dx = ops.conv_bwd_data(desc, dy.to(DEV), packed, add=dy.to(DEV), mask=x.detach().to(DEV), slope=0.1)
+    assert max_abs(dx.cpu(), want) < 3e-5 * max(1.0, float(want.abs().max()))
