@@ -41,6 +41,9 @@ SIGNATURES = {
     "agx_conv_bwd_packed_floats": (c_int64, [_PD]),
     "agx_conv_pack_bwd": (c_int, [_PD, c_void_p, c_void_p, c_void_p, c_void_p]),
     "agx_conv_bwd_data": (c_int, [_PD, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
+    "agx_conv_bwd_weight_workspace_bytes": (c_size_t, [_PD]),
+    "agx_conv_bwd_weight": (c_int, [_PD, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_size_t, c_void_p]),
     "agx_conv_kernel_name": (c_int, [_PD, c_char_p, c_size_t]),
     "agx_resblock_workspace_bytes": (c_size_t, [_PD]),
     "agx_resblock_kernel_name": (c_int, [_PD, c_char_p, c_size_t]),

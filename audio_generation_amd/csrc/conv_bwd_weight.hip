@@ -1,0 +1,234 @@
+// Weight / bias gradients of a conv layer for gfx950.
+//
+// In the polyphase weight space the gradient is one more GEMM,
+//   dWp[n = ci*J + j][m = co*q + p] = sum_{b,t} dy[b, co, q t + p] * x[b, ci, t s + j d - P],
+// with the long dimension (batch x time) as the contraction: M = q*Cout rows (A = dy),
+// N = Cin*J columns (B = shifted views of x), K = B * Lt.  fp32-input MFMA again (exact fp32).
+// The contraction is cut into `n_slices` slices that different workgroups accumulate in
+// registers; every slice writes its partial tile to the workspace and a second kernel adds the
+// slices in a fixed order (deterministic -- no float atomics), folds the polyphase space back to
+// the torch weight layout and applies the weight-norm chain rule (w = g v / |v|, utils.py:34-42):
+//   dg[r] = <dw_r, v_r> / |v_r|,   dv_r = (g_r / |v_r|) (dw_r - v_r <dw_r, v_r> / |v_r|^2).
+#include "mfma_tile.hpp"
+
+namespace agx {
+
+constexpr int BW_T = 64;        // time positions per LDS stage
+constexpr int BW_TS = BW_T + 1; // dyS row stride (odd: conflict-free column reads)
+
+__global__ __launch_bounds__(256) void conv_bwd_weight_kernel(ConvPlan p, int span, int n_chan, int n_slices,
+                                                              const float *__restrict__ x,
+                                                              const float *__restrict__ dy,
+                                                              float *__restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *dys = sm;                 // [64][BW_TS]
+    float *xs = sm + 64 * BW_TS;     // [n_chan][span]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int NK = p.Cin * p.J;
+    const int n_base = blockIdx.x * 64, m_base = blockIdx.y * 64, slice = blockIdx.z;
+    const int ci_first = n_base / p.J;
+
+    const int n = n_base + wn * 32 + li;
+    const bool nvalid = n < NK;
+    const int nc = min(n, NK - 1);
+    const int ci = nc / p.J, j = nc - ci * p.J;
+    const int boff = (ci - ci_first) * span + j * p.d;
+    const int arow = (wm * 32 + li) * BW_TS;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    const int chunks = (p.Lt + BW_T - 1) / BW_T;
+    const int items = p.B * chunks;
+    for (int item = slice; item < items; item += n_slices) {
+        const int b = item / chunks, t0 = (item - b * chunks) * BW_T;
+        __syncthreads();
+        // dy tile: row r <-> m = m_base + r = co*q + ph, column tt <-> dy[b, co, q*(t0+tt) + ph]
+        for (int e = tid; e < 64 * BW_T; e += 256) {
+            const int r = e / BW_T, tt = e - r * BW_T;
+            const int m = m_base + r;
+            float v = 0.f;
+            if (m < p.M) {
+                const int co = m / p.q, ph = m - co * p.q;
+                const int t = t0 + tt, u = p.q * t + ph;
+                if (t < p.Lt && u < p.Lout) v = dy[(size_t(b) * p.Cout + co) * p.Lout + u];
+            }
+            dys[r * BW_TS + tt] = v;
+        }
+        // x tile: channels ci_first .. ci_first + n_chan - 1, positions t0*s - P + [0, span)
+        const int in0 = t0 * p.s - p.P;
+        for (int e = tid; e < n_chan * span; e += 256) {
+            const int c = e / span, i = e - c * span;
+            const int ch = ci_first + c, pos = in0 + i;
+            xs[e] = (ch < p.Cin && pos >= 0 && pos < p.Lvalid) ? x[(size_t(b) * p.Cin + ch) * p.Lin + pos] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int ks = 0; ks < BW_T / 2; ++ks) {
+            const int tt = 2 * ks + lh;
+            const float a = dys[arow + tt];
+            const float bv = nvalid ? xs[boff + tt * p.s] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+        }
+    }
+    // partial tile: column = lane & 31 <-> n, rows (registers) <-> m
+    if (nvalid) {
+        float *dst = part + (size_t(slice) * NK + n) * p.M;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m_base + wm * 32 + acc_row(r, lh);
+            if (m < p.M) dst[m] = acc[r];
+        }
+    }
+}
+
+// dWp[e] = sum over slices (fixed order)
+__global__ __launch_bounds__(256) void bwd_weight_reduce_kernel(const float *__restrict__ part, int n_slices,
+                                                                int64_t n, float *__restrict__ dwp) {
+    const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (e >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < n_slices; ++k) s += part[size_t(k) * n + e];
+    dwp[e] = s;
+}
+
+__device__ __forceinline__ int floordiv_bw(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
+// One block per dim-0 row r of the torch weight: fold dWp back to dw_r, then the weight-norm chain rule.
+__global__ __launch_bounds__(256) void bwd_weight_unpack_kernel(const float *__restrict__ dwp,
+                                                                const float *__restrict__ v,
+                                                                const float *__restrict__ g, float *__restrict__ dv,
+                                                                float *__restrict__ dg, int kind, int Cin, int Cout,
+                                                                int K, int q, int J, int P, int up) {
+    __shared__ float red[4];
+    const int r = blockIdx.x;
+    const bool transposed = kind == AGX_CONV_TRANSPOSED;
+    const int inner = (transposed ? Cout : Cin) * K;
+    const int M = q * Cout;
+    const float *vr = v + size_t(r) * inner;
+    float *dvr = dv + size_t(r) * inner;
+    auto dw_at = [&](int e) -> float {  // gradient w.r.t. the folded weight element (r, e)
+        const int o = e / K, k = e - o * K;  // o = ci (normal layouts) or co (transposed layout)
+        if (kind == AGX_CONV_CAUSAL || kind == AGX_CONV_SAME) return dwp[(size_t(o) * J + k) * M + r];
+        if (kind == AGX_CONV_UPSAMPLE) {
+            const int pl = (K - 1) / 2;
+            float s = 0.f;
+            for (int ph = 0; ph < q; ++ph) {
+                const int j = floordiv_bw(ph + k - pl, up) + P;
+                s += dwp[(size_t(o) * J + j) * M + r * q + ph];
+            }
+            return s;
+        }
+        // transposed: r = ci, o = co; tap k = ph + up*(J-1-j)
+        const int ph = k % up, j = J - 1 - k / up;
+        return dwp[(size_t(r) * J + j) * M + o * q + ph];
+    };
+    float dot = 0.f, nrm = 0.f;
+    for (int e = threadIdx.x; e < inner; e += 256) {
+        const float w = dw_at(e), vv = vr[e];
+        dot = fmaf(w, vv, dot);
+        nrm = fmaf(vv, vv, nrm);
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        float val = pass == 0 ? dot : nrm;
+        for (int off = 32; off > 0; off >>= 1) val += __shfl_xor(val, off);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = val;
+        __syncthreads();
+        val = (red[0] + red[1]) + (red[2] + red[3]);
+        if (pass == 0) dot = val; else nrm = val;
+    }
+    if (!g) {  // plain weight: dv is the weight gradient itself
+        for (int e = threadIdx.x; e < inner; e += 256) dvr[e] = dw_at(e);
+        return;
+    }
+    const float norm = sqrtf(nrm), scale = g[r] / norm;
+    if (threadIdx.x == 0) dg[r] = dot / norm;
+    for (int e = threadIdx.x; e < inner; e += 256) dvr[e] = scale * (dw_at(e) - vr[e] * (dot / nrm));
+}
+
+// db[co] = sum_{b,u} dy[b, co, u]
+__global__ __launch_bounds__(256) void bwd_bias_kernel(const float *__restrict__ dy, float *__restrict__ db, int B,
+                                                       int Cout, int Lout) {
+    __shared__ float red[4];
+    const int co = blockIdx.x;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float *row = dy + (size_t(b) * Cout + co) * Lout;
+        for (int u = threadIdx.x; u < Lout; u += 256) s += row[u];
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) db[co] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+static void bw_geometry(const ConvPlan &p, int *span, int *n_chan, int *n_slices, dim3 *grid) {
+    *span = (BW_T - 1) * p.s + (p.J - 1) * p.d + 1;
+    *n_chan = 63 / p.J + 2;  // channels a 64-column tile of n = ci*J + j can touch
+    const int nt = ceil_div(p.Cin * p.J, 64), mt = ceil_div(p.M, 64);
+    const int items = p.B * ceil_div(p.Lt, BW_T);
+    int ns = ceil_div(768, nt * mt);  // ~3 workgroups per CU in total
+    if (ns > items) ns = items;
+    if (ns < 1) ns = 1;
+    if (ns > 65535) ns = 65535;
+    *n_slices = ns;
+    *grid = dim3(nt, mt, ns);
+}
+
+}  // namespace agx
+
+extern "C" {
+
+size_t agx_conv_bwd_weight_workspace_bytes(const agx_conv_desc *d) {
+    using namespace agx;
+    ConvPlan p;
+    if (lower_conv(d, &p) != AGX_OK) return 0;
+    int span, n_chan, ns;
+    dim3 grid;
+    bw_geometry(p, &span, &n_chan, &ns, &grid);
+    return (size_t(ns) + 1) * p.Cin * p.J * p.M * sizeof(float);  // slices + the reduced dWp
+}
+
+int agx_conv_bwd_weight(const agx_conv_desc *d, const float *x, const float *dy, const float *v, const float *g,
+                        float *dv, float *dg, float *dbias, void *workspace, size_t workspace_bytes,
+                        void *stream) {
+    using namespace agx;
+    ConvPlan p;
+    int rc = lower_conv(d, &p);
+    if (rc != AGX_OK) return rc;
+    if (!x || !dy || !v || !dv || (g && !dg)) return fail(AGX_ERR_NULL_POINTER, "agx_conv_bwd_weight: NULL pointer");
+    if (!workspace || workspace_bytes < agx_conv_bwd_weight_workspace_bytes(d))
+        return fail(AGX_ERR_WORKSPACE, "agx_conv_bwd_weight: workspace too small (%zu < %zu)", workspace_bytes,
+                    agx_conv_bwd_weight_workspace_bytes(d));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int span, n_chan, ns;
+    dim3 grid;
+    bw_geometry(p, &span, &n_chan, &ns, &grid);
+    const size_t lds = (size_t(64) * BW_TS + size_t(n_chan) * span) * sizeof(float);
+    if (lds > 160 * 1024) return fail(AGX_ERR_UNSUPPORTED, "agx_conv_bwd_weight: tile needs %zu B of LDS", lds);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_bwd_weight_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    float *part = static_cast<float *>(workspace);
+    const int64_t nw = int64_t(p.Cin) * p.J * p.M;
+    float *dwp = part + size_t(ns) * nw;
+    hipLaunchKernelGGL(conv_bwd_weight_kernel, grid, dim3(256), lds, st, p, span, n_chan, ns, x, dy, part);
+    hipLaunchKernelGGL(bwd_weight_reduce_kernel, dim3((unsigned)ceil_div64(nw, 256)), dim3(256), 0, st, part, ns, nw, dwp);
+    const bool transposed = d->kind == AGX_CONV_TRANSPOSED;
+    const int dim0 = transposed ? d->c_in : d->c_out;
+    hipLaunchKernelGGL(bwd_weight_unpack_kernel, dim3(dim0), dim3(256), 0, st, dwp, v, g, dv, dg, d->kind, p.Cin,
+                       p.Cout, d->kernel, p.q, p.J, p.P, d->stride);
+    if (dbias)
+        hipLaunchKernelGGL(bwd_bias_kernel, dim3(p.Cout), dim3(256), 0, st, dy, dbias, p.B, p.Cout, p.Lout);
+    return check_launch("agx_conv_bwd_weight");
+}
+
+}  // extern "C"

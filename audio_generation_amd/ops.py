@@ -151,6 +151,22 @@ def conv_bwd_data(desc: ConvDesc, dy: Tensor, packed_bwd: Tensor, add: Optional[
     return dx
 
 
+def conv_bwd_weight(desc: ConvDesc, x: Tensor, dy: Tensor, v: Tensor, g: Optional[Tensor], want_bias: bool = True):
+    """(dv, dg or None, dbias or None) of the layer ``desc`` describes."""
+    lib = _lib.load()
+    _need_gpu(x, dy, v, g)
+    x, dy, v = _f32c(x), _f32c(dy), _f32c(v)
+    g = None if g is None else _f32c(g)
+    dv = torch.empty_like(v)
+    dg = None if g is None else torch.empty_like(g)
+    db = torch.empty(desc.c_out, dtype=torch.float32, device=x.device) if want_bias else None
+    ws_bytes = int(lib.agx_conv_bwd_weight_workspace_bytes(ctypes.byref(desc)))
+    ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=x.device)
+    _lib.check(lib.agx_conv_bwd_weight(ctypes.byref(desc), _ptr(x), _ptr(dy), _ptr(v), _ptr(g), _ptr(dv), _ptr(dg),
+                                       _ptr(db), _ptr(ws), ws_bytes, _stream()), "agx_conv_bwd_weight")
+    return dv, dg, db
+
+
 def resblock_forward(desc: ConvDesc, x: Tensor, packed1: Tensor, bias1: Optional[Tensor],
                      packed2: Tensor, bias2: Optional[Tensor], post_act: bool = True) -> Tensor:
     lib = _lib.load()

@@ -123,6 +123,15 @@ int agx_conv_pack_bwd(const agx_conv_desc *d, const float *v, const float *g, fl
 int agx_conv_bwd_data(const agx_conv_desc *d, const float *dy, const float *packed_bwd, const float *add,
                       const float *mask, float slope, float *dx, void *stream);
 
+/* Gradients w.r.t. the layer's parameters.  x (B,c_in,l_in) is the saved layer input, dy the gradient
+ * w.r.t. the linear output; v/g are the weight-norm parameters as in agx_conv_pack (g NULL = plain weight).
+ * Writes dv (shape of v), dg (dim0) when g != NULL, dbias (c_out) when dbias != NULL.  The time x batch
+ * contraction runs on the fp32 MFMA in slices reduced in a fixed order (deterministic). */
+size_t agx_conv_bwd_weight_workspace_bytes(const agx_conv_desc *d);
+int agx_conv_bwd_weight(const agx_conv_desc *d, const float *x, const float *dy, const float *v, const float *g,
+                        float *dv, float *dg, float *dbias, void *workspace, size_t workspace_bytes,
+                        void *stream);
+
 /* Name of the kernel family/tile variant agx_conv_forward would launch for this
  * descriptor (e.g. "conv_mfma<2,2,2,2,16>"), for profilers and bench.py; matches
  * the template arguments in the rocprofv3 kernel names.  Returns AGX_OK. */

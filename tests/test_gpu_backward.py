@@ -61,3 +61,32 @@ def test_backward_data_residual_and_activation_gradient():
     packed = ops.conv_pack_bwd(desc, v.to(DEV), g.to(DEV))
     dx = ops.conv_bwd_data(desc, dy.to(DEV), packed, add=dy.to(DEV), mask=x.detach().to(DEV), slope=0.1)
     assert max_abs(dx.cpu(), want) < 3e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_backward_weight_bias_and_weight_norm_match_autograd():
+    gen = torch.Generator().manual_seed(33)
+    checked = 0
+    for (kind, cin, cout, k, s, d, b, length) in SHAPES:
+        wshape = (cin, cout, k) if kind == "convt" else (cout, cin, k)
+        v = (torch.randn(wshape, generator=gen) / (cin * k) ** 0.5).requires_grad_(True)
+        g = (torch.rand((wshape[0], 1, 1), generator=gen) + 0.5).requires_grad_(True)
+        bias = (torch.randn(cout, generator=gen) * 0.1).requires_grad_(True)
+        x = torch.randn(b, cin, length, generator=gen)
+        y = _oracle_conv(kind, x, codec.fold_weight_norm(g, v), bias, s, d)
+        dy = torch.randn(y.shape, generator=gen)
+        want_v, want_g, want_b = torch.autograd.grad(y, (v, g, bias), dy)
+        desc = ops.conv_desc(KIND[kind], b, cin, cout, length, k, s, d)
+        dv, dg, db = ops.conv_bwd_weight(desc, x.to(DEV), dy.to(DEV), v.detach().to(DEV), g.detach().to(DEV))
+        for got, want, nm in ((dv, want_v, "dv"), (dg, want_g, "dg"), (db, want_b, "db")):
+            err, scale = max_abs(got.cpu(), want), float(want.abs().max())
+            assert err < 2e-4 * max(1.0, scale), (kind, cin, cout, k, s, d, nm, err, scale)
+        # plain (not weight-normed) weights: dv is the weight gradient
+        w_plain = v.detach().clone().requires_grad_(True)
+        y2 = _oracle_conv(kind, x, w_plain, None, s, d)
+        (want_w,) = torch.autograd.grad(y2, w_plain, dy)
+        dw, none_g, none_b = ops.conv_bwd_weight(desc, x.to(DEV), dy.to(DEV), w_plain.detach().to(DEV), None,
+                                                 want_bias=False)
+        assert none_g is None and none_b is None
+        assert max_abs(dw.cpu(), want_w) < 2e-4 * max(1.0, float(want_w.abs().max())), (kind, cin, cout, k, s, d)
+        checked += 1
+    assert checked == len(SHAPES)
