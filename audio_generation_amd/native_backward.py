@@ -1,0 +1,154 @@
+"""Native backward of the conv stacks on the HIP kernels.
+
+A stack (``model.encoders`` / ``model.decoders``) is flattened into *units*:
+
+* conv unit      ``y = act(conv(x) + b)``             (act optional)
+* residual unit  ``y = act(x + conv2(act(conv1(x) + b1)) + b2)``
+
+Forward runs the usual fused kernels and keeps every unit's input.  Backward walks the
+units in reverse with three C-ABI ops per conv:
+
+* ``agx_conv_bwd_data``   -- gradient w.r.t. the unit input; the residual branch is added and
+  the LeakyReLU gradient of the *producing* unit is applied in the same kernel's epilogue
+  (mask = the saved activation), so the gradient that travels between units is always the
+  one w.r.t. the pre-activation;
+* ``agx_conv_bwd_weight`` -- dv / dg / dbias (weight-norm chain rule included);
+* one ``agx_conv_forward`` per residual unit to re-materialise the hidden activation the
+  fused forward kernel never wrote.
+
+Stacks containing a layer without native backward kernels (the wavelet layer) use the ATen
+bridge of ``autograd_bridge.py`` instead.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+from torch import nn
+
+from . import ops
+from ._lib import CONV_CAUSAL, EPI_LEAKY_PRE
+
+Tensor = torch.Tensor
+
+
+class _Unit:
+    """One conv or residual unit of a stack."""
+
+    def __init__(self, kind: str, convs: Sequence[nn.Module], slope: Optional[float], inner_slope: Optional[float] = None):
+        self.kind = kind            # "conv" | "res"
+        self.convs = list(convs)    # [_ConvBase] or [conv1, conv2]
+        self.slope = slope          # activation after the unit (None = linear output)
+        self.inner_slope = inner_slope
+
+    def params(self) -> List[Tensor]:
+        out = []
+        for c in self.convs:
+            cp = c.conv
+            out += [cp.weight_v, cp.weight_g] if hasattr(cp, "weight_v") else [cp.weight]
+            if cp.bias is not None:
+                out.append(cp.bias)
+        return out
+
+
+def build_units(stack: nn.ModuleList) -> Optional[List[_Unit]]:
+    """Flatten a ``CausalVQAE`` encoder / decoder ModuleList; ``None`` if some layer has no native backward."""
+    from .vae import (CausalDecoderBlock, CausalEncoderBlock, CausalResidualBlock1d, _ConvBase, _leaky_slope)
+
+    units: List[_Unit] = []
+
+    def add(layer, act):
+        slope = _leaky_slope(act) if act is not None else None
+        if isinstance(layer, CausalResidualBlock1d):
+            inner = _leaky_slope(layer.activation)
+            if inner is None:
+                return False
+            units.append(_Unit("res", [layer.conv1, layer.conv2], slope, inner))
+            return True
+        if isinstance(layer, _ConvBase):
+            units.append(_Unit("conv", [layer], slope))
+            return True
+        return False
+
+    for m in stack:
+        if isinstance(m, nn.Sequential) and len(m) == 2 and isinstance(m[0], nn.Identity):   # encoders[0]
+            ok = add(m[1], None)
+        elif isinstance(m, CausalEncoderBlock):
+            ok = all(add(seq[0], seq[1]) for seq in m.layers)
+        elif isinstance(m, CausalDecoderBlock):
+            ok = add(m.in_conv[0], m.in_conv[1]) and all(add(seq[0], seq[1]) for seq in m.layers)
+        else:
+            ok = add(m, None)
+        if not ok:
+            return None
+    return units
+
+
+def _desc(conv, x: Tensor, epilogue: int = 0, slope: float = 0.1):
+    c = conv.conv
+    return ops.conv_desc(conv.kind, x.shape[0], c.in_channels, c.out_channels, x.shape[2], c.kernel_size[0],
+                         c.stride[0], c.dilation[0], epilogue, slope, conv.impl)
+
+
+def _vg(conv):
+    cp = conv.conv
+    return (cp.weight_v.detach(), cp.weight_g.detach()) if hasattr(cp, "weight_v") else (cp.weight.detach(), None)
+
+
+def _grads_of(conv, x: Tensor, dz: Tensor) -> List[Tensor]:
+    """[dv, dg, dbias] / [dweight, dbias] in the order of ``_Unit.params``."""
+    v, g = _vg(conv)
+    dv, dg, db = ops.conv_bwd_weight(_desc(conv, x), x, dz, v, g, want_bias=conv.conv.bias is not None)
+    out = [dv] if g is None else [dv, dg]
+    if db is not None:
+        out.append(db)
+    return out
+
+
+class _NativeStack(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, units: List[_Unit], x: Tensor, *params: Tensor):
+        from .vae import _run_unit_forward
+        ctx.units = units
+        inputs = []
+        with torch.no_grad():
+            for u in units:
+                inputs.append(x)
+                x = _run_unit_forward(u, x)
+        ctx.save_for_backward(*inputs)
+        ctx.mark_non_differentiable()
+        return x
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        units, inputs = ctx.units, ctx.saved_tensors
+        if units[-1].slope is not None:
+            raise NotImplementedError("a stack ending in an activation needs its output saved for the mask")
+        dz = grad_out.contiguous()                    # gradient w.r.t. the last unit's linear output
+        grads: List[List[Tensor]] = [None] * len(units)
+        for i in range(len(units) - 1, -1, -1):
+            u, x = units[i], inputs[i]
+            # the unit that produced x (if any) applied an activation: fold its gradient into dx
+            prev_slope = units[i - 1].slope if i > 0 else None
+            mask = x if prev_slope is not None else None
+            if u.kind == "conv":
+                conv = u.convs[0]
+                grads[i] = _grads_of(conv, x, dz)
+                dz = ops.conv_bwd_data(_desc(conv, x), dz, conv.conv.packed_bwd(conv.kind), None, mask,
+                                       prev_slope or 0.0)
+            else:
+                c1, c2 = u.convs
+                h = c1.run(x, EPI_LEAKY_PRE, u.inner_slope)                       # re-materialise the hidden act.
+                g2 = _grads_of(c2, h, dz)
+                dh = ops.conv_bwd_data(_desc(c2, h), dz, c2.conv.packed_bwd(CONV_CAUSAL), None, h, u.inner_slope)
+                g1 = _grads_of(c1, x, dh)
+                dz = ops.conv_bwd_data(_desc(c1, x), dh, c1.conv.packed_bwd(CONV_CAUSAL), dz, mask,
+                                       prev_slope or 0.0)
+                grads[i] = g1 + g2
+        flat = [g for gl in grads for g in gl]
+        return (None, dz, *flat)
+
+
+def run_stack(units: List[_Unit], x: Tensor) -> Tensor:
+    params = [p for u in units for p in u.params()]
+    return _NativeStack.apply(units, x, *params)

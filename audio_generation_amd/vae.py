@@ -93,6 +93,21 @@ class _ConvParams(nn.Module):
             return v * (g / norm)
         return self.weight
 
+    def packed_bwd(self, kind: int) -> Tensor:
+        """Packed image of the layer's backward-data op (same invalidation rule as ``packed``)."""
+        if hasattr(self, "weight_v"):
+            v, g = self.weight_v, self.weight_g
+            key = (kind, v.data_ptr(), v._version, g.data_ptr(), g._version)
+        else:
+            v, g = self.weight, None
+            key = (kind, v.data_ptr(), v._version)
+        if getattr(self, "_packed_bwd", None) is None or self._packed_bwd_key != key:
+            desc = ops.conv_desc(kind, 1, self.in_channels, self.out_channels, 1 << 20,
+                                 self.kernel_size[0], self.stride[0], self.dilation[0])
+            self._packed_bwd = ops.conv_pack_bwd(desc, v.detach(), None if g is None else g.detach())
+            self._packed_bwd_key = key
+        return self._packed_bwd
+
     def packed(self, kind: int) -> Tensor:
         """Packed (weight-norm folded) image, rebuilt when the parameters change
         (optimizer step, ``load_state_dict``, ``.to(device)``)."""
@@ -199,6 +214,7 @@ class CausalResidualBlock1d(nn.Module):
             raise AgxError("residual block needs in_channels == out_channels (as the reference's add does)")
         self.conv1 = CausalConv1d(in_channels, out_channels, kernel_size, dilation=dilation, bias=bias)
         self.conv2 = CausalConv1d(out_channels, out_channels, 1, bias=bias)
+        object.__setattr__(self.conv1, "_parent_block", self)   # plain attribute: no module cycle
         self.activation = nn.LeakyReLU(0.1) if activation is None else activation
         self.dropout = nn.Dropout(dropout)
 
@@ -290,6 +306,15 @@ class CausalDecoderBlock(nn.Module):
         for seq in self.layers:
             x = _act_aten(seq[0]._aten(x), _leaky_slope(seq[1]))
         return x
+
+
+def _run_unit_forward(unit, x: Tensor) -> Tensor:
+    """Forward of one unit of native_backward.build_units (same fused kernels as inference)."""
+    if unit.kind == "res":
+        res = unit.convs[0]._parent_block
+        return res.run(x, unit.slope)
+    conv = unit.convs[0]
+    return conv.run(x, EPI_LEAKY_PRE if unit.slope is not None else 0, unit.slope or 0.0)
 
 
 def _run_fused_pair(layer: nn.Module, act: nn.Module, x: Tensor) -> Tensor:
@@ -390,15 +415,33 @@ class CausalVQAE(nn.Module):
         """Encoder stack: libagx forward; when a gradient is needed the backward is bridged
         through ATen (autograd_bridge.py -- interim until SURVEY 8(f1))."""
         if needs_grad(x, self.encoders):
+            units = self._units("encoders")
+            if units is not None:                       # native backward kernels (native_backward.py)
+                from .native_backward import run_stack
+                return run_stack(units, x)
             return hip_forward_aten_backward(self._encoders_hip, self._encoders_aten, x,
                                              list(self.encoders.parameters()))
         return self._encoders_hip(x)
 
     def _run_decoders(self, x: Tensor) -> Tensor:
         if needs_grad(x, self.decoders):
+            units = self._units("decoders")
+            if units is not None:
+                from .native_backward import run_stack
+                return run_stack(units, x)
             return hip_forward_aten_backward(self._decoders_hip, self._decoders_aten, x,
                                              list(self.decoders.parameters()))
         return self._decoders_hip(x)
+
+    def _units(self, which: str):
+        """Flattened unit list of a stack for the native backward (None: some layer lacks kernels)."""
+        cache = self.__dict__.setdefault("_unit_cache", {})
+        if which not in cache:
+            from .native_backward import build_units
+            first = self.encoders[0]
+            ok = which != "encoders" or isinstance(first[0], nn.Identity)
+            cache[which] = build_units(getattr(self, which)) if ok else None
+        return cache[which]
 
     def encode(self, x, update_codebook=False, codebook_n=None, prioritize_early=False):
         """vae.py:307-322 -> (x_q (B,C,T), commit_loss, index (B,T,Q))."""

@@ -4,6 +4,7 @@ Gradients are checked against the CPU oracle's autograd; a few Adam steps must r
 import pytest
 import torch
 
+from audio_generation_amd import ops
 from audio_generation_amd.transformers import Transformer, TransformerBottleneck
 from audio_generation_amd.vae import CausalVQAE
 from oracle import attention as oattn
@@ -41,6 +42,13 @@ def test_gradients_match_oracle_autograd(channels, wavelet):
 
     model = model.to(DEV).train()
     xd = x.to(DEV)
+    # which backward runs: native HIP kernels for plain conv stacks, the ATen bridge for the wavelet decoder
+    assert model._units("encoders") is not None
+    assert (model._units("decoders") is None) == wavelet
+    calls = {"bwd_data": 0, "bwd_weight": 0}
+    real_bd, real_bw = ops.conv_bwd_data, ops.conv_bwd_weight
+    ops.conv_bwd_data = lambda *a, **k: (calls.__setitem__("bwd_data", calls["bwd_data"] + 1), real_bd(*a, **k))[1]
+    ops.conv_bwd_weight = lambda *a, **k: (calls.__setitem__("bwd_weight", calls["bwd_weight"] + 1), real_bw(*a, **k))[1]
     y, commit, index = model(xd)
     assert torch.equal(index.cpu(), want_idx)
     loss = ((y - xd) ** 2).mean() + commit
@@ -55,8 +63,11 @@ def test_gradients_match_oracle_autograd(channels, wavelet):
         scale = float(w.abs().max()) + 1e-12
         assert float((g - w).abs().max()) <= 2e-3 * scale + 1e-9, (name, float((g - w).abs().max()), scale)
         checked += 1
+    ops.conv_bwd_data, ops.conv_bwd_weight = real_bd, real_bw
     n_params = sum(1 for n, _ in model.named_parameters() if not n.startswith("quantizer."))
     assert checked == n_params and checked >= 180
+    # 30 convs per stack, one bwd_data + one bwd_weight each
+    assert calls["bwd_weight"] == (30 if wavelet else 60) and calls["bwd_data"] == calls["bwd_weight"]
 
 
 def test_adam_steps_reduce_the_loss_and_repack_weights():
