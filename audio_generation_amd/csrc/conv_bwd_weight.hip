@@ -16,30 +16,51 @@ namespace agx {
 constexpr int BW_T = 64;        // time positions per LDS stage
 constexpr int BW_TS = BW_T + 1; // dyS row stride (odd: conflict-free column reads)
 
+// Workgroup tile = (32*MW*WM) rows of m x (32*NW*WN) columns of n; 4 waves as WM x WN.
+// The n-tile-0 workgroups also accumulate the bias gradient (row sums of the staged dy tile).
+template <int MW, int NW, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(ConvPlan p, int span, int n_chan, int n_slices,
                                                               const float *__restrict__ x,
                                                               const float *__restrict__ dy,
-                                                              float *__restrict__ part) {
+                                                              float *__restrict__ part,
+                                                              float *__restrict__ bias_part) {
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int BM = 32 * MW * WM, BN = 32 * NW * WN;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float *dys = sm;                 // [64][BW_TS]
-    float *xs = sm + 64 * BW_TS;     // [n_chan][span]
+    float *dys = sm;                 // [BM][BW_TS]
+    float *xs = sm + BM * BW_TS;     // [n_chan][span]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int NK = p.Cin * p.J;
-    const int n_base = blockIdx.x * 64, m_base = blockIdx.y * 64, slice = blockIdx.z;
+    const int n_base = blockIdx.x * BN, m_base = blockIdx.y * BM, slice = blockIdx.z;
     const int ci_first = n_base / p.J;
 
-    const int n = n_base + wn * 32 + li;
-    const bool nvalid = n < NK;
-    const int nc = min(n, NK - 1);
-    const int ci = nc / p.J, j = nc - ci * p.J;
-    const int boff = (ci - ci_first) * span + j * p.d;
-    const int arow = (wm * 32 + li) * BW_TS;
-
-    f32x16 acc;
+    int boff[NW];
+    bool nvalid[NW];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k = 0; k < NW; ++k) {
+        const int n = n_base + (wn * NW + k) * 32 + li;
+        nvalid[k] = n < NK;
+        const int nc = min(n, NK - 1);
+        const int ci = nc / p.J, j = nc - ci * p.J;
+        boff[k] = (ci - ci_first) * span + j * p.d;
+    }
+    int arow[MW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i) arow[i] = ((wm * MW + i) * 32 + li) * BW_TS;
+
+    f32x16 acc[MW][NW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
+    // bias gradient: TPR threads per row of the dy tile, each summing BW_T / TPR columns
+    constexpr int TPR = 256 / BM, CPT = BW_T / TPR;
+    float bsum = 0.f;
+    const bool do_bias = bias_part != nullptr && blockIdx.x == 0;
 
     const int chunks = (p.Lt + BW_T - 1) / BW_T;
     const int items = p.B * chunks;
@@ -47,7 +68,7 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(ConvPlan p, int sp
         const int b = item / chunks, t0 = (item - b * chunks) * BW_T;
         __syncthreads();
         // dy tile: row r <-> m = m_base + r = co*q + ph, column tt <-> dy[b, co, q*(t0+tt) + ph]
-        for (int e = tid; e < 64 * BW_T; e += 256) {
+        for (int e = tid; e < BM * BW_T; e += 256) {
             const int r = e / BW_T, tt = e - r * BW_T;
             const int m = m_base + r;
             float v = 0.f;
@@ -66,22 +87,45 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(ConvPlan p, int sp
             xs[e] = (ch < p.Cin && pos >= 0 && pos < p.Lvalid) ? x[(size_t(b) * p.Cin + ch) * p.Lin + pos] : 0.f;
         }
         __syncthreads();
-#pragma unroll 8
+        if (do_bias) {
+            const float *row = dys + (tid / TPR) * BW_TS + (tid % TPR) * CPT;
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) bsum += row[c];
+        }
+#pragma unroll 4
         for (int ks = 0; ks < BW_T / 2; ++ks) {
             const int tt = 2 * ks + lh;
-            const float a = dys[arow + tt];
-            const float bv = nvalid ? xs[boff + tt * p.s] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+            float a[MW], bv[NW];
+#pragma unroll
+            for (int i = 0; i < MW; ++i) a[i] = dys[arow[i] + tt];
+#pragma unroll
+            for (int k = 0; k < NW; ++k) bv[k] = nvalid[k] ? xs[boff[k] + tt * p.s] : 0.f;
+#pragma unroll
+            for (int i = 0; i < MW; ++i)
+#pragma unroll
+                for (int k = 0; k < NW; ++k)
+                    acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv[k], acc[i][k], 0, 0, 0);
         }
     }
-    // partial tile: column = lane & 31 <-> n, rows (registers) <-> m
-    if (nvalid) {
+    // partial tiles: column = lane & 31 <-> n, rows (registers) <-> m
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const int n = n_base + (wn * NW + k) * 32 + li;
+        if (n >= NK) continue;
         float *dst = part + (size_t(slice) * NK + n) * p.M;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m_base + wm * 32 + acc_row(r, lh);
-            if (m < p.M) dst[m] = acc[r];
-        }
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m_base + (wm * MW + i) * 32 + acc_row(r, lh);
+                if (m < p.M) dst[m] = acc[i][k][r];
+            }
+    }
+    if (do_bias) {   // block-uniform branch
+#pragma unroll
+        for (int off = 1; off < TPR; off <<= 1) bsum += __shfl_xor(bsum, off);
+        const int m = m_base + tid / TPR;
+        if (tid % TPR == 0 && m < p.M) bias_part[size_t(slice) * p.M + m] = bsum;
     }
 }
 
@@ -150,33 +194,40 @@ __global__ __launch_bounds__(256) void bwd_weight_unpack_kernel(const float *__r
     for (int e = threadIdx.x; e < inner; e += 256) dvr[e] = scale * (dw_at(e) - vr[e] * (dot / nrm));
 }
 
-// db[co] = sum_{b,u} dy[b, co, u]
-__global__ __launch_bounds__(256) void bwd_bias_kernel(const float *__restrict__ dy, float *__restrict__ db, int B,
-                                                       int Cout, int Lout) {
-    __shared__ float red[4];
-    const int co = blockIdx.x;
+// db[co] = sum over slices and output phases of the per-slice row sums (fixed order)
+__global__ __launch_bounds__(256) void bwd_bias_reduce_kernel(const float *__restrict__ bias_part, int n_slices,
+                                                              int M, int q, int Cout, float *__restrict__ db) {
+    const int co = blockIdx.x * 256 + threadIdx.x;
+    if (co >= Cout) return;
     float s = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const float *row = dy + (size_t(b) * Cout + co) * Lout;
-        for (int u = threadIdx.x; u < Lout; u += 256) s += row[u];
-    }
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) db[co] = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int k = 0; k < n_slices; ++k)
+        for (int ph = 0; ph < q; ++ph) s += bias_part[size_t(k) * M + co * q + ph];
+    db[co] = s;
 }
 
-static void bw_geometry(const ConvPlan &p, int *span, int *n_chan, int *n_slices, dim3 *grid) {
-    *span = (BW_T - 1) * p.s + (p.J - 1) * p.d + 1;
-    *n_chan = 63 / p.J + 2;  // channels a 64-column tile of n = ci*J + j can touch
-    const int nt = ceil_div(p.Cin * p.J, 64), mt = ceil_div(p.M, 64);
+struct BwGeom {
+    int cfg;  // 0: 128x128 tile, 1: 64x128, 2: 32x128
+    int bm, span, n_chan, n_slices;
+    dim3 grid;
+    size_t lds;
+};
+
+static BwGeom bw_geometry(const ConvPlan &p) {
+    BwGeom g;
+    g.cfg = p.M >= 128 ? 0 : (p.M >= 64 ? 1 : 2);
+    g.bm = g.cfg == 0 ? 128 : (g.cfg == 1 ? 64 : 32);
+    g.span = (BW_T - 1) * p.s + (p.J - 1) * p.d + 1;
+    g.n_chan = 127 / p.J + 2;  // channels a 128-column tile of n = ci*J + j can touch
+    const int nt = ceil_div(p.Cin * p.J, 128), mt = ceil_div(p.M, g.bm);
     const int items = p.B * ceil_div(p.Lt, BW_T);
     int ns = ceil_div(768, nt * mt);  // ~3 workgroups per CU in total
     if (ns > items) ns = items;
     if (ns < 1) ns = 1;
     if (ns > 65535) ns = 65535;
-    *n_slices = ns;
-    *grid = dim3(nt, mt, ns);
+    g.n_slices = ns;
+    g.grid = dim3(nt, mt, ns);
+    g.lds = (size_t(g.bm) * BW_TS + size_t(g.n_chan) * g.span) * sizeof(float);
+    return g;
 }
 
 }  // namespace agx
@@ -187,10 +238,9 @@ size_t agx_conv_bwd_weight_workspace_bytes(const agx_conv_desc *d) {
     using namespace agx;
     ConvPlan p;
     if (lower_conv(d, &p) != AGX_OK) return 0;
-    int span, n_chan, ns;
-    dim3 grid;
-    bw_geometry(p, &span, &n_chan, &ns, &grid);
-    return (size_t(ns) + 1) * p.Cin * p.J * p.M * sizeof(float);  // slices + the reduced dWp
+    const BwGeom g = bw_geometry(p);
+    // slices of dWp + the reduced dWp + slices of the bias row sums
+    return ((size_t(g.n_slices) + 1) * p.Cin * p.J * p.M + size_t(g.n_slices) * p.M) * sizeof(float);
 }
 
 int agx_conv_bwd_weight(const agx_conv_desc *d, const float *x, const float *dy, const float *v, const float *g,
@@ -205,29 +255,33 @@ int agx_conv_bwd_weight(const agx_conv_desc *d, const float *x, const float *dy,
         return fail(AGX_ERR_WORKSPACE, "agx_conv_bwd_weight: workspace too small (%zu < %zu)", workspace_bytes,
                     agx_conv_bwd_weight_workspace_bytes(d));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    int span, n_chan, ns;
-    dim3 grid;
-    bw_geometry(p, &span, &n_chan, &ns, &grid);
-    const size_t lds = (size_t(64) * BW_TS + size_t(n_chan) * span) * sizeof(float);
-    if (lds > 160 * 1024) return fail(AGX_ERR_UNSUPPORTED, "agx_conv_bwd_weight: tile needs %zu B of LDS", lds);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_bwd_weight_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    const BwGeom geo = bw_geometry(p);
+    if (geo.lds > 160 * 1024) return fail(AGX_ERR_UNSUPPORTED, "agx_conv_bwd_weight: tile needs %zu B of LDS", geo.lds);
     float *part = static_cast<float *>(workspace);
     const int64_t nw = int64_t(p.Cin) * p.J * p.M;
-    float *dwp = part + size_t(ns) * nw;
-    hipLaunchKernelGGL(conv_bwd_weight_kernel, grid, dim3(256), lds, st, p, span, n_chan, ns, x, dy, part);
-    hipLaunchKernelGGL(bwd_weight_reduce_kernel, dim3((unsigned)ceil_div64(nw, 256)), dim3(256), 0, st, part, ns, nw, dwp);
+    float *dwp = part + size_t(geo.n_slices) * nw;
+    float *bias_part = dbias ? dwp + nw : nullptr;
+    auto launch = [&](auto kern) -> int {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(kern, geo.grid, dim3(256), geo.lds, st, p, geo.span, geo.n_chan, geo.n_slices, x, dy, part,
+                           bias_part);
+        return AGX_OK;
+    };
+    rc = geo.cfg == 0 ? launch(conv_bwd_weight_kernel<2, 2, 2, 2>)
+       : geo.cfg == 1 ? launch(conv_bwd_weight_kernel<1, 2, 2, 2>)
+                      : launch(conv_bwd_weight_kernel<1, 1, 1, 4>);
+    if (rc != AGX_OK) return rc;
+    hipLaunchKernelGGL(bwd_weight_reduce_kernel, dim3((unsigned)ceil_div64(nw, 256)), dim3(256), 0, st, part,
+                       geo.n_slices, nw, dwp);
     const bool transposed = d->kind == AGX_CONV_TRANSPOSED;
     const int dim0 = transposed ? d->c_in : d->c_out;
     hipLaunchKernelGGL(bwd_weight_unpack_kernel, dim3(dim0), dim3(256), 0, st, dwp, v, g, dv, dg, d->kind, p.Cin,
                        p.Cout, d->kernel, p.q, p.J, p.P, d->stride);
     if (dbias)
-        hipLaunchKernelGGL(bwd_bias_kernel, dim3(p.Cout), dim3(256), 0, st, dy, dbias, p.B, p.Cout, p.Lout);
+        hipLaunchKernelGGL(bwd_bias_reduce_kernel, dim3(ceil_div(p.Cout, 256)), dim3(256), 0, st, bias_part,
+                           geo.n_slices, p.M, p.q, p.Cout, dbias);
     return check_launch("agx_conv_bwd_weight");
 }
 
