@@ -129,14 +129,20 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(ConvPlan p, int sp
     }
 }
 
-// dWp[e] = sum over slices (fixed order)
-__global__ __launch_bounds__(256) void bwd_weight_reduce_kernel(const float *__restrict__ part, int n_slices,
-                                                                int64_t n, float *__restrict__ dwp) {
-    const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    if (e >= n) return;
+// out[e] = sum over slices of part[slice][e], in a fixed order: 4 slice groups (the 4 waves of a
+// block) sum every 4th slice, then the groups are added 0+1+2+3 -- deterministic, and 4x shorter
+// dependent load chains than one thread per element.
+__global__ __launch_bounds__(256) void bwd_slice_reduce_kernel(const float *__restrict__ part, int n_slices,
+                                                               int64_t n, float *__restrict__ out) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int64_t e = int64_t(blockIdx.x) * 64 + lane;
     float s = 0.f;
-    for (int k = 0; k < n_slices; ++k) s += part[size_t(k) * n + e];
-    dwp[e] = s;
+    if (e < n)
+        for (int k = grp; k < n_slices; k += 4) s += part[size_t(k) * n + e];
+    red[grp][lane] = s;
+    __syncthreads();
+    if (grp == 0 && e < n) out[e] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 __device__ __forceinline__ int floordiv_bw(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
@@ -194,14 +200,13 @@ __global__ __launch_bounds__(256) void bwd_weight_unpack_kernel(const float *__r
     for (int e = threadIdx.x; e < inner; e += 256) dvr[e] = scale * (dw_at(e) - vr[e] * (dot / nrm));
 }
 
-// db[co] = sum over slices and output phases of the per-slice row sums (fixed order)
-__global__ __launch_bounds__(256) void bwd_bias_reduce_kernel(const float *__restrict__ bias_part, int n_slices,
-                                                              int M, int q, int Cout, float *__restrict__ db) {
+// db[co] = sum over the output phases of the slice-reduced row sums
+__global__ __launch_bounds__(256) void bwd_bias_fold_kernel(const float *__restrict__ rowsum, int q, int Cout,
+                                                            float *__restrict__ db) {
     const int co = blockIdx.x * 256 + threadIdx.x;
     if (co >= Cout) return;
     float s = 0.f;
-    for (int k = 0; k < n_slices; ++k)
-        for (int ph = 0; ph < q; ++ph) s += bias_part[size_t(k) * M + co * q + ph];
+    for (int ph = 0; ph < q; ++ph) s += rowsum[co * q + ph];
     db[co] = s;
 }
 
@@ -240,7 +245,7 @@ size_t agx_conv_bwd_weight_workspace_bytes(const agx_conv_desc *d) {
     if (lower_conv(d, &p) != AGX_OK) return 0;
     const BwGeom g = bw_geometry(p);
     // slices of dWp + the reduced dWp + slices of the bias row sums
-    return ((size_t(g.n_slices) + 1) * p.Cin * p.J * p.M + size_t(g.n_slices) * p.M) * sizeof(float);
+    return ((size_t(g.n_slices) + 1) * p.Cin * p.J * p.M + (size_t(g.n_slices) + 1) * p.M) * sizeof(float);
 }
 
 int agx_conv_bwd_weight(const agx_conv_desc *d, const float *x, const float *dy, const float *v, const float *g,
@@ -273,15 +278,19 @@ int agx_conv_bwd_weight(const agx_conv_desc *d, const float *x, const float *dy,
        : geo.cfg == 1 ? launch(conv_bwd_weight_kernel<1, 2, 2, 2>)
                       : launch(conv_bwd_weight_kernel<1, 1, 1, 4>);
     if (rc != AGX_OK) return rc;
-    hipLaunchKernelGGL(bwd_weight_reduce_kernel, dim3((unsigned)ceil_div64(nw, 256)), dim3(256), 0, st, part,
+    hipLaunchKernelGGL(bwd_slice_reduce_kernel, dim3((unsigned)ceil_div64(nw, 64)), dim3(256), 0, st, part,
                        geo.n_slices, nw, dwp);
     const bool transposed = d->kind == AGX_CONV_TRANSPOSED;
     const int dim0 = transposed ? d->c_in : d->c_out;
     hipLaunchKernelGGL(bwd_weight_unpack_kernel, dim3(dim0), dim3(256), 0, st, dwp, v, g, dv, dg, d->kind, p.Cin,
                        p.Cout, d->kernel, p.q, p.J, p.P, d->stride);
-    if (dbias)
-        hipLaunchKernelGGL(bwd_bias_reduce_kernel, dim3(ceil_div(p.Cout, 256)), dim3(256), 0, st, bias_part,
-                           geo.n_slices, p.M, p.q, p.Cout, dbias);
+    if (dbias) {
+        float *rowsum = bias_part + size_t(geo.n_slices) * p.M;
+        hipLaunchKernelGGL(bwd_slice_reduce_kernel, dim3(ceil_div(p.M, 64)), dim3(256), 0, st, bias_part,
+                           geo.n_slices, int64_t(p.M), rowsum);
+        hipLaunchKernelGGL(bwd_bias_fold_kernel, dim3(ceil_div(p.Cout, 256)), dim3(256), 0, st, rowsum, p.q, p.Cout,
+                           dbias);
+    }
     return check_launch("agx_conv_bwd_weight");
 }
 
