@@ -176,6 +176,7 @@ int agx_set_tuning(const char *name, int32_t value) {
     if (!name) return agx::fail(AGX_ERR_NULL_POINTER, "agx_set_tuning: NULL name");
     if (!strcmp(name, "rb_cc")) agx::tuning().rb_cc = value;
     else if (!strcmp(name, "rb_wgs")) agx::tuning().rb_wgs = value;
+    else if (!strcmp(name, "rb_sched")) agx::tuning().rb_sched = value;
     else return agx::fail(AGX_ERR_BAD_SHAPE, "agx_set_tuning: unknown knob '%s'", name);
     return AGX_OK;
 }
@@ -184,6 +185,7 @@ int agx_get_tuning(const char *name) {
     if (!name) return agx::fail(AGX_ERR_NULL_POINTER, "agx_get_tuning: NULL name");
     if (!strcmp(name, "rb_cc")) return agx::tuning().rb_cc;
     if (!strcmp(name, "rb_wgs")) return agx::tuning().rb_wgs;
+    if (!strcmp(name, "rb_sched")) return agx::tuning().rb_sched;
     return agx::fail(AGX_ERR_BAD_SHAPE, "agx_get_tuning: unknown knob '%s'", name);
 }
 

@@ -28,6 +28,12 @@ __device__ unsigned long long g_stamps[1 << 16];
 #define AGX_STAMP_ADD(slot, t0) ((void)0)
 #endif
 
+// Phase scheduling of conv_gemm (template parameter SCHED):
+//   0  operand requests as one block ahead of the MFMAs (sched_barrier between them)
+//   1  weights block ahead, B-fragment ds_reads threaded between the MFMAs
+//   2  weights (global loads) and B fragments both threaded between the MFMAs
+constexpr int kSchedDefault = 1;
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Row of accumulator register r in lane half lh (C/D layout of v_mfma_f32_32x32x2_f32:
@@ -145,7 +151,7 @@ __device__ __forceinline__ void load_b_phase(float (&bf)[CC / 2][NW], const floa
 
 // CC = channels per LDS chunk (one DMA hand-over + barrier per chunk); the register pipeline
 // works in phases of PC = min(CC, 16) channels x one tap (operand arrays sized for PC).
-template <int MW, int NW, int CC>
+template <int MW, int NW, int CC, int SCHED = kSchedDefault>
 __device__ __forceinline__ void conv_gemm(f32x16 (&acc)[MW][NW], float *__restrict__ xs,
                                           const float *__restrict__ xb, const float *__restrict__ wp,
                                           const ConvPlan &p, int M, int span, int in0,
@@ -197,23 +203,21 @@ __device__ __forceinline__ void conv_gemm(f32x16 (&acc)[MW][NW], float *__restri
                         nc0 += CC;
                     }
                 }
-                // Operands of the NEXT phase are requested before this phase's MFMAs issue, so neither
-                // the L2 latency of the weights nor the LDS latency of the input sits in front of an
-                // MFMA (a bare MFMA loop with its ds_read directly ahead of it loses 13-22 %:
-                // tools/mfma_peak.hip).
-                // (branch-free on purpose: behind a conditional load hipcc puts a full s_waitcnt in front
-                // of the MFMAs; after the very last phase the prefetch just re-reads phase 0)
-                const bool last = nc0 >= p.Cin;
-                load_a_phase<MW, PC>(a_nxt, wp, last ? 0 : nc0 + nh * PC, last ? 0 : nj, p.J, M, lh, arow);
-                // The next chunk's DMA goes out behind this phase's weight prefetch: vmcnt retires in
-                // order and hipcc waits vmcnt(0) for the prefetched weights at the top of the next
-                // phase, so the DMA gets a full phase of MFMAs to land instead of none.
+                // The next chunk's input DMA goes out first (once per chunk) ...
                 if (h == 0 && j == 0 && c0 + CC < p.Cin)
                     issue_rows_dma<CC>(nxt, xb + size_t(c0 + CC) * p.Lin, p.Lin, p.Lvalid, in0, span, wave, lane);
-                // next phase in this chunk; across a chunk boundary the value is discarded (b_cur is
-                // re-read after the barrier), so any in-range address will do
+                // ... then the operands of the NEXT phase are requested, in the same basic block as this
+                // phase's MFMAs so that the scheduler can thread them between the MFMAs: neither the L2
+                // latency of the weights nor the LDS latency of the input sits in front of an MFMA (a
+                // bare MFMA loop with its ds_read directly ahead of it loses 13-22 %: tools/mfma_peak.hip).
+                // Branch-free on purpose (behind a conditional load hipcc puts a full s_waitcnt in front
+                // of the MFMAs): after the very last phase the prefetch re-reads phase 0, and across a
+                // chunk boundary the B prefetch is discarded (b_cur is re-read after the barrier).
+                const bool last = nc0 >= p.Cin;
+                load_a_phase<MW, PC>(a_nxt, wp, last ? 0 : nc0 + nh * PC, last ? 0 : nj, p.J, M, lh, arow);
+                if (SCHED == 1) __builtin_amdgcn_sched_barrier(0);
                 load_b_phase<NW, PC>(b_nxt, cur + (nc0 == c0 ? nh * PC * span + nj * p.d : 0), span, bcol);
-                __builtin_amdgcn_sched_barrier(0);
+                if (SCHED == 0) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ks = 0; ks < PC / 2; ++ks)
 #pragma unroll
@@ -221,6 +225,17 @@ __device__ __forceinline__ void conv_gemm(f32x16 (&acc)[MW][NW], float *__restri
 #pragma unroll
                         for (int k = 0; k < NW; ++k)
                             acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ks][i], b_cur[ks][k], acc[i][k], 0, 0, 0);
+                if (SCHED != 0) {
+                    // Thread the next phase's operand requests between this phase's MFMAs (2 MFMA : 1 VMEM
+                    // read : 1 DS read ...): an MFMA occupies the issue port for a fraction of its 64
+                    // cycles, so the requests ride in its shadow.
+#pragma unroll
+                    for (int gidx = 0; gidx < 2 * MW * (PC / 8) + NW * (PC / 2); ++gidx) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA
+                        if (SCHED == 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ks = 0; ks < PC / 2; ++ks) {

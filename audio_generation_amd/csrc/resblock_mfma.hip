@@ -20,7 +20,7 @@
 
 namespace agx {
 
-template <int MW, int NW, int CC>
+template <int MW, int NW, int CC, int SCHED = kSchedDefault>
 __global__ __launch_bounds__(256, (MW <= 4 ? 2 : 1)) void resblock_mfma_kernel(ConvPlan p, int span, int post_act,
                                                             const float *__restrict__ x,
                                                             const float *__restrict__ w1,
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256, (MW <= 4 ? 2 : 1)) void resblock_mfma_kernel(C
     const float *xb = x + size_t(b) * C * p.Lin;
 
     // ---- GEMM1: h = W1 (*) x ------------------------------------------------------
-    conv_gemm<MW, NW, CC>(acc, xs, xb, w1, p, C, span, in0, arow, bcol, wave, lane);
+    conv_gemm<MW, NW, CC, SCHED>(acc, xs, xb, w1, p, C, span, in0, arow, bcol, wave, lane);
 
     // ---- hidden activation, in registers --------------------------------------------
 #pragma unroll
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, (MW <= 4 ? 2 : 1)) void resblock_mfma_kernel(C
     AGX_STAMP(5);
 }
 
-template <int MW, int NW, int CC>
+template <int MW, int NW, int CC, int SCHED = kSchedDefault>
 static int launch_rb(const ConvPlan &p, const float *x, const float *w1, const float *b1, const float *w2,
                      const float *b2, float *y, int post_act, hipStream_t st) {
     constexpr int BN = 32 * NW * 4;
@@ -150,7 +150,7 @@ static int launch_rb(const ConvPlan &p, const float *x, const float *w1, const f
     if (lds > 160 * 1024) return fail(AGX_ERR_UNSUPPORTED, "resblock: tile needs %zu B of LDS", lds);
     const int wgs = tuning().rb_wgs;  // diagnostic: cap workgroups per CU by requesting more LDS
     if (wgs >= 1 && wgs <= 3 && lds < size_t(160 * 1024) / wgs) lds = size_t(160 * 1024) / wgs;
-    auto kern = resblock_mfma_kernel<MW, NW, CC>;
+    auto kern = resblock_mfma_kernel<MW, NW, CC, SCHED>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -192,14 +192,20 @@ int launch_resblock_fused(const ConvPlan &p, const float *x, const float *w1, co
                           const float *w2, const float *b2, float *y, int post_act, hipStream_t st) {
     if (!resblock_fused_supported(p)) return fail(AGX_ERR_UNSUPPORTED, "resblock: no fused kernel for C=%d", p.Cin);
     const bool c32 = rb_use_cc32(p);
-#define AGX_RB(MW, NW)                                                          \
-    (c32 ? launch_rb<MW, NW, 32>(p, x, w1, b1, w2, b2, y, post_act, st)        \
-         : launch_rb<MW, NW, 16>(p, x, w1, b1, w2, b2, y, post_act, st))
+    // phase scheduling: measured best per shape (tools/ab_bench.py rb_sched 0 1 2, in-process A/B):
+    // C=32: 1 (-12 % vs 0), C=64: 2 (-6 %), C=128: 1 (-11 %), C=256: 2 (-2 %); knob -1 = this table
+    int sched = tuning().rb_sched;
+    if (sched < 0) sched = (p.Cin == 64 || p.Cin == 256) ? 2 : 1;
+#define AGX_RB(MW, NW)                                                                                   \
+    (c32 ? launch_rb<MW, NW, 32>(p, x, w1, b1, w2, b2, y, post_act, st)                                 \
+         : sched == 0 ? launch_rb<MW, NW, 16, 0>(p, x, w1, b1, w2, b2, y, post_act, st)                 \
+         : sched == 2 ? launch_rb<MW, NW, 16, 2>(p, x, w1, b1, w2, b2, y, post_act, st)                 \
+                      : launch_rb<MW, NW, 16, 1>(p, x, w1, b1, w2, b2, y, post_act, st))
     switch (p.Cin) {
         case 32: return AGX_RB(1, 4);
         case 64: return AGX_RB(2, 2);
         case 128: return AGX_RB(4, 1);
-        default: return launch_rb<8, 1, 16>(p, x, w1, b1, w2, b2, y, post_act, st);
+        default: return AGX_RB(8, 1);
     }
 #undef AGX_RB
 }

@@ -41,7 +41,8 @@ const char *agx_last_error(void);
 /* Diagnostic tuning knobs (A/B experiments from one process; defaults are the
  * shipped configuration).  Unknown names return AGX_ERR_BAD_SHAPE.
  *   "rb_cc"  16 | 32   channels per LDS chunk of the fused residual block
- *   "rb_wgs" 0 | 1..3  cap on resident workgroups per CU of the fused residual block (0 = natural) */
+ *   "rb_wgs" 0 | 1..3  cap on resident workgroups per CU of the fused residual block (0 = natural)
+ *   "rb_sched" 0|1|2   phase scheduling of the fused residual block (csrc/mfma_tile.hpp)          */
 int agx_set_tuning(const char *name, int32_t value);
 int agx_get_tuning(const char *name);
 
