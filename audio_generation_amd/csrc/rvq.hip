@@ -246,26 +246,37 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
             const float *rb = R + (4 * lh) * RS + li;
             const float *ab = img + size_t(lh) * K * 4;
             f32x4 a_cur[MT], a_nxt[MT];
+            float b_cur[4], b_nxt[4];
 #pragma unroll
             for (int i = 0; i < MT; ++i) a_cur[i] = *reinterpret_cast<const f32x4 *>(ab + size_t(acol[i]) * 4);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) b_cur[ks] = rb[ks * RS] - mus[4 * lh + ks];
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // retire the LDS reads here, not in front of every block's MFMAs
             for (int d8 = 0; d8 < Dp; d8 += 8) {
-                if (d8 + 8 < Dp) {
-                    const float *an = ab + size_t((d8 + 8) >> 2) * K * 4;
+                // operands of the NEXT 8-deep block are requested while this block's MFMAs issue
+                // (threaded between them by the scheduler); past the end the prefetch re-reads block 0
+                const int dn = d8 + 8 < Dp ? d8 + 8 : 0;
+                const float *an = ab + size_t(dn >> 2) * K * 4;
 #pragma unroll
-                    for (int i = 0; i < MT; ++i) a_nxt[i] = *reinterpret_cast<const f32x4 *>(an + size_t(acol[i]) * 4);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                float bf[4];
+                for (int i = 0; i < MT; ++i) a_nxt[i] = *reinterpret_cast<const f32x4 *>(an + size_t(acol[i]) * 4);
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) bf[ks] = rb[(d8 + ks) * RS] - mus[d8 + 4 * lh + ks];
+                for (int ks = 0; ks < 4; ++ks) b_nxt[ks] = rb[(dn + ks) * RS] - mus[dn + 4 * lh + ks];
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i][ks], bf[ks], acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i][ks], b_cur[ks], acc[i], 0, 0, 0);
+#pragma unroll
+                for (int gidx = 0; gidx < 4; ++gidx) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);  // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read (residual + mean)
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < MT; ++i) a_cur[i] = a_nxt[i];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) b_cur[ks] = b_nxt[ks];
             }
             // lower bounds in place; rows of register r: (r&3) + 8*(r>>2) + 4*lh.  One subtile at a
             // time (the sched_barrier keeps hipcc from hoisting all 2*16*MT table loads at once,
