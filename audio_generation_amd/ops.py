@@ -53,7 +53,7 @@ def _need_gpu(*tensors: Optional[Tensor]) -> None:
         if not t.is_cuda:
             raise AgxError("audio_generation_amd runs on the MI355X only: got a tensor on "
                            f"'{t.device}'.  There is no CPU / eager fallback.")
-        if t.dtype not in (torch.float32, torch.int64, torch.float64):
+        if t.dtype not in (torch.float32, torch.int64, torch.float64, torch.uint8):
             raise AgxError(f"unsupported dtype {t.dtype}")
 
 
@@ -319,3 +319,28 @@ def wavelet_fold(h: Tensor, space: Tensor, sigma: Tensor, scale: int) -> Tensor:
     _lib.check(lib.agx_wavelet_fold(_ptr(h), _ptr(space), _ptr(sigma), sigma.numel(), _ptr(y), b, c, length,
                                     space.numel(), scale, _stream()), "agx_wavelet_fold")
     return y
+
+
+# ------------------------------------------------------------------ bitstream
+def codes_pack(index: Tensor, bits: int) -> Tensor:
+    """(..,) int64 codes -> uint8 stream, `bits` bits per code (dense, little-endian)."""
+    lib = _lib.load()
+    _need_gpu(index)
+    idx = index.contiguous().to(torch.int64)
+    n = idx.numel()
+    nbytes = lib.agx_codes_packed_bytes(n, bits)
+    if nbytes < 0 or n == 0:
+        raise AgxError(f"codes_pack: bad arguments (n={n}, bits={bits})")
+    out = torch.empty(int(nbytes), dtype=torch.uint8, device=idx.device)
+    _lib.check(lib.agx_codes_pack(_ptr(idx), n, bits, _ptr(out), _stream()), "agx_codes_pack")
+    return out
+
+
+def codes_unpack(stream: Tensor, n_codes: int, bits: int) -> Tensor:
+    lib = _lib.load()
+    _need_gpu(stream)
+    if stream.dtype != torch.uint8 or stream.numel() < lib.agx_codes_packed_bytes(n_codes, bits):
+        raise AgxError("codes_unpack: stream must be uint8 and hold ceil(n_codes*bits/8) bytes")
+    out = torch.empty(n_codes, dtype=torch.int64, device=stream.device)
+    _lib.check(lib.agx_codes_unpack(_ptr(stream.contiguous()), n_codes, bits, _ptr(out), _stream()), "agx_codes_unpack")
+    return out

@@ -484,6 +484,26 @@ class CausalVQAE(nn.Module):
         del was_training
         return y
 
+    # -- codec wire format (bit budget of utils.py:137-147) ---------------------
+    def compress(self, x, codebook_n=None):
+        """Waveform -> (uint8 bitstream, (B, T, Q)).  ceil(log2(K)) bits per code, dense."""
+        with torch.no_grad():
+            _, _, index = self.encode(x, codebook_n=codebook_n)
+        bits = max(1, (int(self.codebook_size[0]) - 1).bit_length())
+        return ops.codes_pack(index, bits), tuple(index.shape)
+
+    def decompress(self, stream, shape):
+        """Inverse of ``compress``: bitstream -> codes -> sum of codewords -> decoder."""
+        b, t, q = shape
+        bits = max(1, (int(self.codebook_size[0]) - 1).bit_length())
+        index = ops.codes_unpack(stream, b * t * q, bits).reshape(b, t, q)
+        with torch.no_grad():
+            zq = None
+            for i in range(q):
+                zq = ops.rvq_dequantize(self.quantizer.codebooks.detach()[i], index[..., i], out=zq,
+                                        accumulate=zq is not None)
+            return self.decode(zq.transpose(1, 2).contiguous()), index
+
     def replace_quantizer(self, new_quantizer):
         self.quantizer = new_quantizer
 

@@ -230,6 +230,16 @@ int agx_wavelet_fold(const float *h, const float *space, const float *sigma, int
                      float *y, int32_t batch, int32_t channels, int32_t length, int32_t n_points,
                      int32_t scale, void *stream);
 
+/* ------------------------------------------------------------------------- *
+ * Codec bitstream (wire size per utils.py:137-147)               *
+ * ------------------------------------------------------------------------- */
+
+/* Dense little-endian packing of n_codes indices at `bits` (1..16) bits each: code e occupies
+ * bits [e*bits, (e+1)*bits) of the stream.  packed bytes = ceil(n_codes*bits/8). */
+int64_t agx_codes_packed_bytes(int64_t n_codes, int32_t bits);
+int agx_codes_pack(const int64_t *codes, int64_t n_codes, int32_t bits, uint8_t *out, void *stream);
+int agx_codes_unpack(const uint8_t *in, int64_t n_codes, int32_t bits, int64_t *codes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -110,3 +110,12 @@ def test_graph_replay_matches_eager(setup):
     assert torch.equal(yg, y[:8]) and torch.equal(ig, index[:8])
     yg2, _, ig2 = g(x[8:16])
     assert torch.equal(yg2, y[8:16]) and torch.equal(ig2, index[8:16])
+
+
+def test_bitstream_round_trip_reproduces_the_forward(setup):
+    """compress -> 10-bit stream -> decompress gives exactly the codes and waveform of forward()."""
+    model, x, z, y, commit, index = setup
+    stream, shape = model.compress(x[:4])
+    assert stream.numel() == (4 * 225 * 8 * 10 + 7) // 8 and shape == (4, 225, 8)    # 9 000 bytes for 12 s of audio
+    y2, idx2 = model.decompress(stream, shape)
+    assert torch.equal(idx2, index[:4]) and torch.equal(y2, y[:4])

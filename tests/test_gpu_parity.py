@@ -318,3 +318,18 @@ def test_ragged_length_matches_reference_padding():
     assert tuple(z.shape) == (2, 32, z_ref.shape[1])
     assert max_abs(z.cpu().transpose(1, 2), z_ref) < 1e-5
     assert max_abs(y.cpu(), codec.decode_latents(z.cpu().transpose(1, 2), sd, spec)) < 1e-5
+
+
+# ------------------------------------------------------------------------- bitstream
+@pytest.mark.parametrize("bits,n", [(10, 32 * 225 * 8), (10, 7), (9, 1001), (1, 64), (16, 33), (12, 8)])
+def test_code_packing_bit_exact_and_round_trip(bits, n):
+    from oracle import bitstream
+    gen = torch.Generator().manual_seed(bits * 1000 + n)
+    codes = torch.randint(0, 2 ** bits, (n,), generator=gen)
+    packed = ops.codes_pack(codes.to(DEV), bits)
+    want = bitstream.pack(codes.numpy(), bits)
+    assert packed.dtype == torch.uint8 and packed.numel() == (n * bits + 7) // 8 == want.size
+    assert np.array_equal(packed.cpu().numpy(), want)
+    back = ops.codes_unpack(packed, n, bits)
+    assert torch.equal(back.cpu(), codes)
+    assert np.array_equal(bitstream.unpack(want, n, bits), codes.numpy())
