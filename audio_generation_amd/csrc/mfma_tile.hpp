@@ -45,37 +45,6 @@ __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? 
 // torch.nn.GELU() default (approximate='none'): 0.5 x (1 + erf(x / sqrt 2))
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
 
-// Stage CC channel rows of the input, positions [in0, in0 + span), into LDS
-// (xs[c * span + i]); positions outside [0, Lvalid) read as zero.  Loads are
-// issued unconditionally on clamped addresses so that RPW * U of them are in
-// flight per wave before the first LDS write (a conditional load makes hipcc
-// wait for every element separately).
-template <int CC, int U = 2>
-__device__ __forceinline__ void stage_rows(float *__restrict__ xs, const float *__restrict__ xb, int Lin,
-                                           int Lvalid, int in0, int span, int wave, int lane) {
-    constexpr int RPW = CC / 4;  // rows per wave (4 waves)
-    for (int i0 = lane; i0 < span; i0 += 64 * U) {
-        float v[RPW][U];
-#pragma unroll
-        for (int rr = 0; rr < RPW; ++rr) {
-            const float *src = xb + size_t(wave + 4 * rr) * Lin;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int pos = in0 + i0 + u * 64;
-                const float t = src[min(max(pos, 0), Lvalid - 1)];
-                v[rr][u] = (pos >= 0 && pos < Lvalid) ? t : 0.f;
-            }
-        }
-#pragma unroll
-        for (int rr = 0; rr < RPW; ++rr)
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = i0 + u * 64;
-                if (i < span) xs[(wave + 4 * rr) * span + i] = v[rr][u];
-            }
-    }
-}
-
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // k-step mapping inside a CC-channel chunk: MFMA step ks multiplies channel

@@ -21,7 +21,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$tag -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --cpu-items 0 --no-roofline --no-graph > $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.log 2>&1
 rc=$?
 if [ $rc -ge 124 ]; then exit $rc; fi
-cd $GRAFT_REPO_ROOT && ./scripts_gpu_pmc.sh $tag > gpurun_out/pmc_$tag.log 2>&1
+cd $GRAFT_REPO_ROOT && ./scripts/gpu_pmc.sh $tag > gpurun_out/pmc_$tag.log 2>&1
 rc=$?
 tail -3 gpurun_out/pmc_$tag.log
 python tools/pmc_summary.py gpurun_out/pmc_$tag 100 gpurun_out/pmc_traffic_$tag.json > gpurun_out/pmc_summary_$tag.txt 2>&1
