@@ -20,6 +20,7 @@ const char *last_error();
 struct Tuning {
     int rb_cc = 16;   // channels per LDS chunk of the fused residual block (16 or 32)
     int rb_wgs = 0;   // 1..3: cap resident workgroups per CU of the fused residual block (0 = natural)
+    int rb_occ = 2;    // 3: build of the fused residual block capped at 168 VGPRs (3 waves/SIMD)
     int rb_sched = -1; // phase scheduling of the fused residual block (mfma_tile.hpp: 0 / 1 / 2; -1 = per-shape table)
 };
 Tuning &tuning();

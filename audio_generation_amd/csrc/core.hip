@@ -177,6 +177,7 @@ int agx_set_tuning(const char *name, int32_t value) {
     if (!strcmp(name, "rb_cc")) agx::tuning().rb_cc = value;
     else if (!strcmp(name, "rb_wgs")) agx::tuning().rb_wgs = value;
     else if (!strcmp(name, "rb_sched")) agx::tuning().rb_sched = value;
+    else if (!strcmp(name, "rb_occ")) agx::tuning().rb_occ = value;
     else return agx::fail(AGX_ERR_BAD_SHAPE, "agx_set_tuning: unknown knob '%s'", name);
     return AGX_OK;
 }
@@ -186,6 +187,7 @@ int agx_get_tuning(const char *name) {
     if (!strcmp(name, "rb_cc")) return agx::tuning().rb_cc;
     if (!strcmp(name, "rb_wgs")) return agx::tuning().rb_wgs;
     if (!strcmp(name, "rb_sched")) return agx::tuning().rb_sched;
+    if (!strcmp(name, "rb_occ")) return agx::tuning().rb_occ;
     return agx::fail(AGX_ERR_BAD_SHAPE, "agx_get_tuning: unknown knob '%s'", name);
 }
 

@@ -20,8 +20,8 @@
 
 namespace agx {
 
-template <int MW, int NW, int CC, int SCHED = kSchedDefault>
-__global__ __launch_bounds__(256, (MW <= 4 ? 2 : 1)) void resblock_mfma_kernel(ConvPlan p, int span, int post_act,
+template <int MW, int NW, int CC, int SCHED = kSchedDefault, int OCC = (MW <= 4 ? 2 : 1)>
+__global__ __launch_bounds__(256, OCC) void resblock_mfma_kernel(ConvPlan p, int span, int post_act,
                                                             const float *__restrict__ x,
                                                             const float *__restrict__ w1,
                                                             const float *__restrict__ b1,
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, (MW <= 4 ? 2 : 1)) void resblock_mfma_kernel(C
     AGX_STAMP(5);
 }
 
-template <int MW, int NW, int CC, int SCHED = kSchedDefault>
+template <int MW, int NW, int CC, int SCHED = kSchedDefault, int OCC = (MW <= 4 ? 2 : 1)>
 static int launch_rb(const ConvPlan &p, const float *x, const float *w1, const float *b1, const float *w2,
                      const float *b2, float *y, int post_act, hipStream_t st) {
     constexpr int BN = 32 * NW * 4;
@@ -150,7 +150,7 @@ static int launch_rb(const ConvPlan &p, const float *x, const float *w1, const f
     if (lds > 160 * 1024) return fail(AGX_ERR_UNSUPPORTED, "resblock: tile needs %zu B of LDS", lds);
     const int wgs = tuning().rb_wgs;  // diagnostic: cap workgroups per CU by requesting more LDS
     if (wgs >= 1 && wgs <= 3 && lds < size_t(160 * 1024) / wgs) lds = size_t(160 * 1024) / wgs;
-    auto kern = resblock_mfma_kernel<MW, NW, CC, SCHED>;
+    auto kern = resblock_mfma_kernel<MW, NW, CC, SCHED, OCC>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -201,6 +201,14 @@ int launch_resblock_fused(const ConvPlan &p, const float *x, const float *w1, co
          : sched == 0 ? launch_rb<MW, NW, 16, 0>(p, x, w1, b1, w2, b2, y, post_act, st)                 \
          : sched == 2 ? launch_rb<MW, NW, 16, 2>(p, x, w1, b1, w2, b2, y, post_act, st)                 \
                       : launch_rb<MW, NW, 16, 1>(p, x, w1, b1, w2, b2, y, post_act, st))
+    if (tuning().rb_occ == 3 && !c32) {  // diagnostic: cap VGPRs at 168 so that 3 waves/SIMD fit
+        switch (p.Cin) {
+            case 32: return launch_rb<1, 4, 16, 1, 3>(p, x, w1, b1, w2, b2, y, post_act, st);
+            case 64: return launch_rb<2, 2, 16, 2, 3>(p, x, w1, b1, w2, b2, y, post_act, st);
+            case 128: return launch_rb<4, 1, 16, 1, 3>(p, x, w1, b1, w2, b2, y, post_act, st);
+            default: break;
+        }
+    }
     switch (p.Cin) {
         case 32: return AGX_RB(1, 4);
         case 64: return AGX_RB(2, 2);

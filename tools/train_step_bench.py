@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Secondary measurement (not the headline metric): one full training step of the codec on the
-native kernels -- forward, backward (native_backward.py) and an Adam step -- at config S.
-usage: train_step_bench.py [batch] [steps]"""
+native kernels -- forward, backward (native_backward.py), gradient all-reduce and an Adam step --
+at config S.  One process per GPU (torchrun sets RANK / WORLD_SIZE); the only collective is ONE
+flattened all-reduce of the gradients per step (RCCL over xGMI; AGX_DIST_BACKEND=gloo rehearses the
+same code on a box with fewer GPUs than ranks).
+usage: [torchrun --nproc-per-node N] train_step_bench.py [batch_per_gpu] [steps]"""
 import json
 import os
 import sys
@@ -10,17 +13,24 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from audio_generation_amd import dist as agx_dist  # noqa: E402
 from audio_generation_amd.vae import CausalVQAE  # noqa: E402
 
 
 def main():
     batch = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-    dev = "cuda"
-    torch.manual_seed(0)
+    rank, local_rank, world = agx_dist.env_world()
+    backend = os.environ.get("AGX_DIST_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    torch.cuda.set_device(local_rank % n_dev)
+    dev = torch.device("cuda", local_rank % n_dev)
+    agx_dist.init(backend)
+    torch.manual_seed(0)                      # identical initial weights on every rank
     model = CausalVQAE(in_channels=1, n_blocks=4, strides=(2, 4, 5, 8), num_quantizers=8, codebook_size=1024,
                        codebook_dim=512, input_format="n c l", wavelet_decoders=False).to(dev).train()
-    x = (0.1 * torch.randn(batch, 1, 72000, device=dev)).clamp(-1, 1)
+    gen = torch.Generator().manual_seed(1234 + rank)          # every rank its own shard of the batch
+    x = (0.1 * torch.randn(batch, 1, 72000, generator=gen)).clamp(-1, 1).to(dev)
     with torch.no_grad():
         model.quantizer.init_from_latents(model._run_encoders(x[:4]))
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
@@ -30,6 +40,15 @@ def main():
         y, commit, _ = model(x)
         loss = ((y - x) ** 2).mean() + commit
         loss.backward()
+        if world > 1:                          # one flattened bucket, mean over ranks
+            grads = [p.grad for p in model.parameters() if p.grad is not None]
+            if backend == "gloo":
+                cpu = [g.cpu() for g in grads]
+                agx_dist.allreduce_mean_(cpu)
+                for g, c in zip(grads, cpu):
+                    g.copy_(c)
+            else:
+                agx_dist.allreduce_mean_(grads)
         opt.step()
         return float(loss.detach())
 
@@ -41,10 +60,18 @@ def main():
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / steps
     fwd_flop = 2 * (195194 + 13107 + 208713) * 72000 * batch          # executed (polyphase) MACs of the forward
-    print(json.dumps({"what": "train step (fwd + native bwd + Adam), config S", "batch": batch, "ms_per_step": ms,
-                      "samples_per_s": batch * 72000 / ms * 1e3, "losses": losses,
-                      "approx_tflops_at_3x_forward": 3 * fwd_flop / ms * 1e-9,
-                      "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}))
+    ms = agx_dist.max_over_ranks(ms, device=dev if backend == "nccl" else "cpu")
+    # replicas must stay identical: compare a parameter checksum across ranks
+    chk = float(sum(p.detach().double().sum() for p in model.parameters()))
+    same = abs(agx_dist.max_over_ranks(chk, device=dev if backend == "nccl" else "cpu") - chk) < 1e-9 * max(1.0, abs(chk))
+    if rank == 0:
+        print(json.dumps({"what": "train step (fwd + native bwd + grad all-reduce + Adam), config S",
+                          "n_gpus": world, "batch_per_gpu": batch, "ms_per_step": ms, "replicas_in_sync": same,
+                          "samples_per_s": world * batch * 72000 / ms * 1e3, "losses": losses,
+                          "approx_tflops_at_3x_forward": world * 3 * fwd_flop / ms * 1e-9,
+                          "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}))
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
