@@ -333,3 +333,28 @@ def test_code_packing_bit_exact_and_round_trip(bits, n):
     back = ops.codes_unpack(packed, n, bits)
     assert torch.equal(back.cpu(), codes)
     assert np.array_equal(bitstream.unpack(want, n, bits), codes.numpy())
+
+
+def test_shipped_yaml_config_topology():
+    """config/training.yml `vae_args`: default 5 blocks, strides (2,3,4,4,5), channels 32..1024, wavelet
+    layer in the second decoder block, 10 x 512 'base' (learnable) codebooks, 'n c l' input."""
+    torch.manual_seed(6)
+    model = CausalVQAE(in_channels=1, num_quantizers=10, codebook_size=512, input_format="n c l", vq_cutoff_freq=0.1,
+                       use_som=True, som_kernel_type="hard", vq_type="base").eval()
+    assert model.scale_factor == 480 and len(list(model.quantizer.parameters())) == 1
+    spec = codec.CodecSpec(in_channels=1, input_format="n c l")          # every default of vae.py:205-223
+    x = 0.1 * torch.randn(1, 1, 4800)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    z_ref = codec.encode_latents(x, sd, spec)
+    with torch.no_grad():
+        model.quantizer.init_from_latents(z_ref.transpose(1, 2))
+    sd["quantizer.codebooks"] = model.quantizer.codebooks.detach().clone()
+    model = model.to(DEV)
+    with torch.no_grad():
+        y, commit, index = model(x.to(DEV))
+        z = model._run_encoders(x.to(DEV))
+    assert tuple(index.shape) == (1, 10, 10) and tuple(z.shape) == (1, 512, 10)
+    assert rms(z.cpu().transpose(1, 2), z_ref) < 1e-5
+    zq_o, idx_o, _ = rvq.residual_quantize(z.cpu().transpose(1, 2).contiguous(), sd["quantizer.codebooks"])
+    assert torch.equal(index.cpu(), idx_o)
+    assert rms(y.cpu(), codec.decode_latents(zq_o, sd, spec)) < 1e-4
