@@ -66,6 +66,8 @@ SIGNATURES = {
                                      c_int32, c_int32, c_void_p]),
     "agx_wavelet_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32,
                                  c_int32, c_int32, c_void_p]),
+    "agx_wavelet_fold_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
+                                          c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "agx_codes_packed_bytes": (c_int64, [c_int64, c_int32]),
     "agx_codes_pack": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "agx_codes_unpack": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),

@@ -137,9 +137,120 @@ __global__ __launch_bounds__(256) void wavelet_fold_kernel(const float *__restri
     }
 }
 
+// Backward of the fold: dh (B,C,L) and, per (b, c) row, the partial derivative w.r.t. the row's
+// wavelet scale sigma (d kern[p] / d sigma = kern[p] t_p^2 / sigma^2).  One block per row.
+__global__ __launch_bounds__(256) void wavelet_fold_bwd_kernel(const float *__restrict__ h,
+                                                               const float *__restrict__ dout,
+                                                               const float *__restrict__ space,
+                                                               const float *__restrict__ sigma, int sigma_len,
+                                                               float *__restrict__ dh,
+                                                               float *__restrict__ dsig_part, int C, int L, int P,
+                                                               int scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *kern = sm;               // [P]
+    float *dkern = sm + P;          // [P]
+    float *s_lo = dkern + P;        // [scale]
+    float *s_hi = s_lo + scale;
+    float *ds_lo = s_hi + scale;
+    float *ds_hi = ds_lo + scale;
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const int c = blockIdx.x % C;
+    const float sg = sigma[sigma_len == 1 ? 0 : c];
+    if (tid < P) {
+        const float t = space[tid];
+        const float k = cosf(t) * expf(-(t * t) / sg);
+        kern[tid] = k;
+        dkern[tid] = k * (t * t) / (sg * sg);
+    }
+    __syncthreads();
+    const int fold = P / scale;
+    if (tid < scale) {
+        float lo = 0.f, hi = 0.f, dlo = 0.f, dhi = 0.f;
+        for (int p = 0; p < tid * fold; ++p) { lo += kern[p]; dlo += dkern[p]; }
+        for (int p = tid * fold; p < P; ++p) { hi += kern[p]; dhi += dkern[p]; }
+        s_lo[tid] = lo; s_hi[tid] = hi; ds_lo[tid] = dlo; ds_hi[tid] = dhi;
+    }
+    __syncthreads();
+    const size_t in_row = size_t(blockIdx.x) * L, out_row = in_row * scale;
+    const int n_win = (L - 1) * scale + 1;
+    float dsig = 0.f;
+    for (int l = tid; l < L; l += 256) {
+        const float hl = h[in_row + l];
+        float g = 0.f;
+        // windows starting in frame l (u = l*scale + ph < n_win)
+        for (int ph = 0; ph < scale; ++ph) {
+            const int u = l * scale + ph;
+            if (u < n_win) {
+                const float d = dout[out_row + u];
+                g = fmaf(d, s_hi[ph], g);
+                dsig = fmaf(d * hl, ds_hi[ph], dsig);
+            }
+        }
+        // windows starting in frame l-1 that spill into frame l (ph > 0)
+        if (l >= 1)
+            for (int ph = 1; ph < scale; ++ph) {
+                const float d = dout[out_row + (l - 1) * scale + ph];
+                g = fmaf(d, s_lo[ph], g);
+                dsig = fmaf(d * hl, ds_lo[ph], dsig);
+            }
+        // the reference's raw-sample tail: out[n_win + e] = kern[P - (scale-1) + e] * h[L-1]
+        if (l == L - 1)
+            for (int e = 0; e < scale - 1; ++e) {
+                const float d = dout[out_row + n_win + e];
+                g = fmaf(d, kern[P - (scale - 1) + e], g);
+                dsig = fmaf(d * hl, dkern[P - (scale - 1) + e], dsig);
+            }
+        dh[in_row + l] = g;
+    }
+    for (int off = 32; off > 0; off >>= 1) dsig += __shfl_xor(dsig, off);
+    if ((tid & 63) == 0) red[tid >> 6] = dsig;
+    __syncthreads();
+    if (tid == 0) dsig_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// dsigma[c] = sum_b part[b*C + c]   (or the sum over everything when sigma is shared)
+__global__ __launch_bounds__(256) void wavelet_sigma_reduce_kernel(const float *__restrict__ part, int B, int C,
+                                                                   int sigma_len, float *__restrict__ dsigma) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (sigma_len == 1) {
+        if (c == 0) {
+            float s = 0.f;
+            for (int i = 0; i < B * C; ++i) s += part[i];
+            dsigma[0] = s;
+        }
+        return;
+    }
+    if (c >= C) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += part[b * C + c];
+    dsigma[c] = s;
+}
+
 }  // namespace agx
 
 extern "C" {
+
+int agx_wavelet_fold_backward(const float *h, const float *dout, const float *space, const float *sigma,
+                              int32_t sigma_len, float *dh, float *dsigma, float *workspace, int32_t batch,
+                              int32_t channels, int32_t length, int32_t n_points, int32_t scale, void *stream) {
+    using namespace agx;
+    if (batch <= 0 || channels <= 0 || length <= 0 || n_points <= 0 || scale <= 0 || n_points % scale != 0)
+        return fail(AGX_ERR_BAD_SHAPE, "wavelet_fold_backward: bad shape");
+    if (n_points > 256 || scale > 256) return fail(AGX_ERR_UNSUPPORTED, "wavelet_fold_backward: n_points/scale > 256");
+    if (sigma_len != 1 && sigma_len != channels) return fail(AGX_ERR_BAD_SHAPE, "wavelet_fold_backward: sigma_len must be 1 or C");
+    if (!h || !dout || !space || !sigma || !dh || !dsigma || !workspace)
+        return fail(AGX_ERR_NULL_POINTER, "wavelet_fold_backward: NULL pointer");
+    const int64_t rows = int64_t(batch) * channels;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t lds = (2 * n_points + 4 * scale) * sizeof(float);
+    hipLaunchKernelGGL(wavelet_fold_bwd_kernel, dim3((unsigned)rows), dim3(256), lds, st, h, dout, space, sigma,
+                       sigma_len, dh, workspace, channels, length, n_points, scale);
+    hipLaunchKernelGGL(wavelet_sigma_reduce_kernel, dim3(ceil_div(channels, 256)), dim3(256), 0, st, workspace, batch,
+                       channels, sigma_len, dsigma);
+    return check_launch("wavelet_fold_backward");
+}
+
 
 int agx_multires_forward(const float *x, const float *h0, const float *h1, const float *w, float *y,
                          int32_t batch, int32_t channels, int32_t length, int32_t kernel, int32_t depth,

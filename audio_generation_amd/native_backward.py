@@ -4,6 +4,7 @@ A stack (``model.encoders`` / ``model.decoders``) is flattened into *units*:
 
 * conv unit      ``y = act(conv(x) + b)``             (act optional)
 * residual unit  ``y = act(x + conv2(act(conv1(x) + b1)) + b2)``
+* wavelet unit   ``y = act(conv_out(fold(conv_in(x))))``  (``WaveletLayer.backward_native``)
 
 Forward runs the usual fused kernels and keeps every unit's input.  Backward walks the
 units in reverse with three C-ABI ops per conv:
@@ -16,8 +17,8 @@ units in reverse with three C-ABI ops per conv:
 * one ``agx_conv_forward`` per residual unit to re-materialise the hidden activation the
   fused forward kernel never wrote.
 
-Stacks containing a layer without native backward kernels (the wavelet layer) use the ATen
-bridge of ``autograd_bridge.py`` instead.
+Stacks containing a layer without native backward kernels (e.g. a non-LeakyReLU activation)
+use the ATen bridge of ``autograd_bridge.py`` instead.
 """
 from __future__ import annotations
 
@@ -36,12 +37,14 @@ class _Unit:
     """One conv or residual unit of a stack."""
 
     def __init__(self, kind: str, convs: Sequence[nn.Module], slope: Optional[float], inner_slope: Optional[float] = None):
-        self.kind = kind            # "conv" | "res"
+        self.kind = kind            # "conv" | "res" | "wavelet"
         self.convs = list(convs)    # [_ConvBase] or [conv1, conv2]
         self.slope = slope          # activation after the unit (None = linear output)
         self.inner_slope = inner_slope
 
     def params(self) -> List[Tensor]:
+        if self.kind == "wavelet":
+            return self.convs[0].params()
         out = []
         for c in self.convs:
             cp = c.conv
@@ -67,6 +70,9 @@ def build_units(stack: nn.ModuleList) -> Optional[List[_Unit]]:
             return True
         if isinstance(layer, _ConvBase):
             units.append(_Unit("conv", [layer], slope))
+            return True
+        if hasattr(layer, "backward_native"):                 # WaveletLayer
+            units.append(_Unit("wavelet", [layer], slope))
             return True
         return False
 
@@ -131,7 +137,9 @@ class _NativeStack(torch.autograd.Function):
             # the unit that produced x (if any) applied an activation: fold its gradient into dx
             prev_slope = units[i - 1].slope if i > 0 else None
             mask = x if prev_slope is not None else None
-            if u.kind == "conv":
+            if u.kind == "wavelet":
+                dz, grads[i] = u.convs[0].backward_native(x, dz, mask, prev_slope or 0.0)
+            elif u.kind == "conv":
                 conv = u.convs[0]
                 grads[i] = _grads_of(conv, x, dz)
                 dz = ops.conv_bwd_data(_desc(conv, x), dz, conv.conv.packed_bwd(conv.kind), None, mask,

@@ -321,6 +321,23 @@ def wavelet_fold(h: Tensor, space: Tensor, sigma: Tensor, scale: int) -> Tensor:
     return y
 
 
+def wavelet_fold_backward(h: Tensor, dout: Tensor, space: Tensor, sigma: Tensor, scale: int):
+    """(dh, dsigma) of ``wavelet_fold``; dsigma has sigma's number of elements."""
+    lib = _lib.load()
+    _need_gpu(h, dout, space, sigma)
+    h, dout = _f32c(h), _f32c(dout)
+    b, c, length = h.shape
+    space = _f32c(space.reshape(-1))
+    sig = _f32c(sigma.reshape(-1))
+    dh = torch.empty_like(h)
+    dsig = torch.empty_like(sig)
+    ws = torch.empty(b * c, dtype=torch.float32, device=h.device)
+    _lib.check(lib.agx_wavelet_fold_backward(_ptr(h), _ptr(dout), _ptr(space), _ptr(sig), sig.numel(), _ptr(dh),
+                                             _ptr(dsig), _ptr(ws), b, c, length, space.numel(), scale, _stream()),
+               "agx_wavelet_fold_backward")
+    return dh, dsig.reshape(sigma.shape)
+
+
 # ------------------------------------------------------------------ bitstream
 def codes_pack(index: Tensor, bits: int) -> Tensor:
     """(..,) int64 codes -> uint8 stream, `bits` bits per code (dense, little-endian)."""

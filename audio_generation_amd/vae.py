@@ -313,6 +313,8 @@ def _run_unit_forward(unit, x: Tensor) -> Tensor:
     if unit.kind == "res":
         res = unit.convs[0]._parent_block
         return res.run(x, unit.slope)
+    if unit.kind == "wavelet":
+        return unit.convs[0].run_fused(x, unit.slope)
     conv = unit.convs[0]
     return conv.run(x, EPI_LEAKY_PRE if unit.slope is not None else 0, unit.slope or 0.0)
 

@@ -58,6 +58,18 @@ class _PlainConv(nn.Module):
         self.weight, self.bias = ref.weight, ref.bias
         self.in_channels, self.out_channels, self.kernel_size = c_in, c_out, (kernel,)
         self._key, self._packed = None, None
+        self._bkey, self._packed_bwd = None, None
+
+    def desc(self, kind: int, x: Tensor, epilogue: int = 0, slope: float = 0.1):
+        return ops.conv_desc(kind, x.shape[0], self.in_channels, self.out_channels, x.shape[2],
+                             self.kernel_size[0], 1, 1, epilogue, slope)
+
+    def packed_bwd(self, kind: int) -> Tensor:
+        key = (kind, self.weight.data_ptr(), self.weight._version)
+        if key != self._bkey:
+            d = ops.conv_desc(kind, 1, self.in_channels, self.out_channels, 1 << 20, self.kernel_size[0])
+            self._packed_bwd, self._bkey = ops.conv_pack_bwd(d, self.weight.detach()), key
+        return self._packed_bwd
 
     def run(self, x: Tensor, kind: int, epilogue: int = 0, slope: float = 0.1) -> Tensor:
         key = (kind, self.weight.data_ptr(), self.weight._version)
@@ -134,3 +146,20 @@ class WaveletLayer(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         return self.run_fused(x, None)
+
+    # -- native backward (used by native_backward.py as one unit of a decoder stack) --------------
+    def params(self):
+        return [self.conv_in.weight, self.conv_in.bias, self.conv_out.weight, self.conv_out.bias, self.wavelet_scale]
+
+    def backward_native(self, x: Tensor, dz: Tensor, mask: Optional[Tensor], mask_slope: float):
+        """``dz`` = gradient w.r.t. conv_out's linear output.  Returns (dx, grads in ``params()`` order);
+        the hidden tensors are re-materialised (two cheap kernels) rather than kept from the forward."""
+        h = self.conv_in.run(x, CONV_SAME)
+        y = ops.wavelet_fold(h, self.space, self.wavelet_scale.detach(), self.scale_factor)
+        dwo, _, dbo = ops.conv_bwd_weight(self.conv_out.desc(CONV_SAME, y), y, dz, self.conv_out.weight.detach(), None)
+        dy = ops.conv_bwd_data(self.conv_out.desc(CONV_SAME, y), dz, self.conv_out.packed_bwd(CONV_SAME))
+        dh, dsig = ops.wavelet_fold_backward(h, dy, self.space, self.wavelet_scale.detach(), self.scale_factor)
+        dwi, _, dbi = ops.conv_bwd_weight(self.conv_in.desc(CONV_SAME, x), x, dh, self.conv_in.weight.detach(), None)
+        dx = ops.conv_bwd_data(self.conv_in.desc(CONV_SAME, x), dh, self.conv_in.packed_bwd(CONV_SAME), None, mask,
+                               mask_slope)
+        return dx, [dwi, dbi, dwo, dbo, dsig]

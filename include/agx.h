@@ -230,6 +230,12 @@ int agx_wavelet_fold(const float *h, const float *space, const float *sigma, int
                      float *y, int32_t batch, int32_t channels, int32_t length, int32_t n_points,
                      int32_t scale, void *stream);
 
+/* Backward of agx_wavelet_fold: dh (B,C,L) and dsigma (sigma_len) from dout (B,C,L*scale).
+ * workspace: B*C floats (per-row partials of dsigma, reduced in a fixed order). */
+int agx_wavelet_fold_backward(const float *h, const float *dout, const float *space, const float *sigma,
+                              int32_t sigma_len, float *dh, float *dsigma, float *workspace, int32_t batch,
+                              int32_t channels, int32_t length, int32_t n_points, int32_t scale, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * Codec bitstream (wire size per utils.py:137-147)               *
  * ------------------------------------------------------------------------- */

@@ -90,3 +90,23 @@ def test_backward_weight_bias_and_weight_norm_match_autograd():
         assert max_abs(dw.cpu(), want_w) < 2e-4 * max(1.0, float(want_w.abs().max())), (kind, cin, cout, k, s, d)
         checked += 1
     assert checked == len(SHAPES)
+
+
+@pytest.mark.parametrize("channelwise", [True, False])
+@pytest.mark.parametrize("scale,n_points,length", [(2, 16, 37), (5, 40, 300), (4, 8, 1), (1, 4, 19)])
+def test_wavelet_fold_backward_matches_autograd(channelwise, scale, n_points, length):
+    """dh and d(wavelet_scale) of the fold (two-tap collapsed form) against autograd through the oracle's
+    (B,C,L,n_points) expansion, incl. the raw-sample tail, L = 1 and the shared-sigma variant."""
+    from oracle import wavelets as ow
+    torch.manual_seed(scale * 10 + length)
+    b, c = 3, 6
+    h = torch.randn(b, c, length, requires_grad=True)
+    space = torch.linspace(-10, 10, n_points)
+    sigma = (40.0 + 5 * torch.rand(1, c, 1, 1) if channelwise else torch.tensor(33.0)).requires_grad_(True)
+    dout = torch.randn(b, c, length * scale)
+    out = ow.wavelet_fold(h, space, sigma, scale)
+    out.backward(dout)
+    dh, dsig = ops.wavelet_fold_backward(h.detach().to(DEV), dout.to(DEV), space.to(DEV), sigma.detach().to(DEV), scale)
+    assert dsig.shape == sigma.shape
+    assert max_abs(dh.cpu(), h.grad) <= 1e-5 * float(h.grad.abs().max())
+    assert max_abs(dsig.cpu(), sigma.grad) <= 1e-4 * float(sigma.grad.abs().max()) + 1e-9
