@@ -73,12 +73,118 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvPlan p, int ci_til
     }
 }
 
+// ------------------------------------------------------------------ streaming fast path
+// The two pure-bandwidth layers of every codec configuration are causal K=7, stride-1 convs
+// between the waveform and first_block_channels (vae.py:257, :281).  No LDS, no barrier: one
+// thread owns 4 consecutive outputs of CO_T rows, reads the 12-sample aligned window
+// [t-8, t+4) of each input row as three float4 (neighbouring threads share two of them through
+// L1) and writes float4.  Same summation order as the generic kernel (channel-major, tap-minor).
+constexpr int kNarrowJ = 7, kNarrowP = 6;
+
+static inline bool narrow_ok(const ConvPlan &p) {
+    return p.J == kNarrowJ && p.P == kNarrowP && p.s == 1 && p.d == 1 && p.q == 1 && p.oshift == 0 &&
+           p.Lin % 4 == 0 && p.Lvalid % 4 == 0 && p.Lout % 4 == 0 && p.Lt == p.Lout && p.Lvalid >= 4 &&
+           (p.M == 1 || p.M == 2 || p.M == 32);
+}
+
+template <int CO_T>
+__global__ __launch_bounds__(256) void conv_narrow_kernel(ConvPlan p, const float *__restrict__ x,
+                                                          const float *__restrict__ wp,
+                                                          const float *__restrict__ bias,
+                                                          const float *__restrict__ res,
+                                                          float *__restrict__ y) {
+    const int t = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int b = blockIdx.y;
+    const int m0 = blockIdx.z * CO_T;  // M == 32 runs as two 16-row halves (register budget)
+    const bool live = t < p.Lt;
+    float acc[CO_T][4];
+#pragma unroll
+    for (int r = 0; r < CO_T; ++r)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[r][u] = 0.f;
+
+    const float *xb = x + size_t(b) * p.Cin * p.Lin;
+    // aligned window pieces [t-8,t-4) [t-4,t) [t,t+4): each wholly inside or outside [0, Lvalid)
+    int off[3];
+    bool ok[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int pos = t - 8 + 4 * k;
+        ok[k] = pos >= 0 && pos + 4 <= p.Lvalid;
+        off[k] = ok[k] ? pos : 0;
+    }
+    constexpr int CU = CO_T >= 16 ? 1 : 4;  // channels in flight per step
+    for (int c0 = 0; c0 < p.Cin; c0 += CU) {
+        float win[CU][12];
+#pragma unroll
+        for (int cc = 0; cc < CU; ++cc) {
+            const int c = min(c0 + cc, p.Cin - 1);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float4 v = *reinterpret_cast<const float4 *>(xb + size_t(c) * p.Lin + off[k]);
+                win[cc][4 * k + 0] = ok[k] ? v.x : 0.f;
+                win[cc][4 * k + 1] = ok[k] ? v.y : 0.f;
+                win[cc][4 * k + 2] = ok[k] ? v.z : 0.f;
+                win[cc][4 * k + 3] = ok[k] ? v.w : 0.f;
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < CU; ++cc) {
+            if (c0 + cc >= p.Cin) break;
+#pragma unroll
+            for (int j = 0; j < kNarrowJ; ++j) {
+                const float *wj = wp + packed_weight_index(c0 + cc, j, m0, kNarrowJ, p.M);
+#pragma unroll
+                for (int r = 0; r < CO_T; ++r) {
+                    const float w = wj[size_t(r) * kWG];  // wave-uniform -> scalar load
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[r][u] = fmaf(w, win[cc][2 + u + j], acc[r][u]);
+                }
+            }
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int r = 0; r < CO_T; ++r) {
+        const size_t o = (size_t(b) * p.Cout + m0 + r) * p.Lout + t;
+        const float bv = bias ? bias[m0 + r] : 0.f;
+        float4 rv = make_float4(0.f, 0.f, 0.f, 0.f), mv = rv;
+        if (p.epilogue & AGX_EPI_RESIDUAL) rv = *reinterpret_cast<const float4 *>(res + o);
+        if (p.epilogue & AGX_EPI_MASK) mv = *reinterpret_cast<const float4 *>(p.mask + o);
+        const float rr[4] = {rv.x, rv.y, rv.z, rv.w}, mm[4] = {mv.x, mv.y, mv.z, mv.w};
+        float out[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float v = acc[r][u] + bv;
+            if (p.epilogue & AGX_EPI_LEAKY_PRE) v = v > 0.f ? v : v * p.slope;
+            if (p.epilogue & AGX_EPI_GELU_PRE) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+            if (p.epilogue & AGX_EPI_RESIDUAL) v += rr[u];
+            if (p.epilogue & AGX_EPI_LEAKY_POST) v = v > 0.f ? v : v * p.slope;
+            if (p.epilogue & AGX_EPI_MASK) v = mm[u] > 0.f ? v : v * p.slope;
+            out[u] = v;
+        }
+        *reinterpret_cast<float4 *>(y + o) = make_float4(out[0], out[1], out[2], out[3]);
+    }
+}
+
 const char *conv_direct_variant(const ConvPlan &p) {
+    if (narrow_ok(p)) return p.M == 32 ? "conv_narrow<16>" : (p.M == 2 ? "conv_narrow<2>" : "conv_narrow<1>");
     return p.M >= 32 ? "conv_direct<32>" : (p.M > 4 ? "conv_direct<16>" : (p.M > 1 ? "conv_direct<4>" : "conv_direct<1>"));
 }
 
 int launch_conv_direct(const ConvPlan &p, const float *x, const float *wp, const float *bias,
                        const float *res, float *y, hipStream_t st) {
+    if (narrow_ok(p)) {
+        dim3 grid(ceil_div(p.Lt, 1024), p.B, p.M == 32 ? 2 : 1), block(256);
+        if (grid.y > 65535) return fail(AGX_ERR_BAD_SHAPE, "conv_narrow: grid too large");
+        if (p.M == 32)
+            hipLaunchKernelGGL(conv_narrow_kernel<16>, grid, block, 0, st, p, x, wp, bias, res, y);
+        else if (p.M == 2)
+            hipLaunchKernelGGL(conv_narrow_kernel<2>, grid, block, 0, st, p, x, wp, bias, res, y);
+        else
+            hipLaunchKernelGGL(conv_narrow_kernel<1>, grid, block, 0, st, p, x, wp, bias, res, y);
+        return check_launch("conv_narrow");
+    }
     const int span = 255 * p.s + (p.J - 1) * p.d + 1;
     int ci_tile = (12 * 1024) / span;  // <= 48 KB of LDS
     if (ci_tile < 1) ci_tile = 1;
