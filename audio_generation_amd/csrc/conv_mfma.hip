@@ -149,6 +149,10 @@ struct Variant {
     { MW, NW, WM, WN, CC, "conv_mfma<" #MW "," #NW "," #WM "," #WN "," #CC ">", launch_variant<MW, NW, WM, WN, CC> }
 
 static const Variant kWide[] = {AGX_VARIANT(2, 2, 2, 2, 16), AGX_VARIANT(2, 2, 2, 2, 8), AGX_VARIANT(2, 2, 2, 2, 32)};
+// 128 x 64 tiles for short signals: twice the workgroups when the 128 x 128 grid would leave
+// a CU with a single resident workgroup (nothing to overlap staging / epilogue with).
+static const Variant kWideShort[] = {AGX_VARIANT(1, 2, 4, 1, 16), AGX_VARIANT(1, 2, 4, 1, 8), AGX_VARIANT(1, 2, 4, 1, 32)};
+static const Variant kWideAlt[] = {AGX_VARIANT(1, 4, 4, 1, 16), AGX_VARIANT(1, 4, 4, 1, 8), AGX_VARIANT(1, 4, 4, 1, 32)};
 static const Variant kMid[] = {AGX_VARIANT(2, 2, 1, 4, 16), AGX_VARIANT(2, 2, 1, 4, 8), AGX_VARIANT(2, 1, 1, 4, 16),
                                AGX_VARIANT(2, 1, 1, 4, 8),  AGX_VARIANT(2, 2, 1, 4, 32)};
 static const Variant kNarrow[] = {AGX_VARIANT(1, 4, 1, 4, 16), AGX_VARIANT(1, 4, 1, 4, 8), AGX_VARIANT(1, 1, 1, 4, 16),
@@ -160,20 +164,37 @@ static size_t variant_lds(const Variant &v, const ConvPlan &p) {
     return size_t(2) * v.cc * span * sizeof(float);
 }
 
-static const Variant *select_variant(const ConvPlan &p) {
-    if (p.Cin % 16 != 0 || p.M < 32) return nullptr;
-    const Variant *list = p.M >= 128 ? kWide : (p.M >= 64 ? kMid : kNarrow);
-    const int n = p.M >= 128 ? 3 : 5;
-    // few taps per channel (k=1 / k=3 / polyphase): a 32-channel chunk halves the number of
-    // barrier + DMA hand-overs per MFMA
-    if (p.J <= 4 && p.Cin % 32 == 0)
+static const Variant *pick(const Variant *list, int n, const ConvPlan &p, int want_cc) {
+    if (want_cc) {
         for (int i = 0; i < n; ++i)
-            if (list[i].cc == 32 && variant_lds(list[i], p) <= 72 * 1024) return &list[i];
+            if (list[i].cc == want_cc && (want_cc != 32 || p.Cin % 32 == 0) && variant_lds(list[i], p) <= 160 * 1024)
+                return &list[i];
+        return nullptr;
+    }
+    // (32-channel chunks measured no better than 16 on any config-S shape: kept as forced variants only)
     for (int i = 0; i < n; ++i)
         if (list[i].cc != 32 && variant_lds(list[i], p) <= 72 * 1024) return &list[i];
     for (int i = 0; i < n; ++i)
         if (list[i].cc != 32 && variant_lds(list[i], p) <= 160 * 1024) return &list[i];
     return nullptr;
+}
+
+static const Variant *select_variant(const ConvPlan &p) {
+    if (p.Cin % 16 != 0 || p.M < 32) return nullptr;
+    const Variant *list = p.M >= 128 ? kWide : (p.M >= 64 ? kMid : kNarrow);
+    const int n = p.M >= 128 ? 3 : 5;
+    if (p.M >= 128 && tuning().conv_shape == 1) list = kWideAlt;
+    const Variant *v = pick(list, n, p, tuning().conv_cc);
+    if (v && p.M >= 128 && tuning().conv_short) {
+        // Short signals: the same channel chunk (= the same summation order, so results do not depend on
+        // the batch size or the signal length) on 128 x 64 tiles.
+        const long wgs = long(ceil_div(p.Lt, 128)) * ceil_div(p.M, 128) * p.B;
+        if (wgs < 2 * 256) {
+            const Variant *vs = pick(kWideShort, 3, p, v->cc);
+            if (vs) v = vs;
+        }
+    }
+    return v;
 }
 
 bool conv_mfma_supported(const ConvPlan &p) { return select_variant(p) != nullptr; }

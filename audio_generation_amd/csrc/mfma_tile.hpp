@@ -206,6 +206,14 @@ __device__ __forceinline__ void conv_gemm(f32x16 (&acc)[MW][NW], float *__restri
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef AGX_STAMPS
+                {   // how long does the end-of-phase wait for the prefetched weights take?
+                    const unsigned long long tq = __builtin_amdgcn_s_memtime();
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (h == 0 && j == 0) AGX_STAMP_ADD(9, tq); else AGX_STAMP_ADD(10, tq);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#endif
 #pragma unroll
                 for (int ks = 0; ks < PC / 2; ++ks) {
 #pragma unroll

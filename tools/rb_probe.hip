@@ -43,18 +43,20 @@ int main(int argc, char **argv) {
     float ms; hipEventElapsedTime(&ms, e0, e1);
     hipMemcpyFromSymbol(z.data(), HIP_SYMBOL(agx::g_stamps), z.size() * 8);
     const int nb = (L + 127) / 128 > 500 ? 500 : (L + (C == 32 ? 511 : C == 64 ? 255 : 127)) / (C == 32 ? 512 : C == 64 ? 256 : 128);
-    double seg[6] = {0}, waitsum = 0; int n = 0;
+    double seg[6] = {0}, waitsum = 0, w9 = 0, w10 = 0; int n = 0;
     for (int blk = 0; blk < nb; ++blk) {
         unsigned long long *t = &z[blk * 16];
         if (!t[5]) continue;
         for (int i = 0; i < 5; ++i) seg[i] += double(t[i + 1] - t[i]);
-        waitsum += double(t[8]); ++n;
+        waitsum += double(t[8]); w9 += double(t[9]); w10 += double(t[10]); ++n;
     }
     printf("C=%d L=%d d=%d: kernel %.1f us; per-workgroup cycles (mean of %d WGs of batch 0):\n", C, L, dil, ms * 1e3, n);
     const char *name[5] = {"prologue (zero-fill, first DMA, first weights)", "GEMM1 main loop", "hidden activation", "GEMM2", "epilogue (bias + residual + store)"};
     double tot = 0; for (int i = 0; i < 5; ++i) tot += seg[i] / n;
     for (int i = 0; i < 5; ++i) printf("  %-50s %10.0f  (%4.1f %%)\n", name[i], seg[i] / n, 100 * seg[i] / n / tot);
     printf("  %-50s %10.0f  (%4.1f %% of the main loop)\n", "  of which chunk-end vmcnt(0)+barrier waits", waitsum / n, 100 * waitsum / seg[1]);
+    printf("  %-50s %10.0f  (%4.1f %% of the main loop)\n", "  of which weight waits in the DMA-issuing phase", w9 / n, 100 * w9 / seg[1]);
+    printf("  %-50s %10.0f  (%4.1f %% of the main loop)\n", "  of which weight waits in the other phases", w10 / n, 100 * w10 / seg[1]);
     printf("  total %10.0f cycles = %.1f us at 100 MHz memtime ticks?\n", tot, tot / 100.0);
     return 0;
 }
