@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libagx.so")
 
 # constants mirrored from include/agx.h
-CONV_CAUSAL, CONV_TRANSPOSED, CONV_UPSAMPLE, CONV_SAME = 0, 1, 2, 3
+CONV_CAUSAL, CONV_TRANSPOSED, CONV_UPSAMPLE, CONV_SAME, CONV_PADDED = 0, 1, 2, 3, 4
 IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA = 0, 1, 2
 EPI_LEAKY_PRE, EPI_RESIDUAL, EPI_LEAKY_POST, EPI_GELU_PRE, EPI_MASK = 1, 2, 4, 8, 16
 
@@ -24,11 +24,21 @@ class ConvDesc(Structure):
     """``agx_conv_desc`` (include/agx.h)."""
     _fields_ = [("kind", c_int32), ("batch", c_int32), ("c_in", c_int32), ("c_out", c_int32),
                 ("l_in", c_int32), ("kernel", c_int32), ("stride", c_int32), ("dilation", c_int32),
-                ("epilogue", c_int32), ("slope", c_float), ("impl", c_int32)]
+                ("epilogue", c_int32), ("slope", c_float), ("impl", c_int32), ("groups", c_int32),
+                ("padding", c_int32)]
+
+
+class Conv2dDesc(Structure):
+    """``agx_conv2d_desc`` (include/agx.h)."""
+    _fields_ = [("batch", c_int32), ("c_in", c_int32), ("c_out", c_int32), ("h_in", c_int32), ("w_in", c_int32),
+                ("kh", c_int32), ("kw", c_int32), ("stride_h", c_int32), ("stride_w", c_int32),
+                ("pad_h", c_int32), ("pad_w", c_int32), ("epilogue", c_int32), ("slope", c_float),
+                ("impl", c_int32)]
 
 
 # every symbol include/agx.h declares: name -> (restype, argtypes)
 _PD = POINTER(ConvDesc)
+_P2 = POINTER(Conv2dDesc)
 SIGNATURES = {
     "agx_version": (c_int, []),
     "agx_last_error": (c_char_p, []),
@@ -68,6 +78,24 @@ SIGNATURES = {
                                  c_int32, c_int32, c_void_p]),
     "agx_wavelet_fold_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
                                           c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "agx_spectral_sigma": (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_float, c_void_p,
+                                   c_void_p, c_void_p]),
+    "agx_conv_pack_sigma": (c_int, [_PD, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "agx_avgpool1d_out_len": (c_int64, [c_int32, c_int32, c_int32, c_int32]),
+    "agx_avgpool1d": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "agx_conv2d_out_shape": (c_int, [_P2, POINTER(c_int32), POINTER(c_int32)]),
+    "agx_conv2d_packed_floats": (c_int64, [_P2]),
+    "agx_conv2d_pack": (c_int, [_P2, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "agx_conv2d_forward": (c_int, [_P2, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "agx_conv2d_kernel_name": (c_int, [_P2, c_char_p, c_size_t]),
+    "agx_stft_frames": (c_int64, [c_int32, c_int32]),
+    "agx_stft_packed_floats": (c_int64, [c_int32]),
+    "agx_stft_pack": (c_int, [c_int32, c_int32, c_void_p, c_void_p]),
+    "agx_stft_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32]),
+    "agx_stft_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "agx_reduce_mean": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
+    "agx_reduce_mean_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "agx_sigmoid": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "agx_codes_packed_bytes": (c_int64, [c_int64, c_int32]),
     "agx_codes_pack": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "agx_codes_unpack": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),

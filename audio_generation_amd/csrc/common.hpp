@@ -55,6 +55,15 @@ struct ConvPlan {
     float slope;
     int oshift;         // output index = q*t + p - oshift (backward-data of strided convs), 0 otherwise
     const float *mask;  // AGX_EPI_MASK: v *= (mask[o] > 0 ? 1 : slope)  (LeakyReLU gradient), else unused
+    // grouped layers (direct kernel only): Cin / Cout are the layer totals, the packed image has Cin / G
+    // channels and output row m reads input channels (m / (Cout / G)) * (Cin / G) + [0, Cin / G)
+    int G;
+    // 2-D layers (conv2d.hip) as 1-D convs along the last axis: virtual channel c' = ci * kh + dh (Cin counts
+    // those), virtual batch z = b * Tout + t; input row of (z, c') = t * sh - ph + dh (zero outside [0, Tin)).
+    // 1-D layers: kh = 1, Tin = Tout = 1, x_cstride = Lin, y_cstride = Lout.
+    int kh, sh, ph, Tin, Tout;
+    int ncv, cin_real;             // virtual channels actually present (Cin rounds them up to 16) / real input channels
+    int64_t x_cstride, y_cstride;  // elements between consecutive real channels of x / y
 };
 
 // Packed weight image ("group-K-major"): channels in groups of 16,
@@ -74,5 +83,7 @@ int lower_conv(const agx_conv_desc *d, ConvPlan *p);
 // Plan of the backward-data op of layer `d` (gradient w.r.t. the layer input, given the gradient
 // w.r.t. its output): the same polyphase form with input/output channels swapped.
 int lower_conv_bwd_data(const agx_conv_desc *d, ConvPlan *p);
+// 2-D layer (torch.nn.Conv2d, zero padding) as a 1-D conv over virtual channels / batch (see ConvPlan).
+int lower_conv2d(const agx_conv2d_desc *d, ConvPlan *p);
 
 }  // namespace agx

@@ -22,29 +22,35 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvPlan p, int ci_til
     const int tid = threadIdx.x;
     const int t0 = blockIdx.x * 256;
     const int m0 = blockIdx.y * CO_T;
-    const int b = blockIdx.z;
+    const int b = blockIdx.z / p.Tout, trow = blockIdx.z - b * p.Tout;  // 1-D: Tout = 1
     const int t = t0 + tid;
     const int in0 = t0 * p.s - p.P;  // input index of xs[.][0]
+    // grouped layers: this block's rows all sit in one group (the launcher picks CO_T | Cout / G)
+    const int cpg = p.ncv / p.G;                       // (virtual) input channels per group
+    const int grp = p.G > 1 ? m0 / (p.Cout / p.G) : 0;
+    const int row0 = trow * p.sh - p.ph;
 
     float acc[CO_T];
 #pragma unroll
     for (int r = 0; r < CO_T; ++r) acc[r] = 0.f;
 
-    const float *xb = x + size_t(b) * p.Cin * p.Lin;
-    for (int c0 = 0; c0 < p.Cin; c0 += ci_tile) {
-        const int nc = min(ci_tile, p.Cin - c0);
+    const float *xb = x + size_t(b) * p.cin_real * p.x_cstride + size_t(grp) * cpg * p.x_cstride;
+    for (int c0 = 0; c0 < cpg; c0 += ci_tile) {
+        const int nc = min(ci_tile, cpg - c0);
         __syncthreads();
         for (int e = tid; e < nc * span; e += 256) {
             const int c = e / span, i = e - c * span;
             const int pos = in0 + i;
-            xs[e] = (pos >= 0 && pos < p.Lvalid) ? xb[size_t(c0 + c) * p.Lin + pos] : 0.f;
+            const int cv = c0 + c, ci = cv / p.kh, r = row0 + (cv - ci * p.kh);  // 1-D: kh = 1, r = 0
+            const bool ok = pos >= 0 && pos < p.Lvalid && r >= 0 && r < p.Tin;
+            xs[e] = ok ? xb[size_t(ci) * p.x_cstride + size_t(r) * p.Lin + pos] : 0.f;
         }
         __syncthreads();
         for (int c = 0; c < nc; ++c) {
             const float *xr = xs + c * span + tid * p.s;
             for (int j = 0; j < p.J; ++j) {
                 const float xv = xr[j * p.d];
-                const float *wj = wp + packed_weight_index(c0 + c, j, 0, p.J, p.M);
+                const float *wj = wp + packed_weight_index(c0 + c, j, 0, p.J, p.M);  // image has cpg channels
 #pragma unroll
                 for (int r = 0; r < CO_T; ++r) {
                     const int m = min(m0 + r, p.M - 1);  // wave-uniform -> scalar load
@@ -65,7 +71,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvPlan p, int ci_til
         float v = acc[r] + (bias ? bias[co] : 0.f);
         if (p.epilogue & AGX_EPI_LEAKY_PRE) v = v > 0.f ? v : v * p.slope;
         if (p.epilogue & AGX_EPI_GELU_PRE) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
-        const size_t o = (size_t(b) * p.Cout + co) * p.Lout + u;
+        const size_t o = (size_t(b) * p.Cout + co) * p.y_cstride + size_t(trow) * p.Lout + u;
         if (p.epilogue & AGX_EPI_RESIDUAL) v += res[o];
         if (p.epilogue & AGX_EPI_LEAKY_POST) v = v > 0.f ? v : v * p.slope;
         if (p.epilogue & AGX_EPI_MASK) v = p.mask[o] > 0.f ? v : v * p.slope;
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvPlan p, int ci_til
 constexpr int kNarrowJ = 7, kNarrowP = 6;
 
 static inline bool narrow_ok(const ConvPlan &p) {
-    return p.J == kNarrowJ && p.P == kNarrowP && p.s == 1 && p.d == 1 && p.q == 1 && p.oshift == 0 &&
+    return p.G == 1 && p.kh == 1 && p.J == kNarrowJ && p.P == kNarrowP && p.s == 1 && p.d == 1 && p.q == 1 && p.oshift == 0 &&
            p.Lin % 4 == 0 && p.Lvalid % 4 == 0 && p.Lout % 4 == 0 && p.Lt == p.Lout && p.Lvalid >= 4 &&
            (p.M == 1 || p.M == 2 || p.M == 32);
 }
@@ -168,6 +174,10 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(ConvPlan p, const floa
 }
 
 const char *conv_direct_variant(const ConvPlan &p) {
+    if (p.G > 1) {
+        const int rpg = p.Cout / p.G;
+        return rpg % 32 == 0 ? "conv_direct<32>" : (rpg % 16 == 0 ? "conv_direct<16>" : (rpg % 4 == 0 ? "conv_direct<4>" : "conv_direct<1>"));
+    }
     if (narrow_ok(p)) return p.M == 32 ? "conv_narrow<16>" : (p.M == 2 ? "conv_narrow<2>" : "conv_narrow<1>");
     return p.M >= 32 ? "conv_direct<32>" : (p.M > 4 ? "conv_direct<16>" : (p.M > 1 ? "conv_direct<4>" : "conv_direct<1>"));
 }
@@ -186,13 +196,19 @@ int launch_conv_direct(const ConvPlan &p, const float *x, const float *wp, const
         return check_launch("conv_narrow");
     }
     const int span = 255 * p.s + (p.J - 1) * p.d + 1;
+    const int cpg = p.ncv / p.G;
     int ci_tile = (12 * 1024) / span;  // <= 48 KB of LDS
     if (ci_tile < 1) ci_tile = 1;
-    if (ci_tile > p.Cin) ci_tile = p.Cin;
+    if (ci_tile > cpg) ci_tile = cpg;
     const size_t lds = size_t(ci_tile) * span * sizeof(float);
     if (lds > 150 * 1024) return fail(AGX_ERR_UNSUPPORTED, "conv_direct: tile needs %zu B of LDS", lds);
-    const int co_t = p.M >= 32 ? 32 : (p.M > 4 ? 16 : (p.M > 1 ? 4 : 1));
-    dim3 grid(ceil_div(p.Lt, 256), ceil_div(p.M, co_t), p.B), block(256);
+    int co_t = p.M >= 32 ? 32 : (p.M > 4 ? 16 : (p.M > 1 ? 4 : 1));
+    if (p.G > 1) {
+        if (p.q != 1) return fail(AGX_ERR_UNSUPPORTED, "conv_direct: grouped polyphase layers");
+        const int rpg = p.Cout / p.G;  // a block's rows must share their group
+        co_t = rpg % 32 == 0 ? 32 : (rpg % 16 == 0 ? 16 : (rpg % 4 == 0 ? 4 : 1));
+    }
+    dim3 grid(ceil_div(p.Lt, 256), ceil_div(p.M, co_t), p.B * p.Tout), block(256);
     if (grid.y > 65535 || grid.z > 65535) return fail(AGX_ERR_BAD_SHAPE, "conv_direct: grid too large");
     switch (co_t) {
         case 32:

@@ -24,7 +24,7 @@
 
 namespace agx {
 
-template <int MW, int NW, int WM, int WN, int CC>
+template <int MW, int NW, int WM, int WN, int CC, bool TWO_D = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
                                                         const float *__restrict__ x,
                                                         const float *__restrict__ wp,
@@ -40,7 +40,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
     const int t0 = blockIdx.x * BN;
     const int m0 = blockIdx.y * BM + wm * (32 * MW);
     const int n0 = wn * (32 * NW);
-    const int b = blockIdx.z;
+    // 2-D layers: blockIdx.z = b * Tout + output row (common.hpp)
+    const int b = TWO_D ? blockIdx.z / p.Tout : blockIdx.z;
+    const int trow = TWO_D ? blockIdx.z - b * p.Tout : 0;
     const int in0 = t0 * p.s - p.P;
 
     f32x16 acc[MW][NW];
@@ -60,8 +62,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
 #pragma unroll
     for (int k = 0; k < NW; ++k) bcol[k] = (n0 + k * 32 + li) * p.s + lh * ((CC < 16 ? CC : 16) / 2) * span;
 
-    const float *xb = x + size_t(b) * p.Cin * p.Lin;
-    conv_gemm<MW, NW, CC>(acc, xs, xb, wp, p, p.M, span, in0, arow, bcol, wave, lane);
+    if (TWO_D) {
+        const RowMap2D rm{x + size_t(b) * p.cin_real * p.x_cstride, p.x_cstride, p.Lin, p.kh,
+                          trow * p.sh - p.ph, p.Tin, p.ncv};
+        conv_gemm_rows<MW, NW, CC, kSchedDefault, RowMap2D>(acc, xs, rm, wp, p, p.M, span, in0, arow, bcol, wave, lane);
+    } else {
+        const float *xb = x + size_t(b) * p.Cin * p.Lin;
+        conv_gemm<MW, NW, CC>(acc, xs, xb, wp, p, p.M, span, in0, arow, bcol, wave, lane);
+    }
 
     // ---- epilogue.  All loads (bias, residual, mask) are issued on clamped addresses before
     // any use so they overlap; only the stores are predicated.
@@ -88,7 +96,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int u = min(max(tc * p.q + ph[r] - p.oshift, 0), p.Lout - 1);
-                off[r] = (size_t(b) * p.Cout + co[r]) * p.Lout + u;
+                off[r] = TWO_D ? (size_t(b) * p.Cout + co[r]) * p.y_cstride + size_t(trow) * p.Lout + u
+                               : (size_t(b) * p.Cout + co[r]) * p.Lout + u;
             }
             if (has_res) {
 #pragma unroll
@@ -114,14 +123,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
     }
 }
 
-template <int MW, int NW, int WM, int WN, int CC>
+template <int MW, int NW, int WM, int WN, int CC, bool TWO_D = false>
 static int launch_variant(const ConvPlan &p, const float *x, const float *wp, const float *bias,
                           const float *res, float *y, hipStream_t st) {
     constexpr int BM = 32 * MW * WM, BN = 32 * NW * WN;
     const int span = (BN - 1) * p.s + (p.J - 1) * p.d + 1;
     const size_t lds = size_t(2) * CC * span * sizeof(float);  // double-buffered input tile
     if (lds > 160 * 1024) return fail(AGX_ERR_UNSUPPORTED, "conv_mfma: tile needs %zu B of LDS", lds);
-    auto kern = conv_mfma_kernel<MW, NW, WM, WN, CC>;
+    auto kern = conv_mfma_kernel<MW, NW, WM, WN, CC, TWO_D>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -129,7 +138,7 @@ static int launch_variant(const ConvPlan &p, const float *x, const float *wp, co
         if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    dim3 grid(ceil_div(p.Lt, BN), ceil_div(p.M, BM), p.B), block(256);
+    dim3 grid(ceil_div(p.Lt, BN), ceil_div(p.M, BM), p.B * p.Tout), block(256);
     if (grid.y > 65535 || grid.z > 65535) return fail(AGX_ERR_BAD_SHAPE, "conv_mfma: grid too large");
     hipLaunchKernelGGL(kern, grid, block, lds, st, p, span, x, wp, bias, res, y);
     return check_launch("conv_mfma");
@@ -143,20 +152,25 @@ struct Variant {
     const char *name;
     int (*launch)(const ConvPlan &, const float *, const float *, const float *, const float *, float *,
                   hipStream_t);
+    int (*launch2d)(const ConvPlan &, const float *, const float *, const float *, const float *, float *,
+                    hipStream_t);  // nullptr: no 2-D instantiation of this tile
 };
 
 #define AGX_VARIANT(MW, NW, WM, WN, CC) \
-    { MW, NW, WM, WN, CC, "conv_mfma<" #MW "," #NW "," #WM "," #WN "," #CC ">", launch_variant<MW, NW, WM, WN, CC> }
+    { MW, NW, WM, WN, CC, "conv_mfma<" #MW "," #NW "," #WM "," #WN "," #CC ">", launch_variant<MW, NW, WM, WN, CC>, nullptr }
+#define AGX_VARIANT2(MW, NW, WM, WN, CC) \
+    { MW, NW, WM, WN, CC, "conv_mfma<" #MW "," #NW "," #WM "," #WN "," #CC ">", launch_variant<MW, NW, WM, WN, CC>, \
+      launch_variant<MW, NW, WM, WN, CC, true> }
 
-static const Variant kWide[] = {AGX_VARIANT(2, 2, 2, 2, 16), AGX_VARIANT(2, 2, 2, 2, 8), AGX_VARIANT(2, 2, 2, 2, 32)};
+static const Variant kWide[] = {AGX_VARIANT2(2, 2, 2, 2, 16), AGX_VARIANT2(2, 2, 2, 2, 8), AGX_VARIANT(2, 2, 2, 2, 32)};
 // 128 x 64 tiles for short signals: twice the workgroups when the 128 x 128 grid would leave
 // a CU with a single resident workgroup (nothing to overlap staging / epilogue with).
-static const Variant kWideShort[] = {AGX_VARIANT(1, 2, 4, 1, 16), AGX_VARIANT(1, 2, 4, 1, 8), AGX_VARIANT(1, 2, 4, 1, 32)};
+static const Variant kWideShort[] = {AGX_VARIANT2(1, 2, 4, 1, 16), AGX_VARIANT2(1, 2, 4, 1, 8), AGX_VARIANT(1, 2, 4, 1, 32)};
 static const Variant kWideAlt[] = {AGX_VARIANT(1, 4, 4, 1, 16), AGX_VARIANT(1, 4, 4, 1, 8), AGX_VARIANT(1, 4, 4, 1, 32)};
-static const Variant kMid[] = {AGX_VARIANT(2, 2, 1, 4, 16), AGX_VARIANT(2, 2, 1, 4, 8), AGX_VARIANT(2, 1, 1, 4, 16),
-                               AGX_VARIANT(2, 1, 1, 4, 8),  AGX_VARIANT(2, 2, 1, 4, 32)};
-static const Variant kNarrow[] = {AGX_VARIANT(1, 4, 1, 4, 16), AGX_VARIANT(1, 4, 1, 4, 8), AGX_VARIANT(1, 1, 1, 4, 16),
-                                  AGX_VARIANT(1, 1, 1, 4, 8),  AGX_VARIANT(1, 4, 1, 4, 32)};
+static const Variant kMid[] = {AGX_VARIANT2(2, 2, 1, 4, 16), AGX_VARIANT2(2, 2, 1, 4, 8), AGX_VARIANT2(2, 1, 1, 4, 16),
+                               AGX_VARIANT2(2, 1, 1, 4, 8),  AGX_VARIANT(2, 2, 1, 4, 32)};
+static const Variant kNarrow[] = {AGX_VARIANT2(1, 4, 1, 4, 16), AGX_VARIANT2(1, 4, 1, 4, 8), AGX_VARIANT2(1, 1, 1, 4, 16),
+                                  AGX_VARIANT2(1, 1, 1, 4, 8),  AGX_VARIANT(1, 4, 1, 4, 32)};
 
 static size_t variant_lds(const Variant &v, const ConvPlan &p) {
     const int bn = 32 * v.nw * v.wn;
@@ -180,7 +194,7 @@ static const Variant *pick(const Variant *list, int n, const ConvPlan &p, int wa
 }
 
 static const Variant *select_variant(const ConvPlan &p) {
-    if (p.Cin % 16 != 0 || p.M < 32) return nullptr;
+    if (p.Cin % 16 != 0 || p.M < 32 || p.G != 1) return nullptr;
     const Variant *list = p.M >= 128 ? kWide : (p.M >= 64 ? kMid : kNarrow);
     const int n = p.M >= 128 ? 3 : 5;
     if (p.M >= 128 && tuning().conv_shape == 1) list = kWideAlt;
@@ -188,7 +202,7 @@ static const Variant *select_variant(const ConvPlan &p) {
     if (v && p.M >= 128 && tuning().conv_short) {
         // Short signals: the same channel chunk (= the same summation order, so results do not depend on
         // the batch size or the signal length) on 128 x 64 tiles.
-        const long wgs = long(ceil_div(p.Lt, 128)) * ceil_div(p.M, 128) * p.B;
+        const long wgs = long(ceil_div(p.Lt, 128)) * ceil_div(p.M, 128) * p.B * p.Tout;
         if (wgs < 2 * 256) {
             const Variant *vs = pick(kWideShort, 3, p, v->cc);
             if (vs) v = vs;
@@ -211,6 +225,10 @@ int launch_conv_mfma(const ConvPlan &p, const float *x, const float *wp, const f
         return fail(AGX_ERR_UNSUPPORTED,
                     "conv_mfma: needs Cin %% 16 == 0, q*Cout >= 32 and an input tile that fits LDS (Cin=%d M=%d s=%d J=%d d=%d)",
                     p.Cin, p.M, p.s, p.J, p.d);
+    if (p.kh > 1 || p.Tout > 1 || p.ncv != p.Cin) {
+        if (!v->launch2d) return fail(AGX_ERR_UNSUPPORTED, "conv_mfma: no 2-D instantiation of %s", v->name);
+        return v->launch2d(p, x, wp, bias, res, y, st);
+    }
     return v->launch(p, x, wp, bias, res, y, st);
 }
 

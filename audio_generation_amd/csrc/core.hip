@@ -105,12 +105,40 @@ int lower_conv(const agx_conv_desc *d, ConvPlan *p) {
             p->Lout = L * s;  // (L-1)s + K, minus the K - s crop of vae.py:58,63-64
             break;
         }
+        case AGX_CONV_PADDED: {
+            // torch.nn.Conv1d: Lout = floor((L + 2 pad - d (K - 1) - 1) / s) + 1
+            if (d->padding < 0) return fail(AGX_ERR_BAD_SHAPE, "conv: negative padding");
+            const int span = dil * (K - 1) + 1;
+            if (L + 2 * d->padding < span) return fail(AGX_ERR_BAD_SHAPE, "conv: input too short (L=%d)", L);
+            p->q = 1;
+            p->J = K;
+            p->s = s;
+            p->d = dil;
+            p->P = d->padding;
+            p->Lt = (L + 2 * d->padding - span) / s + 1;
+            p->Lout = p->Lt;
+            break;
+        }
         default:
             return fail(AGX_ERR_BAD_SHAPE, "conv: unknown kind %d", d->kind);
+    }
+    p->G = 1;
+    if (d->groups > 1) {
+        if (d->kind != AGX_CONV_PADDED) return fail(AGX_ERR_UNSUPPORTED, "conv: groups only with AGX_CONV_PADDED");
+        if (d->c_in % d->groups || d->c_out % d->groups)
+            return fail(AGX_ERR_BAD_SHAPE, "conv: groups=%d does not divide Cin=%d / Cout=%d", d->groups, d->c_in, d->c_out);
+        p->G = d->groups;
     }
     p->M = p->q * p->Cout;
     p->oshift = 0;
     p->mask = nullptr;
+    p->kh = 1;
+    p->sh = 1;
+    p->ph = 0;
+    p->Tin = p->Tout = 1;
+    p->ncv = p->cin_real = p->Cin;
+    p->x_cstride = p->Lin;
+    p->y_cstride = p->Lout;
     return AGX_OK;
 }
 
@@ -126,6 +154,7 @@ int lower_conv_bwd_data(const agx_conv_desc *d, ConvPlan *b) {
     int rc = lower_conv(d, &f);
     if (rc != AGX_OK) return rc;
     if (f.Lvalid != f.Lin) return fail(AGX_ERR_UNSUPPORTED, "bwd_data: cropped inputs (negative right pad) not supported");
+    if (f.G != 1) return fail(AGX_ERR_UNSUPPORTED, "bwd_data: grouped convs have no backward kernel");
     *b = f;
     b->Cin = f.Cout;
     b->Cout = f.Cin;
@@ -161,6 +190,9 @@ int lower_conv_bwd_data(const agx_conv_desc *d, ConvPlan *b) {
         b->Lt = f.Lin;
     }
     b->M = b->q * b->Cout;
+    b->x_cstride = b->Lin;
+    b->y_cstride = b->Lout;
+    b->ncv = b->cin_real = b->Cin;
     return AGX_OK;
 }
 
@@ -209,7 +241,7 @@ int64_t agx_conv_packed_floats(const agx_conv_desc *d) {
     if (rc != AGX_OK) return rc;
     // + dim0 floats of scratch at the tail for the weight-norm scales
     const int dim0 = (d->kind == AGX_CONV_TRANSPOSED) ? d->c_in : d->c_out;
-    return agx::packed_weight_floats(p.Cin, p.J, p.M) + dim0;
+    return agx::packed_weight_floats(p.Cin / p.G, p.J, p.M) + dim0;
 }
 
 }  // extern "C"

@@ -1,0 +1,343 @@
+// Small kernels of the discriminators (networks/discriminator.py): spectral-norm sigma, AvgPool1d,
+// the STFT front end (as a polyphase conv on the MFMA kernels) and the loss reductions.
+// All are bandwidth- or latency-trivial next to the conv stacks; written for determinism
+// (fixed reduction orders, no atomics).
+#include "common.hpp"
+
+namespace agx {
+
+int launch_conv_mfma(const ConvPlan &p, const float *x, const float *wp, const float *bias,
+                     const float *res, float *y, hipStream_t st);
+
+__device__ __forceinline__ float block_sum_256(float v, float *sh4) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh4[0] + sh4[1]) + (sh4[2] + sh4[3]);
+}
+
+// ------------------------------------------------------------------ spectral norm
+// t[c] = sum_r W[r, c] u[r]   (64 columns per block, rows in 4 interleaved slices)
+__global__ __launch_bounds__(256) void sn_wt_u_kernel(const float *__restrict__ w, const float *__restrict__ u,
+                                                      float *__restrict__ t, int rows, int cols) {
+    __shared__ float part[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    float acc = 0.f;
+    if (c < cols)
+        for (int r = ry; r < rows; r += 4) acc = fmaf(w[size_t(r) * cols + c], u[r], acc);
+    part[ry][cx] = acc;
+    __syncthreads();
+    if (ry == 0 && c < cols) t[c] = (part[0][cx] + part[1][cx]) + (part[2][cx] + part[3][cx]);
+}
+
+// s[r] = sum_c W[r, c] v[c]   (one wave per row)
+__global__ __launch_bounds__(256) void sn_w_v_kernel(const float *__restrict__ w, const float *__restrict__ v,
+                                                     float *__restrict__ s, int rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float acc = 0.f;
+    for (int c = lane; c < cols; c += 64) acc = fmaf(w[size_t(r) * cols + c], v[c], acc);
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) s[r] = acc;
+}
+
+// dst = src / max(||src||, eps)   (F.normalize)   -- single block
+__global__ __launch_bounds__(256) void sn_normalize_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                           int n, float eps) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc = fmaf(src[i], src[i], acc);
+    const float nrm = fmaxf(sqrtf(block_sum_256(acc, sh)), eps);
+    for (int i = threadIdx.x; i < n; i += 256) dst[i] = src[i] / nrm;
+}
+
+// sigma = u . s   -- single block
+__global__ __launch_bounds__(256) void sn_dot_kernel(const float *__restrict__ u, const float *__restrict__ s,
+                                                     int n, float *__restrict__ sigma) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc = fmaf(u[i], s[i], acc);
+    const float tot = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) sigma[0] = tot;
+}
+
+// ------------------------------------------------------------------ AvgPool1d
+__global__ __launch_bounds__(256) void avgpool1d_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                        int l_in, int l_out, int kernel, int stride, int padding) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= l_out) return;
+    const float *row = x + size_t(blockIdx.y) * l_in;
+    const int i0 = o * stride - padding;
+    float acc = 0.f;
+    for (int k = 0; k < kernel; ++k) {
+        const int i = i0 + k;
+        if (i >= 0 && i < l_in) acc += row[i];
+    }
+    y[size_t(blockIdx.y) * l_out + o] = acc / float(kernel);  // count_include_pad=True
+}
+
+// ------------------------------------------------------------------ STFT front end
+// Polyphase view of the framed DFT: with hop H = N / 4 and n = j H + p,
+//   Y[c, f, t] = sum_{p < H} sum_{j < 4} D_c[f, j H + p] xp[(t + j) H + p]
+// = an unpadded K = 4 conv over H channels xc[p][tau] = xp[tau H + p] (xp = reflect-padded input).
+__global__ __launch_bounds__(256) void stft_prep_kernel(const float *__restrict__ x, float *__restrict__ xc,
+                                                        int L, int N, int H, int Ttau) {
+    // one block per (tau-tile of 64, batch); thread -> (p fastest over reads, tau fastest over writes)
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z, tau0 = blockIdx.x * 64, p0 = blockIdx.y * 64;
+    const int Lp = L + N;
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int tt = e >> 6, pp = e & 63;  // consecutive threads: consecutive p = consecutive samples
+        const int tau = tau0 + tt, p = p0 + pp;
+        float v = 0.f;
+        if (tau < Ttau && p < H) {
+            const int i = tau * H + p;
+            if (i < Lp) {
+                int src = i - N / 2;
+                if (src < 0) src = -src;
+                if (src >= L) src = 2 * (L - 1) - src;
+                v = x[size_t(b) * L + src];
+            }
+        }
+        tile[tt][pp] = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int pp = e >> 6, tt = e & 63;
+        const int tau = tau0 + tt, p = p0 + pp;
+        if (tau < Ttau && p < H) xc[(size_t(b) * H + p) * Ttau + tau] = tile[tt][pp];
+    }
+}
+
+// conv output (B, 2N, T) -> (B, 2, T, N)
+__global__ __launch_bounds__(256) void stft_transpose_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                             int N, int T) {
+    __shared__ float tile[64][65];
+    const int bc = blockIdx.z;  // b * 2 + c
+    const int f0 = blockIdx.y * 64, t0 = blockIdx.x * 64;
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int ff = e >> 6, tt = e & 63;
+        const int f = f0 + ff, t = t0 + tt;
+        tile[ff][tt] = (f < N && t < T) ? src[(size_t(bc) * N + f) * T + t] : 0.f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int tt = e >> 6, ff = e & 63;
+        const int f = f0 + ff, t = t0 + tt;
+        if (f < N && t < T) dst[(size_t(bc) * T + t) * N + f] = tile[ff][tt];
+    }
+}
+
+// packed image of the DFT "weights": row m = c * N + f, channel p, tap j  ->  D_c[f, j H + p] * scale
+__global__ __launch_bounds__(256) void stft_pack_kernel(float *__restrict__ packed, int N, int H, float scale) {
+    const int M = 2 * N;
+    const int64_t total = packed_weight_floats(H, 4, M);
+    const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int c16 = int(e % kWG);
+    const int m = int((e / kWG) % M);
+    const int gj = int(e / (int64_t(kWG) * M));
+    const int j = gj % 4, p = (gj / 4) * kWG + c16;
+    const int c = m / N, f = m - c * N, n = j * H + p;
+    const long long k = (long long)f * n % N;  // exact argument reduction
+    double sn, cs;
+    sincospi(2.0 * double(k) / double(N), &sn, &cs);
+    packed[e] = float((c == 0 ? cs : -sn) * double(scale));
+}
+
+// ------------------------------------------------------------------ loss reductions
+__device__ __forceinline__ float loss_term(int mode, float a, float b) {
+    switch (mode) {
+        case 0: return a;
+        case 1: return fminf(a - 1.f, 0.f);
+        case 2: return fminf(-a - 1.f, 0.f);
+        case 3: return fabsf(a - b);
+        default: return fabsf(a + 1e-3f);
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_partial_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                             int64_t n, int mode, float *__restrict__ part) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256)
+        acc += loss_term(mode, x[i], mode == 3 ? y[i] : 0.f);
+    const float tot = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void reduce_final_kernel(const float *__restrict__ part, int nparts, double inv_n,
+                                                           float *__restrict__ out) {
+    __shared__ double shd[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) acc += double(part[i]);
+    shd[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) shd[threadIdx.x] += shd[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = float(shd[0] * inv_n);
+}
+
+// d mean(term(x, y)) / dx * g  (and / dy for the L1 term), g a device scalar
+__global__ __launch_bounds__(256) void reduce_mean_bwd_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                              int64_t n, int mode, const float *__restrict__ g,
+                                                              float inv_n, float *__restrict__ dx,
+                                                              float *__restrict__ dy) {
+    const float gs = g[0] * inv_n;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256) {
+        const float a = x[i];
+        float d;
+        switch (mode) {
+            case 0: d = 1.f; break;
+            case 1: d = (a - 1.f < 0.f) ? 1.f : 0.f; break;       // torch.minimum(a - 1, 0): gradient to a where smaller
+            case 2: d = (-a - 1.f < 0.f) ? -1.f : 0.f; break;
+            case 3: { const float t = a - y[i]; d = t > 0.f ? 1.f : (t < 0.f ? -1.f : 0.f); break; }
+            default: { const float t = a + 1e-3f; d = t > 0.f ? 1.f : (t < 0.f ? -1.f : 0.f); break; }
+        }
+        dx[i] = d * gs;
+        if (mode == 3 && dy) dy[i] = -d * gs;
+    }
+}
+
+__global__ __launch_bounds__(256) void sigmoid_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t n) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n) y[i] = 1.f / (1.f + expf(-x[i]));
+}
+
+}  // namespace agx
+
+extern "C" {
+
+int agx_spectral_sigma(const float *w, int32_t rows, int32_t cols, float *u, float *v, int32_t power_iterations,
+                       float eps, float *sigma, float *workspace, void *stream) {
+    using namespace agx;
+    if (rows <= 0 || cols <= 0 || power_iterations < 0) return fail(AGX_ERR_BAD_SHAPE, "spectral_sigma: bad shape");
+    if (!w || !u || !v || !sigma || !workspace) return fail(AGX_ERR_NULL_POINTER, "spectral_sigma: NULL pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float *t = workspace, *s = workspace + cols;
+    for (int it = 0; it < power_iterations; ++it) {
+        hipLaunchKernelGGL(sn_wt_u_kernel, dim3(ceil_div(cols, 64)), dim3(256), 0, st, w, u, t, rows, cols);
+        hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, st, t, v, cols, eps);
+        hipLaunchKernelGGL(sn_w_v_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, st, w, v, s, rows, cols);
+        hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, st, s, u, rows, eps);
+    }
+    if (power_iterations == 0)
+        hipLaunchKernelGGL(sn_w_v_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, st, w, v, s, rows, cols);
+    hipLaunchKernelGGL(sn_dot_kernel, dim3(1), dim3(256), 0, st, u, s, rows, sigma);
+    return check_launch("agx_spectral_sigma");
+}
+
+int64_t agx_avgpool1d_out_len(int32_t l_in, int32_t kernel, int32_t stride, int32_t padding) {
+    if (l_in <= 0 || kernel <= 0 || stride <= 0 || padding < 0 || l_in + 2 * padding < kernel)
+        return agx::fail(AGX_ERR_BAD_SHAPE, "avgpool1d: bad shape");
+    return (l_in + 2 * padding - kernel) / stride + 1;
+}
+
+int agx_avgpool1d(const float *x, float *y, int64_t rows, int32_t l_in, int32_t kernel, int32_t stride,
+                  int32_t padding, void *stream) {
+    using namespace agx;
+    const int64_t l_out = agx_avgpool1d_out_len(l_in, kernel, stride, padding);
+    if (l_out < 0) return int(l_out);
+    if (rows <= 0 || rows > 65535) return fail(AGX_ERR_BAD_SHAPE, "avgpool1d: rows must be in [1, 65535]");
+    if (!x || !y) return fail(AGX_ERR_NULL_POINTER, "avgpool1d: NULL pointer");
+    hipLaunchKernelGGL(avgpool1d_kernel, dim3(ceil_div(int(l_out), 256), unsigned(rows)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, y, l_in, int(l_out), kernel, stride, padding);
+    return check_launch("agx_avgpool1d");
+}
+
+static int stft_check(int32_t length, int32_t n_fft) {
+    if (n_fft < 64 || (n_fft & (n_fft - 1))) return agx::fail(AGX_ERR_UNSUPPORTED, "stft: n_fft must be a power of two >= 64");
+    if (length <= n_fft / 2) return agx::fail(AGX_ERR_BAD_SHAPE, "stft: reflect padding needs length > n_fft / 2");
+    return AGX_OK;
+}
+
+int64_t agx_stft_frames(int32_t length, int32_t n_fft) {
+    int rc = stft_check(length, n_fft);
+    return rc != AGX_OK ? rc : 1 + length / (n_fft / 4);
+}
+
+int64_t agx_stft_packed_floats(int32_t n_fft) {
+    if (n_fft < 64 || (n_fft & (n_fft - 1))) return agx::fail(AGX_ERR_UNSUPPORTED, "stft: n_fft must be a power of two >= 64");
+    return agx::packed_weight_floats(n_fft / 4, 4, 2 * n_fft);
+}
+
+int agx_stft_pack(int32_t n_fft, int32_t normalized, float *packed, void *stream) {
+    using namespace agx;
+    const int64_t n = agx_stft_packed_floats(n_fft);
+    if (n < 0) return int(n);
+    if (!packed) return fail(AGX_ERR_NULL_POINTER, "stft_pack: NULL pointer");
+    const float scale = normalized ? float(1.0 / sqrt(double(n_fft))) : 1.f;
+    hipLaunchKernelGGL(stft_pack_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), packed, n_fft, n_fft / 4, scale);
+    return check_launch("agx_stft_pack");
+}
+
+int64_t agx_stft_workspace_bytes(int32_t batch, int32_t length, int32_t n_fft) {
+    const int64_t T = agx_stft_frames(length, n_fft);
+    if (T < 0) return T;
+    if (batch <= 0) return agx::fail(AGX_ERR_BAD_SHAPE, "stft: batch <= 0");
+    return (int64_t(batch) * (n_fft / 4) * (T + 3) + int64_t(batch) * 2 * n_fft * T) * int64_t(sizeof(float));
+}
+
+int agx_stft_forward(const float *x, const float *packed, float *y, void *workspace, int32_t batch, int32_t length,
+                     int32_t n_fft, void *stream) {
+    using namespace agx;
+    const int64_t T64 = agx_stft_frames(length, n_fft);
+    if (T64 < 0) return int(T64);
+    if (batch <= 0 || batch > 32767) return fail(AGX_ERR_BAD_SHAPE, "stft: batch out of range");
+    if (!x || !packed || !y || !workspace) return fail(AGX_ERR_NULL_POINTER, "stft_forward: NULL pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int N = n_fft, H = N / 4, T = int(T64), Ttau = T + 3;
+    float *xc = static_cast<float *>(workspace);
+    float *cv = xc + size_t(batch) * H * Ttau;
+    hipLaunchKernelGGL(stft_prep_kernel, dim3(ceil_div(Ttau, 64), ceil_div(H, 64), batch), dim3(256), 0, st, x, xc,
+                       length, N, H, Ttau);
+    agx_conv_desc d{AGX_CONV_PADDED, batch, H, 2 * N, Ttau, 4, 1, 1, 0, 0.f, AGX_IMPL_MFMA, 1, 0};
+    ConvPlan p;
+    int rc = lower_conv(&d, &p);
+    if (rc != AGX_OK) return rc;
+    rc = launch_conv_mfma(p, xc, packed, nullptr, nullptr, cv, st);
+    if (rc != AGX_OK) return rc;
+    hipLaunchKernelGGL(stft_transpose_kernel, dim3(ceil_div(T, 64), ceil_div(N, 64), batch * 2), dim3(256), 0, st, cv,
+                       y, N, T);
+    return check_launch("agx_stft_forward");
+}
+
+int agx_reduce_mean(const float *x, const float *y, int64_t n, int32_t mode, float *out, float *workspace,
+                    void *stream) {
+    using namespace agx;
+    if (n <= 0 || mode < 0 || mode > 4) return fail(AGX_ERR_BAD_SHAPE, "reduce_mean: bad n / mode");
+    if (!x || !out || !workspace || (mode == 3 && !y)) return fail(AGX_ERR_NULL_POINTER, "reduce_mean: NULL pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nb = int(ceil_div64(n, 256) < 1024 ? ceil_div64(n, 256) : 1024);
+    hipLaunchKernelGGL(reduce_partial_kernel, dim3(nb), dim3(256), 0, st, x, y, n, mode, workspace);
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, st, workspace, nb, 1.0 / double(n), out);
+    return check_launch("agx_reduce_mean");
+}
+
+int agx_reduce_mean_backward(const float *x, const float *y, int64_t n, int32_t mode, const float *grad, float *dx,
+                             float *dy, void *stream) {
+    using namespace agx;
+    if (n <= 0 || mode < 0 || mode > 4) return fail(AGX_ERR_BAD_SHAPE, "reduce_mean_backward: bad n / mode");
+    if (!x || !grad || !dx || (mode == 3 && !y)) return fail(AGX_ERR_NULL_POINTER, "reduce_mean_backward: NULL pointer");
+    const int nb = int(ceil_div64(n, 256) < 4096 ? ceil_div64(n, 256) : 4096);
+    hipLaunchKernelGGL(reduce_mean_bwd_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, n, mode,
+                       grad, float(1.0 / double(n)), dx, dy);
+    return check_launch("agx_reduce_mean_backward");
+}
+
+int agx_sigmoid(const float *x, float *y, int64_t n, void *stream) {
+    using namespace agx;
+    if (n <= 0) return fail(AGX_ERR_BAD_SHAPE, "sigmoid: n <= 0");
+    if (!x || !y) return fail(AGX_ERR_NULL_POINTER, "sigmoid: NULL pointer");
+    hipLaunchKernelGGL(sigmoid_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, y, n);
+    return check_launch("agx_sigmoid");
+}
+
+}  // extern "C"

@@ -83,21 +83,48 @@ __device__ __forceinline__ void glds_dword(const float *gsrc_lane, float *lds_wa
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 4, 0, 0);
 }
 
-// Issue the LDS-DMA of CC channel rows, positions [in0, in0 + span), into buf
+// Where the input rows of the implicit GEMM live.  1-D layers: row c = channel c of one batch item.
+struct RowMap1D {
+    const float *xb;  // x + b * Cin * Lin
+    int Lin;
+    __device__ __forceinline__ const float *row(int c, bool &ok) const {
+        ok = true;
+        return xb + size_t(c) * Lin;
+    }
+};
+// 2-D layers run as 1-D convs along the last axis over virtual channels c' = ci * kh + dh (input row
+// t*sh - ph + dh of channel ci; rows outside [0, Tin) and channels >= ncv read as zero).
+struct RowMap2D {
+    const float *xb;  // x + b * Cin * cstride
+    int64_t cstride;  // elements between channels (Tin * Lin)
+    int Lin, kh, row0, Tin, ncv;
+    __device__ __forceinline__ const float *row(int c, bool &ok) const {
+        const int ci = c / kh, dh = c - ci * kh, r = row0 + dh;
+        ok = c < ncv && r >= 0 && r < Tin;
+        return xb + ci * cstride + int64_t(ok ? r : 0) * Lin;
+    }
+};
+
+// Issue the LDS-DMA of CC channel rows (c0 ..), positions [in0, in0 + span), into buf
 // (row stride span).  Out-of-range positions are never written: the caller
 // zero-fills both buffers once and they stay zero (the in-range set does not
-// depend on the channel chunk).
-template <int CC>
-__device__ __forceinline__ void issue_rows_dma(float *__restrict__ buf, const float *__restrict__ xb, int Lin,
+// depend on the channel chunk).  Rows the map reports absent (2-D only) are zeroed here.
+template <int CC, class RowMap>
+__device__ __forceinline__ void issue_rows_dma(float *__restrict__ buf, const RowMap &rm, int c0,
                                                int Lvalid, int in0, int span, int wave, int lane) {
 #pragma unroll
     for (int rr = 0; rr < CC / 4; ++rr) {
         const int c = wave + 4 * rr;
-        const float *src = xb + size_t(c) * Lin + in0 + lane;
+        bool ok;
+        const float *src = rm.row(c0 + c, ok) + in0 + lane;
         float *dst = buf + c * span;
-        for (int i0 = 0; i0 < span; i0 += 64) {
-            const int i = i0 + lane, pos = in0 + i;
-            if (i < span && pos >= 0 && pos < Lvalid) glds_dword(src + i0, dst + i0);
+        if (ok) {
+            for (int i0 = 0; i0 < span; i0 += 64) {
+                const int i = i0 + lane, pos = in0 + i;
+                if (i < span && pos >= 0 && pos < Lvalid) glds_dword(src + i0, dst + i0);
+            }
+        } else {
+            for (int i = lane; i < span; i += 64) dst[i] = 0.f;
         }
     }
 }
@@ -120,11 +147,11 @@ __device__ __forceinline__ void load_b_phase(float (&bf)[CC / 2][NW], const floa
 
 // CC = channels per LDS chunk (one DMA hand-over + barrier per chunk); the register pipeline
 // works in phases of PC = min(CC, 16) channels x one tap (operand arrays sized for PC).
-template <int MW, int NW, int CC, int SCHED = kSchedDefault>
-__device__ __forceinline__ void conv_gemm(f32x16 (&acc)[MW][NW], float *__restrict__ xs,
-                                          const float *__restrict__ xb, const float *__restrict__ wp,
-                                          const ConvPlan &p, int M, int span, int in0,
-                                          const int (&arow)[MW], const int (&bcol)[NW], int wave, int lane) {
+template <int MW, int NW, int CC, int SCHED = kSchedDefault, class RowMap = RowMap1D>
+__device__ __forceinline__ void conv_gemm_rows(f32x16 (&acc)[MW][NW], float *__restrict__ xs,
+                                               const RowMap &rm, const float *__restrict__ wp,
+                                               const ConvPlan &p, int M, int span, int in0,
+                                               const int (&arow)[MW], const int (&bcol)[NW], int wave, int lane) {
     constexpr int PC = CC < 16 ? CC : 16;
     constexpr int NH = CC / PC;  // register phases groups per chunk
     const int lh = lane >> 5;
@@ -147,7 +174,7 @@ __device__ __forceinline__ void conv_gemm(f32x16 (&acc)[MW][NW], float *__restri
     float b_cur[PC / 2][NW], b_nxt[PC / 2][NW];
     load_a_phase<MW, PC>(a_cur, wp, 0, 0, p.J, M, lh, arow);
     __syncthreads();
-    issue_rows_dma<CC>(buf0, xb, p.Lin, p.Lvalid, in0, span, wave, lane);
+    issue_rows_dma<CC>(buf0, rm, 0, p.Lvalid, in0, span, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     AGX_STAMP(1);
@@ -174,7 +201,7 @@ __device__ __forceinline__ void conv_gemm(f32x16 (&acc)[MW][NW], float *__restri
                 }
                 // The next chunk's input DMA goes out first (once per chunk) ...
                 if (h == 0 && j == 0 && c0 + CC < p.Cin)
-                    issue_rows_dma<CC>(nxt, xb + size_t(c0 + CC) * p.Lin, p.Lin, p.Lvalid, in0, span, wave, lane);
+                    issue_rows_dma<CC>(nxt, rm, c0 + CC, p.Lvalid, in0, span, wave, lane);
                 // ... then the operands of the NEXT phase are requested, in the same basic block as this
                 // phase's MFMAs so that the scheduler can thread them between the MFMAs: neither the L2
                 // latency of the weights nor the LDS latency of the input sits in front of an MFMA (a
@@ -231,6 +258,16 @@ __device__ __forceinline__ void conv_gemm(f32x16 (&acc)[MW][NW], float *__restri
         AGX_STAMP_ADD(8, tw);
     }
     AGX_STAMP(2);
+}
+
+// 1-D entry point (rows = channels of one batch item at xb).
+template <int MW, int NW, int CC, int SCHED = kSchedDefault>
+__device__ __forceinline__ void conv_gemm(f32x16 (&acc)[MW][NW], float *__restrict__ xs,
+                                          const float *__restrict__ xb, const float *__restrict__ wp,
+                                          const ConvPlan &p, int M, int span, int in0,
+                                          const int (&arow)[MW], const int (&bcol)[NW], int wave, int lane) {
+    const RowMap1D rm{xb, p.Lin};
+    conv_gemm_rows<MW, NW, CC, SCHED, RowMap1D>(acc, xs, rm, wp, p, M, span, in0, arow, bcol, wave, lane);
 }
 
 }  // namespace agx

@@ -30,13 +30,19 @@ __global__ void fill_ones_kernel(float *p, int n) {
     if (i < n) p[i] = 1.f;
 }
 
+// spectral norm: every row scaled by 1 / sigma (sigma lives on the device: no host sync)
+__global__ void fill_inv_sigma_kernel(float *p, int n, const float *__restrict__ sigma) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 1.f / sigma[0];
+}
+
 __device__ __forceinline__ int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
 // Folded forward weight of the polyphase form: coefficient of x[ci, t*s + j*d - P] in y[co, q*t + ph].
 __device__ __forceinline__ float fwd_weight(const float *__restrict__ v, const float *__restrict__ scale,
                                             int kind, int Cin, int Cout, int K, int J, int P, int up, int ci,
                                             int j, int co, int ph) {
-    if (kind == AGX_CONV_CAUSAL || kind == AGX_CONV_SAME) return v[(size_t(co) * Cin + ci) * K + j] * scale[co];
+    if (kind == AGX_CONV_CAUSAL || kind == AGX_CONV_SAME || kind == AGX_CONV_PADDED) return v[(size_t(co) * Cin + ci) * K + j] * scale[co];
     if (kind == AGX_CONV_UPSAMPLE) {
         // taps k of the high-rate 'same' conv that land on low-rate offset j - P
         const int pl = (K - 1) / 2;
@@ -144,24 +150,65 @@ extern "C" int agx_conv_pack_bwd(const agx_conv_desc *d, const float *v, const f
     return check_launch("agx_conv_pack_bwd");
 }
 
-extern "C" int agx_conv_pack(const agx_conv_desc *d, const float *v, const float *g, float *packed,
-                             void *stream) {
+static int pack_forward(const agx_conv_desc *d, const float *v, const float *g, const float *sigma,
+                        float *packed, hipStream_t st, const char *who) {
     using namespace agx;
     ConvPlan p;
     int rc = lower_conv(d, &p);
     if (rc != AGX_OK) return rc;
-    if (!v || !packed) return fail(AGX_ERR_NULL_POINTER, "agx_conv_pack: NULL pointer");
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!v || !packed) return fail(AGX_ERR_NULL_POINTER, "%s: NULL pointer", who);
     const bool transposed = d->kind == AGX_CONV_TRANSPOSED;
+    const int cpg = p.Cin / p.G;  // the weight tensor is (Cout, Cin / groups, K)
     const int dim0 = transposed ? d->c_in : d->c_out;
-    const int inner = (transposed ? d->c_out : d->c_in) * d->kernel;
-    const int64_t n_w = packed_weight_floats(p.Cin, p.J, p.M);
+    const int inner = (transposed ? d->c_out : cpg) * d->kernel;
+    const int64_t n_w = packed_weight_floats(cpg, p.J, p.M);
     float *scale = packed + n_w;  // tail scratch reserved by agx_conv_packed_floats
     if (g)
         hipLaunchKernelGGL(wn_scale_kernel, dim3(dim0), dim3(256), 0, st, v, g, scale, inner);
+    else if (sigma)
+        hipLaunchKernelGGL(fill_inv_sigma_kernel, dim3(ceil_div(dim0, 256)), dim3(256), 0, st, scale, dim0, sigma);
     else
         hipLaunchKernelGGL(fill_ones_kernel, dim3(ceil_div(dim0, 256)), dim3(256), 0, st, scale, dim0);
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)ceil_div64(n_w, 256)), dim3(256), 0, st, v, scale,
-                       packed, d->kind, p.Cin, p.Cout, d->kernel, p.q, p.J, p.P, d->stride);
-    return check_launch("agx_conv_pack");
+                       packed, d->kind, cpg, p.Cout, d->kernel, p.q, p.J, p.P, d->stride);
+    return check_launch(who);
+}
+
+extern "C" int agx_conv_pack(const agx_conv_desc *d, const float *v, const float *g, float *packed,
+                             void *stream) {
+    return pack_forward(d, v, g, nullptr, packed, static_cast<hipStream_t>(stream), "agx_conv_pack");
+}
+
+extern "C" int agx_conv_pack_sigma(const agx_conv_desc *d, const float *w, const float *sigma, float *packed,
+                                   void *stream) {
+    if (!sigma) return agx::fail(AGX_ERR_NULL_POINTER, "agx_conv_pack_sigma: NULL sigma");
+    return pack_forward(d, w, nullptr, sigma, packed, static_cast<hipStream_t>(stream), "agx_conv_pack_sigma");
+}
+
+// 2-D layers: the (Cout, Cin, kh, kw) tensor read as (Cout, Cin * kh, kw) is already in virtual-channel
+// order c' = ci * kh + dh (common.hpp), so the 1-D pack kernel applies as is.
+extern "C" int64_t agx_conv2d_packed_floats(const agx_conv2d_desc *d) {
+    agx::ConvPlan p;
+    int rc = agx::lower_conv2d(d, &p);
+    if (rc != AGX_OK) return rc;
+    return agx::packed_weight_floats(p.ncv, p.J, p.M) + p.Cout;
+}
+
+extern "C" int agx_conv2d_pack(const agx_conv2d_desc *d, const float *w, const float *sigma, float *packed,
+                               void *stream) {
+    using namespace agx;
+    ConvPlan p;
+    int rc = lower_conv2d(d, &p);
+    if (rc != AGX_OK) return rc;
+    if (!w || !packed) return fail(AGX_ERR_NULL_POINTER, "agx_conv2d_pack: NULL pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t n_w = packed_weight_floats(p.ncv, p.J, p.M);
+    float *scale = packed + n_w;
+    if (sigma)
+        hipLaunchKernelGGL(fill_inv_sigma_kernel, dim3(ceil_div(p.Cout, 256)), dim3(256), 0, st, scale, p.Cout, sigma);
+    else
+        hipLaunchKernelGGL(fill_ones_kernel, dim3(ceil_div(p.Cout, 256)), dim3(256), 0, st, scale, p.Cout);
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)ceil_div64(n_w, 256)), dim3(256), 0, st, w, scale, packed,
+                       AGX_CONV_PADDED, p.ncv, p.Cout, p.J, 1, p.J, p.P, 1);
+    return check_launch("agx_conv2d_pack");
 }

@@ -1,0 +1,382 @@
+"""Drop-in discriminators executed by libagx.
+
+Mirrors ``networks/discriminator.py``: ``WaveformDiscriminatorBlock`` (:7-57),
+``WaveFormDiscriminator`` (:59-84), ``STFTDiscriminatorBlock`` (:87-117), ``STFTDiscriminator``
+(:119-202) and ``discriminator_generator_loss`` (:204-246) -- same constructor arguments, attributes
+(``name``, ``layers`` / ``blocks``), return values ``(outputs, features)`` and ``state_dict`` keys
+(old-style ``torch.nn.utils.spectral_norm``: ``bias, weight_orig, weight_u, weight_v``).
+
+Forward, all on HIP kernels through the C ABI:
+
+* spectral norm  -> ``agx_spectral_sigma`` (one power iteration in training mode, buffers updated in
+  place) + ``agx_conv_pack_sigma`` / ``agx_conv2d_pack`` (1 / sigma folded into the packed image);
+* waveform block -> ``agx_avgpool1d`` + grouped unpadded convs (``AGX_CONV_PADDED``), LeakyReLU fused;
+* STFT block     -> ``agx_stft_forward`` (framed DFT as a polyphase conv on the MFMA kernel) +
+  ``agx_conv2d_forward`` (kernel rows folded into virtual channels of the 1-D MFMA conv);
+* loss           -> ``agx_reduce_mean`` / ``agx_reduce_mean_backward`` (every mean of the hinge and
+  feature-matching terms, with hand-written gradients).
+
+Backward through the discriminator bodies is bridged through an ATen restatement for now
+(``autograd_bridge.py``; the conv2d / grouped-conv backward kernels are the next row) -- the forward
+never is.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+from ._lib import CONV_PADDED, EPI_LEAKY_PRE
+from .autograd_bridge import needs_grad
+from .quantizer import tuple_checker
+
+Tensor = torch.Tensor
+
+
+def _slope(act: nn.Module) -> float:
+    if not isinstance(act, nn.LeakyReLU):
+        raise NotImplementedError("only LeakyReLU is fused into the discriminator convs")
+    return float(act.negative_slope)
+
+
+class _SNConv(nn.Module):
+    """Parameter holder standing where the reference has ``spectral_norm(Conv1d / Conv2d)`` (or the plain
+    conv when ``norm`` is not "spectral").  Initialised by building that very torch module, so the same
+    seed gives the same parameters and ``u`` / ``v`` vectors as the reference."""
+
+    def __init__(self, conv: nn.Module, norm: str = "spectral"):
+        super().__init__()
+        self.norm = norm
+        self.eps = 1e-12
+        self.nd = 2 if isinstance(conv, nn.Conv2d) else 1
+        self.in_channels, self.out_channels = conv.in_channels, conv.out_channels
+        self.kernel_size, self.stride, self.padding, self.groups = conv.kernel_size, conv.stride, conv.padding, conv.groups
+        if norm == "spectral":
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                conv = nn.utils.spectral_norm(conv)
+            self.bias = conv.bias
+            self.weight_orig = conv.weight_orig
+            self.register_buffer("weight_u", conv.weight_u.detach().clone())
+            self.register_buffer("weight_v", conv.weight_v.detach().clone())
+        elif norm == "weight":
+            raise NotImplementedError("weight-normalised discriminators are not wired (the reference default is spectral)")
+        else:
+            self.bias, self.weight = conv.bias, conv.weight
+        self._key, self._packed, self._iter = None, None, 0
+        self._uv_override = None   # (u, v) of the forward being differentiated (backward bridge only)
+
+    @property
+    def raw_weight(self) -> Tensor:
+        return self.weight_orig if self.norm == "spectral" else self.weight
+
+    def _sigma(self) -> Optional[Tensor]:
+        if self.norm != "spectral":
+            return None
+        n_iter = 1 if self.training else 0
+        self._iter += n_iter
+        return ops.spectral_sigma(self.weight_orig.detach(), self.weight_u, self.weight_v, n_iter, self.eps)
+
+    def packed(self, make_desc, pack_plain, pack_sigma) -> Tensor:
+        """Packed image; rebuilt when the weight, the buffers or the mode changed (always in training mode:
+        the power iteration moves sigma)."""
+        w = self.raw_weight
+        key = (w.data_ptr(), w._version, self.training, self._iter,
+               None if self.norm != "spectral" else (self.weight_u._version, self.weight_v._version))
+        if self.training or key != self._key:
+            sigma = self._sigma()
+            desc = make_desc()
+            self._packed = pack_plain(desc, w.detach()) if sigma is None else pack_sigma(desc, w.detach(), sigma)
+            self._key = (w.data_ptr(), w._version, self.training, self._iter,
+                         None if self.norm != "spectral" else (self.weight_u._version, self.weight_v._version))
+        return self._packed
+
+    def aten_weight(self) -> Tensor:
+        """Differentiable normalised weight from the CURRENT buffers (no power iteration): backward bridge."""
+        if self.norm != "spectral":
+            return self.weight
+        w = self.weight_orig
+        u, v = self._uv_override if self._uv_override is not None else (self.weight_u, self.weight_v)
+        sigma = torch.dot(u, torch.mv(w.reshape(w.shape[0], -1), v))
+        return w / sigma
+
+    # -- 1-D --------------------------------------------------------------------------------------
+    def run1d(self, x: Tensor, slope: Optional[float]) -> Tensor:
+        b, _, length = x.shape
+
+        def desc(batch=b, l_in=length):
+            return ops.conv_desc(CONV_PADDED, batch, self.in_channels, self.out_channels, l_in, self.kernel_size[0],
+                                 self.stride[0], 1, EPI_LEAKY_PRE if slope is not None else 0, slope or 0.0,
+                                 groups=self.groups, padding=self.padding[0])
+
+        packed = self.packed(lambda: desc(1, 1 << 20), ops.conv_pack, ops.conv_pack_sigma)
+        return ops.conv_forward(desc(), x, packed, None if self.bias is None else self.bias.detach())
+
+    # -- 2-D --------------------------------------------------------------------------------------
+    def run2d(self, x: Tensor, slope: Optional[float]) -> Tensor:
+        b, _, h, w = x.shape
+
+        def desc(batch=b, hh=h, ww=w):
+            return ops.conv2d_desc(batch, self.in_channels, self.out_channels, hh, ww, self.kernel_size[0],
+                                   self.kernel_size[1], self.stride, self.padding,
+                                   EPI_LEAKY_PRE if slope is not None else 0, slope or 0.0)
+
+        packed = self.packed(lambda: desc(1, 64, 64), ops.conv2d_pack, ops.conv2d_pack)
+        return ops.conv2d_forward(desc(), x, packed, None if self.bias is None else self.bias.detach())
+
+
+class _MultiOutBridge(torch.autograd.Function):
+    """HIP forward returning several tensors, backward by differentiating the ATen restatement
+    (same contract as autograd_bridge._HipForwardAtenBackward)."""
+
+    @staticmethod
+    def forward(ctx, module, hip_fn, aten_fn, x: Tensor, *params: Tensor):
+        ctx.aten_fn, ctx.params = aten_fn, params
+        ctx.save_for_backward(x)
+        with torch.no_grad():
+            out = tuple(hip_fn(x.detach()))
+        # the u / v this forward normalised with (later forwards move the buffers on)
+        ctx.convs = [m for m in module.modules() if isinstance(m, _SNConv) and m.norm == "spectral"]
+        ctx.uv = [(m.weight_u.clone(), m.weight_v.clone()) for m in ctx.convs]
+        return out
+
+    @staticmethod
+    def backward(ctx, *grads: Tensor):
+        (x,) = ctx.saved_tensors
+        params = [p for p in ctx.params if p.requires_grad]
+        for m, uv in zip(ctx.convs, ctx.uv):
+            m._uv_override = uv
+        try:
+            with torch.enable_grad():
+                xl = x.detach().requires_grad_(True)
+                outs = list(ctx.aten_fn(xl))
+                pairs = [(o, g.contiguous()) for o, g in zip(outs, grads) if g is not None and o.requires_grad]
+                got = torch.autograd.grad([o for o, _ in pairs], [xl] + params, [g for _, g in pairs],
+                                          allow_unused=True)
+        finally:
+            for m in ctx.convs:
+                m._uv_override = None
+        it = iter(got[1:])
+        pg = [next(it) if p.requires_grad else None for p in ctx.params]
+        return (None, None, None, got[0], *pg)
+
+
+def _run_bridged(module: nn.Module, x: Tensor, hip_fn, aten_fn, n_out: int) -> Tuple[List[Tensor], List[Tensor]]:
+    """``hip_fn(x) -> outs + feats`` (flat list); differentiable when a gradient is needed."""
+    if needs_grad(x, module):
+        flat = _MultiOutBridge.apply(module, hip_fn, aten_fn, x, *list(module.parameters()))
+    else:
+        flat = hip_fn(x)
+    flat = list(flat)
+    return flat[:n_out], flat[n_out:]
+
+
+class WaveformDiscriminatorBlock(nn.Module):
+    """discriminator.py:7-57."""
+
+    def __init__(self, in_channels, channel_sizes=(16, 64, 256, 512, 1024, 1024, 1024),
+                 kernel_sizes=(15, 41, 41, 41, 41, 5, 3), strides=(1, 4, 4, 4, 4, 1, 1),
+                 groups=(1, 4, 16, 64, 256, 1, 1), activation=None, scale=1, norm="spectral", apply_sigmoid=True):
+        super().__init__()
+        activation = nn.LeakyReLU(0.2) if activation is None else activation
+        n_steps = len(channel_sizes)
+        self.channel_sizes = [in_channels] + list(channel_sizes)
+        self.kernel_sizes = tuple_checker(kernel_sizes, n_steps)
+        self.strides = tuple_checker(strides, n_steps)
+        self.groups = tuple_checker(groups, n_steps)
+        self.scale = scale
+        layers: List[nn.Module] = [nn.AvgPool1d(2 * scale, stride=scale, padding=scale)]
+        for i in range(n_steps - 1):
+            conv = nn.Conv1d(self.channel_sizes[i], self.channel_sizes[i + 1], self.kernel_sizes[i],
+                             stride=self.strides[i], groups=self.groups[i])
+            layers.append(nn.Sequential(_SNConv(conv, norm), activation))
+        layers.append(_SNConv(nn.Conv1d(channel_sizes[-1], 1, self.kernel_sizes[-1], stride=self.strides[-1],
+                                        groups=self.groups[-1]), norm))
+        self.layers = nn.ModuleList(layers)
+        self.final_activation = nn.Sigmoid() if apply_sigmoid else nn.Identity()
+
+    def _hip(self, x: Tensor) -> List[Tensor]:
+        pool = self.layers[0]
+        x = ops.avgpool1d(x, pool.kernel_size[0] if isinstance(pool.kernel_size, tuple) else pool.kernel_size,
+                          pool.stride[0] if isinstance(pool.stride, tuple) else pool.stride,
+                          pool.padding[0] if isinstance(pool.padding, tuple) else pool.padding)
+        feats = [x]
+        for layer in list(self.layers)[1:]:
+            if isinstance(layer, nn.Sequential):
+                x = layer[0].run1d(x, _slope(layer[1]))
+            else:
+                x = layer.run1d(x, None)
+            feats.append(x)
+        out = ops.sigmoid(x) if isinstance(self.final_activation, nn.Sigmoid) else x.clone()
+        return [out] + feats
+
+    def _aten(self, x: Tensor) -> List[Tensor]:  # backward bridge only
+        x = self.layers[0](x)
+        feats = [x]
+        for layer in list(self.layers)[1:]:
+            conv, act = (layer[0], layer[1]) if isinstance(layer, nn.Sequential) else (layer, None)
+            x = F.conv1d(x, conv.aten_weight(), conv.bias, stride=conv.stride, padding=conv.padding, groups=conv.groups)
+            if act is not None:
+                x = act(x)
+            feats.append(x)
+        return [self.final_activation(x)] + feats
+
+    def forward(self, x: Tensor):
+        outs, feats = _run_bridged(self, x, self._hip, self._aten, 1)
+        return outs[0], feats
+
+
+class WaveFormDiscriminator(nn.Module):
+    """discriminator.py:59-84."""
+
+    def __init__(self, in_channels, name="waveform_discriminator", n_blocks=3, scalefactor_per_block=2,
+                 norm="spectral"):
+        super().__init__()
+        self.name = name
+        scales = [scalefactor_per_block ** i for i in range(n_blocks)]
+        self.layers = nn.ModuleList([WaveformDiscriminatorBlock(in_channels, scale=s, norm=norm) for s in scales])
+
+    def forward(self, x: Tensor):
+        features, outputs = [], []
+        for layer in self.layers:
+            out, layer_features = layer(x)
+            outputs.append(out)
+            features.extend(layer_features)
+        return outputs, features
+
+
+class STFTDiscriminatorBlock(nn.Module):
+    """discriminator.py:87-117 (conv 3x3 -> activation -> strided conv; the residual is commented out there)."""
+
+    def __init__(self, in_channels, channel_multiplier, stride, kernel_size=None, padding=None, activation=None,
+                 norm="spectral"):
+        super().__init__()
+        activation = nn.LeakyReLU(0.2) if activation is None else activation
+        if kernel_size is None:
+            kernel_size = (stride[0] + 2, stride[1] + 2)
+        if padding is None:
+            padding = ((kernel_size[0] - 1) // 2, (kernel_size[1] - 1) // 2)
+        self.layers = nn.Sequential(
+            _SNConv(nn.Conv2d(in_channels, in_channels, kernel_size=3, padding=1), norm),
+            activation,
+            _SNConv(nn.Conv2d(in_channels, in_channels * channel_multiplier, stride=stride, kernel_size=kernel_size,
+                              padding=padding), norm))
+
+    def forward(self, x: Tensor) -> Tensor:
+        x = self.layers[0].run2d(x, _slope(self.layers[1]))
+        return self.layers[2].run2d(x, None)
+
+    def _aten(self, x: Tensor) -> Tensor:  # backward bridge only
+        c0, c2 = self.layers[0], self.layers[2]
+        x = self.layers[1](F.conv2d(x, c0.aten_weight(), c0.bias, stride=c0.stride, padding=c0.padding))
+        return F.conv2d(x, c2.aten_weight(), c2.bias, stride=c2.stride, padding=c2.padding)
+
+
+class STFTDiscriminator(nn.Module):
+    """discriminator.py:119-202."""
+
+    def __init__(self, in_channels=2, first_channel_size=32, channel_multipliers=(2, 2, 1, 2, 1, 2),
+                 strides=((1, 2), (2, 2)) * 3, win_length=1024, n_fft=None, hop_length=None, feature_multiplier=1,
+                 normalize_stft=True, norm="spectral", base_name="stft_discriminator", apply_sigmoid=True):
+        super().__init__()
+        self.win_length = win_length
+        self.n_fft = win_length if n_fft is None else n_fft
+        self.hop_length = win_length // 4 if hop_length is None else hop_length
+        if self.n_fft != win_length or self.hop_length * 4 != win_length:
+            raise NotImplementedError("the HIP STFT covers the reference wiring: n_fft = win_length, hop = win_length / 4")
+        self.normalize_stft = normalize_stft
+        self.feature_multiplier = feature_multiplier
+        self.name = f"{base_name}_{win_length}"
+        self.num_blocks = len(channel_multipliers)
+        self.first_conv = _SNConv(nn.Conv2d(in_channels, first_channel_size, kernel_size=7, padding=3), norm)
+        blocks, ch = [], first_channel_size
+        for mult, stride in zip(channel_multipliers, strides):
+            blocks.append(STFTDiscriminatorBlock(ch, mult, tuple(stride), norm=norm))
+            ch *= mult
+        self.blocks = nn.ModuleList(blocks)
+        fk = win_length // (2 ** (self.num_blocks + 1))
+        self.final_conv = _SNConv(nn.Conv2d(ch, 1, kernel_size=(1, fk), padding=(0, (fk - 1) // 2)), norm)
+        self.final_activation = nn.Sigmoid() if apply_sigmoid else nn.Identity()
+
+    def _hip(self, x: Tensor) -> List[Tensor]:
+        x = ops.stft(x.squeeze(1), self.n_fft, self.normalize_stft)          # (B, 2, T, F)
+        x = self.first_conv.run2d(x, None)
+        feats = [x]
+        for block in self.blocks:
+            x = block(x)
+            feats.append(x)
+        x = self.final_conv.run2d(x, None)
+        out = ops.sigmoid(x) if isinstance(self.final_activation, nn.Sigmoid) else x.clone()
+        return [out] + feats
+
+    def _aten(self, x: Tensor) -> List[Tensor]:  # backward bridge only
+        x = x.squeeze(1)
+        pad = self.n_fft // 2
+        xp = F.pad(x.unsqueeze(1), (pad, pad), mode="reflect").squeeze(1)
+        spec = torch.fft.fft(xp.unfold(-1, self.n_fft, self.hop_length), dim=-1)
+        if self.normalize_stft:
+            spec = spec * (self.n_fft ** -0.5)
+        x = torch.stack([spec.real, spec.imag], dim=1)
+        fc = self.first_conv
+        x = F.conv2d(x, fc.aten_weight(), fc.bias, padding=fc.padding)
+        feats = [x]
+        for block in self.blocks:
+            x = block._aten(x)
+            feats.append(x)
+        fc = self.final_conv
+        x = F.conv2d(x, fc.aten_weight(), fc.bias, padding=fc.padding)
+        return [self.final_activation(x)] + feats
+
+    def forward(self, x: Tensor):
+        outs, feats = _run_bridged(self, x, self._hip, self._aten, 1)
+        return outs, feats
+
+
+class _Mean(torch.autograd.Function):
+    """One mean of the loss on ``agx_reduce_mean`` with its hand-written gradient."""
+
+    @staticmethod
+    def forward(ctx, mode: int, x: Tensor, y: Optional[Tensor]):
+        ctx.mode = mode
+        ctx.save_for_backward(x, y) if y is not None else ctx.save_for_backward(x)
+        return ops.reduce_mean(x.detach(), mode, None if y is None else y.detach())
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        saved = ctx.saved_tensors
+        x, y = saved[0], (saved[1] if len(saved) > 1 else None)
+        want_dy = y is not None and ctx.needs_input_grad[2]
+        dx, dy = ops.reduce_mean_backward(x, ctx.mode, g.contiguous(), y, want_dy)
+        return None, (dx if ctx.needs_input_grad[1] else None), dy
+
+
+def _mean(mode: int, x: Tensor, y: Optional[Tensor] = None) -> Tensor:
+    return _Mean.apply(mode, x, y)
+
+
+def discriminator_generator_loss(original: Tensor, reconstruction: Tensor, discriminator: nn.Module,
+                                 feature_multipier: float = 100, scale_feature_loss: bool = True):
+    """discriminator.py:204-246 (argument spelling kept): three passes through the discriminator, hinge
+    GAN terms averaged over its outputs, L1 feature matching."""
+    original_d, original_features = discriminator(original.clone().requires_grad_())
+    reconstruction_d, reconstruction_features = discriminator(reconstruction)
+    reconstruction_d2, _ = discriminator(reconstruction.detach().clone().requires_grad_())
+    k = len(original_d)
+    discriminator_loss, generation_loss = 0, 0
+    for x, y, y_disc in zip(original_d, reconstruction_d, reconstruction_d2):
+        real_d_loss = -_mean(ops.REDUCE_HINGE_REAL, x)
+        fake_d_loss = -_mean(ops.REDUCE_HINGE_FAKE, y_disc)
+        discriminator_loss = discriminator_loss + (real_d_loss + fake_d_loss) / k
+        generation_loss = generation_loss - _mean(ops.REDUCE_MEAN, y) / k
+    feature_loss, n_features = 0, len(original_features)
+    for x, y in zip(original_features, reconstruction_features):
+        feature_loss_i = _mean(ops.REDUCE_L1, x, y) / n_features
+        if scale_feature_loss:
+            feature_loss_i = feature_loss_i / _mean(ops.REDUCE_ABS_EPS, x)
+        feature_loss = feature_loss + feature_loss_i
+    generator_loss = generation_loss + feature_multipier * feature_loss
+    return generator_loss, discriminator_loss

@@ -65,8 +65,9 @@ def _f32c(t: Tensor) -> Tensor:
 
 # --------------------------------------------------------------------------- conv
 def conv_desc(kind: int, batch: int, c_in: int, c_out: int, l_in: int, kernel: int, stride: int = 1,
-              dilation: int = 1, epilogue: int = 0, slope: float = 0.1, impl: int = IMPL_AUTO) -> ConvDesc:
-    return ConvDesc(kind, batch, c_in, c_out, l_in, kernel, stride, dilation, epilogue, slope, impl)
+              dilation: int = 1, epilogue: int = 0, slope: float = 0.1, impl: int = IMPL_AUTO, groups: int = 1,
+              padding: int = 0) -> ConvDesc:
+    return ConvDesc(kind, batch, c_in, c_out, l_in, kernel, stride, dilation, epilogue, slope, impl, groups, padding)
 
 
 def conv_out_len(desc: ConvDesc) -> int:
@@ -336,6 +337,155 @@ def wavelet_fold_backward(h: Tensor, dout: Tensor, space: Tensor, sigma: Tensor,
                                              _ptr(dsig), _ptr(ws), b, c, length, space.numel(), scale, _stream()),
                "agx_wavelet_fold_backward")
     return dh, dsig.reshape(sigma.shape)
+
+
+# ------------------------------------------------------------------ discriminators
+def spectral_sigma(w: Tensor, u: Tensor, v: Tensor, power_iterations: int, eps: float = 1e-12) -> Tensor:
+    """sigma (1-element device tensor) of ``w`` viewed as (dim 0, rest); ``u`` / ``v`` are updated IN PLACE
+    when ``power_iterations > 0`` (torch spectral_norm in training mode)."""
+    lib = _lib.load()
+    _need_gpu(w, u, v)
+    w = _f32c(w)
+    rows, cols = w.shape[0], w.numel() // w.shape[0]
+    assert u.is_contiguous() and v.is_contiguous() and u.numel() == rows and v.numel() == cols
+    sigma = torch.empty(1, dtype=torch.float32, device=w.device)
+    ws = torch.empty(rows + cols, dtype=torch.float32, device=w.device)
+    _lib.check(lib.agx_spectral_sigma(_ptr(w), rows, cols, _ptr(u), _ptr(v), power_iterations, eps, _ptr(sigma),
+                                      _ptr(ws), _stream()), "agx_spectral_sigma")
+    return sigma
+
+
+def conv_pack_sigma(desc: ConvDesc, w: Tensor, sigma: Tensor) -> Tensor:
+    lib = _lib.load()
+    _need_gpu(w, sigma)
+    n = lib.agx_conv_packed_floats(ctypes.byref(desc))
+    if n < 0:
+        _lib.check(int(n), "agx_conv_packed_floats")
+    w = _f32c(w)
+    packed = torch.empty(int(n), dtype=torch.float32, device=w.device)
+    _lib.check(lib.agx_conv_pack_sigma(ctypes.byref(desc), _ptr(w), _ptr(sigma), _ptr(packed), _stream()),
+               "agx_conv_pack_sigma")
+    return packed
+
+
+def avgpool1d(x: Tensor, kernel: int, stride: int, padding: int) -> Tensor:
+    lib = _lib.load()
+    _need_gpu(x)
+    x = _f32c(x)
+    l_in = x.shape[-1]
+    l_out = lib.agx_avgpool1d_out_len(l_in, kernel, stride, padding)
+    if l_out < 0:
+        _lib.check(int(l_out), "agx_avgpool1d_out_len")
+    rows = x.numel() // l_in
+    y = torch.empty(*x.shape[:-1], int(l_out), dtype=torch.float32, device=x.device)
+    _lib.check(lib.agx_avgpool1d(_ptr(x), _ptr(y), rows, l_in, kernel, stride, padding, _stream()), "agx_avgpool1d")
+    return y
+
+
+def conv2d_desc(batch, c_in, c_out, h_in, w_in, kh, kw, stride=(1, 1), padding=(0, 0), epilogue=0, slope=0.2,
+                impl=IMPL_AUTO) -> _lib.Conv2dDesc:
+    return _lib.Conv2dDesc(batch, c_in, c_out, h_in, w_in, kh, kw, stride[0], stride[1], padding[0], padding[1],
+                           epilogue, slope, impl)
+
+
+def conv2d_pack(desc, w: Tensor, sigma: Optional[Tensor] = None) -> Tensor:
+    lib = _lib.load()
+    _need_gpu(w, sigma)
+    n = lib.agx_conv2d_packed_floats(ctypes.byref(desc))
+    if n < 0:
+        _lib.check(int(n), "agx_conv2d_packed_floats")
+    w = _f32c(w)
+    packed = torch.empty(int(n), dtype=torch.float32, device=w.device)
+    _lib.check(lib.agx_conv2d_pack(ctypes.byref(desc), _ptr(w), _ptr(sigma), _ptr(packed), _stream()),
+               "agx_conv2d_pack")
+    return packed
+
+
+def conv2d_forward(desc, x: Tensor, packed: Tensor, bias: Optional[Tensor]) -> Tensor:
+    lib = _lib.load()
+    _need_gpu(x, packed, bias)
+    x = _f32c(x)
+    ho, wo = ctypes.c_int32(), ctypes.c_int32()
+    _lib.check(lib.agx_conv2d_out_shape(ctypes.byref(desc), ctypes.byref(ho), ctypes.byref(wo)), "agx_conv2d_out_shape")
+    y = torch.empty(desc.batch, desc.c_out, ho.value, wo.value, dtype=torch.float32, device=x.device)
+    bias = None if bias is None else _f32c(bias)
+    tok = _observer.begin("other", ("conv2d", 4 * (x.numel() + y.numel()))) if _observer is not None else None
+    _lib.check(lib.agx_conv2d_forward(ctypes.byref(desc), _ptr(x), _ptr(packed), _ptr(bias), _ptr(y), _stream()),
+               "agx_conv2d_forward")
+    if tok is not None:
+        _observer.end(tok)
+    return y
+
+
+def conv2d_kernel_name(desc) -> str:
+    buf = ctypes.create_string_buffer(96)
+    _lib.check(_lib.load().agx_conv2d_kernel_name(ctypes.byref(desc), buf, 96), "agx_conv2d_kernel_name")
+    return buf.value.decode()
+
+
+_STFT_IMAGES = {}
+
+
+def stft(x: Tensor, n_fft: int, normalized: bool = True) -> Tensor:
+    """(B, L) -> (B, 2, T, n_fft): two-sided rectangular-window STFT, hop n_fft / 4, reflect-centred."""
+    lib = _lib.load()
+    _need_gpu(x)
+    x = _f32c(x)
+    b, length = x.shape
+    t = lib.agx_stft_frames(length, n_fft)
+    if t < 0:
+        _lib.check(int(t), "agx_stft_frames")
+    key = (n_fft, bool(normalized), x.device)
+    if key not in _STFT_IMAGES:
+        img = torch.empty(int(lib.agx_stft_packed_floats(n_fft)), dtype=torch.float32, device=x.device)
+        _lib.check(lib.agx_stft_pack(n_fft, int(normalized), _ptr(img), _stream()), "agx_stft_pack")
+        _STFT_IMAGES[key] = img
+    ws = torch.empty(int(lib.agx_stft_workspace_bytes(b, length, n_fft)) // 4, dtype=torch.float32, device=x.device)
+    y = torch.empty(b, 2, int(t), n_fft, dtype=torch.float32, device=x.device)
+    tok = _observer.begin("other", ("stft", 4 * (x.numel() + y.numel()))) if _observer is not None else None
+    _lib.check(lib.agx_stft_forward(_ptr(x), _ptr(_STFT_IMAGES[key]), _ptr(y), _ptr(ws), b, length, n_fft, _stream()),
+               "agx_stft_forward")
+    if tok is not None:
+        _observer.end(tok)
+    return y
+
+
+REDUCE_MEAN, REDUCE_HINGE_REAL, REDUCE_HINGE_FAKE, REDUCE_L1, REDUCE_ABS_EPS = 0, 1, 2, 3, 4
+
+
+def reduce_mean(x: Tensor, mode: int, y: Optional[Tensor] = None) -> Tensor:
+    """One of the means of ``discriminator_generator_loss`` as a 0-d device tensor."""
+    lib = _lib.load()
+    _need_gpu(x, y)
+    x = _f32c(x)
+    y = None if y is None else _f32c(y)
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    ws = torch.empty(1024, dtype=torch.float32, device=x.device)
+    _lib.check(lib.agx_reduce_mean(_ptr(x), _ptr(y), x.numel(), mode, _ptr(out), _ptr(ws), _stream()),
+               "agx_reduce_mean")
+    return out[0]
+
+
+def reduce_mean_backward(x: Tensor, mode: int, grad: Tensor, y: Optional[Tensor] = None, want_dy: bool = False):
+    lib = _lib.load()
+    _need_gpu(x, y, grad)
+    x = _f32c(x)
+    y = None if y is None else _f32c(y)
+    grad = _f32c(grad.reshape(1))
+    dx = torch.empty_like(x)
+    dy = torch.empty_like(x) if want_dy else None
+    _lib.check(lib.agx_reduce_mean_backward(_ptr(x), _ptr(y), x.numel(), mode, _ptr(grad), _ptr(dx), _ptr(dy),
+                                            _stream()), "agx_reduce_mean_backward")
+    return dx, dy
+
+
+def sigmoid(x: Tensor) -> Tensor:
+    lib = _lib.load()
+    _need_gpu(x)
+    x = _f32c(x)
+    y = torch.empty_like(x)
+    _lib.check(lib.agx_sigmoid(_ptr(x), _ptr(y), x.numel(), _stream()), "agx_sigmoid")
+    return y
 
 
 # ------------------------------------------------------------------ bitstream

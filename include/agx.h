@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AGX_VERSION 100 /* 0.1.0 */
+#define AGX_VERSION 110 /* 0.1.1: agx_conv_desc gained groups / padding (zero = old behaviour) */
 
 #define AGX_OK 0
 #define AGX_ERR_BAD_SHAPE (-1)
@@ -59,6 +59,7 @@ int agx_get_tuning(const char *name);
 #define AGX_CONV_TRANSPOSED 1 /* CausalConvT1d,       networks/vae.py:45-64  */
 #define AGX_CONV_UPSAMPLE 2 /* CausalUpsampleConv1d,  networks/vae.py:66-89  */
 #define AGX_CONV_SAME 3     /* Conv1d(padding="same"), networks/wavelets.py:193-201 */
+#define AGX_CONV_PADDED 4 /* torch.nn.Conv1d(padding=p, stride, dilation, groups): discriminator.py:33-41 */
 
 /* Which kernel family executes it (AGX_IMPL_AUTO picks by shape). */
 #define AGX_IMPL_AUTO 0
@@ -84,6 +85,8 @@ typedef struct agx_conv_desc {
     int32_t epilogue;  /* OR of AGX_EPI_*                                         */
     float slope;       /* LeakyReLU negative slope (reference: 0.1)               */
     int32_t impl;      /* AGX_IMPL_*                                              */
+    int32_t groups;    /* PADDED only: conv groups (0 or 1 = dense); grouped layers run on the direct kernel */
+    int32_t padding;   /* PADDED only: zeros on both sides (torch Conv1d padding=)  */
 } agx_conv_desc;
 
 /* Output length of the layer exactly as the reference computes it
@@ -239,6 +242,69 @@ int agx_wavelet_fold(const float *h, const float *space, const float *sigma, int
 int agx_wavelet_fold_backward(const float *h, const float *dout, const float *space, const float *sigma,
                               int32_t sigma_len, float *dh, float *dsigma, float *workspace, int32_t batch,
                               int32_t channels, int32_t length, int32_t n_points, int32_t scale, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Discriminators: networks/discriminator.py
+ * ------------------------------------------------------------------------- */
+
+/* Spectral norm (torch.nn.utils.spectral_norm, utils.py:34-42 with norm="spectral"): W is the weight
+ * viewed as (rows = dim 0, cols = the rest).  power_iterations > 0 (training mode) first updates the
+ * buffers in place, v = normalize(W^T u), u = normalize(W v) (eps as F.normalize); then
+ * sigma[0] = u . (W v).  sigma stays on the device (consumed by agx_conv_pack_sigma / agx_conv2d_pack).
+ * workspace: rows + cols floats. */
+int agx_spectral_sigma(const float *w, int32_t rows, int32_t cols, float *u, float *v,
+                       int32_t power_iterations, float eps, float *sigma, float *workspace, void *stream);
+
+/* agx_conv_pack for a spectrally normalised layer: every row scaled by 1 / sigma[0] (device scalar). */
+int agx_conv_pack_sigma(const agx_conv_desc *d, const float *w, const float *sigma, float *packed,
+                        void *stream);
+
+/* torch.nn.AvgPool1d(kernel, stride, padding) with count_include_pad=True (discriminator.py:32) over
+ * `rows` independent rows of length l_in; returns the output length via agx_avgpool1d_out_len. */
+int64_t agx_avgpool1d_out_len(int32_t l_in, int32_t kernel, int32_t stride, int32_t padding);
+int agx_avgpool1d(const float *x, float *y, int64_t rows, int32_t l_in, int32_t kernel, int32_t stride,
+                  int32_t padding, void *stream);
+
+/* torch.nn.Conv2d(c_in, c_out, (kh, kw), stride, padding) + optional fused LeakyReLU, NCHW fp32
+ * (discriminator.py:101-114, 150-167).  Runs on the 1-D MFMA / direct conv kernels with the kernel rows
+ * folded into virtual input channels. */
+typedef struct agx_conv2d_desc {
+    int32_t batch, c_in, c_out, h_in, w_in;
+    int32_t kh, kw, stride_h, stride_w, pad_h, pad_w;
+    int32_t epilogue; /* AGX_EPI_LEAKY_PRE or 0 */
+    float slope;
+    int32_t impl;     /* AGX_IMPL_* */
+} agx_conv2d_desc;
+int agx_conv2d_out_shape(const agx_conv2d_desc *d, int32_t *h_out, int32_t *w_out);
+int64_t agx_conv2d_packed_floats(const agx_conv2d_desc *d);
+/* w (c_out, c_in, kh, kw); sigma: device scalar of agx_spectral_sigma or NULL (no normalisation). */
+int agx_conv2d_pack(const agx_conv2d_desc *d, const float *w, const float *sigma, float *packed, void *stream);
+int agx_conv2d_forward(const agx_conv2d_desc *d, const float *x, const float *packed, const float *bias,
+                       float *y, void *stream);
+int agx_conv2d_kernel_name(const agx_conv2d_desc *d, char *buf, size_t buf_len);
+
+/* The torch.stft call of STFTDiscriminator.forward (discriminator.py:181-187): rectangular window,
+ * center=True (reflect padding), two-sided, optionally normalised by n_fft^-1/2, hop = n_fft / 4.
+ * x (B, L) -> y (B, 2, T, n_fft) with T = 1 + L / hop, channel 0 real / 1 imaginary (the layout after the
+ * reference's rearrange "b f t c -> b c t f").  The DFT runs as a conv on the MFMA kernels:
+ * agx_stft_pack builds its weight image once per n_fft. */
+int64_t agx_stft_frames(int32_t length, int32_t n_fft);
+int64_t agx_stft_packed_floats(int32_t n_fft);
+int agx_stft_pack(int32_t n_fft, int32_t normalized, float *packed, void *stream);
+int64_t agx_stft_workspace_bytes(int32_t batch, int32_t length, int32_t n_fft);
+int agx_stft_forward(const float *x, const float *packed, float *y, void *workspace, int32_t batch,
+                     int32_t length, int32_t n_fft, void *stream);
+
+/* Reductions of discriminator_generator_loss (discriminator.py:204-246), one launch each, result in
+ * out[0] (device):  mode 0 mean(x) | 1 mean(min(x - 1, 0)) | 2 mean(min(-x - 1, 0)) |
+ * 3 mean|x - y| | 4 mean|x + 1e-3|.   y only for mode 3.  workspace: 1024 floats. */
+int agx_reduce_mean(const float *x, const float *y, int64_t n, int32_t mode, float *out, float *workspace,
+                    void *stream);
+/* Gradient of the above: dx = grad[0] * d mean(term) / dx (and dy = -dx for the L1 term; dy may be NULL). */
+int agx_reduce_mean_backward(const float *x, const float *y, int64_t n, int32_t mode, const float *grad, float *dx,
+                             float *dy, void *stream);
+/* final_activation of the discriminators (torch.nn.Sigmoid, discriminator.py:46, 173). */
+int agx_sigmoid(const float *x, float *y, int64_t n, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Codec bitstream (wire size per utils.py:137-147)               *

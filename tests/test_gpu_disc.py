@@ -1,0 +1,274 @@
+"""Discriminators on the HIP kernels against the oracle and the reference's goldens (G7)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from audio_generation_amd import discriminator as ad
+from audio_generation_amd import ops
+from audio_generation_amd._lib import CONV_PADDED, EPI_LEAKY_PRE, IMPL_DIRECT, IMPL_MFMA
+from oracle import discriminator as od
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def g7():
+    z = np.load(os.path.join(GOLD, "g7_discriminators.npz"))
+    return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+@pytest.fixture(scope="module")
+def meta():
+    with open(os.path.join(GOLD, "meta_g7.json")) as f:
+        return json.load(f)
+
+
+def sub(g, prefix):
+    return {k[len(prefix):]: v.clone() for k, v in g.items() if k.startswith(prefix)}
+
+
+def close(a, b, tol=2e-5):
+    a, b = a.detach().cpu(), b.detach().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = float(b.abs().max()) + 1e-12
+    err = float((a - b).abs().max())
+    assert err <= tol * scale + 1e-7, err / scale
+
+
+# ------------------------------------------------------------------ primitives
+@pytest.mark.parametrize("win", [64, 256, 1024])
+def test_stft_matches_torch_stft_golden(g7, win):
+    x, want = g7[f"stft_only_{win}/x"], g7[f"stft_only_{win}/y"]            # want (B, F, T, 2)
+    got = ops.stft(x.to(DEV), win, True)
+    close(got, want.permute(0, 3, 2, 1), 2e-5)
+
+
+def test_stft_full_size_against_oracle():
+    torch.manual_seed(0)
+    x = 0.3 * torch.randn(3, 72000)
+    for win in (2048, 1024, 512):
+        got = ops.stft(x.to(DEV), win, True)
+        assert got.shape == (3, 2, 1 + 72000 // (win // 4), win)
+        close(got, od.stft_two_sided(x, win, win // 4), 2e-5)
+    # unnormalised, and the Hermitian symmetry of a real signal's two-sided spectrum: X[N - f] = conj X[f]
+    got = ops.stft(x.to(DEV), 256, False).cpu()
+    close(got, od.stft_two_sided(x, 256, 64, False), 2e-5)
+    close(got[:, 0, :, 1:], got[:, 0, :, 1:].flip(-1), 1e-4)
+    close(got[:, 1, :, 1:], -got[:, 1, :, 1:].flip(-1), 1e-4)
+
+
+@pytest.mark.parametrize("cin,cout,k,s,g,pad,length,impl", [
+    (1, 16, 15, 1, 1, 0, 700, 0), (16, 64, 41, 4, 4, 0, 3000, 0), (64, 256, 41, 4, 16, 0, 900, 0),
+    (256, 512, 41, 4, 64, 0, 300, 0), (512, 1024, 41, 4, 256, 0, 200, 0), (64, 64, 5, 1, 1, 0, 77, IMPL_MFMA),
+    (64, 64, 5, 1, 1, 0, 77, IMPL_DIRECT), (32, 1, 3, 1, 1, 0, 19, 0), (6, 9, 4, 3, 3, 2, 50, 0),
+    (16, 32, 7, 2, 1, 5, 333, IMPL_MFMA)])
+def test_padded_grouped_conv1d(cin, cout, k, s, g, pad, length, impl):
+    torch.manual_seed(cin + cout)
+    x = torch.randn(2, cin, length)
+    w = torch.randn(cout, cin // g, k) / (cin // g * k) ** 0.5
+    b = torch.randn(cout)
+    want = F.leaky_relu(F.conv1d(x, w, b, stride=s, padding=pad, groups=g), 0.2)
+    d = ops.conv_desc(CONV_PADDED, 2, cin, cout, length, k, s, 1, EPI_LEAKY_PRE, 0.2, impl, groups=g, padding=pad)
+    got = ops.conv_forward(d, x.to(DEV), ops.conv_pack(d, w.to(DEV)), b.to(DEV))
+    close(got, want, 1e-5)
+
+
+@pytest.mark.parametrize("scale,length", [(1, 100), (2, 101), (4, 1000)])
+def test_avgpool1d(scale, length):
+    x = torch.randn(3, 2, length)
+    close(ops.avgpool1d(x.to(DEV), 2 * scale, scale, scale), F.avg_pool1d(x, 2 * scale, stride=scale, padding=scale), 1e-6)
+
+
+@pytest.mark.parametrize("shape", [(16, 1, 15), (64, 4, 41), (32, 32, 3, 3), (1, 512, 1, 8), (4, 2, 7, 7)])
+@pytest.mark.parametrize("n_iter", [0, 1, 3])
+def test_spectral_sigma(shape, n_iter):
+    torch.manual_seed(len(shape) + n_iter)
+    w = torch.randn(*shape)
+    rows, cols = shape[0], w.numel() // shape[0]
+    u, v = F.normalize(torch.randn(rows), dim=0), F.normalize(torch.randn(cols), dim=0)
+    sd = {"weight_orig": w, "weight_u": u.clone(), "weight_v": v.clone()}
+    for _ in range(max(n_iter, 1)):
+        wn = od.spectral_weight(sd, "", train=n_iter > 0)
+    sigma_want = float((w / wn).flatten()[0])
+    ud, vd = u.to(DEV), v.to(DEV)
+    sigma = ops.spectral_sigma(w.to(DEV), ud, vd, n_iter)
+    assert abs(float(sigma) - sigma_want) <= 2e-5 * abs(sigma_want) + 1e-7
+    close(ud, sd["weight_u"], 2e-5)
+    close(vd, sd["weight_v"], 2e-5)
+
+
+@pytest.mark.parametrize("cin,cout,kh,kw,sh,sw,ph,pw,h,w,impl", [
+    (2, 32, 7, 7, 1, 1, 3, 3, 21, 70, 0), (2, 8, 7, 7, 1, 1, 3, 3, 9, 64, IMPL_DIRECT),
+    (32, 32, 3, 3, 1, 1, 1, 1, 17, 200, 0), (32, 64, 3, 4, 1, 2, 1, 1, 17, 200, 0),
+    (64, 128, 4, 4, 2, 2, 1, 1, 18, 130, 0), (128, 128, 3, 3, 1, 1, 1, 1, 9, 64, 0),
+    (16, 32, 3, 3, 1, 1, 1, 1, 5, 33, IMPL_MFMA), (16, 32, 3, 3, 1, 1, 1, 1, 5, 33, IMPL_DIRECT),
+    (512, 1, 1, 8, 1, 1, 0, 3, 5, 16, 0), (4, 4, 3, 3, 1, 1, 1, 1, 1, 5, 0), (48, 40, 2, 5, 3, 2, 0, 4, 11, 41, 0)])
+def test_conv2d(cin, cout, kh, kw, sh, sw, ph, pw, h, w, impl):
+    torch.manual_seed(cin * 7 + kh)
+    x = torch.randn(2, cin, h, w)
+    wt = torch.randn(cout, cin, kh, kw) / (cin * kh * kw) ** 0.5
+    b = torch.randn(cout)
+    want = F.leaky_relu(F.conv2d(x, wt, b, stride=(sh, sw), padding=(ph, pw)), 0.2)
+    d = ops.conv2d_desc(2, cin, cout, h, w, kh, kw, (sh, sw), (ph, pw), EPI_LEAKY_PRE, 0.2, impl)
+    got = ops.conv2d_forward(d, x.to(DEV), ops.conv2d_pack(d, wt.to(DEV)), b.to(DEV))
+    close(got, want, 1e-5)
+    name = ops.conv2d_kernel_name(d)
+    if impl == IMPL_MFMA or (impl == 0 and cout >= 32):
+        assert name.startswith("conv_mfma"), name
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
+def test_loss_means_and_their_gradients(mode):
+    torch.manual_seed(mode)
+    x = (1.5 * torch.randn(3, 5, 1000)).requires_grad_(True)
+    y = (1.5 * torch.randn(3, 5, 1000)).requires_grad_(True)
+    want = [lambda: x.mean(), lambda: torch.minimum(x - 1, torch.zeros_like(x)).mean(),
+            lambda: torch.minimum(-x - 1, torch.zeros_like(x)).mean(), lambda: F.l1_loss(x, y),
+            lambda: torch.abs(x + 1e-3).mean()][mode]()
+    (want * 3.0).backward()
+    xd, yd = x.detach().to(DEV).requires_grad_(True), y.detach().to(DEV).requires_grad_(True)
+    got = ad._mean(mode, xd, yd if mode == 3 else None)
+    assert abs(float(got) - float(want)) <= 1e-6 * abs(float(want)) + 1e-7
+    (got * 3.0).backward()
+    close(xd.grad, x.grad, 1e-6)
+    if mode == 3:
+        close(yd.grad, y.grad, 1e-6)
+
+
+# ------------------------------------------------------------------ modules vs the reference's goldens
+def _wave_block(meta, scale):
+    kw = meta["wave"]["kwargs"]
+    return ad.WaveformDiscriminatorBlock(1, channel_sizes=kw["channel_sizes"], groups=kw["groups"], scale=scale)
+
+
+@pytest.mark.parametrize("scale", [1, 2])
+def test_waveform_block_matches_reference(g7, meta, scale):
+    blk = _wave_block(meta, scale)
+    name = f"wave_s{scale}_eval"
+    blk.load_state_dict(sub(g7, name + "/sd/"), strict=True)
+    blk = blk.to(DEV).eval()
+    with torch.no_grad():
+        out, feats = blk(g7[name + "/x"].to(DEV))
+    # eval mode on never-iterated u / v: sigma is a small random number, the activations are huge and
+    # sigmoid saturates (the reference does exactly this) -- compare the features relative to their scale
+    assert len(feats) == meta["wave"]["n_features"]
+    for i, f in enumerate(feats):
+        close(f, g7[f"{name}/feat{i}"], 2e-4)
+    close(out, g7[name + "/out0"], 1e-5)
+    # training mode: one power iteration per forward, buffers move exactly as the reference's
+    name = f"wave_s{scale}_train"
+    blk.load_state_dict(sub(g7, name + "/sd/"), strict=True)
+    blk.train()
+    with torch.no_grad():
+        out, _ = blk(g7[name + "/x"].to(DEV))
+    close(out, g7[name + "/out0"], 2e-5)
+    sd = blk.state_dict()
+    for k, v in sub(g7, name + "/sd_after/").items():
+        close(sd[k], v, 2e-5)
+
+
+def test_state_dict_keys_match_reference(meta):
+    assert list(ad.WaveformDiscriminatorBlock(1).state_dict().keys()) == meta["wave_default_keys"]
+    kw = meta["stft"]["kwargs"]
+    d = ad.STFTDiscriminator(**kw)
+    assert list(d.state_dict().keys()) == meta["stft"]["keys"] and d.name == meta["stft"]["name"]
+    # default layer tables
+    full = ad.STFTDiscriminator()
+    rows = [m for m in full.modules() if isinstance(m, ad._SNConv)]
+    assert [(m.in_channels, m.out_channels, list(m.kernel_size), list(m.stride), list(m.padding)) for m in rows] == \
+           [(r["cin"], r["cout"], r["k"], r["stride"], r["padding"]) for r in meta["stft_default_layers"]]
+    rows = [m for m in ad.WaveformDiscriminatorBlock(1).modules() if isinstance(m, ad._SNConv)]
+    assert [(m.in_channels, m.out_channels, m.kernel_size[0], m.stride[0], m.groups) for m in rows] == \
+           [(r["cin"], r["cout"], r["k"], r["stride"], r["groups"]) for r in meta["wave_default_layers"]]
+
+
+def test_stft_discriminator_matches_reference(g7, meta):
+    kw = meta["stft"]["kwargs"]
+    d = ad.STFTDiscriminator(**kw)
+    d.load_state_dict(sub(g7, "stft_eval/sd/"), strict=True)
+    d = d.to(DEV).eval()
+    with torch.no_grad():
+        outs, feats = d(g7["stft_eval/x"].to(DEV))
+    assert len(feats) == meta["stft"]["n_features"] and len(outs) == 1
+    for i, f in enumerate(feats):
+        close(f, g7[f"stft_eval/feat{i}"], 5e-4)
+    close(outs[0], g7["stft_eval/out0"], 1e-4)
+    d.load_state_dict(sub(g7, "stft_train/sd/"), strict=True)
+    d.train()
+    with torch.no_grad():
+        outs, _ = d(g7["stft_train/x"].to(DEV))
+    close(outs[0], g7["stft_train/out0"], 5e-5)
+    sd = d.state_dict()
+    for k, v in sub(g7, "stft_train/sd_after/").items():
+        close(sd[k], v, 2e-5)
+
+
+@pytest.mark.parametrize("tag", ["wave", "stft"])
+def test_loss_matches_reference_and_oracle_gradients(g7, meta, tag):
+    orig, rec = g7["loss/original"], g7["loss/reconstruction"]
+    sd0 = sub(g7, f"loss_{tag}/sd/")
+    if tag == "wave":
+        disc = ad.WaveFormDiscriminator(1, n_blocks=2)
+        disc.layers = torch.nn.ModuleList([_wave_block(meta, s) for s in (1, 2)])
+        groups = meta["wave"]["kwargs"]["groups"]
+        oracle = lambda sd: (lambda t: od.waveform_discriminator(t, sd, n_blocks=2, train=True, groups=groups))  # noqa: E731
+    else:
+        disc = ad.STFTDiscriminator(**meta["stft"]["kwargs"])
+        win = meta["stft"]["kwargs"]["win_length"]
+        oracle = lambda sd: (lambda t: od.stft_discriminator(t, sd, win, train=True))  # noqa: E731
+    disc.load_state_dict(sd0, strict=True)
+    disc = disc.to(DEV).train()
+    rec_d = rec.to(DEV).requires_grad_(True)
+    gl, dl = ad.discriminator_generator_loss(orig.to(DEV), rec_d, disc)
+    close(gl, g7[f"loss_{tag}/generator_loss"], 2e-4)
+    close(dl, g7[f"loss_{tag}/discriminator_loss"], 2e-5)
+    # gradients of both losses against the oracle's autograd (same state, same three passes)
+    sd = {k: (v.clone().requires_grad_(True) if k.endswith("weight_orig") or k.endswith("bias") else v.clone())
+          for k, v in sd0.items()}
+    rec_c = rec.clone().requires_grad_(True)
+    gl_o, dl_o = od.discriminator_generator_loss(orig, rec_c, oracle(sd))
+    g_rec = torch.autograd.grad(gl_o, rec_c, retain_graph=True)[0]
+    leaves = [k for k in sd if sd[k].requires_grad]
+    g_par = torch.autograd.grad(dl_o, [sd[k] for k in leaves], allow_unused=True)
+    got_rec = torch.autograd.grad(gl, rec_d, retain_graph=True)[0]
+    close(got_rec, g_rec, 2e-3)
+    params = dict(disc.named_parameters())
+    got_par = torch.autograd.grad(dl, [params[k] for k in leaves], allow_unused=True)
+    checked = 0
+    for k, a, b in zip(leaves, got_par, g_par):
+        if b is None:
+            assert a is None or float(a.abs().max()) == 0.0
+            continue
+        close(a, b, 3e-3)
+        checked += 1
+    assert checked >= 14
+    # second call continues from the moved buffers, like the reference's second call
+    gl2, dl2 = ad.discriminator_generator_loss(orig.to(DEV), rec.to(DEV), disc, feature_multipier=3.0,
+                                               scale_feature_loss=False)
+    close(gl2, g7[f"loss_{tag}/generator_loss_unscaled_fm3"], 2e-4)
+    close(dl2, g7[f"loss_{tag}/discriminator_loss_2nd_call"], 2e-5)
+
+
+def test_full_size_stft_discriminator_against_oracle():
+    """Default widths, win 1024, one 24 kHz second: every feature map against the CPU restatement."""
+    torch.manual_seed(3)
+    d = ad.STFTDiscriminator()
+    sd = {k: v.clone() for k, v in d.state_dict().items()}
+    x = 0.3 * torch.randn(2, 1, 24000)
+    d = d.to(DEV).train()
+    with torch.no_grad():
+        outs, feats = d(x.to(DEV))
+    want_o, want_f = od.stft_discriminator(x, sd, 1024, train=True)
+    for a, b in zip(feats, want_f):
+        close(a, b, 2e-4)
+    close(outs[0], want_o[0], 1e-4)
+    names = {ops.conv2d_kernel_name(ops.conv2d_desc(2, m.in_channels, m.out_channels, 95, 1024, *m.kernel_size,
+                                                    m.stride, m.padding))
+             for m in d.modules() if isinstance(m, ad._SNConv) and m.out_channels >= 32}
+    assert all(n.startswith("conv_mfma") for n in names), names
