@@ -64,6 +64,9 @@ struct ConvPlan {
     int kh, sh, ph, Tin, Tout;
     int ncv, cin_real;             // virtual channels actually present (Cin rounds them up to 16) / real input channels
     int64_t x_cstride, y_cstride;  // elements between consecutive real channels of x / y
+    // patch mode (conv2d.hip; 0 = off): Cin counts REAL channels, tap j = dh * kw + dw (J = kh * kw); a tile is
+    // pm_R output rows x pm_WF output columns, chosen by the launcher
+    int pm_R, pm_WF;
 };
 
 // Packed weight image ("group-K-major"): channels in groups of 16,

@@ -5,7 +5,7 @@
 // is, for one output row (b, t), a 1-D conv along f over the kh * Cin "virtual channels"
 // c' = ci * kh + dh whose rows are rows t*sh + dh - ph of the input planes (zero rows outside the
 // image).  The MFMA kernel's LDS-DMA staging takes its row pointers from a RowMap (mfma_tile.hpp), so
-// the same tiles, pipeline and epilogue serve; blockIdx.z walks (b, t).
+// the same tiles, pipeline and epilogue serve; blockIdx.x walks (b, t).
 #include "common.hpp"
 
 namespace agx {
@@ -25,14 +25,20 @@ int lower_conv2d(const agx_conv2d_desc *d, ConvPlan *p) {
     if (d->h_in + 2 * d->pad_h < d->kh || d->w_in + 2 * d->pad_w < d->kw)
         return fail(AGX_ERR_BAD_SHAPE, "conv2d: kernel larger than the padded input");
     if (d->epilogue & ~AGX_EPI_LEAKY_PRE) return fail(AGX_ERR_UNSUPPORTED, "conv2d: only the LEAKY_PRE epilogue");
+    // Two lowerings (the packed image differs, so pack and forward both come through here):
+    //  * patches   -- MFMA path for Cin % 16 == 0, Cout >= 32: real channels, taps j = dh * kw + dw, a tile is
+    //                 several output rows x columns staged as one 2-D input patch per channel;
+    //  * row-folded -- everything else (the 2-channel 7x7 first conv, the 1-channel final conv, the direct
+    //                 kernel): virtual channels c' = ci * kh + dh, one output row per tile.
+    const bool patch = d->impl != AGX_IMPL_DIRECT && d->c_in % kWG == 0 && d->c_out >= 32;
     p->B = d->batch;
-    p->ncv = d->c_in * d->kh;
     p->cin_real = d->c_in;
+    p->ncv = patch ? d->c_in : d->c_in * d->kh;
     p->Cin = ceil_div(p->ncv, kWG) * kWG;
     p->Cout = d->c_out;
     p->Lin = p->Lvalid = d->w_in;
     p->q = 1;
-    p->J = d->kw;
+    p->J = patch ? d->kh * d->kw : d->kw;
     p->s = d->stride_w;
     p->d = 1;
     p->P = d->pad_w;
@@ -50,7 +56,9 @@ int lower_conv2d(const agx_conv2d_desc *d, ConvPlan *p) {
     p->Tout = (d->h_in + 2 * d->pad_h - d->kh) / d->stride_h + 1;
     p->x_cstride = int64_t(d->h_in) * d->w_in;
     p->y_cstride = int64_t(p->Tout) * p->Lout;
-    if (int64_t(p->B) * p->Tout > 65535) return fail(AGX_ERR_BAD_SHAPE, "conv2d: batch * output rows > 65535");
+    p->pm_R = patch ? 1 : 0;  // the launcher fixes the tile (conv_mfma.hip: tile_span)
+    p->pm_WF = 0;
+    if (int64_t(p->B) * p->Tout > (int64_t(1) << 30)) return fail(AGX_ERR_BAD_SHAPE, "conv2d: batch * output rows too large");
     return AGX_OK;
 }
 }  // namespace agx
@@ -81,6 +89,8 @@ int agx_conv2d_forward(const agx_conv2d_desc *d, const float *x, const float *pa
     if (!x || !packed || !y) return fail(AGX_ERR_NULL_POINTER, "agx_conv2d_forward: NULL pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int impl = conv2d_impl(d, p);
+    if (p.pm_R && impl != AGX_IMPL_MFMA)
+        return fail(AGX_ERR_UNSUPPORTED, "conv2d: no MFMA tile fits this layer (set impl = AGX_IMPL_DIRECT for pack and forward)");
     if (impl == AGX_IMPL_MFMA) return launch_conv_mfma(p, x, packed, bias, nullptr, y, st);
     if (impl == AGX_IMPL_DIRECT) return launch_conv_direct(p, x, packed, bias, nullptr, y, st);
     return fail(AGX_ERR_BAD_SHAPE, "conv2d: unknown impl %d", impl);

@@ -20,9 +20,12 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvPlan p, int ci_til
                                                           float *__restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) float xs[];  // [ci_tile][span]
     const int tid = threadIdx.x;
-    const int t0 = blockIdx.x * 256;
+    // 2-D layers (Tout > 1 or kh > 1) put the (b, output row) index on grid.x: it can exceed 65535
+    const bool two_d = p.Tout > 1 || p.kh > 1;
+    const int t0 = (two_d ? blockIdx.z : blockIdx.x) * 256;
     const int m0 = blockIdx.y * CO_T;
-    const int b = blockIdx.z / p.Tout, trow = blockIdx.z - b * p.Tout;  // 1-D: Tout = 1
+    const int zrow = two_d ? blockIdx.x : blockIdx.z;
+    const int b = zrow / p.Tout, trow = zrow - b * p.Tout;  // 1-D: Tout = 1
     const int t = t0 + tid;
     const int in0 = t0 * p.s - p.P;  // input index of xs[.][0]
     // grouped layers: this block's rows all sit in one group (the launcher picks CO_T | Cout / G)
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvPlan p, int ci_til
 constexpr int kNarrowJ = 7, kNarrowP = 6;
 
 static inline bool narrow_ok(const ConvPlan &p) {
-    return p.G == 1 && p.kh == 1 && p.J == kNarrowJ && p.P == kNarrowP && p.s == 1 && p.d == 1 && p.q == 1 && p.oshift == 0 &&
+    return p.G == 1 && p.kh == 1 && p.Tout == 1 && p.J == kNarrowJ && p.P == kNarrowP && p.s == 1 && p.d == 1 && p.q == 1 && p.oshift == 0 &&
            p.Lin % 4 == 0 && p.Lvalid % 4 == 0 && p.Lout % 4 == 0 && p.Lt == p.Lout && p.Lvalid >= 4 &&
            (p.M == 1 || p.M == 2 || p.M == 32);
 }
@@ -209,6 +212,7 @@ int launch_conv_direct(const ConvPlan &p, const float *x, const float *wp, const
         co_t = rpg % 32 == 0 ? 32 : (rpg % 16 == 0 ? 16 : (rpg % 4 == 0 ? 4 : 1));
     }
     dim3 grid(ceil_div(p.Lt, 256), ceil_div(p.M, co_t), p.B * p.Tout), block(256);
+    if (p.Tout > 1 || p.kh > 1) grid = dim3(p.B * p.Tout, ceil_div(p.M, co_t), ceil_div(p.Lt, 256));
     if (grid.y > 65535 || grid.z > 65535) return fail(AGX_ERR_BAD_SHAPE, "conv_direct: grid too large");
     switch (co_t) {
         case 32:

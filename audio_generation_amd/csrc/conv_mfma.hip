@@ -24,7 +24,7 @@
 
 namespace agx {
 
-template <int MW, int NW, int WM, int WN, int CC, bool TWO_D = false>
+template <int MW, int NW, int WM, int WN, int CC, int MODE = 0>  // 0: 1-D  1: 2-D row-folded  2: 2-D patches
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
                                                         const float *__restrict__ x,
                                                         const float *__restrict__ wp,
@@ -37,12 +37,29 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const int t0 = blockIdx.x * BN;
+    constexpr bool TWO_D = MODE != 0;
+    // 2-D layers put the (b, output row / tile) index on grid.x (it can exceed the 65535 limit of grid.z)
+    int t0, b, trow = 0, f0 = 0;
+    if (MODE == 0) {
+        t0 = blockIdx.x * BN;
+        b = blockIdx.z;
+    } else if (MODE == 1) {                      // blockIdx.x = b * Tout + output row
+        t0 = blockIdx.z * BN;
+        b = blockIdx.x / p.Tout;
+        trow = blockIdx.x - b * p.Tout;
+    } else {                                     // blockIdx.x = (b * row groups + rg) * column tiles + ft
+        const int nft = (p.Lout + p.pm_WF - 1) / p.pm_WF, nrg = (p.Tout + p.pm_R - 1) / p.pm_R;
+        int bx = blockIdx.x;
+        const int ft = bx % nft;
+        bx /= nft;
+        const int rg = bx % nrg;
+        b = bx / nrg;
+        trow = rg * p.pm_R;
+        f0 = ft * p.pm_WF;
+        t0 = 0;
+    }
     const int m0 = blockIdx.y * BM + wm * (32 * MW);
     const int n0 = wn * (32 * NW);
-    // 2-D layers: blockIdx.z = b * Tout + output row (common.hpp)
-    const int b = TWO_D ? blockIdx.z / p.Tout : blockIdx.z;
-    const int trow = TWO_D ? blockIdx.z - b * p.Tout : 0;
     const int in0 = t0 * p.s - p.P;
 
     f32x16 acc[MW][NW];
@@ -59,13 +76,31 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
     for (int i = 0; i < MW; ++i) arow[i] = min(m0 + i * 32 + li, p.M - 1);
     // per-lane B column offsets inside the staged tile
     int bcol[NW];
+    int prow[NW], pcol[NW];  // patch mode: output row / column (inside the tile) of this lane's column k
+    const int SW = MODE == 2 ? (p.pm_WF - 1) * p.s + p.J / p.kh : 0;  // patch pitch
 #pragma unroll
-    for (int k = 0; k < NW; ++k) bcol[k] = (n0 + k * 32 + li) * p.s + lh * ((CC < 16 ? CC : 16) / 2) * span;
+    for (int k = 0; k < NW; ++k) {
+        const int n = n0 + k * 32 + li;
+        if (MODE == 2) {
+            const int r = n / p.pm_WF;
+            prow[k] = r;
+            pcol[k] = n - r * p.pm_WF;
+            bcol[k] = (min(r, p.pm_R - 1) * p.sh) * SW + pcol[k] * p.s + lh * ((CC < 16 ? CC : 16) / 2) * span;
+        } else {
+            prow[k] = pcol[k] = 0;
+            bcol[k] = n * p.s + lh * ((CC < 16 ? CC : 16) / 2) * span;
+        }
+    }
 
-    if (TWO_D) {
-        const RowMap2D rm{x + size_t(b) * p.cin_real * p.x_cstride, p.x_cstride, p.Lin, p.kh,
-                          trow * p.sh - p.ph, p.Tin, p.ncv};
-        conv_gemm_rows<MW, NW, CC, kSchedDefault, RowMap2D>(acc, xs, rm, wp, p, p.M, span, in0, arow, bcol, wave, lane);
+    if (MODE == 2) {
+        const StagerPatch stg{x + size_t(b) * p.cin_real * p.x_cstride, p.x_cstride, p.Lin, p.Tin,
+                              trow * p.sh - p.ph, f0 * p.s - p.P, SW, p.J / p.kh, p.cin_real, 1.f / float(SW)};
+        conv_gemm_rows<MW, NW, CC, kSchedDefault>(acc, xs, stg, wp, p, p.M, span, arow, bcol, wave, lane);
+    } else if (MODE == 1) {
+        const StagerRows<RowMap2D> stg{RowMap2D{x + size_t(b) * p.cin_real * p.x_cstride, p.x_cstride, p.Lin, p.kh,
+                                                trow * p.sh - p.ph, p.Tin, p.ncv},
+                                       p.Lvalid, in0, p.d};
+        conv_gemm_rows<MW, NW, CC, kSchedDefault>(acc, xs, stg, wp, p, p.M, span, arow, bcol, wave, lane);
     } else {
         const float *xb = x + size_t(b) * p.Cin * p.Lin;
         conv_gemm<MW, NW, CC>(acc, xs, xb, wp, p, p.M, span, in0, arow, bcol, wave, lane);
@@ -89,14 +124,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
         }
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
-            const int t = t0 + n0 + k * 32 + li;
+            // output position of this lane's column: 1-D / row-folded (row trow, position t) or patch
+            // (row trow + prow, column f0 + pcol)
+            const int t = MODE == 2 ? f0 + pcol[k] : t0 + n0 + k * 32 + li;
+            const int orow = MODE == 2 ? trow + prow[k] : trow;
+            const bool col_ok = MODE == 2 ? (prow[k] < p.pm_R && orow < p.Tout && t < p.Lt) : t < p.Lt;
             const int tc = min(t, p.Lt - 1);
+            const int orc = TWO_D ? min(orow, p.Tout - 1) : 0;
             size_t off[16];
             float rv[16], mv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int u = min(max(tc * p.q + ph[r] - p.oshift, 0), p.Lout - 1);
-                off[r] = TWO_D ? (size_t(b) * p.Cout + co[r]) * p.y_cstride + size_t(trow) * p.Lout + u
+                off[r] = TWO_D ? (size_t(b) * p.Cout + co[r]) * p.y_cstride + size_t(orc) * p.Lout + u
                                : (size_t(b) * p.Cout + co[r]) * p.Lout + u;
             }
             if (has_res) {
@@ -116,21 +156,34 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
                 if (post) v = leaky(v, p.slope);
                 if (has_mask) v = mv[r] > 0.f ? v : v * p.slope;
                 const int u = t * p.q + ph[r] - p.oshift;
-                const bool ok = t < p.Lt && (m0 + i * 32 + acc_row(r, lh)) < p.M && u >= 0 && u < p.Lout;
+                const bool ok = col_ok && (m0 + i * 32 + acc_row(r, lh)) < p.M && u >= 0 && u < p.Lout;
                 if (ok) y[off[r]] = v;
             }
         }
     }
 }
 
-template <int MW, int NW, int WM, int WN, int CC, bool TWO_D = false>
-static int launch_variant(const ConvPlan &p, const float *x, const float *wp, const float *bias,
+// LDS floats per staged channel for a BN-column tile (patch mode also fixes the tile's rows x columns).
+static int tile_span(const ConvPlan &p, int BN, int *R, int *WF) {
+    if (!p.pm_R) return (BN - 1) * p.s + (p.J - 1) * p.d + 1;
+    // tile = R output rows x WF output columns (R * WF <= BN): a whole output row when it fits
+    int wf = p.Lout < BN ? p.Lout : BN;
+    int r = BN / wf;
+    if (r > p.Tout) r = p.Tout;
+    if (R) *R = r;
+    if (WF) *WF = wf;
+    return ((r - 1) * p.sh + p.kh) * ((wf - 1) * p.s + p.J / p.kh);
+}
+
+template <int MW, int NW, int WM, int WN, int CC, int MODE = 0>
+static int launch_variant(const ConvPlan &p0, const float *x, const float *wp, const float *bias,
                           const float *res, float *y, hipStream_t st) {
     constexpr int BM = 32 * MW * WM, BN = 32 * NW * WN;
-    const int span = (BN - 1) * p.s + (p.J - 1) * p.d + 1;
+    ConvPlan p = p0;
+    const int span = tile_span(p0, BN, &p.pm_R, &p.pm_WF);
     const size_t lds = size_t(2) * CC * span * sizeof(float);  // double-buffered input tile
     if (lds > 160 * 1024) return fail(AGX_ERR_UNSUPPORTED, "conv_mfma: tile needs %zu B of LDS", lds);
-    auto kern = conv_mfma_kernel<MW, NW, WM, WN, CC, TWO_D>;
+    auto kern = conv_mfma_kernel<MW, NW, WM, WN, CC, MODE>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -138,7 +191,10 @@ static int launch_variant(const ConvPlan &p, const float *x, const float *wp, co
         if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    dim3 grid(ceil_div(p.Lt, BN), ceil_div(p.M, BM), p.B * p.Tout), block(256);
+    dim3 grid(ceil_div(p.Lt, BN), ceil_div(p.M, BM), p.B), block(256);
+    if (MODE == 1) grid = dim3(p.B * p.Tout, ceil_div(p.M, BM), ceil_div(p.Lt, BN));
+    if (MODE == 2)
+        grid = dim3(unsigned(int64_t(p.B) * ceil_div(p.Tout, p.pm_R) * ceil_div(p.Lout, p.pm_WF)), ceil_div(p.M, BM), 1);
     if (grid.y > 65535 || grid.z > 65535) return fail(AGX_ERR_BAD_SHAPE, "conv_mfma: grid too large");
     hipLaunchKernelGGL(kern, grid, block, lds, st, p, span, x, wp, bias, res, y);
     return check_launch("conv_mfma");
@@ -153,14 +209,16 @@ struct Variant {
     int (*launch)(const ConvPlan &, const float *, const float *, const float *, const float *, float *,
                   hipStream_t);
     int (*launch2d)(const ConvPlan &, const float *, const float *, const float *, const float *, float *,
-                    hipStream_t);  // nullptr: no 2-D instantiation of this tile
+                    hipStream_t);  // row-folded 2-D; nullptr: no 2-D instantiation of this tile
+    int (*launch_patch)(const ConvPlan &, const float *, const float *, const float *, const float *, float *,
+                        hipStream_t);  // patch 2-D
 };
 
 #define AGX_VARIANT(MW, NW, WM, WN, CC) \
-    { MW, NW, WM, WN, CC, "conv_mfma<" #MW "," #NW "," #WM "," #WN "," #CC ">", launch_variant<MW, NW, WM, WN, CC>, nullptr }
+    { MW, NW, WM, WN, CC, "conv_mfma<" #MW "," #NW "," #WM "," #WN "," #CC ">", launch_variant<MW, NW, WM, WN, CC>, nullptr, nullptr }
 #define AGX_VARIANT2(MW, NW, WM, WN, CC) \
     { MW, NW, WM, WN, CC, "conv_mfma<" #MW "," #NW "," #WM "," #WN "," #CC ">", launch_variant<MW, NW, WM, WN, CC>, \
-      launch_variant<MW, NW, WM, WN, CC, true> }
+      launch_variant<MW, NW, WM, WN, CC, 1>, launch_variant<MW, NW, WM, WN, CC, 2> }
 
 static const Variant kWide[] = {AGX_VARIANT2(2, 2, 2, 2, 16), AGX_VARIANT2(2, 2, 2, 2, 8), AGX_VARIANT(2, 2, 2, 2, 32)};
 // 128 x 64 tiles for short signals: twice the workgroups when the 128 x 128 grid would leave
@@ -174,8 +232,7 @@ static const Variant kNarrow[] = {AGX_VARIANT2(1, 4, 1, 4, 16), AGX_VARIANT2(1, 
 
 static size_t variant_lds(const Variant &v, const ConvPlan &p) {
     const int bn = 32 * v.nw * v.wn;
-    const size_t span = size_t(bn - 1) * p.s + size_t(p.J - 1) * p.d + 1;
-    return size_t(2) * v.cc * span * sizeof(float);
+    return size_t(2) * v.cc * size_t(tile_span(p, bn, nullptr, nullptr)) * sizeof(float);
 }
 
 static const Variant *pick(const Variant *list, int n, const ConvPlan &p, int want_cc) {
@@ -199,7 +256,7 @@ static const Variant *select_variant(const ConvPlan &p) {
     const int n = p.M >= 128 ? 3 : 5;
     if (p.M >= 128 && tuning().conv_shape == 1) list = kWideAlt;
     const Variant *v = pick(list, n, p, tuning().conv_cc);
-    if (v && p.M >= 128 && tuning().conv_short) {
+    if (v && p.M >= 128 && tuning().conv_short && !p.pm_R) {
         // Short signals: the same channel chunk (= the same summation order, so results do not depend on
         // the batch size or the signal length) on 128 x 64 tiles.
         const long wgs = long(ceil_div(p.Lt, 128)) * ceil_div(p.M, 128) * p.B * p.Tout;
@@ -225,6 +282,10 @@ int launch_conv_mfma(const ConvPlan &p, const float *x, const float *wp, const f
         return fail(AGX_ERR_UNSUPPORTED,
                     "conv_mfma: needs Cin %% 16 == 0, q*Cout >= 32 and an input tile that fits LDS (Cin=%d M=%d s=%d J=%d d=%d)",
                     p.Cin, p.M, p.s, p.J, p.d);
+    if (p.pm_R) {
+        if (!v->launch_patch) return fail(AGX_ERR_UNSUPPORTED, "conv_mfma: no 2-D instantiation of %s", v->name);
+        return v->launch_patch(p, x, wp, bias, res, y, st);
+    }
     if (p.kh > 1 || p.Tout > 1 || p.ncv != p.Cin) {
         if (!v->launch2d) return fail(AGX_ERR_UNSUPPORTED, "conv_mfma: no 2-D instantiation of %s", v->name);
         return v->launch2d(p, x, wp, bias, res, y, st);

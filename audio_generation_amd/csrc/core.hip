@@ -137,6 +137,7 @@ int lower_conv(const agx_conv_desc *d, ConvPlan *p) {
     p->ph = 0;
     p->Tin = p->Tout = 1;
     p->ncv = p->cin_real = p->Cin;
+    p->pm_R = p->pm_WF = 0;
     p->x_cstride = p->Lin;
     p->y_cstride = p->Lout;
     return AGX_OK;
@@ -193,6 +194,7 @@ int lower_conv_bwd_data(const agx_conv_desc *d, ConvPlan *b) {
     b->x_cstride = b->Lin;
     b->y_cstride = b->Lout;
     b->ncv = b->cin_real = b->Cin;
+    b->pm_R = b->pm_WF = 0;
     return AGX_OK;
 }
 

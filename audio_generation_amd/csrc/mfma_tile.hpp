@@ -105,29 +105,102 @@ struct RowMap2D {
     }
 };
 
-// Issue the LDS-DMA of CC channel rows (c0 ..), positions [in0, in0 + span), into buf
-// (row stride span).  Out-of-range positions are never written: the caller
-// zero-fills both buffers once and they stay zero (the in-range set does not
-// depend on the channel chunk).  Rows the map reports absent (2-D only) are zeroed here.
-template <int CC, class RowMap>
-__device__ __forceinline__ void issue_rows_dma(float *__restrict__ buf, const RowMap &rm, int c0,
-                                               int Lvalid, int in0, int span, int wave, int lane) {
-#pragma unroll
-    for (int rr = 0; rr < CC / 4; ++rr) {
-        const int c = wave + 4 * rr;
-        bool ok;
-        const float *src = rm.row(c0 + c, ok) + in0 + lane;
-        float *dst = buf + c * span;
-        if (ok) {
-            for (int i0 = 0; i0 < span; i0 += 64) {
-                const int i = i0 + lane, pos = in0 + i;
-                if (i < span && pos >= 0 && pos < Lvalid) glds_dword(src + i0, dst + i0);
+// ---- input staging policies of conv_gemm_rows ----------------------------------------------------
+// A stager owns the global -> LDS traffic of one workgroup tile: the one-off zero fill of the positions
+// the DMA never writes, the per-chunk DMA issue, and the LDS offset of tap j relative to tap 0.
+
+// Rows: LDS row c = positions [in0, in0 + span) of input row rm.row(c).  Out-of-range positions are never
+// written (zero-filled once: the in-range set does not depend on the channel chunk); rows the map reports
+// absent (row-folded 2-D only) are zeroed at issue time.
+template <class RowMap>
+struct StagerRows {
+    RowMap rm;
+    int Lvalid, in0, d;
+
+    __device__ __forceinline__ int tapoff(int j) const { return j * d; }
+
+    __device__ __forceinline__ void zero_fill(float *xs, int nrows, int span, int tid) const {
+        // interior tiles have nothing to fill: skipped instead of costing nrows*span/256 LDS stores per thread
+        const int lo = min(max(-in0, 0), span);             // first in-range tile position
+        const int hi = max(min(Lvalid - in0, span), lo);    // one past the last
+        if (lo > 0 || hi < span) {
+            const int nz = lo + (span - hi);                // out-of-range positions per row
+            for (int e = tid; e < nrows * nz; e += 256) {
+                const int row = e / nz, i = e - row * nz;
+                xs[row * span + (i < lo ? i : hi + (i - lo))] = 0.f;
             }
-        } else {
-            for (int i = lane; i < span; i += 64) dst[i] = 0.f;
         }
     }
-}
+
+    template <int CC>
+    __device__ __forceinline__ void issue(float *__restrict__ buf, int c0, int span, int wave, int lane) const {
+#pragma unroll
+        for (int rr = 0; rr < CC / 4; ++rr) {
+            const int c = wave + 4 * rr;
+            bool ok;
+            const float *src = rm.row(c0 + c, ok) + in0 + lane;
+            float *dst = buf + c * span;
+            if (ok) {
+                for (int i0 = 0; i0 < span; i0 += 64) {
+                    const int i = i0 + lane, pos = in0 + i;
+                    if (i < span && pos >= 0 && pos < Lvalid) glds_dword(src + i0, dst + i0);
+                }
+            } else {
+                for (int i = lane; i < span; i += 64) dst[i] = 0.f;
+            }
+        }
+    }
+};
+
+// Patches (2-D layers, conv2d.hip): LDS row c = the RH x SW input patch of REAL channel c that the tile's
+// R output rows x WF output columns need, row-major with pitch SW; tap j = dh * kw + dw sits at
+// dh * SW + dw.  Out-of-image positions are zero-filled once (same set for every channel).
+struct StagerPatch {
+    const float *xb;   // x + b * Cin * cstride
+    int64_t cstride;   // elements between channels (Tin * Fin)
+    int Fin, Tin, row0, col0, SW, kw, ncr;  // ncr: real channels (the packed image rounds up to 16)
+    float inv_sw;      // 1 / SW for the exact small-integer division below
+
+    __device__ __forceinline__ int tapoff(int j) const {
+        const int dh = j / kw;
+        return dh * SW + (j - dh * kw);
+    }
+    __device__ __forceinline__ bool inside(int i, int &goff) const {
+        const int r = int((float(i) + 0.5f) * inv_sw);  // exact: i < 2^16, quotient < 2^8
+        const int c = i - r * SW;
+        const int gr = row0 + r, gc = col0 + c;
+        goff = gr * Fin + gc;
+        return gr >= 0 && gr < Tin && gc >= 0 && gc < Fin;
+    }
+    __device__ __forceinline__ void zero_fill(float *xs, int nrows, int span, int tid) const {
+        const int RH = span / SW;
+        const bool interior = row0 >= 0 && row0 + RH <= Tin && col0 >= 0 && col0 + SW <= Fin;
+        if (interior) return;
+        for (int i = tid; i < span; i += 256) {
+            int goff;
+            if (!inside(i, goff))
+                for (int row = 0; row < nrows; ++row) xs[row * span + i] = 0.f;
+        }
+    }
+    template <int CC>
+    __device__ __forceinline__ void issue(float *__restrict__ buf, int c0, int span, int wave, int lane) const {
+#pragma unroll
+        for (int rr = 0; rr < CC / 4; ++rr) {
+            const int c = wave + 4 * rr;
+            float *dst = buf + c * span;
+            if (c0 + c < ncr) {
+                const float *src = xb + (c0 + c) * cstride;
+                for (int i0 = 0; i0 < span; i0 += 64) {
+                    int goff;
+                    const int i = i0 + lane;
+                    if (inside(i, goff) && i < span) glds_dword(src + goff, dst + i0);
+                }
+            } else {
+                for (int i = lane; i < span; i += 64) dst[i] = 0.f;
+            }
+        }
+    }
+};
 
 // The implicit-GEMM main loop over all (channel chunk, tap) phases.
 //   acc[i][k] += sum_{c, j} Wp[c*J + j][arow[i]] * x[c][bcol0[k] + j*d]   (x via the LDS tile)
@@ -147,34 +220,22 @@ __device__ __forceinline__ void load_b_phase(float (&bf)[CC / 2][NW], const floa
 
 // CC = channels per LDS chunk (one DMA hand-over + barrier per chunk); the register pipeline
 // works in phases of PC = min(CC, 16) channels x one tap (operand arrays sized for PC).
-template <int MW, int NW, int CC, int SCHED = kSchedDefault, class RowMap = RowMap1D>
+template <int MW, int NW, int CC, int SCHED, class Stager>
 __device__ __forceinline__ void conv_gemm_rows(f32x16 (&acc)[MW][NW], float *__restrict__ xs,
-                                               const RowMap &rm, const float *__restrict__ wp,
-                                               const ConvPlan &p, int M, int span, int in0,
+                                               const Stager &stg, const float *__restrict__ wp,
+                                               const ConvPlan &p, int M, int span,
                                                const int (&arow)[MW], const int (&bcol)[NW], int wave, int lane) {
     constexpr int PC = CC < 16 ? CC : 16;
     constexpr int NH = CC / PC;  // register phases groups per chunk
     const int lh = lane >> 5;
     const int tid = wave * 64 + lane;
     float *buf0 = xs, *buf1 = xs + CC * span;
-    // Zero only the positions the DMA will never write (outside [0, Lvalid)): interior tiles have
-    // none, so the fill is skipped there instead of costing 2*CC*span/256 LDS stores per thread.
-    {
-        const int lo = min(max(-in0, 0), span);                 // first in-range tile position
-        const int hi = max(min(p.Lvalid - in0, span), lo);      // one past the last
-        if (lo > 0 || hi < span) {
-            const int nz = lo + (span - hi);                    // out-of-range positions per row
-            for (int e = tid; e < 2 * CC * nz; e += 256) {
-                const int row = e / nz, i = e - row * nz;
-                xs[row * span + (i < lo ? i : hi + (i - lo))] = 0.f;
-            }
-        }
-    }
+    stg.zero_fill(xs, 2 * CC, span, tid);
     float a_cur[PC / 2][MW], a_nxt[PC / 2][MW];
     float b_cur[PC / 2][NW], b_nxt[PC / 2][NW];
     load_a_phase<MW, PC>(a_cur, wp, 0, 0, p.J, M, lh, arow);
     __syncthreads();
-    issue_rows_dma<CC>(buf0, rm, 0, p.Lvalid, in0, span, wave, lane);
+    stg.template issue<CC>(buf0, 0, span, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     AGX_STAMP(1);
@@ -201,7 +262,7 @@ __device__ __forceinline__ void conv_gemm_rows(f32x16 (&acc)[MW][NW], float *__r
                 }
                 // The next chunk's input DMA goes out first (once per chunk) ...
                 if (h == 0 && j == 0 && c0 + CC < p.Cin)
-                    issue_rows_dma<CC>(nxt, rm, c0 + CC, p.Lvalid, in0, span, wave, lane);
+                    stg.template issue<CC>(nxt, c0 + CC, span, wave, lane);
                 // ... then the operands of the NEXT phase are requested, in the same basic block as this
                 // phase's MFMAs so that the scheduler can thread them between the MFMAs: neither the L2
                 // latency of the weights nor the LDS latency of the input sits in front of an MFMA (a
@@ -212,7 +273,7 @@ __device__ __forceinline__ void conv_gemm_rows(f32x16 (&acc)[MW][NW], float *__r
                 const bool last = nc0 >= p.Cin;
                 load_a_phase<MW, PC>(a_nxt, wp, last ? 0 : nc0 + nh * PC, last ? 0 : nj, p.J, M, lh, arow);
                 if (SCHED == 1) __builtin_amdgcn_sched_barrier(0);
-                load_b_phase<NW, PC>(b_nxt, cur + (nc0 == c0 ? nh * PC * span + nj * p.d : 0), span, bcol);
+                load_b_phase<NW, PC>(b_nxt, cur + (nc0 == c0 ? nh * PC * span + stg.tapoff(nj) : 0), span, bcol);
                 if (SCHED == 0) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ks = 0; ks < PC / 2; ++ks)
@@ -266,8 +327,8 @@ __device__ __forceinline__ void conv_gemm(f32x16 (&acc)[MW][NW], float *__restri
                                           const float *__restrict__ xb, const float *__restrict__ wp,
                                           const ConvPlan &p, int M, int span, int in0,
                                           const int (&arow)[MW], const int (&bcol)[NW], int wave, int lane) {
-    const RowMap1D rm{xb, p.Lin};
-    conv_gemm_rows<MW, NW, CC, SCHED, RowMap1D>(acc, xs, rm, wp, p, M, span, in0, arow, bcol, wave, lane);
+    const StagerRows<RowMap1D> stg{RowMap1D{xb, p.Lin}, p.Lvalid, in0, p.d};
+    conv_gemm_rows<MW, NW, CC, SCHED>(acc, xs, stg, wp, p, M, span, arow, bcol, wave, lane);
 }
 
 }  // namespace agx
