@@ -67,6 +67,9 @@ struct ConvPlan {
     // patch mode (conv2d.hip; 0 = off): Cin counts REAL channels, tap j = dh * kw + dw (J = kh * kw); a tile is
     // pm_R output rows x pm_WF output columns, chosen by the launcher
     int pm_R, pm_WF;
+    // patch mode, backward-data of strided layers: qh output-row phases per base row (rows m = (co*qh + a)*q + c),
+    // output row = qh * base row + a - oshift_h; Tt base rows (forward: qh = 1, oshift_h = 0, Tt = Tout)
+    int qh, oshift_h, Tt;
 };
 
 // Packed weight image ("group-K-major"): channels in groups of 16,
@@ -88,5 +91,6 @@ int lower_conv(const agx_conv_desc *d, ConvPlan *p);
 int lower_conv_bwd_data(const agx_conv_desc *d, ConvPlan *p);
 // 2-D layer (torch.nn.Conv2d, zero padding) as a 1-D conv over virtual channels / batch (see ConvPlan).
 int lower_conv2d(const agx_conv2d_desc *d, ConvPlan *p);
+int lower_conv2d_bwd_data(const agx_conv2d_desc *d, ConvPlan *p);
 
 }  // namespace agx

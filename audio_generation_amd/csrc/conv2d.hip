@@ -58,12 +58,150 @@ int lower_conv2d(const agx_conv2d_desc *d, ConvPlan *p) {
     p->y_cstride = int64_t(p->Tout) * p->Lout;
     p->pm_R = patch ? 1 : 0;  // the launcher fixes the tile (conv_mfma.hip: tile_span)
     p->pm_WF = 0;
+    p->qh = 1;
+    p->oshift_h = 0;
+    p->Tt = p->Tout;
     if (int64_t(p->B) * p->Tout > (int64_t(1) << 30)) return fail(AGX_ERR_BAD_SHAPE, "conv2d: batch * output rows too large");
     return AGX_OK;
+}
+
+// Gradient w.r.t. the layer input.  With i' = i + ph = sh t' + a (and the same along the columns),
+//   dx[ci, sh t' + a - ph, sw f' + c - pw] = sum_{co, mh, mw} W[co, ci, a + sh mh, c + sw mw] dy[co, t' - mh, f' - mw]:
+// a stride-1 conv over dy with a ceil(kh/sh) x ceil(kw/sw) kernel whose M = Cin*sh*sw rows carry the output
+// phases (a, c) -- the 2-D form of core.hip:lower_conv_bwd_data, on the patch tiles.  Layers the patch
+// form does not cover (fewer than 32 rows: the 2-channel first conv) must be stride 1 and run row-folded
+// with the flipped kernel.
+int lower_conv2d_bwd_data(const agx_conv2d_desc *d, ConvPlan *b) {
+    ConvPlan f;
+    int rc = lower_conv2d(d, &f);
+    if (rc != AGX_OK) return rc;
+    const int Hout = f.Tout, Wout = f.Lout;
+    const bool patch = d->impl != AGX_IMPL_DIRECT && d->c_out % kWG == 0 && d->c_in * d->stride_h * d->stride_w >= 32;
+    *b = f;
+    b->cin_real = d->c_out;
+    b->Cout = d->c_in;
+    b->Lin = b->Lvalid = Wout;
+    b->Tin = Hout;
+    b->Lout = d->w_in;
+    b->Tout = d->h_in;
+    b->x_cstride = int64_t(Hout) * Wout;
+    b->y_cstride = int64_t(d->h_in) * d->w_in;
+    b->epilogue = 0;
+    b->mask = nullptr;
+    b->d = 1;
+    b->s = 1;
+    b->sh = 1;
+    if (patch) {
+        const int Jh = ceil_div(d->kh, d->stride_h), Jw = ceil_div(d->kw, d->stride_w);
+        b->ncv = d->c_out;
+        b->Cin = d->c_out;
+        b->q = d->stride_w;
+        b->qh = d->stride_h;
+        b->J = Jh * Jw;
+        b->kh = Jh;
+        b->P = Jw - 1;
+        b->ph = Jh - 1;
+        b->Lt = ceil_div(d->w_in + d->pad_w, d->stride_w);
+        b->Tt = ceil_div(d->h_in + d->pad_h, d->stride_h);
+        b->M = d->c_in * d->stride_h * d->stride_w;
+        b->oshift = d->pad_w;
+        b->oshift_h = d->pad_h;
+        b->pm_R = 1;
+    } else {
+        if (d->stride_h != 1 || d->stride_w != 1)
+            return fail(AGX_ERR_UNSUPPORTED, "conv2d bwd_data: strided layers need Cout %% 16 == 0 and Cin*sh*sw >= 32");
+        if (d->kh - 1 - d->pad_h < 0 || d->kw - 1 - d->pad_w < 0)
+            return fail(AGX_ERR_UNSUPPORTED, "conv2d bwd_data: padding larger than kernel - 1");
+        b->ncv = d->c_out * d->kh;
+        b->Cin = ceil_div(b->ncv, kWG) * kWG;
+        b->q = 1;
+        b->qh = 1;
+        b->J = d->kw;
+        b->kh = d->kh;
+        b->P = d->kw - 1 - d->pad_w;
+        b->ph = d->kh - 1 - d->pad_h;
+        b->Lt = d->w_in;
+        b->Tt = d->h_in;
+        b->M = d->c_in;
+        b->oshift = 0;
+        b->oshift_h = 0;
+        b->pm_R = 0;
+    }
+    b->pm_WF = 0;
+    return AGX_OK;
+}
+
+// Packed image of the backward-data op (both lowerings above).
+__global__ __launch_bounds__(256) void pack_bwd2d_kernel(const float *__restrict__ w, const float *__restrict__ sigma,
+                                                         float *__restrict__ packed, int Cin, int Cout, int kh, int kw,
+                                                         int sh, int sw, int patch, int nch, int J, int M) {
+    const int64_t total = packed_weight_floats(nch, J, M);
+    const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int c16 = int(e % kWG);
+    const int m = int((e / kWG) % M);
+    const int gj = int(e / (int64_t(kWG) * M));
+    const int j = gj % J, c = (gj / J) * kWG + c16;
+    float out = 0.f;
+    if (c < nch) {
+        int co, ci, dh, dw;
+        if (patch) {   // channel = co; tap j = jh * Jw + jw; row m = (ci * sh + a) * sw + cph
+            const int Jh = (kh + sh - 1) / sh, Jw = (kw + sw - 1) / sw;
+            const int jh = j / Jw, jw = j - jh * Jw;
+            const int cph = m % sw, a = (m / sw) % sh;
+            ci = m / (sw * sh);
+            co = c;
+            dh = a + sh * (Jh - 1 - jh);
+            dw = cph + sw * (Jw - 1 - jw);
+        } else {       // channel = co * kh + dh'; tap j = dw'; row m = ci; flipped kernel
+            co = c / kh;
+            dh = kh - 1 - (c - co * kh);
+            dw = kw - 1 - j;
+            ci = m;
+        }
+        if (dh < kh && dw < kw) out = w[((size_t(co) * Cin + ci) * kh + dh) * kw + dw] * (sigma ? 1.f / sigma[0] : 1.f);
+    }
+    packed[e] = out;
 }
 }  // namespace agx
 
 extern "C" {
+
+int64_t agx_conv2d_bwd_packed_floats(const agx_conv2d_desc *d) {
+    agx::ConvPlan b;
+    int rc = agx::lower_conv2d_bwd_data(d, &b);
+    if (rc != AGX_OK) return rc;
+    return agx::packed_weight_floats(b.ncv, b.J, b.M);
+}
+
+int agx_conv2d_pack_bwd(const agx_conv2d_desc *d, const float *w, const float *sigma, float *packed, void *stream) {
+    using namespace agx;
+    ConvPlan b;
+    int rc = lower_conv2d_bwd_data(d, &b);
+    if (rc != AGX_OK) return rc;
+    if (!w || !packed) return fail(AGX_ERR_NULL_POINTER, "agx_conv2d_pack_bwd: NULL pointer");
+    const int64_t n = packed_weight_floats(b.ncv, b.J, b.M);
+    hipLaunchKernelGGL(pack_bwd2d_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), w, sigma, packed, d->c_in, d->c_out, d->kh, d->kw, d->stride_h,
+                       d->stride_w, b.pm_R ? 1 : 0, b.ncv, b.J, b.M);
+    return check_launch("agx_conv2d_pack_bwd");
+}
+
+int agx_conv2d_bwd_data(const agx_conv2d_desc *d, const float *dy, const float *packed_bwd, const float *mask,
+                        float slope, float *dx, void *stream) {
+    using namespace agx;
+    ConvPlan b;
+    int rc = lower_conv2d_bwd_data(d, &b);
+    if (rc != AGX_OK) return rc;
+    if (!dy || !packed_bwd || !dx) return fail(AGX_ERR_NULL_POINTER, "agx_conv2d_bwd_data: NULL pointer");
+    b.epilogue = mask ? AGX_EPI_MASK : 0;
+    b.mask = mask;
+    b.slope = slope;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (b.pm_R || (d->impl != AGX_IMPL_DIRECT && conv_mfma_supported(b)))
+        return launch_conv_mfma(b, dy, packed_bwd, nullptr, nullptr, dx, st);
+    return launch_conv_direct(b, dy, packed_bwd, nullptr, nullptr, dx, st);
+}
 
 int agx_conv2d_out_shape(const agx_conv2d_desc *d, int32_t *h_out, int32_t *w_out) {
     agx::ConvPlan p;

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
         b = blockIdx.x / p.Tout;
         trow = blockIdx.x - b * p.Tout;
     } else {                                     // blockIdx.x = (b * row groups + rg) * column tiles + ft
-        const int nft = (p.Lout + p.pm_WF - 1) / p.pm_WF, nrg = (p.Tout + p.pm_R - 1) / p.pm_R;
+        const int nft = (p.Lt + p.pm_WF - 1) / p.pm_WF, nrg = (p.Tt + p.pm_R - 1) / p.pm_R;
         int bx = blockIdx.x;
         const int ft = bx % nft;
         bx /= nft;
@@ -113,13 +113,20 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
     const bool gelu = (p.epilogue & AGX_EPI_GELU_PRE) != 0;
 #pragma unroll
     for (int i = 0; i < MW; ++i) {
-        int co[16], ph[16];
+        int co[16], ph[16], pa[16];  // output channel, column phase, row phase (patch backward-data only)
         float bv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = min(m0 + i * 32 + acc_row(r, lh), p.M - 1);
-            co[r] = (p.q == 1) ? m : m / p.q;
-            ph[r] = m - co[r] * p.q;
+            const int mq = (p.q == 1) ? m : m / p.q;
+            ph[r] = m - mq * p.q;
+            if (MODE == 2 && p.qh > 1) {
+                co[r] = mq / p.qh;
+                pa[r] = mq - co[r] * p.qh;
+            } else {
+                co[r] = mq;
+                pa[r] = 0;
+            }
             bv[r] = bias ? bias[co[r]] : 0.f;
         }
 #pragma unroll
@@ -128,14 +135,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
             // (row trow + prow, column f0 + pcol)
             const int t = MODE == 2 ? f0 + pcol[k] : t0 + n0 + k * 32 + li;
             const int orow = MODE == 2 ? trow + prow[k] : trow;
-            const bool col_ok = MODE == 2 ? (prow[k] < p.pm_R && orow < p.Tout && t < p.Lt) : t < p.Lt;
+            const bool col_ok = MODE == 2 ? (prow[k] < p.pm_R && orow < p.Tt && t < p.Lt) : t < p.Lt;
             const int tc = min(t, p.Lt - 1);
-            const int orc = TWO_D ? min(orow, p.Tout - 1) : 0;
             size_t off[16];
             float rv[16], mv[16];
+            bool row_ok[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int u = min(max(tc * p.q + ph[r] - p.oshift, 0), p.Lout - 1);
+                const int orr = MODE == 2 ? orow * p.qh + pa[r] - p.oshift_h : orow;  // output row of this element
+                row_ok[r] = !TWO_D || (orr >= 0 && orr < p.Tout);
+                const int orc = TWO_D ? min(max(orr, 0), p.Tout - 1) : 0;
                 off[r] = TWO_D ? (size_t(b) * p.Cout + co[r]) * p.y_cstride + size_t(orc) * p.Lout + u
                                : (size_t(b) * p.Cout + co[r]) * p.Lout + u;
             }
@@ -156,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
                 if (post) v = leaky(v, p.slope);
                 if (has_mask) v = mv[r] > 0.f ? v : v * p.slope;
                 const int u = t * p.q + ph[r] - p.oshift;
-                const bool ok = col_ok && (m0 + i * 32 + acc_row(r, lh)) < p.M && u >= 0 && u < p.Lout;
+                const bool ok = col_ok && row_ok[r] && (m0 + i * 32 + acc_row(r, lh)) < p.M && u >= 0 && u < p.Lout;
                 if (ok) y[off[r]] = v;
             }
         }
@@ -167,9 +177,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
 static int tile_span(const ConvPlan &p, int BN, int *R, int *WF) {
     if (!p.pm_R) return (BN - 1) * p.s + (p.J - 1) * p.d + 1;
     // tile = R output rows x WF output columns (R * WF <= BN): a whole output row when it fits
-    int wf = p.Lout < BN ? p.Lout : BN;
+    int wf = p.Lt < BN ? p.Lt : BN;
     int r = BN / wf;
-    if (r > p.Tout) r = p.Tout;
+    if (r > p.Tt) r = p.Tt;
     if (R) *R = r;
     if (WF) *WF = wf;
     return ((r - 1) * p.sh + p.kh) * ((wf - 1) * p.s + p.J / p.kh);
@@ -194,7 +204,7 @@ static int launch_variant(const ConvPlan &p0, const float *x, const float *wp, c
     dim3 grid(ceil_div(p.Lt, BN), ceil_div(p.M, BM), p.B), block(256);
     if (MODE == 1) grid = dim3(p.B * p.Tout, ceil_div(p.M, BM), ceil_div(p.Lt, BN));
     if (MODE == 2)
-        grid = dim3(unsigned(int64_t(p.B) * ceil_div(p.Tout, p.pm_R) * ceil_div(p.Lout, p.pm_WF)), ceil_div(p.M, BM), 1);
+        grid = dim3(unsigned(int64_t(p.B) * ceil_div(p.Tt, p.pm_R) * ceil_div(p.Lt, p.pm_WF)), ceil_div(p.M, BM), 1);
     if (grid.y > 65535 || grid.z > 65535) return fail(AGX_ERR_BAD_SHAPE, "conv_mfma: grid too large");
     hipLaunchKernelGGL(kern, grid, block, lds, st, p, span, x, wp, bias, res, y);
     return check_launch("conv_mfma");

@@ -138,6 +138,9 @@ int lower_conv(const agx_conv_desc *d, ConvPlan *p) {
     p->Tin = p->Tout = 1;
     p->ncv = p->cin_real = p->Cin;
     p->pm_R = p->pm_WF = 0;
+    p->qh = 1;
+    p->oshift_h = 0;
+    p->Tt = 1;
     p->x_cstride = p->Lin;
     p->y_cstride = p->Lout;
     return AGX_OK;
@@ -195,6 +198,9 @@ int lower_conv_bwd_data(const agx_conv_desc *d, ConvPlan *b) {
     b->y_cstride = b->Lout;
     b->ncv = b->cin_real = b->Cin;
     b->pm_R = b->pm_WF = 0;
+    b->qh = 1;
+    b->oshift_h = 0;
+    b->Tt = 1;
     return AGX_OK;
 }
 

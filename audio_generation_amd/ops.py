@@ -417,6 +417,31 @@ def conv2d_forward(desc, x: Tensor, packed: Tensor, bias: Optional[Tensor]) -> T
     return y
 
 
+def conv2d_pack_bwd(desc, w: Tensor, sigma: Optional[Tensor] = None) -> Tensor:
+    lib = _lib.load()
+    _need_gpu(w, sigma)
+    n = lib.agx_conv2d_bwd_packed_floats(ctypes.byref(desc))
+    if n < 0:
+        _lib.check(int(n), "agx_conv2d_bwd_packed_floats")
+    w = _f32c(w)
+    packed = torch.empty(int(n), dtype=torch.float32, device=w.device)
+    _lib.check(lib.agx_conv2d_pack_bwd(ctypes.byref(desc), _ptr(w), _ptr(sigma), _ptr(packed), _stream()),
+               "agx_conv2d_pack_bwd")
+    return packed
+
+
+def conv2d_bwd_data(desc, dy: Tensor, packed_bwd: Tensor, mask: Optional[Tensor] = None, slope: float = 0.2) -> Tensor:
+    """Gradient w.r.t. the input of the Conv2d layer ``desc`` describes (forward descriptor)."""
+    lib = _lib.load()
+    _need_gpu(dy, packed_bwd, mask)
+    dy = _f32c(dy)
+    mask = None if mask is None else _f32c(mask)
+    dx = torch.empty(desc.batch, desc.c_in, desc.h_in, desc.w_in, dtype=torch.float32, device=dy.device)
+    _lib.check(lib.agx_conv2d_bwd_data(ctypes.byref(desc), _ptr(dy), _ptr(packed_bwd), _ptr(mask), slope, _ptr(dx),
+                                       _stream()), "agx_conv2d_bwd_data")
+    return dx
+
+
 def conv2d_kernel_name(desc) -> str:
     buf = ctypes.create_string_buffer(96)
     _lib.check(_lib.load().agx_conv2d_kernel_name(ctypes.byref(desc), buf, 96), "agx_conv2d_kernel_name")

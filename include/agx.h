@@ -282,6 +282,13 @@ int agx_conv2d_pack(const agx_conv2d_desc *d, const float *w, const float *sigma
 int agx_conv2d_forward(const agx_conv2d_desc *d, const float *x, const float *packed, const float *bias,
                        float *y, void *stream);
 int agx_conv2d_kernel_name(const agx_conv2d_desc *d, char *buf, size_t buf_len);
+/* Backward of the Conv2d layer `d` describes (forward descriptor): gradient w.r.t. its input from the
+ * gradient w.r.t. its output, on the same kernels (strided layers as a 2-D polyphase conv over dy);
+ * mask/slope: optional fused LeakyReLU gradient of the layer that produced the input (mask = its output). */
+int64_t agx_conv2d_bwd_packed_floats(const agx_conv2d_desc *d);
+int agx_conv2d_pack_bwd(const agx_conv2d_desc *d, const float *w, const float *sigma, float *packed, void *stream);
+int agx_conv2d_bwd_data(const agx_conv2d_desc *d, const float *dy, const float *packed_bwd, const float *mask,
+                        float slope, float *dx, void *stream);
 
 /* The torch.stft call of STFTDiscriminator.forward (discriminator.py:181-187): rectangular window,
  * center=True (reflect padding), two-sided, optionally normalised by n_fft^-1/2, hop = n_fft / 4.

@@ -272,3 +272,27 @@ def test_full_size_stft_discriminator_against_oracle():
                                                     m.stride, m.padding))
              for m in d.modules() if isinstance(m, ad._SNConv) and m.out_channels >= 32}
     assert all(n.startswith("conv_mfma") for n in names), names
+
+
+@pytest.mark.parametrize("cin,cout,kh,kw,sh,sw,ph,pw,h,w", [
+    (32, 32, 3, 3, 1, 1, 1, 1, 17, 200), (32, 64, 3, 4, 1, 2, 1, 1, 17, 200), (64, 128, 4, 4, 2, 2, 1, 1, 18, 130),
+    (64, 128, 4, 4, 2, 2, 1, 1, 19, 131), (128, 128, 3, 4, 1, 2, 1, 1, 9, 16), (256, 512, 4, 4, 2, 2, 1, 1, 6, 4),
+    (2, 32, 7, 7, 1, 1, 3, 3, 21, 70), (512, 1, 1, 8, 1, 1, 0, 3, 5, 16), (16, 48, 3, 3, 2, 2, 1, 1, 11, 23),
+    (32, 16, 5, 3, 1, 1, 2, 1, 8, 40)])
+def test_conv2d_backward_data(cin, cout, kh, kw, sh, sw, ph, pw, h, w):
+    """dx of every Conv2d shape of the STFT discriminators (+ odd sizes) against autograd, with the fused
+    LeakyReLU-gradient mask."""
+    torch.manual_seed(cin + cout + kh)
+    x = torch.randn(2, cin, h, w, requires_grad=True)
+    wt = torch.randn(cout, cin, kh, kw) / (cin * kh * kw) ** 0.5
+    pre = torch.randn(2, cin, h, w)                                # stands for the activation that produced x
+    xin = F.leaky_relu(pre, 0.2).detach().requires_grad_(True)
+    y = F.conv2d(xin, wt, None, stride=(sh, sw), padding=(ph, pw))
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    want_plain = xin.grad
+    want_masked = want_plain * torch.where(xin.detach() > 0, 1.0, 0.2)
+    d = ops.conv2d_desc(2, cin, cout, h, w, kh, kw, (sh, sw), (ph, pw))
+    pk = ops.conv2d_pack_bwd(d, wt.to(DEV))
+    close(ops.conv2d_bwd_data(d, dy.to(DEV), pk), want_plain, 2e-5)
+    close(ops.conv2d_bwd_data(d, dy.to(DEV), pk, xin.detach().to(DEV), 0.2), want_masked, 2e-5)

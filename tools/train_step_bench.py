@@ -4,6 +4,11 @@ native kernels -- forward, backward (native_backward.py), gradient all-reduce an
 at config S.  One process per GPU (torchrun sets RANK / WORLD_SIZE); the only collective is ONE
 flattened all-reduce of the gradients per step (RCCL over xGMI; AGX_DIST_BACKEND=gloo rehearses the
 same code on a box with fewer GPUs than ranks).
+AGX_GAN=1 adds the reference's six training discriminators (training.py:570-576) and runs the step as
+Trainer.mini_epoch does (training.py:363-385): discriminator_generator_loss per discriminator, the
+discriminator loss backward, the generator loss backward, one Adam step each -- BASELINE config 5 without the
+mel / pre-emphasis terms (torchaudio).  Discriminator forwards run on the HIP kernels; their
+backward is still the ATen bridge (discriminator.py), so this number is a starting point, not a roofline.
 usage: [torchrun --nproc-per-node N] train_step_bench.py [batch_per_gpu] [steps]"""
 import json
 import os
@@ -34,14 +39,35 @@ def main():
     with torch.no_grad():
         model.quantizer.init_from_latents(model._run_encoders(x[:4]))
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    gan = os.environ.get("AGX_GAN", "0") == "1"
+    discs, opt_d = [], []
+    if gan:
+        from audio_generation_amd.discriminator import (STFTDiscriminator, WaveFormDiscriminator,
+                                                        discriminator_generator_loss)
+        wins = [int(w) for w in os.environ.get("AGX_GAN_WINS", "2048,1024,512,256,128").split(",") if w]
+        discs = [WaveFormDiscriminator(1)] + [STFTDiscriminator(win_length=w) for w in wins]
+        discs = [d.to(dev).train() for d in discs]
+        opt_d = [torch.optim.Adam(d.parameters(), lr=8e-4) for d in discs]
+
+    def all_params():
+        return list(model.parameters()) + [p for d in discs for p in d.parameters()]
 
     def step():
         opt.zero_grad(set_to_none=True)
+        for o in opt_d:
+            o.zero_grad(set_to_none=True)
         y, commit, _ = model(x)
         loss = ((y - x) ** 2).mean() + commit
+        if gan:                                 # training.py:363-376
+            d_loss = 0
+            for d in discs:
+                g_loss, d_loss_i = discriminator_generator_loss(x, y, d)
+                loss = loss + g_loss
+                d_loss = d_loss + d_loss_i
+            d_loss.backward(retain_graph=True)
         loss.backward()
         if world > 1:                          # one flattened bucket, mean over ranks
-            grads = [p.grad for p in model.parameters() if p.grad is not None]
+            grads = [p.grad for p in all_params() if p.grad is not None]
             if backend == "gloo":
                 cpu = [g.cpu() for g in grads]
                 agx_dist.allreduce_mean_(cpu)
@@ -50,6 +76,8 @@ def main():
             else:
                 agx_dist.allreduce_mean_(grads)
         opt.step()
+        for o in opt_d:
+            o.step()
         return float(loss.detach())
 
     for _ in range(2):
@@ -62,10 +90,11 @@ def main():
     fwd_flop = 2 * (195194 + 13107 + 208713) * 72000 * batch          # executed (polyphase) MACs of the forward
     ms = agx_dist.max_over_ranks(ms, device=dev if backend == "nccl" else "cpu")
     # replicas must stay identical: compare a parameter checksum across ranks
-    chk = float(sum(p.detach().double().sum() for p in model.parameters()))
+    chk = float(sum(p.detach().double().sum() for p in all_params()))
     same = abs(agx_dist.max_over_ranks(chk, device=dev if backend == "nccl" else "cpu") - chk) < 1e-9 * max(1.0, abs(chk))
     if rank == 0:
-        print(json.dumps({"what": "train step (fwd + native bwd + grad all-reduce + Adam), config S",
+        print(json.dumps({"what": "train step (fwd + native bwd + grad all-reduce + Adam), config S" +
+                          (f" + {len(discs)} discriminators (HIP forward, bridged backward)" if gan else ""),
                           "n_gpus": world, "batch_per_gpu": batch, "ms_per_step": ms, "replicas_in_sync": same,
                           "samples_per_s": world * batch * 72000 / ms * 1e3, "losses": losses,
                           "approx_tflops_at_3x_forward": world * 3 * fwd_flop / ms * 1e-9,
