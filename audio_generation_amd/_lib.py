@@ -91,6 +91,9 @@ SIGNATURES = {
     "agx_conv2d_bwd_packed_floats": (c_int64, [_P2]),
     "agx_conv2d_pack_bwd": (c_int, [_P2, c_void_p, c_void_p, c_void_p, c_void_p]),
     "agx_conv2d_bwd_data": (c_int, [_P2, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
+    "agx_conv2d_bwd_weight_workspace_bytes": (c_size_t, [_P2]),
+    "agx_conv2d_bwd_weight": (c_int, [_P2, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_size_t, c_void_p]),
     "agx_stft_frames": (c_int64, [c_int32, c_int32]),
     "agx_stft_packed_floats": (c_int64, [c_int32]),
     "agx_stft_pack": (c_int, [c_int32, c_int32, c_void_p, c_void_p]),

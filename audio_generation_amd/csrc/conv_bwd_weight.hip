@@ -162,7 +162,8 @@ __global__ __launch_bounds__(256) void bwd_weight_unpack_kernel(const float *__r
     float *dvr = dv + size_t(r) * inner;
     auto dw_at = [&](int e) -> float {  // gradient w.r.t. the folded weight element (r, e)
         const int o = e / K, k = e - o * K;  // o = ci (normal layouts) or co (transposed layout)
-        if (kind == AGX_CONV_CAUSAL || kind == AGX_CONV_SAME) return dwp[(size_t(o) * J + k) * M + r];
+        if (kind == AGX_CONV_CAUSAL || kind == AGX_CONV_SAME || kind == AGX_CONV_PADDED)
+            return dwp[(size_t(o) * J + k) * M + r];
         if (kind == AGX_CONV_UPSAMPLE) {
             const int pl = (K - 1) / 2;
             float s = 0.f;
@@ -208,6 +209,207 @@ __global__ __launch_bounds__(256) void bwd_bias_fold_kernel(const float *__restr
     float s = 0.f;
     for (int ph = 0; ph < q; ++ph) s += rowsum[co * q + ph];
     db[co] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Conv2d weight gradient (discriminator.py:101-114, 150-167):
+//   dW[co][n = (ci, dh, dw)] = sum_{b, t, f} dy[b, co, t, f] x[b, ci, t sh + dh - ph, f sw + dw - pw].
+// Same GEMM as above with the contraction tile of 64 positions laid out as R output rows x WF output
+// columns (a whole row when it fits), the x operand staged as one (R-1) sh + kh by (WF-1) sw + kw patch per
+// channel -- so the tile stays full when the frequency axis is short.
+struct Bw2dGeom {
+    int B, Cin, Cout, Hin, Win, Hout, Wout, kh, kw, sh, sw, ph, pw;
+    int R, WF, RH, SW, span, n_chan, n_slices;
+};
+
+template <int MW, int NW, int WM, int WN>
+__global__ __launch_bounds__(256) void conv2d_bwd_weight_kernel(Bw2dGeom g, const float *__restrict__ x,
+                                                                const float *__restrict__ dy,
+                                                                float *__restrict__ part,
+                                                                float *__restrict__ bias_part) {
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int BM = 32 * MW * WM, BN = 32 * NW * WN;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *dys = sm;                          // [BM][BW_TS]
+    float *xs = sm + BM * BW_TS;              // [n_chan][span]
+    int *kofft = reinterpret_cast<int *>(xs + g.n_chan * g.span);  // [BW_T] patch offset of contraction index k
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int KK = g.kh * g.kw, NK = g.Cin * KK, M = g.Cout;
+    const int n_base = blockIdx.x * BN, m_base = blockIdx.y * BM, slice = blockIdx.z;
+    const int ci_first = n_base / KK;
+    const int npos = g.R * g.WF;              // contraction positions per tile (<= BW_T)
+
+    if (tid < BW_T) {
+        const int r = tid / g.WF, fc = tid - r * g.WF;
+        kofft[tid] = tid < npos ? (r * g.sh) * g.SW + fc * g.sw : 0;
+    }
+    int boff[NW];
+    bool nvalid[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const int n = n_base + (wn * NW + k) * 32 + li;
+        nvalid[k] = n < NK;
+        const int nc = min(n, NK - 1);
+        const int ci = nc / KK, rem = nc - ci * KK;
+        const int dh = rem / g.kw, dw = rem - dh * g.kw;
+        boff[k] = (ci - ci_first) * g.span + dh * g.SW + dw;
+    }
+    int arow[MW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i) arow[i] = ((wm * MW + i) * 32 + li) * BW_TS;
+
+    f32x16 acc[MW][NW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
+    constexpr int TPR = 256 / BM, CPT = BW_T / TPR;
+    float bsum = 0.f;
+    const bool do_bias = bias_part != nullptr && blockIdx.x == 0;
+
+    const int nft = (g.Wout + g.WF - 1) / g.WF, nrg = (g.Hout + g.R - 1) / g.R;
+    const int items = g.B * nrg * nft;
+    for (int item = slice; item < items; item += g.n_slices) {
+        int it = item;
+        const int ft = it % nft;
+        it /= nft;
+        const int rg = it % nrg, b = it / nrg;
+        const int trow0 = rg * g.R, f0 = ft * g.WF;
+        __syncthreads();
+        // dy tile: row r <-> co = m_base + r, column k = rr * WF + fc <-> dy[b, co, trow0 + rr, f0 + fc]
+        for (int e = tid; e < BM * BW_T; e += 256) {
+            const int r = e / BW_T, k = e - r * BW_T;
+            const int co = m_base + r;
+            float v = 0.f;
+            if (co < M && k < npos) {
+                const int rr = k / g.WF, fc = k - rr * g.WF;
+                const int t = trow0 + rr, f = f0 + fc;
+                if (t < g.Hout && f < g.Wout) v = dy[((size_t(b) * g.Cout + co) * g.Hout + t) * g.Wout + f];
+            }
+            dys[r * BW_TS + k] = v;
+        }
+        // x patches of channels ci_first .. ci_first + n_chan - 1
+        const int row0 = trow0 * g.sh - g.ph, col0 = f0 * g.sw - g.pw;
+        for (int e = tid; e < g.n_chan * g.span; e += 256) {
+            const int c = e / g.span, i = e - c * g.span;
+            const int rr = i / g.SW, cc = i - rr * g.SW;
+            const int ch = ci_first + c, gr = row0 + rr, gc = col0 + cc;
+            xs[e] = (ch < g.Cin && gr >= 0 && gr < g.Hin && gc >= 0 && gc < g.Win)
+                        ? x[((size_t(b) * g.Cin + ch) * g.Hin + gr) * g.Win + gc] : 0.f;
+        }
+        __syncthreads();
+        if (do_bias) {
+            const float *row = dys + (tid / TPR) * BW_TS + (tid % TPR) * CPT;
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) bsum += row[c];
+        }
+#pragma unroll 4
+        for (int ks = 0; ks < BW_T / 2; ++ks) {
+            const int tt = 2 * ks + lh;
+            const int ko = kofft[tt];
+            float a[MW], bv[NW];
+#pragma unroll
+            for (int i = 0; i < MW; ++i) a[i] = dys[arow[i] + tt];
+#pragma unroll
+            for (int k = 0; k < NW; ++k) bv[k] = nvalid[k] ? xs[boff[k] + ko] : 0.f;
+#pragma unroll
+            for (int i = 0; i < MW; ++i)
+#pragma unroll
+                for (int k = 0; k < NW; ++k)
+                    acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv[k], acc[i][k], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const int n = n_base + (wn * NW + k) * 32 + li;
+        if (n >= NK) continue;
+        float *dst = part + (size_t(slice) * NK + n) * M;
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m_base + (wm * MW + i) * 32 + acc_row(r, lh);
+                if (m < M) dst[m] = acc[i][k][r];
+            }
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int off = 1; off < TPR; off <<= 1) bsum += __shfl_xor(bsum, off);
+        const int m = m_base + tid / TPR;
+        if (tid % TPR == 0 && m < M) bias_part[size_t(slice) * M + m] = bsum;
+    }
+}
+
+// Gradient w.r.t. the normalised weight G[co][n] = dwp[n][co] -> dw (torch layout), and per-row <G, W>.
+__global__ __launch_bounds__(256) void bwd2d_unpack_kernel(const float *__restrict__ dwp, const float *__restrict__ w,
+                                                           float *__restrict__ dw, float *__restrict__ rowdot, int NK,
+                                                           int M) {
+    __shared__ float red[4];
+    const int co = blockIdx.x;
+    float dot = 0.f;
+    for (int n = threadIdx.x; n < NK; n += 256) {
+        const float gv = dwp[size_t(n) * M + co];
+        dw[size_t(co) * NK + n] = gv;
+        if (w) dot = fmaf(gv, w[size_t(co) * NK + n], dot);
+    }
+    for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) rowdot[co] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// Spectral-norm chain rule (W_n = W / sigma, sigma = u^T W v with u, v constants):
+//   dW = G / sigma - (<G, W> / sigma^2) u v^T
+__global__ __launch_bounds__(256) void bwd2d_spectral_kernel(float *__restrict__ dw, const float *__restrict__ rowdot,
+                                                             const float *__restrict__ sigma,
+                                                             const float *__restrict__ u, const float *__restrict__ v,
+                                                             int NK, int M) {
+    __shared__ float tot_s;
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < M; ++i) t += rowdot[i];
+        tot_s = t;
+    }
+    __syncthreads();
+    const int co = blockIdx.x;
+    const float sg = sigma[0], coef = tot_s / (sg * sg) * u[co], inv = 1.f / sg;
+    for (int n = threadIdx.x; n < NK; n += 256) {
+        const size_t e = size_t(co) * NK + n;
+        dw[e] = dw[e] * inv - coef * v[n];
+    }
+}
+
+static int bw2d_geometry(const agx_conv2d_desc *d, Bw2dGeom *g, int *cfg, int *bm, dim3 *grid, size_t *lds) {
+    ConvPlan f;
+    int rc = lower_conv2d(d, &f);
+    if (rc != AGX_OK) return rc;
+    g->B = d->batch; g->Cin = d->c_in; g->Cout = d->c_out; g->Hin = d->h_in; g->Win = d->w_in;
+    g->Hout = f.Tout; g->Wout = f.Lout; g->kh = d->kh; g->kw = d->kw; g->sh = d->stride_h; g->sw = d->stride_w;
+    g->ph = d->pad_h; g->pw = d->pad_w;
+    g->WF = g->Wout < BW_T ? g->Wout : BW_T;
+    g->R = BW_T / g->WF;
+    if (g->R > g->Hout) g->R = g->Hout;
+    g->RH = (g->R - 1) * g->sh + g->kh;
+    g->SW = (g->WF - 1) * g->sw + g->kw;
+    g->span = g->RH * g->SW;
+    const int KK = g->kh * g->kw;
+    g->n_chan = 127 / KK + 2;
+    *cfg = g->Cout >= 128 ? 0 : (g->Cout >= 64 ? 1 : 2);
+    *bm = *cfg == 0 ? 128 : (*cfg == 1 ? 64 : 32);
+    const int nt = ceil_div(g->Cin * KK, 128), mt = ceil_div(g->Cout, *bm);
+    const int64_t items = int64_t(g->B) * ceil_div(g->Hout, g->R) * ceil_div(g->Wout, g->WF);
+    int64_t ns = ceil_div(768, nt * mt);
+    if (ns > items) ns = items;
+    if (ns < 1) ns = 1;
+    if (ns > 65535) ns = 65535;
+    g->n_slices = int(ns);
+    *grid = dim3(nt, mt, g->n_slices);
+    *lds = (size_t(*bm) * BW_TS + size_t(g->n_chan) * g->span + BW_T) * sizeof(float);
+    return AGX_OK;
 }
 
 struct BwGeom {
@@ -292,6 +494,61 @@ int agx_conv_bwd_weight(const agx_conv_desc *d, const float *x, const float *dy,
                            dbias);
     }
     return check_launch("agx_conv_bwd_weight");
+}
+
+size_t agx_conv2d_bwd_weight_workspace_bytes(const agx_conv2d_desc *d) {
+    using namespace agx;
+    Bw2dGeom g;
+    int cfg, bm;
+    dim3 grid;
+    size_t lds;
+    if (bw2d_geometry(d, &g, &cfg, &bm, &grid, &lds) != AGX_OK) return 0;
+    const size_t nw = size_t(g.Cin) * g.kh * g.kw * g.Cout;
+    return ((size_t(g.n_slices) + 1) * nw + (size_t(g.n_slices) + 2) * g.Cout) * sizeof(float);
+}
+
+int agx_conv2d_bwd_weight(const agx_conv2d_desc *d, const float *x, const float *dy, const float *w,
+                          const float *sigma, const float *u, const float *v, float *dw, float *dbias,
+                          void *workspace, size_t workspace_bytes, void *stream) {
+    using namespace agx;
+    Bw2dGeom g;
+    int cfg, bm;
+    dim3 grid;
+    size_t lds;
+    int rc = bw2d_geometry(d, &g, &cfg, &bm, &grid, &lds);
+    if (rc != AGX_OK) return rc;
+    if (!x || !dy || !dw || (sigma && (!w || !u || !v)))
+        return fail(AGX_ERR_NULL_POINTER, "agx_conv2d_bwd_weight: NULL pointer");
+    if (!workspace || workspace_bytes < agx_conv2d_bwd_weight_workspace_bytes(d))
+        return fail(AGX_ERR_WORKSPACE, "agx_conv2d_bwd_weight: workspace too small");
+    if (lds > 160 * 1024) return fail(AGX_ERR_UNSUPPORTED, "agx_conv2d_bwd_weight: tile needs %zu B of LDS", lds);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int NK = g.Cin * g.kh * g.kw, M = g.Cout;
+    const int64_t nw = int64_t(NK) * M;
+    float *part = static_cast<float *>(workspace);
+    float *dwp = part + size_t(g.n_slices) * nw;
+    float *bias_part = dwp + nw;                       // [n_slices][M], then rowsum [M], then rowdot [M]
+    float *rowsum = bias_part + size_t(g.n_slices) * M;
+    float *rowdot = rowsum + M;
+    auto launch = [&](auto kern) -> int {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, x, dy, part, dbias ? bias_part : nullptr);
+        return AGX_OK;
+    };
+    rc = cfg == 0 ? launch(conv2d_bwd_weight_kernel<2, 2, 2, 2>)
+       : cfg == 1 ? launch(conv2d_bwd_weight_kernel<1, 2, 2, 2>)
+                  : launch(conv2d_bwd_weight_kernel<1, 1, 1, 4>);
+    if (rc != AGX_OK) return rc;
+    hipLaunchKernelGGL(bwd_slice_reduce_kernel, dim3((unsigned)ceil_div64(nw, 64)), dim3(256), 0, st, part, g.n_slices,
+                       nw, dwp);
+    hipLaunchKernelGGL(bwd2d_unpack_kernel, dim3(M), dim3(256), 0, st, dwp, sigma ? w : nullptr, dw, rowdot, NK, M);
+    if (sigma) hipLaunchKernelGGL(bwd2d_spectral_kernel, dim3(M), dim3(256), 0, st, dw, rowdot, sigma, u, v, NK, M);
+    if (dbias)
+        hipLaunchKernelGGL(bwd_slice_reduce_kernel, dim3(ceil_div(M, 64)), dim3(256), 0, st, bias_part, g.n_slices,
+                           int64_t(M), dbias);
+    return check_launch("agx_conv2d_bwd_weight");
 }
 
 }  // extern "C"

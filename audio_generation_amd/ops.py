@@ -442,6 +442,22 @@ def conv2d_bwd_data(desc, dy: Tensor, packed_bwd: Tensor, mask: Optional[Tensor]
     return dx
 
 
+def conv2d_bwd_weight(desc, x: Tensor, dy: Tensor, w: Optional[Tensor] = None, sigma: Optional[Tensor] = None,
+                      u: Optional[Tensor] = None, v: Optional[Tensor] = None, want_bias: bool = True):
+    """(dw, dbias or None); with ``sigma`` the spectral-norm chain rule is applied (dw w.r.t. weight_orig)."""
+    lib = _lib.load()
+    _need_gpu(x, dy, w, sigma, u, v)
+    x, dy = _f32c(x), _f32c(dy)
+    dw = torch.empty(desc.c_out, desc.c_in, desc.kh, desc.kw, dtype=torch.float32, device=x.device)
+    db = torch.empty(desc.c_out, dtype=torch.float32, device=x.device) if want_bias else None
+    nbytes = int(lib.agx_conv2d_bwd_weight_workspace_bytes(ctypes.byref(desc)))
+    ws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=x.device)
+    w = None if w is None else _f32c(w)
+    _lib.check(lib.agx_conv2d_bwd_weight(ctypes.byref(desc), _ptr(x), _ptr(dy), _ptr(w), _ptr(sigma), _ptr(u), _ptr(v),
+                                         _ptr(dw), _ptr(db), _ptr(ws), nbytes, _stream()), "agx_conv2d_bwd_weight")
+    return dw, db
+
+
 def conv2d_kernel_name(desc) -> str:
     buf = ctypes.create_string_buffer(96)
     _lib.check(_lib.load().agx_conv2d_kernel_name(ctypes.byref(desc), buf, 96), "agx_conv2d_kernel_name")

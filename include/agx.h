@@ -289,6 +289,13 @@ int64_t agx_conv2d_bwd_packed_floats(const agx_conv2d_desc *d);
 int agx_conv2d_pack_bwd(const agx_conv2d_desc *d, const float *w, const float *sigma, float *packed, void *stream);
 int agx_conv2d_bwd_data(const agx_conv2d_desc *d, const float *dy, const float *packed_bwd, const float *mask,
                         float slope, float *dx, void *stream);
+/* dW (c_out, c_in, kh, kw) and dbias (c_out, may be NULL) of the layer.  With sigma != NULL the layer is
+ * spectrally normalised: w is weight_orig, u / v the vectors sigma was computed with, and dw is the
+ * gradient w.r.t. weight_orig:  G / sigma - (<G, W> / sigma^2) u v^T  (G = gradient w.r.t. W / sigma). */
+size_t agx_conv2d_bwd_weight_workspace_bytes(const agx_conv2d_desc *d);
+int agx_conv2d_bwd_weight(const agx_conv2d_desc *d, const float *x, const float *dy, const float *w,
+                          const float *sigma, const float *u, const float *v, float *dw, float *dbias,
+                          void *workspace, size_t workspace_bytes, void *stream);
 
 /* The torch.stft call of STFTDiscriminator.forward (discriminator.py:181-187): rectangular window,
  * center=True (reflect padding), two-sided, optionally normalised by n_fft^-1/2, hop = n_fft / 4.

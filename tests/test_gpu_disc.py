@@ -296,3 +296,32 @@ def test_conv2d_backward_data(cin, cout, kh, kw, sh, sw, ph, pw, h, w):
     pk = ops.conv2d_pack_bwd(d, wt.to(DEV))
     close(ops.conv2d_bwd_data(d, dy.to(DEV), pk), want_plain, 2e-5)
     close(ops.conv2d_bwd_data(d, dy.to(DEV), pk, xin.detach().to(DEV), 0.2), want_masked, 2e-5)
+
+
+@pytest.mark.parametrize("cin,cout,kh,kw,sh,sw,ph,pw,h,w", [
+    (32, 32, 3, 3, 1, 1, 1, 1, 17, 200), (32, 64, 3, 4, 1, 2, 1, 1, 17, 200), (64, 128, 4, 4, 2, 2, 1, 1, 19, 131),
+    (128, 128, 3, 4, 1, 2, 1, 1, 9, 16), (256, 512, 4, 4, 2, 2, 1, 1, 6, 4), (2, 32, 7, 7, 1, 1, 3, 3, 21, 70),
+    (512, 1, 1, 8, 1, 1, 0, 3, 5, 16), (5, 7, 3, 2, 2, 1, 0, 1, 10, 9)])
+@pytest.mark.parametrize("spectral", [False, True])
+def test_conv2d_backward_weight(cin, cout, kh, kw, sh, sw, ph, pw, h, w, spectral):
+    """dW / dbias against autograd; with spectral norm the gradient w.r.t. weight_orig (sigma = u.Wv, u / v fixed)."""
+    torch.manual_seed(cin + cout + kw)
+    x = torch.randn(3, cin, h, w)
+    wt = (torch.randn(cout, cin, kh, kw) / (cin * kh * kw) ** 0.5).requires_grad_(True)
+    b = torch.randn(cout, requires_grad=True)
+    u, v = F.normalize(torch.randn(cout), dim=0), F.normalize(torch.randn(cin * kh * kw), dim=0)
+    if spectral:
+        sigma = torch.dot(u, torch.mv(wt.reshape(cout, -1), v))
+        y = F.conv2d(x, wt / sigma, b, stride=(sh, sw), padding=(ph, pw))
+    else:
+        y = F.conv2d(x, wt, b, stride=(sh, sw), padding=(ph, pw))
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    d = ops.conv2d_desc(3, cin, cout, h, w, kh, kw, (sh, sw), (ph, pw))
+    if spectral:
+        sg = sigma.detach().reshape(1).to(DEV)
+        dw, db = ops.conv2d_bwd_weight(d, x.to(DEV), dy.to(DEV), wt.detach().to(DEV), sg, u.to(DEV), v.to(DEV))
+    else:
+        dw, db = ops.conv2d_bwd_weight(d, x.to(DEV), dy.to(DEV))
+    close(dw, wt.grad, 1e-4)
+    close(db, b.grad, 2e-5)
