@@ -90,7 +90,7 @@ SIGNATURES = {
     "agx_conv2d_kernel_name": (c_int, [_P2, c_char_p, c_size_t]),
     "agx_conv2d_bwd_packed_floats": (c_int64, [_P2]),
     "agx_conv2d_pack_bwd": (c_int, [_P2, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "agx_conv2d_bwd_data": (c_int, [_P2, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
+    "agx_conv2d_bwd_data": (c_int, [_P2, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     "agx_conv2d_bwd_weight_workspace_bytes": (c_size_t, [_P2]),
     "agx_conv2d_bwd_weight": (c_int, [_P2, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -99,6 +99,13 @@ SIGNATURES = {
     "agx_stft_pack": (c_int, [c_int32, c_int32, c_void_p, c_void_p]),
     "agx_stft_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32]),
     "agx_stft_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "agx_stft_pack_bwd": (c_int, [c_int32, c_int32, c_void_p, c_void_p]),
+    "agx_stft_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "agx_avgpool1d_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
+                                       c_void_p]),
+    "agx_sigmoid_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "agx_spectral_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p,
+                                  c_void_p]),
     "agx_reduce_mean": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "agx_reduce_mean_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "agx_sigmoid": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),

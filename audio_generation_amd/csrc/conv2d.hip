@@ -187,20 +187,20 @@ int agx_conv2d_pack_bwd(const agx_conv2d_desc *d, const float *w, const float *s
     return check_launch("agx_conv2d_pack_bwd");
 }
 
-int agx_conv2d_bwd_data(const agx_conv2d_desc *d, const float *dy, const float *packed_bwd, const float *mask,
-                        float slope, float *dx, void *stream) {
+int agx_conv2d_bwd_data(const agx_conv2d_desc *d, const float *dy, const float *packed_bwd, const float *add,
+                        const float *mask, float slope, float *dx, void *stream) {
     using namespace agx;
     ConvPlan b;
     int rc = lower_conv2d_bwd_data(d, &b);
     if (rc != AGX_OK) return rc;
     if (!dy || !packed_bwd || !dx) return fail(AGX_ERR_NULL_POINTER, "agx_conv2d_bwd_data: NULL pointer");
-    b.epilogue = mask ? AGX_EPI_MASK : 0;
+    b.epilogue = (add ? AGX_EPI_RESIDUAL : 0) | (mask ? AGX_EPI_MASK : 0);
     b.mask = mask;
     b.slope = slope;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (b.pm_R || (d->impl != AGX_IMPL_DIRECT && conv_mfma_supported(b)))
-        return launch_conv_mfma(b, dy, packed_bwd, nullptr, nullptr, dx, st);
-    return launch_conv_direct(b, dy, packed_bwd, nullptr, nullptr, dx, st);
+        return launch_conv_mfma(b, dy, packed_bwd, nullptr, add, dx, st);
+    return launch_conv_direct(b, dy, packed_bwd, nullptr, add, dx, st);
 }
 
 int agx_conv2d_out_shape(const agx_conv2d_desc *d, int32_t *h_out, int32_t *w_out) {

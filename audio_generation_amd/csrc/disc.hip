@@ -8,6 +8,9 @@ namespace agx {
 
 int launch_conv_mfma(const ConvPlan &p, const float *x, const float *wp, const float *bias,
                      const float *res, float *y, hipStream_t st);
+int launch_conv_direct(const ConvPlan &p, const float *x, const float *wp, const float *bias,
+                       const float *res, float *y, hipStream_t st);
+bool conv_mfma_supported(const ConvPlan &p);
 
 __device__ __forceinline__ float block_sum_256(float v, float *sh4) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -131,6 +134,92 @@ __global__ __launch_bounds__(256) void stft_transpose_kernel(const float *__rest
     }
 }
 
+// (B, 2, T, N) -> (B, 2N, T): the transpose back, for the adjoint
+__global__ __launch_bounds__(256) void stft_untranspose_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                               int N, int T) {
+    __shared__ float tile[64][65];
+    const int bc = blockIdx.z;
+    const int f0 = blockIdx.y * 64, t0 = blockIdx.x * 64;
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int tt = e >> 6, ff = e & 63;
+        const int f = f0 + ff, t = t0 + tt;
+        tile[tt][ff] = (f < N && t < T) ? src[(size_t(bc) * T + t) * N + f] : 0.f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int ff = e >> 6, tt = e & 63;
+        const int f = f0 + ff, t = t0 + tt;
+        if (f < N && t < T) dst[(size_t(bc) * N + f) * T + t] = tile[tt][ff];
+    }
+}
+
+// adjoint of stft_prep_kernel: dx[n] = sum over the padded positions i that read x[n]
+// (i = n + N/2 always; the reflected copies i = N/2 - n for 1 <= n <= N/2 and
+//  i = N/2 + 2(L-1) - n for L-1-N/2 <= n <= L-2), with dxc[p][tau] = dxp[tau H + p]
+__global__ __launch_bounds__(256) void stft_unprep_kernel(const float *__restrict__ dxc, float *__restrict__ dx, int L,
+                                                          int N, int H, int Ttau) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= L) return;
+    const int b = blockIdx.y, Lp = L + N, half = N / 2;
+    auto at = [&](int i) -> float {
+        if (i < 0 || i >= Lp) return 0.f;
+        const int tau = i / H, p = i - tau * H;
+        return tau < Ttau ? dxc[(size_t(b) * H + p) * Ttau + tau] : 0.f;
+    };
+    float acc = at(n + half);
+    if (n >= 1 && n <= half) acc += at(half - n);
+    if (n <= L - 2 && n >= L - 1 - half) acc += at(half + 2 * (L - 1) - n);
+    dx[size_t(b) * L + n] = acc;
+}
+
+__global__ __launch_bounds__(256) void avgpool1d_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ add,
+                                                            float *__restrict__ dx, int l_in, int l_out, int kernel,
+                                                            int stride, int padding) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= l_in) return;
+    const float *row = dy + size_t(blockIdx.y) * l_out;
+    // outputs o with o*stride - padding <= i < o*stride - padding + kernel
+    const int hi = (i + padding) / stride;
+    int lo = (i + padding - kernel + stride) / stride;  // ceil((i + padding - kernel + 1) / stride)
+    if (i + padding - kernel + 1 <= 0) lo = 0;
+    float acc = 0.f;
+    for (int o = max(lo, 0); o <= min(hi, l_out - 1); ++o) acc += row[o];
+    const size_t e = size_t(blockIdx.y) * l_in + i;
+    dx[e] = acc / float(kernel) + (add ? add[e] : 0.f);
+}
+
+__global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ s,
+                                                          float *__restrict__ dz, int64_t n) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n) dz[i] = dy[i] * s[i] * (1.f - s[i]);
+}
+
+// per-row <G, W>
+__global__ __launch_bounds__(256) void sn_rowdot_kernel(const float *__restrict__ g, const float *__restrict__ w,
+                                                        float *__restrict__ rowdot, int cols) {
+    __shared__ float sh[4];
+    const size_t base = size_t(blockIdx.x) * cols;
+    float acc = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) acc = fmaf(g[base + c], w[base + c], acc);
+    const float tot = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) rowdot[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void sn_grad_kernel(float *__restrict__ g, const float *__restrict__ rowdot,
+                                                      const float *__restrict__ sigma, const float *__restrict__ u,
+                                                      const float *__restrict__ v, int rows, int cols) {
+    __shared__ float tot_s;
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < rows; ++i) t += rowdot[i];
+        tot_s = t;
+    }
+    __syncthreads();
+    const float sg = sigma[0], coef = tot_s / (sg * sg) * u[blockIdx.x], inv = 1.f / sg;
+    const size_t base = size_t(blockIdx.x) * cols;
+    for (int c = threadIdx.x; c < cols; c += 256) g[base + c] = g[base + c] * inv - coef * v[c];
+}
+
 // packed image of the DFT "weights": row m = c * N + f, channel p, tap j  ->  D_c[f, j H + p] * scale
 __global__ __launch_bounds__(256) void stft_pack_kernel(float *__restrict__ packed, int N, int H, float scale) {
     const int M = 2 * N;
@@ -143,6 +232,24 @@ __global__ __launch_bounds__(256) void stft_pack_kernel(float *__restrict__ pack
     const int j = gj % 4, p = (gj / 4) * kWG + c16;
     const int c = m / N, f = m - c * N, n = j * H + p;
     const long long k = (long long)f * n % N;  // exact argument reduction
+    double sn, cs;
+    sincospi(2.0 * double(k) / double(N), &sn, &cs);
+    packed[e] = float((c == 0 ? cs : -sn) * double(scale));
+}
+
+// image of the adjoint conv (backward-data plan of the DFT conv: channels = the 2N spectrum rows, rows = the
+// H phase channels, tap jb <-> forward tap 3 - jb)
+__global__ __launch_bounds__(256) void stft_pack_bwd_kernel(float *__restrict__ packed, int N, int H, float scale) {
+    const int Mb = H;
+    const int64_t total = packed_weight_floats(2 * N, 4, Mb);
+    const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int c16 = int(e % kWG);
+    const int p = int((e / kWG) % Mb);
+    const int gj = int(e / (int64_t(kWG) * Mb));
+    const int jb = gj % 4, m = (gj / 4) * kWG + c16;
+    const int c = m / N, f = m - c * N, n = (3 - jb) * H + p;
+    const long long k = (long long)f * n % N;
     double sn, cs;
     sincospi(2.0 * double(k) / double(N), &sn, &cs);
     packed[e] = float((c == 0 ? cs : -sn) * double(scale));
@@ -338,6 +445,80 @@ int agx_sigmoid(const float *x, float *y, int64_t n, void *stream) {
     hipLaunchKernelGGL(sigmoid_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, y, n);
     return check_launch("agx_sigmoid");
+}
+
+// The adjoint runs the DFT conv's backward-data plan (core.hip:lower_conv_bwd_data: stride 1 -> the flipped
+// kernel with the channel roles swapped) on the same MFMA kernel.
+static agx_conv_desc stft_conv_desc(int batch, int n_fft, int Ttau) {
+    return agx_conv_desc{AGX_CONV_PADDED, batch, n_fft / 4, 2 * n_fft, Ttau, 4, 1, 1, 0, 0.f, AGX_IMPL_MFMA, 1, 0};
+}
+
+int agx_stft_pack_bwd(int32_t n_fft, int32_t normalized, float *packed_bwd, void *stream) {
+    using namespace agx;
+    const int64_t n = agx_stft_packed_floats(n_fft);
+    if (n < 0) return int(n);
+    if (!packed_bwd) return fail(AGX_ERR_NULL_POINTER, "stft_pack_bwd: NULL pointer");
+    const float scale = normalized ? float(1.0 / sqrt(double(n_fft))) : 1.f;
+    hipLaunchKernelGGL(stft_pack_bwd_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), packed_bwd, n_fft, n_fft / 4, scale);
+    return check_launch("agx_stft_pack_bwd");
+}
+
+int agx_stft_backward(const float *dy, const float *packed_bwd, float *dx, void *workspace, int32_t batch,
+                      int32_t length, int32_t n_fft, void *stream) {
+    using namespace agx;
+    const int64_t T64 = agx_stft_frames(length, n_fft);
+    if (T64 < 0) return int(T64);
+    if (batch <= 0 || batch > 32767) return fail(AGX_ERR_BAD_SHAPE, "stft: batch out of range");
+    if (!dy || !packed_bwd || !dx || !workspace) return fail(AGX_ERR_NULL_POINTER, "stft_backward: NULL pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int N = n_fft, H = N / 4, T = int(T64), Ttau = T + 3;
+    float *dxc = static_cast<float *>(workspace);
+    float *cv = dxc + size_t(batch) * H * Ttau;
+    hipLaunchKernelGGL(stft_untranspose_kernel, dim3(ceil_div(T, 64), ceil_div(N, 64), batch * 2), dim3(256), 0, st, dy,
+                       cv, N, T);
+    const agx_conv_desc d = stft_conv_desc(batch, n_fft, Ttau);
+    ConvPlan p;
+    int rc = lower_conv_bwd_data(&d, &p);
+    if (rc != AGX_OK) return rc;
+    rc = conv_mfma_supported(p) ? launch_conv_mfma(p, cv, packed_bwd, nullptr, nullptr, dxc, st)
+                                : launch_conv_direct(p, cv, packed_bwd, nullptr, nullptr, dxc, st);  // n_fft = 64: 16 rows
+    if (rc != AGX_OK) return rc;
+    hipLaunchKernelGGL(stft_unprep_kernel, dim3(ceil_div(length, 256), batch), dim3(256), 0, st, dxc, dx, length, N, H,
+                       Ttau);
+    return check_launch("agx_stft_backward");
+}
+
+int agx_avgpool1d_backward(const float *dy, const float *add, float *dx, int64_t rows, int32_t l_in, int32_t kernel,
+                           int32_t stride, int32_t padding, void *stream) {
+    using namespace agx;
+    const int64_t l_out = agx_avgpool1d_out_len(l_in, kernel, stride, padding);
+    if (l_out < 0) return int(l_out);
+    if (rows <= 0 || rows > 65535) return fail(AGX_ERR_BAD_SHAPE, "avgpool1d_backward: rows must be in [1, 65535]");
+    if (!dy || !dx) return fail(AGX_ERR_NULL_POINTER, "avgpool1d_backward: NULL pointer");
+    hipLaunchKernelGGL(avgpool1d_bwd_kernel, dim3(ceil_div(l_in, 256), unsigned(rows)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), dy, add, dx, l_in, int(l_out), kernel, stride, padding);
+    return check_launch("agx_avgpool1d_backward");
+}
+
+int agx_sigmoid_backward(const float *dy, const float *s, float *dz, int64_t n, void *stream) {
+    using namespace agx;
+    if (n <= 0) return fail(AGX_ERR_BAD_SHAPE, "sigmoid_backward: n <= 0");
+    if (!dy || !s || !dz) return fail(AGX_ERR_NULL_POINTER, "sigmoid_backward: NULL pointer");
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), dy, s, dz, n);
+    return check_launch("agx_sigmoid_backward");
+}
+
+int agx_spectral_grad(float *g, const float *w, const float *sigma, const float *u, const float *v, int32_t rows,
+                      int32_t cols, float *workspace, void *stream) {
+    using namespace agx;
+    if (rows <= 0 || cols <= 0) return fail(AGX_ERR_BAD_SHAPE, "spectral_grad: bad shape");
+    if (!g || !w || !sigma || !u || !v || !workspace) return fail(AGX_ERR_NULL_POINTER, "spectral_grad: NULL pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(sn_rowdot_kernel, dim3(rows), dim3(256), 0, st, g, w, workspace, cols);
+    hipLaunchKernelGGL(sn_grad_kernel, dim3(rows), dim3(256), 0, st, g, workspace, sigma, u, v, rows, cols);
+    return check_launch("agx_spectral_grad");
 }
 
 }  // extern "C"

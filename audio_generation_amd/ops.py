@@ -430,15 +430,18 @@ def conv2d_pack_bwd(desc, w: Tensor, sigma: Optional[Tensor] = None) -> Tensor:
     return packed
 
 
-def conv2d_bwd_data(desc, dy: Tensor, packed_bwd: Tensor, mask: Optional[Tensor] = None, slope: float = 0.2) -> Tensor:
-    """Gradient w.r.t. the input of the Conv2d layer ``desc`` describes (forward descriptor)."""
+def conv2d_bwd_data(desc, dy: Tensor, packed_bwd: Tensor, mask: Optional[Tensor] = None, slope: float = 0.2,
+                    add: Optional[Tensor] = None) -> Tensor:
+    """Gradient w.r.t. the input of the Conv2d layer ``desc`` describes (forward descriptor); ``add`` is summed
+    in and the LeakyReLU gradient (``mask``) applied in the kernel's epilogue."""
     lib = _lib.load()
-    _need_gpu(dy, packed_bwd, mask)
+    _need_gpu(dy, packed_bwd, mask, add)
     dy = _f32c(dy)
     mask = None if mask is None else _f32c(mask)
+    add = None if add is None else _f32c(add)
     dx = torch.empty(desc.batch, desc.c_in, desc.h_in, desc.w_in, dtype=torch.float32, device=dy.device)
-    _lib.check(lib.agx_conv2d_bwd_data(ctypes.byref(desc), _ptr(dy), _ptr(packed_bwd), _ptr(mask), slope, _ptr(dx),
-                                       _stream()), "agx_conv2d_bwd_data")
+    _lib.check(lib.agx_conv2d_bwd_data(ctypes.byref(desc), _ptr(dy), _ptr(packed_bwd), _ptr(add), _ptr(mask), slope,
+                                       _ptr(dx), _stream()), "agx_conv2d_bwd_data")
     return dx
 
 
@@ -489,6 +492,58 @@ def stft(x: Tensor, n_fft: int, normalized: bool = True) -> Tensor:
     if tok is not None:
         _observer.end(tok)
     return y
+
+
+def stft_backward(dy: Tensor, length: int, n_fft: int, normalized: bool = True) -> Tensor:
+    """Adjoint of ``stft``: (B, 2, T, n_fft) -> (B, L)."""
+    lib = _lib.load()
+    _need_gpu(dy)
+    dy = _f32c(dy)
+    b = dy.shape[0]
+    key = ("bwd", n_fft, bool(normalized), dy.device)
+    if key not in _STFT_IMAGES:
+        img = torch.empty(int(lib.agx_stft_packed_floats(n_fft)), dtype=torch.float32, device=dy.device)
+        _lib.check(lib.agx_stft_pack_bwd(n_fft, int(normalized), _ptr(img), _stream()), "agx_stft_pack_bwd")
+        _STFT_IMAGES[key] = img
+    ws = torch.empty(int(lib.agx_stft_workspace_bytes(b, length, n_fft)) // 4, dtype=torch.float32, device=dy.device)
+    dx = torch.empty(b, length, dtype=torch.float32, device=dy.device)
+    _lib.check(lib.agx_stft_backward(_ptr(dy), _ptr(_STFT_IMAGES[key]), _ptr(dx), _ptr(ws), b, length, n_fft, _stream()),
+               "agx_stft_backward")
+    return dx
+
+
+def avgpool1d_backward(dy: Tensor, l_in: int, kernel: int, stride: int, padding: int,
+                       add: Optional[Tensor] = None) -> Tensor:
+    lib = _lib.load()
+    _need_gpu(dy, add)
+    dy = _f32c(dy)
+    add = None if add is None else _f32c(add)
+    rows = dy.numel() // dy.shape[-1]
+    dx = torch.empty(*dy.shape[:-1], l_in, dtype=torch.float32, device=dy.device)
+    _lib.check(lib.agx_avgpool1d_backward(_ptr(dy), _ptr(add), _ptr(dx), rows, l_in, kernel, stride, padding, _stream()),
+               "agx_avgpool1d_backward")
+    return dx
+
+
+def sigmoid_backward(dy: Tensor, s: Tensor) -> Tensor:
+    lib = _lib.load()
+    _need_gpu(dy, s)
+    dy, s = _f32c(dy), _f32c(s)
+    dz = torch.empty_like(s)
+    _lib.check(lib.agx_sigmoid_backward(_ptr(dy), _ptr(s), _ptr(dz), s.numel(), _stream()), "agx_sigmoid_backward")
+    return dz
+
+
+def spectral_grad_(g: Tensor, w: Tensor, sigma: Tensor, u: Tensor, v: Tensor) -> Tensor:
+    """In place: plain weight gradient -> gradient w.r.t. weight_orig of a spectrally normalised layer."""
+    lib = _lib.load()
+    _need_gpu(g, w, sigma, u, v)
+    assert g.is_contiguous() and g.dtype == torch.float32
+    rows, cols = g.shape[0], g.numel() // g.shape[0]
+    ws = torch.empty(rows, dtype=torch.float32, device=g.device)
+    _lib.check(lib.agx_spectral_grad(_ptr(g), _ptr(_f32c(w)), _ptr(sigma), _ptr(u), _ptr(v), rows, cols, _ptr(ws),
+                                     _stream()), "agx_spectral_grad")
+    return g
 
 
 REDUCE_MEAN, REDUCE_HINGE_REAL, REDUCE_HINGE_FAKE, REDUCE_L1, REDUCE_ABS_EPS = 0, 1, 2, 3, 4

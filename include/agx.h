@@ -284,11 +284,13 @@ int agx_conv2d_forward(const agx_conv2d_desc *d, const float *x, const float *pa
 int agx_conv2d_kernel_name(const agx_conv2d_desc *d, char *buf, size_t buf_len);
 /* Backward of the Conv2d layer `d` describes (forward descriptor): gradient w.r.t. its input from the
  * gradient w.r.t. its output, on the same kernels (strided layers as a 2-D polyphase conv over dy);
- * mask/slope: optional fused LeakyReLU gradient of the layer that produced the input (mask = its output). */
+ * add: optional tensor added to dx (a gradient arriving from another consumer of the input, e.g. the
+ * feature-matching loss); mask/slope: optional fused LeakyReLU gradient of the layer that produced the
+ * input (mask = its output), applied after the add as in agx_conv_bwd_data. */
 int64_t agx_conv2d_bwd_packed_floats(const agx_conv2d_desc *d);
 int agx_conv2d_pack_bwd(const agx_conv2d_desc *d, const float *w, const float *sigma, float *packed, void *stream);
-int agx_conv2d_bwd_data(const agx_conv2d_desc *d, const float *dy, const float *packed_bwd, const float *mask,
-                        float slope, float *dx, void *stream);
+int agx_conv2d_bwd_data(const agx_conv2d_desc *d, const float *dy, const float *packed_bwd, const float *add,
+                        const float *mask, float slope, float *dx, void *stream);
 /* dW (c_out, c_in, kh, kw) and dbias (c_out, may be NULL) of the layer.  With sigma != NULL the layer is
  * spectrally normalised: w is weight_orig, u / v the vectors sigma was computed with, and dw is the
  * gradient w.r.t. weight_orig:  G / sigma - (<G, W> / sigma^2) u v^T  (G = gradient w.r.t. W / sigma). */
@@ -308,6 +310,21 @@ int agx_stft_pack(int32_t n_fft, int32_t normalized, float *packed, void *stream
 int64_t agx_stft_workspace_bytes(int32_t batch, int32_t length, int32_t n_fft);
 int agx_stft_forward(const float *x, const float *packed, float *y, void *workspace, int32_t batch,
                      int32_t length, int32_t n_fft, void *stream);
+
+/* Adjoint of agx_stft_forward: dx (B, L) from dy (B, 2, T, n_fft).  workspace as agx_stft_workspace_bytes;
+ * packed_bwd from agx_stft_pack_bwd (agx_stft_packed_floats floats as well). */
+int agx_stft_pack_bwd(int32_t n_fft, int32_t normalized, float *packed_bwd, void *stream);
+int agx_stft_backward(const float *dy, const float *packed_bwd, float *dx, void *workspace, int32_t batch,
+                      int32_t length, int32_t n_fft, void *stream);
+/* AvgPool1d backward (count_include_pad): dx (rows, l_in) from dy (rows, l_out); add may be NULL. */
+int agx_avgpool1d_backward(const float *dy, const float *add, float *dx, int64_t rows, int32_t l_in, int32_t kernel,
+                           int32_t stride, int32_t padding, void *stream);
+/* dz = dy * s * (1 - s) with s = the sigmoid OUTPUT. */
+int agx_sigmoid_backward(const float *dy, const float *s, float *dz, int64_t n, void *stream);
+/* Spectral-norm chain rule in place on a plain weight gradient G (rows x cols, torch layout):
+ * G <- G / sigma - (<G, W> / sigma^2) u v^T.  workspace: rows floats. */
+int agx_spectral_grad(float *g, const float *w, const float *sigma, const float *u, const float *v, int32_t rows,
+                      int32_t cols, float *workspace, void *stream);
 
 /* Reductions of discriminator_generator_loss (discriminator.py:204-246), one launch each, result in
  * out[0] (device):  mode 0 mean(x) | 1 mean(min(x - 1, 0)) | 2 mean(min(-x - 1, 0)) |

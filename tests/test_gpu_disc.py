@@ -296,6 +296,9 @@ def test_conv2d_backward_data(cin, cout, kh, kw, sh, sw, ph, pw, h, w):
     pk = ops.conv2d_pack_bwd(d, wt.to(DEV))
     close(ops.conv2d_bwd_data(d, dy.to(DEV), pk), want_plain, 2e-5)
     close(ops.conv2d_bwd_data(d, dy.to(DEV), pk, xin.detach().to(DEV), 0.2), want_masked, 2e-5)
+    extra = torch.randn(2, cin, h, w)
+    close(ops.conv2d_bwd_data(d, dy.to(DEV), pk, xin.detach().to(DEV), 0.2, add=extra.to(DEV)),
+          (want_plain + extra) * torch.where(xin.detach() > 0, 1.0, 0.2), 2e-5)
 
 
 @pytest.mark.parametrize("cin,cout,kh,kw,sh,sw,ph,pw,h,w", [
@@ -325,3 +328,36 @@ def test_conv2d_backward_weight(cin, cout, kh, kw, sh, sw, ph, pw, h, w, spectra
         dw, db = ops.conv2d_bwd_weight(d, x.to(DEV), dy.to(DEV))
     close(dw, wt.grad, 1e-4)
     close(db, b.grad, 2e-5)
+
+
+@pytest.mark.parametrize("win,length", [(64, 500), (256, 1024), (1024, 24000)])
+def test_stft_backward_is_the_adjoint(win, length):
+    torch.manual_seed(win)
+    x = torch.randn(2, length, requires_grad=True)
+    y = od.stft_two_sided(x, win, win // 4)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    close(ops.stft_backward(dy.to(DEV), length, win, True), x.grad, 2e-5)
+
+
+def test_small_backward_kernels():
+    torch.manual_seed(1)
+    for scale, length in ((1, 100), (2, 101), (4, 1000)):
+        x = torch.randn(3, 2, length, requires_grad=True)
+        y = F.avg_pool1d(x, 2 * scale, stride=scale, padding=scale)
+        dy, extra = torch.randn_like(y), torch.randn(3, 2, length)
+        y.backward(dy)
+        close(ops.avgpool1d_backward(dy.to(DEV), length, 2 * scale, scale, scale), x.grad, 1e-6)
+        close(ops.avgpool1d_backward(dy.to(DEV), length, 2 * scale, scale, scale, add=extra.to(DEV)), x.grad + extra, 1e-6)
+    z = torch.randn(4, 1, 77, requires_grad=True)
+    s = torch.sigmoid(z)
+    dy = torch.randn_like(s)
+    s.backward(dy)
+    close(ops.sigmoid_backward(dy.to(DEV), s.detach().to(DEV)), z.grad, 1e-6)
+    w = torch.randn(24, 5, 7, requires_grad=True)
+    u, v = F.normalize(torch.randn(24), dim=0), F.normalize(torch.randn(35), dim=0)
+    sigma = torch.dot(u, torch.mv(w.reshape(24, -1), v))
+    gn = torch.randn(24, 5, 7)
+    (w / sigma).backward(gn)
+    got = ops.spectral_grad_(gn.clone().to(DEV), w.detach().to(DEV), sigma.detach().reshape(1).to(DEV), u.to(DEV), v.to(DEV))
+    close(got, w.grad, 1e-5)
