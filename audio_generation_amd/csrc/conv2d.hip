@@ -107,11 +107,14 @@ int lower_conv2d_bwd_data(const agx_conv2d_desc *d, ConvPlan *b) {
         b->oshift = d->pad_w;
         b->oshift_h = d->pad_h;
         b->pm_R = 1;
+    } else if (d->stride_h != 1 || d->stride_w != 1 || d->kh - 1 - d->pad_h < 0 || d->kw - 1 - d->pad_w < 0) {
+        // odd shapes (strided layers with few / unaligned channels: the tiny test models): gather kernel below
+        b->pm_R = -1;
+        b->ncv = d->c_out;
+        b->J = d->kh * d->kw;
+        b->M = d->c_in;
+        return AGX_OK;
     } else {
-        if (d->stride_h != 1 || d->stride_w != 1)
-            return fail(AGX_ERR_UNSUPPORTED, "conv2d bwd_data: strided layers need Cout %% 16 == 0 and Cin*sh*sw >= 32");
-        if (d->kh - 1 - d->pad_h < 0 || d->kw - 1 - d->pad_w < 0)
-            return fail(AGX_ERR_UNSUPPORTED, "conv2d bwd_data: padding larger than kernel - 1");
         b->ncv = d->c_out * d->kh;
         b->Cin = ceil_div(b->ncv, kWG) * kWG;
         b->q = 1;
@@ -129,6 +132,47 @@ int lower_conv2d_bwd_data(const agx_conv2d_desc *d, ConvPlan *b) {
     }
     b->pm_WF = 0;
     return AGX_OK;
+}
+
+// Catch-all backward-data: one thread per dx element, gather over (co, dh, dw).  wimg = the weight tensor
+// (Cout, Cin, kh, kw) scaled by 1 / sigma.
+__global__ __launch_bounds__(256) void conv2d_bwd_data_gather_kernel(const float *__restrict__ dy,
+                                                                     const float *__restrict__ wimg,
+                                                                     const float *__restrict__ add,
+                                                                     const float *__restrict__ mask, float slope,
+                                                                     float *__restrict__ dx, int B, int Cin, int Cout,
+                                                                     int Hin, int Win, int Hout, int Wout, int kh, int kw,
+                                                                     int sh, int sw, int ph, int pw) {
+    const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t total = int64_t(B) * Cin * Hin * Win;
+    if (e >= total) return;
+    const int j = int(e % Win), i = int((e / Win) % Hin), ci = int((e / (int64_t(Win) * Hin)) % Cin);
+    const int b = int(e / (int64_t(Win) * Hin * Cin));
+    float acc = 0.f;
+    for (int dh = 0; dh < kh; ++dh) {
+        const int ti = i + ph - dh;
+        if (ti < 0 || ti % sh) continue;
+        const int t = ti / sh;
+        if (t >= Hout) continue;
+        for (int dw = 0; dw < kw; ++dw) {
+            const int fj = j + pw - dw;
+            if (fj < 0 || fj % sw) continue;
+            const int f = fj / sw;
+            if (f >= Wout) continue;
+            for (int co = 0; co < Cout; ++co)
+                acc = fmaf(wimg[((size_t(co) * Cin + ci) * kh + dh) * kw + dw],
+                           dy[((size_t(b) * Cout + co) * Hout + t) * Wout + f], acc);
+        }
+    }
+    if (add) acc += add[e];
+    if (mask) acc = mask[e] > 0.f ? acc : acc * slope;
+    dx[e] = acc;
+}
+
+__global__ __launch_bounds__(256) void scale_copy_kernel(const float *__restrict__ w, const float *__restrict__ sigma,
+                                                         float *__restrict__ out, int64_t n) {
+    const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (e < n) out[e] = w[e] * (sigma ? 1.f / sigma[0] : 1.f);
 }
 
 // Packed image of the backward-data op (both lowerings above).
@@ -171,6 +215,7 @@ int64_t agx_conv2d_bwd_packed_floats(const agx_conv2d_desc *d) {
     agx::ConvPlan b;
     int rc = agx::lower_conv2d_bwd_data(d, &b);
     if (rc != AGX_OK) return rc;
+    if (b.pm_R < 0) return int64_t(d->c_out) * d->c_in * d->kh * d->kw;
     return agx::packed_weight_floats(b.ncv, b.J, b.M);
 }
 
@@ -180,6 +225,12 @@ int agx_conv2d_pack_bwd(const agx_conv2d_desc *d, const float *w, const float *s
     int rc = lower_conv2d_bwd_data(d, &b);
     if (rc != AGX_OK) return rc;
     if (!w || !packed) return fail(AGX_ERR_NULL_POINTER, "agx_conv2d_pack_bwd: NULL pointer");
+    if (b.pm_R < 0) {
+        const int64_t nraw = int64_t(d->c_out) * d->c_in * d->kh * d->kw;
+        hipLaunchKernelGGL(scale_copy_kernel, dim3((unsigned)ceil_div64(nraw, 256)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), w, sigma, packed, nraw);
+        return check_launch("agx_conv2d_pack_bwd");
+    }
     const int64_t n = packed_weight_floats(b.ncv, b.J, b.M);
     hipLaunchKernelGGL(pack_bwd2d_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), w, sigma, packed, d->c_in, d->c_out, d->kh, d->kw, d->stride_h,
@@ -198,6 +249,13 @@ int agx_conv2d_bwd_data(const agx_conv2d_desc *d, const float *dy, const float *
     b.mask = mask;
     b.slope = slope;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (b.pm_R < 0) {
+        const int64_t total = int64_t(d->batch) * d->c_in * d->h_in * d->w_in;
+        hipLaunchKernelGGL(conv2d_bwd_data_gather_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, dy,
+                           packed_bwd, add, mask, slope, dx, d->batch, d->c_in, d->c_out, d->h_in, d->w_in, b.Tin, b.Lin,
+                           d->kh, d->kw, d->stride_h, d->stride_w, d->pad_h, d->pad_w);
+        return check_launch("agx_conv2d_bwd_data");
+    }
     if (b.pm_R || (d->impl != AGX_IMPL_DIRECT && conv_mfma_supported(b)))
         return launch_conv_mfma(b, dy, packed_bwd, nullptr, add, dx, st);
     return launch_conv_direct(b, dy, packed_bwd, nullptr, add, dx, st);

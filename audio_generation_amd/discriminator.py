@@ -69,6 +69,7 @@ class _SNConv(nn.Module):
             self.bias, self.weight = conv.bias, conv.weight
         self._key, self._packed, self._iter = None, None, 0
         self._uv_override = None   # (u, v) of the forward being differentiated (backward bridge only)
+        self._tape = None          # (sigma, u, v) of the latest forward (native backward)
 
     @property
     def raw_weight(self) -> Tensor:
@@ -89,6 +90,8 @@ class _SNConv(nn.Module):
                None if self.norm != "spectral" else (self.weight_u._version, self.weight_v._version))
         if self.training or key != self._key:
             sigma = self._sigma()
+            # what this forward normalised with (the native backward needs exactly these)
+            self._tape = None if sigma is None else (sigma, self.weight_u.clone(), self.weight_v.clone())
             desc = make_desc()
             self._packed = pack_plain(desc, w.detach()) if sigma is None else pack_sigma(desc, w.detach(), sigma)
             self._key = (w.data_ptr(), w._version, self.training, self._iter,
@@ -127,6 +130,27 @@ class _SNConv(nn.Module):
 
         packed = self.packed(lambda: desc(1, 64, 64), ops.conv2d_pack, ops.conv2d_pack)
         return ops.conv2d_forward(desc(), x, packed, None if self.bias is None else self.bias.detach())
+
+
+    def desc2d(self, x: Tensor, slope: Optional[float] = None):
+        b, _, h, w = x.shape
+        return ops.conv2d_desc(b, self.in_channels, self.out_channels, h, w, self.kernel_size[0], self.kernel_size[1],
+                               self.stride, self.padding, EPI_LEAKY_PRE if slope is not None else 0, slope or 0.0)
+
+    def bwd2d(self, x: Tensor, dy: Tensor, tape, need_dx: bool = True, add: Optional[Tensor] = None,
+              mask: Optional[Tensor] = None, slope: float = 0.2):
+        """(dx or None, [dbias, dweight]) of this layer for the forward that produced ``tape``."""
+        desc = self.desc2d(x)
+        w = self.raw_weight.detach()
+        sigma, u, v = tape if tape is not None else (None, None, None)
+        dw, db = ops.conv2d_bwd_weight(desc, x, dy, w, sigma, u, v, want_bias=self.bias is not None)
+        dx = None
+        if need_dx:
+            dx = ops.conv2d_bwd_data(desc, dy, ops.conv2d_pack_bwd(desc, w, sigma), mask, slope, add)
+        return dx, ([db, dw] if self.bias is not None else [dw])
+
+    def grad_params(self):
+        return ([self.bias] if self.bias is not None else []) + [self.raw_weight]
 
 
 class _MultiOutBridge(torch.autograd.Function):
@@ -332,8 +356,87 @@ class STFTDiscriminator(nn.Module):
         return [self.final_activation(x)] + feats
 
     def forward(self, x: Tensor):
+        if needs_grad(x, self) and all(isinstance(b.layers[1], nn.LeakyReLU) for b in self.blocks):
+            flat = _STFTDiscNative.apply(self, x, *list(self.parameters()))
+            return [flat[0]], list(flat[1:])
         outs, feats = _run_bridged(self, x, self._hip, self._aten, 1)
         return outs, feats
+
+
+class _STFTDiscNative(torch.autograd.Function):
+    """STFTDiscriminator forward + hand-written backward, everything on the HIP kernels: per layer one
+    weight-gradient call (spectral-norm chain rule included) and one backward-data call whose epilogue adds
+    the gradient arriving at that feature map from the feature-matching loss and applies the LeakyReLU
+    gradient of the layer below; the STFT adjoint closes the path to the waveform."""
+
+    @staticmethod
+    def forward(ctx, disc, x: Tensor, *params: Tensor):
+        with torch.no_grad():
+            xd = x.detach()
+            spec = ops.stft(xd.squeeze(1), disc.n_fft, disc.normalize_stft)
+            convs, tapes, acts = [disc.first_conv], [], []
+            h = disc.first_conv.run2d(spec, None)
+            tapes.append(disc.first_conv._tape)
+            feats = [h]
+            for blk in disc.blocks:
+                c0, act, c2 = blk.layers[0], blk.layers[1], blk.layers[2]
+                a = c0.run2d(h, _slope(act))
+                tapes.append(c0._tape)
+                h = c2.run2d(a, None)
+                tapes.append(c2._tape)
+                convs += [c0, c2]
+                acts.append(a)
+                feats.append(h)
+            z = disc.final_conv.run2d(h, None)
+            tapes.append(disc.final_conv._tape)
+            convs.append(disc.final_conv)
+            sig = isinstance(disc.final_activation, nn.Sigmoid)
+            out = ops.sigmoid(z) if sig else z.clone()
+        ctx.disc, ctx.convs, ctx.tapes, ctx.sig, ctx.params = disc, convs, tapes, sig, params
+        ctx.length = x.shape[-1]
+        ctx.n_blocks = len(acts)
+        ctx.save_for_backward(spec, out, *feats, *acts)
+        return (out, *feats)
+
+    @staticmethod
+    def backward(ctx, g_out: Optional[Tensor], *g_feats: Optional[Tensor]):
+        disc, convs, tapes = ctx.disc, ctx.convs, ctx.tapes
+        saved = ctx.saved_tensors
+        nb = ctx.n_blocks
+        spec, out = saved[0], saved[1]
+        feats, acts = saved[2:3 + nb], saved[3 + nb:]
+        grads = {}
+
+        def put(conv, gl):
+            for p_, g_ in zip(conv.grad_params(), gl):
+                grads[p_] = g_
+
+        gf = [None if g is None else g.contiguous() for g in g_feats]
+        dh = None
+        if g_out is not None:
+            dz = ops.sigmoid_backward(g_out.contiguous(), out) if ctx.sig else g_out.contiguous()
+            dh, gl = convs[-1].bwd2d(feats[-1], dz, tapes[-1], add=gf[-1])
+            put(convs[-1], gl)
+        else:
+            dh = gf[-1]
+        for i in range(nb - 1, -1, -1):
+            c0, c2 = convs[1 + 2 * i], convs[2 + 2 * i]
+            slope = _slope(disc.blocks[i].layers[1])
+            if dh is None:                               # nothing arrives at this feature map or above
+                dh = gf[i]
+                continue
+            da, gl = c2.bwd2d(acts[i], dh, tapes[2 + 2 * i], mask=acts[i], slope=slope)
+            put(c2, gl)
+            dh, gl = c0.bwd2d(feats[i], da, tapes[1 + 2 * i], add=gf[i])
+            put(c0, gl)
+        dx = None
+        if dh is not None:
+            need_dx = ctx.needs_input_grad[1]
+            dspec, gl = convs[0].bwd2d(spec, dh, tapes[0], need_dx=need_dx)
+            put(convs[0], gl)
+            if need_dx:
+                dx = ops.stft_backward(dspec, ctx.length, disc.n_fft, disc.normalize_stft).unsqueeze(1)
+        return (None, dx, *[grads.get(p_) for p_ in ctx.params])
 
 
 class _Mean(torch.autograd.Function):

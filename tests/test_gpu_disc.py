@@ -278,7 +278,8 @@ def test_full_size_stft_discriminator_against_oracle():
     (32, 32, 3, 3, 1, 1, 1, 1, 17, 200), (32, 64, 3, 4, 1, 2, 1, 1, 17, 200), (64, 128, 4, 4, 2, 2, 1, 1, 18, 130),
     (64, 128, 4, 4, 2, 2, 1, 1, 19, 131), (128, 128, 3, 4, 1, 2, 1, 1, 9, 16), (256, 512, 4, 4, 2, 2, 1, 1, 6, 4),
     (2, 32, 7, 7, 1, 1, 3, 3, 21, 70), (512, 1, 1, 8, 1, 1, 0, 3, 5, 16), (16, 48, 3, 3, 2, 2, 1, 1, 11, 23),
-    (32, 16, 5, 3, 1, 1, 2, 1, 8, 40)])
+    (32, 16, 5, 3, 1, 1, 2, 1, 8, 40), (4, 8, 3, 4, 1, 2, 1, 1, 9, 20), (8, 16, 4, 4, 2, 2, 1, 1, 10, 12),
+    (3, 5, 2, 2, 1, 1, 3, 2, 6, 7)])
 def test_conv2d_backward_data(cin, cout, kh, kw, sh, sw, ph, pw, h, w):
     """dx of every Conv2d shape of the STFT discriminators (+ odd sizes) against autograd, with the fused
     LeakyReLU-gradient mask."""
@@ -361,3 +362,22 @@ def test_small_backward_kernels():
     (w / sigma).backward(gn)
     got = ops.spectral_grad_(gn.clone().to(DEV), w.detach().to(DEV), sigma.detach().reshape(1).to(DEV), u.to(DEV), v.to(DEV))
     close(got, w.grad, 1e-5)
+
+
+def test_stft_discriminator_backward_runs_on_the_native_kernels(monkeypatch):
+    """No ATen bridge on the STFT discriminator: 14 layers x 3 passes of dW calls, bwd-data everywhere but the
+    first conv of the passes whose input needs no gradient."""
+    torch.manual_seed(5)
+    d = ad.STFTDiscriminator(first_channel_size=16, win_length=256).to(DEV).train()
+    calls = {"dw": 0, "dx": 0, "bridge": 0}
+    real_w, real_x = ops.conv2d_bwd_weight, ops.conv2d_bwd_data
+    monkeypatch.setattr(ops, "conv2d_bwd_weight", lambda *a, **k: (calls.__setitem__("dw", calls["dw"] + 1), real_w(*a, **k))[1])
+    monkeypatch.setattr(ops, "conv2d_bwd_data", lambda *a, **k: (calls.__setitem__("dx", calls["dx"] + 1), real_x(*a, **k))[1])
+    real_b = ad._MultiOutBridge.apply
+    monkeypatch.setattr(ad._MultiOutBridge, "apply", lambda *a, **k: (calls.__setitem__("bridge", calls["bridge"] + 1), real_b(*a, **k))[1])
+    orig = 0.3 * torch.randn(2, 1, 4096, device=DEV)
+    rec = (orig + 0.05 * torch.randn_like(orig)).requires_grad_(True)
+    gl, dl = ad.discriminator_generator_loss(orig, rec, d)
+    (gl + dl).backward()
+    assert calls["bridge"] == 0 and calls["dw"] == 3 * 14 and calls["dx"] == 3 * 14
+    assert rec.grad is not None and all(p.grad is not None for p in d.parameters())
