@@ -103,9 +103,20 @@ int lower_conv2d_bwd_data(const agx_conv2d_desc *d, ConvPlan *b) {
         b->ph = Jh - 1;
         b->Lt = ceil_div(d->w_in + d->pad_w, d->stride_w);
         b->Tt = ceil_div(d->h_in + d->pad_h, d->stride_h);
-        b->M = d->c_in * d->stride_h * d->stride_w;
         b->oshift = d->pad_w;
         b->oshift_h = d->pad_h;
+        // stride-1 axes: the tight form (flipped kernel, padding k - 1 - p) has no shifted / wasted base positions
+        if (d->stride_w == 1 && d->kw - 1 - d->pad_w >= 0) {
+            b->P = d->kw - 1 - d->pad_w;
+            b->Lt = d->w_in;
+            b->oshift = 0;
+        }
+        if (d->stride_h == 1 && d->kh - 1 - d->pad_h >= 0) {
+            b->ph = d->kh - 1 - d->pad_h;
+            b->Tt = d->h_in;
+            b->oshift_h = 0;
+        }
+        b->M = d->c_in * d->stride_h * d->stride_w;
         b->pm_R = 1;
     } else if (d->stride_h != 1 || d->stride_w != 1 || d->kh - 1 - d->pad_h < 0 || d->kw - 1 - d->pad_w < 0) {
         // odd shapes (strided layers with few / unaligned channels: the tiny test models): gather kernel below

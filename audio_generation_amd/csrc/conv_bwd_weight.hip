@@ -67,24 +67,50 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(ConvPlan p, int sp
     for (int item = slice; item < items; item += n_slices) {
         const int b = item / chunks, t0 = (item - b * chunks) * BW_T;
         __syncthreads();
-        // dy tile: row r <-> m = m_base + r = co*q + ph, column tt <-> dy[b, co, q*(t0+tt) + ph]
-        for (int e = tid; e < BM * BW_T; e += 256) {
-            const int r = e / BW_T, tt = e - r * BW_T;
-            const int m = m_base + r;
-            float v = 0.f;
-            if (m < p.M) {
-                const int co = m / p.q, ph = m - co * p.q;
-                const int t = t0 + tt, u = p.q * t + ph;
-                if (t < p.Lt && u < p.Lout) v = dy[(size_t(b) * p.Cout + co) * p.Lout + u];
+        // Staging: all loads of a batch are issued on clamped addresses before any is used (a conditional
+        // load is waited for one by one), zeros are selected afterwards.
+        // dy tile: row r <-> m = m_base + r = co*q + ph, column tt <-> dy[b, co, q*(t0+tt) + ph];
+        // a thread's column tt = tid % 64 is the same for all its elements
+        {
+            const int tt = tid & 63, t = t0 + tt;
+            constexpr int NB = BM * BW_T / 256;
+#pragma unroll
+            for (int u0 = 0; u0 < NB; u0 += 8) {
+                float v[8];
+                bool ok[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int m = min(m_base + (tid >> 6) + 4 * (u0 + u), p.M - 1);
+                    const int co = p.q == 1 ? m : m / p.q, ph = m - co * p.q;
+                    const int uu = p.q * t + ph;
+                    ok[u] = t < p.Lt && uu < p.Lout && m_base + (tid >> 6) + 4 * (u0 + u) < p.M;
+                    v[u] = dy[(size_t(b) * p.Cout + co) * p.Lout + min(uu, p.Lout - 1)];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) dys[((tid >> 6) + 4 * (u0 + u)) * BW_TS + tt] = ok[u] ? v[u] : 0.f;
             }
-            dys[r * BW_TS + tt] = v;
         }
         // x tile: channels ci_first .. ci_first + n_chan - 1, positions t0*s - P + [0, span)
-        const int in0 = t0 * p.s - p.P;
-        for (int e = tid; e < n_chan * span; e += 256) {
-            const int c = e / span, i = e - c * span;
-            const int ch = ci_first + c, pos = in0 + i;
-            xs[e] = (ch < p.Cin && pos >= 0 && pos < p.Lvalid) ? x[(size_t(b) * p.Cin + ch) * p.Lin + pos] : 0.f;
+        {
+            const int in0 = t0 * p.s - p.P;
+            const float *xb = x + size_t(b) * p.Cin * p.Lin;
+            const int total = n_chan * span;
+            const float inv_span = 1.f / float(span);
+            for (int e0 = tid; e0 < total; e0 += 256 * 8) {
+                float v[8];
+                bool ok[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = min(e0 + u * 256, total - 1);
+                    const int c = int((float(e) + 0.5f) * inv_span), i = e - c * span;   // exact: e < 2^20
+                    const int ch = ci_first + c, pos = in0 + i;
+                    ok[u] = ch < p.Cin && pos >= 0 && pos < p.Lvalid;
+                    v[u] = xb[size_t(min(ch, p.Cin - 1)) * p.Lin + min(max(pos, 0), p.Lvalid - 1)];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (e0 + u * 256 < total) xs[e0 + u * 256] = ok[u] ? v[u] : 0.f;
+            }
         }
         __syncthreads();
         if (do_bias) {
@@ -245,6 +271,8 @@ __global__ __launch_bounds__(256) void conv2d_bwd_weight_kernel(Bw2dGeom g, cons
         const int r = tid / g.WF, fc = tid - r * g.WF;
         kofft[tid] = tid < npos ? (r * g.sh) * g.SW + fc * g.sw : 0;
     }
+    const int my_k = tid & 63, my_rr = my_k / g.WF, my_fc = my_k - my_rr * g.WF;   // this thread's dy-tile column
+    const float inv_span = 1.f / float(g.span), inv_sw = 1.f / float(g.SW);
     int boff[NW];
     bool nvalid[NW];
 #pragma unroll
@@ -280,26 +308,53 @@ __global__ __launch_bounds__(256) void conv2d_bwd_weight_kernel(Bw2dGeom g, cons
         const int rg = it % nrg, b = it / nrg;
         const int trow0 = rg * g.R, f0 = ft * g.WF;
         __syncthreads();
-        // dy tile: row r <-> co = m_base + r, column k = rr * WF + fc <-> dy[b, co, trow0 + rr, f0 + fc]
-        for (int e = tid; e < BM * BW_T; e += 256) {
-            const int r = e / BW_T, k = e - r * BW_T;
-            const int co = m_base + r;
-            float v = 0.f;
-            if (co < M && k < npos) {
-                const int rr = k / g.WF, fc = k - rr * g.WF;
-                const int t = trow0 + rr, f = f0 + fc;
-                if (t < g.Hout && f < g.Wout) v = dy[((size_t(b) * g.Cout + co) * g.Hout + t) * g.Wout + f];
+        // Staging: all loads of a batch are issued on clamped addresses before any is used (a conditional
+        // load is waited for one by one), zeros are selected afterwards.
+        // dy tile: row r <-> co = m_base + r, column k = rr * WF + fc <-> dy[b, co, trow0 + rr, f0 + fc];
+        // a thread's column k = tid % 64 is the same for all its elements (256 % 64 == 0)
+        {
+            const int t = trow0 + my_rr, f = f0 + my_fc;
+            const bool pos_ok = my_k < npos && t < g.Hout && f < g.Wout;
+            const size_t pos_off = size_t(min(t, g.Hout - 1)) * g.Wout + min(f, g.Wout - 1);
+            const float *dyb = dy + size_t(b) * g.Cout * g.Hout * g.Wout + pos_off;
+            constexpr int NB = BM * BW_T / 256;   // elements per thread (rows tid / 64 + 4 u)
+#pragma unroll
+            for (int u0 = 0; u0 < NB; u0 += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int co = m_base + (tid >> 6) + 4 * (u0 + u);
+                    v[u] = dyb[size_t(min(co, M - 1)) * g.Hout * g.Wout];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int r = (tid >> 6) + 4 * (u0 + u);
+                    dys[r * BW_TS + my_k] = (pos_ok && m_base + r < M) ? v[u] : 0.f;
+                }
             }
-            dys[r * BW_TS + k] = v;
         }
         // x patches of channels ci_first .. ci_first + n_chan - 1
-        const int row0 = trow0 * g.sh - g.ph, col0 = f0 * g.sw - g.pw;
-        for (int e = tid; e < g.n_chan * g.span; e += 256) {
-            const int c = e / g.span, i = e - c * g.span;
-            const int rr = i / g.SW, cc = i - rr * g.SW;
-            const int ch = ci_first + c, gr = row0 + rr, gc = col0 + cc;
-            xs[e] = (ch < g.Cin && gr >= 0 && gr < g.Hin && gc >= 0 && gc < g.Win)
-                        ? x[((size_t(b) * g.Cin + ch) * g.Hin + gr) * g.Win + gc] : 0.f;
+        {
+            const int row0 = trow0 * g.sh - g.ph, col0 = f0 * g.sw - g.pw;
+            const float *xb = x + size_t(b) * g.Cin * g.Hin * g.Win;
+            const int total = g.n_chan * g.span;
+            for (int e0 = tid; e0 < total; e0 += 256 * 8) {
+                float v[8];
+                bool ok[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = min(e0 + u * 256, total - 1);
+                    const int c = int((float(e) + 0.5f) * inv_span), i = e - c * g.span;   // exact: e < 2^20
+                    const int rr = int((float(i) + 0.5f) * inv_sw), cc = i - rr * g.SW;
+                    const int ch = ci_first + c, gr = row0 + rr, gc = col0 + cc;
+                    ok[u] = ch < g.Cin && gr >= 0 && gr < g.Hin && gc >= 0 && gc < g.Win;
+                    v[u] = xb[(size_t(min(ch, g.Cin - 1)) * g.Hin + min(max(gr, 0), g.Hin - 1)) * g.Win +
+                              min(max(gc, 0), g.Win - 1)];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (e0 + u * 256 < total) xs[e0 + u * 256] = ok[u] ? v[u] : 0.f;
+            }
         }
         __syncthreads();
         if (do_bias) {

@@ -41,12 +41,28 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvPlan p, int ci_til
     for (int c0 = 0; c0 < cpg; c0 += ci_tile) {
         const int nc = min(ci_tile, cpg - c0);
         __syncthreads();
-        for (int e = tid; e < nc * span; e += 256) {
-            const int c = e / span, i = e - c * span;
-            const int pos = in0 + i;
-            const int cv = c0 + c, ci = cv / p.kh, r = row0 + (cv - ci * p.kh);  // 1-D: kh = 1, r = 0
-            const bool ok = pos >= 0 && pos < p.Lvalid && r >= 0 && r < p.Tin;
-            xs[e] = ok ? xb[size_t(ci) * p.x_cstride + size_t(r) * p.Lin + pos] : 0.f;
+        // all loads of a batch go out on clamped addresses before any is used (a conditional load is
+        // waited for one by one); zeros are selected afterwards
+        {
+            const int total = nc * span;
+            const float inv_span = 1.f / float(span);
+            for (int e0 = tid; e0 < total; e0 += 256 * 8) {
+                float v[8];
+                bool okv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = min(e0 + u * 256, total - 1);
+                    const int c = int((float(e) + 0.5f) * inv_span), i = e - c * span;   // exact: e < 2^20
+                    const int pos = in0 + i;
+                    const int cv = c0 + c, ci = cv / p.kh, r = row0 + (cv - ci * p.kh);  // 1-D: kh = 1, r = 0
+                    okv[u] = pos >= 0 && pos < p.Lvalid && r >= 0 && r < p.Tin;
+                    v[u] = xb[size_t(ci) * p.x_cstride + size_t(min(max(r, 0), p.Tin - 1)) * p.Lin +
+                              min(max(pos, 0), p.Lvalid - 1)];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (e0 + u * 256 < total) xs[e0 + u * 256] = okv[u] ? v[u] : 0.f;
+            }
         }
         __syncthreads();
         for (int c = 0; c < nc; ++c) {

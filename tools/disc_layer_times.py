@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Per-layer forward / backward-data / weight-gradient times of one STFT discriminator (HIP events)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from audio_generation_amd import discriminator as ad  # noqa: E402
+from audio_generation_amd import ops  # noqa: E402
+
+
+def timeit(fn, reps=3):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    win = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    b = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    dev = "cuda"
+    d = ad.STFTDiscriminator(win_length=win).to(dev).train()
+    x = 0.1 * torch.randn(b, 1, 72000, device=dev)
+    with torch.no_grad():
+        h = ops.stft(x.squeeze(1), win, True)
+        print(f"stft fwd {timeit(lambda: ops.stft(x.squeeze(1), win, True)):8.3f} ms   bwd {timeit(lambda: ops.stft_backward(h, 72000, win, True)):8.3f} ms")
+        convs = [d.first_conv] + [c for blk in d.blocks for c in (blk.layers[0], blk.layers[2])] + [d.final_conv]
+        tot = [0.0, 0.0, 0.0]
+        for c in convs:
+            y = c.run2d(h, None)
+            tape = c._tape
+            desc = c.desc2d(h)
+            w = c.raw_weight.detach()
+            pk = ops.conv2d_pack_bwd(desc, w, tape[0])
+            dy = torch.randn_like(y)
+            hh = h
+            tf = timeit(lambda: c.run2d(hh, None))
+            tx = timeit(lambda: ops.conv2d_bwd_data(desc, dy, pk))
+            tw = timeit(lambda: ops.conv2d_bwd_weight(desc, hh, dy, w, *tape))
+            fl = 2.0 * y.numel() * c.in_channels * c.kernel_size[0] * c.kernel_size[1]
+            print(f"{c.in_channels:4d}->{c.out_channels:4d} k{tuple(c.kernel_size)} s{tuple(c.stride)} in {tuple(h.shape[2:])}: "
+                  f"fwd {tf:7.3f} ms ({fl / tf * 1e-9:5.1f} TF)  dx {tx:7.3f} ms ({fl / tx * 1e-9:5.1f} TF)  "
+                  f"dW {tw:7.3f} ms ({fl / tw * 1e-9:5.1f} TF)")
+            tot[0] += tf; tot[1] += tx; tot[2] += tw
+            h = y
+        print(f"total fwd {tot[0]:.2f}  dx {tot[1]:.2f}  dW {tot[2]:.2f} ms")
+
+
+main()
