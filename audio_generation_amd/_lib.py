@@ -81,6 +81,11 @@ SIGNATURES = {
     "agx_spectral_sigma": (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_float, c_void_p,
                                    c_void_p, c_void_p]),
     "agx_conv_pack_sigma": (c_int, [_PD, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "agx_conv_grouped_bwd_data": (c_int, [_PD, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
+                                          c_void_p]),
+    "agx_conv_grouped_bwd_weight_workspace_bytes": (c_size_t, [_PD]),
+    "agx_conv_grouped_bwd_weight": (c_int, [_PD, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "agx_conv_pack_bwd_sigma": (c_int, [_PD, c_void_p, c_void_p, c_void_p, c_void_p]),
     "agx_avgpool1d_out_len": (c_int64, [c_int32, c_int32, c_int32, c_int32]),
     "agx_avgpool1d": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "agx_conv2d_out_shape": (c_int, [_P2, POINTER(c_int32), POINTER(c_int32)]),

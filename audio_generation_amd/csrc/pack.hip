@@ -132,22 +132,37 @@ extern "C" int64_t agx_conv_bwd_packed_floats(const agx_conv_desc *d) {
     return agx::packed_weight_floats(b.Cin, b.J, b.M) + dim0;
 }
 
-extern "C" int agx_conv_pack_bwd(const agx_conv_desc *d, const float *v, const float *g, float *packed,
-                                 void *stream) {
+static int pack_backward(const agx_conv_desc *d, const float *v, const float *g, const float *sigma, float *packed,
+                         hipStream_t st, const char *who) {
     using namespace agx;
     ConvPlan f, b;
     int rc = lower_conv(d, &f);
     if (rc != AGX_OK) return rc;
     rc = lower_conv_bwd_data(d, &b);
     if (rc != AGX_OK) return rc;
-    if (!v || !packed) return fail(AGX_ERR_NULL_POINTER, "agx_conv_pack_bwd: NULL pointer");
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!v || !packed) return fail(AGX_ERR_NULL_POINTER, "%s: NULL pointer", who);
     const int64_t n_w = packed_weight_floats(b.Cin, b.J, b.M);
     float *scale = packed + n_w;
-    pack_scales(d, v, g, scale, st);
+    if (sigma) {
+        const int dim0 = d->kind == AGX_CONV_TRANSPOSED ? d->c_in : d->c_out;
+        hipLaunchKernelGGL(fill_inv_sigma_kernel, dim3(ceil_div(dim0, 256)), dim3(256), 0, st, scale, dim0, sigma);
+    } else {
+        pack_scales(d, v, g, scale, st);
+    }
     hipLaunchKernelGGL(pack_bwd_kernel, dim3((unsigned)ceil_div64(n_w, 256)), dim3(256), 0, st, v, scale, packed,
                        d->kind, f.Cin, f.Cout, d->kernel, f.q, f.J, f.P, f.s, d->stride, b.J, b.q);
-    return check_launch("agx_conv_pack_bwd");
+    return check_launch(who);
+}
+
+extern "C" int agx_conv_pack_bwd(const agx_conv_desc *d, const float *v, const float *g, float *packed,
+                                 void *stream) {
+    return pack_backward(d, v, g, nullptr, packed, static_cast<hipStream_t>(stream), "agx_conv_pack_bwd");
+}
+
+extern "C" int agx_conv_pack_bwd_sigma(const agx_conv_desc *d, const float *w, const float *sigma, float *packed,
+                                       void *stream) {
+    if (!sigma) return agx::fail(AGX_ERR_NULL_POINTER, "agx_conv_pack_bwd_sigma: NULL sigma");
+    return pack_backward(d, w, nullptr, sigma, packed, static_cast<hipStream_t>(stream), "agx_conv_pack_bwd_sigma");
 }
 
 static int pack_forward(const agx_conv_desc *d, const float *v, const float *g, const float *sigma,

@@ -149,6 +149,30 @@ class _SNConv(nn.Module):
             dx = ops.conv2d_bwd_data(desc, dy, ops.conv2d_pack_bwd(desc, w, sigma), mask, slope, add)
         return dx, ([db, dw] if self.bias is not None else [dw])
 
+    def desc1d(self, x: Tensor, slope: Optional[float] = None):
+        return ops.conv_desc(CONV_PADDED, x.shape[0], self.in_channels, self.out_channels, x.shape[2],
+                             self.kernel_size[0], self.stride[0], 1, EPI_LEAKY_PRE if slope is not None else 0,
+                             slope or 0.0, groups=self.groups, padding=self.padding[0])
+
+    def bwd1d(self, x: Tensor, dz: Tensor, tape, need_dx: bool = True, add: Optional[Tensor] = None,
+              mask: Optional[Tensor] = None, slope: float = 0.2):
+        """(dx or None, [dbias, dweight]) of this 1-D layer for the forward that produced ``tape``."""
+        desc = self.desc1d(x)
+        w = self.raw_weight.detach()
+        sigma, u, v = tape if tape is not None else (None, None, None)
+        if self.groups > 1:
+            dw, db = ops.conv_grouped_bwd_weight(desc, x, dz, want_bias=self.bias is not None)
+            dx = ops.conv_grouped_bwd_data(desc, dz, w, sigma, add, mask, slope) if need_dx else None
+        else:
+            dw, _, db = ops.conv_bwd_weight(desc, x, dz, w, None, want_bias=self.bias is not None)
+            dx = None
+            if need_dx:
+                pk = ops.conv_pack_bwd(desc, w) if sigma is None else ops.conv_pack_bwd_sigma(desc, w, sigma)
+                dx = ops.conv_bwd_data(desc, dz, pk, add, mask, slope)
+        if sigma is not None:
+            ops.spectral_grad_(dw, w, sigma, u, v)
+        return dx, ([db, dw] if self.bias is not None else [dw])
+
     def grad_params(self):
         return ([self.bias] if self.bias is not None else []) + [self.raw_weight]
 
@@ -250,6 +274,9 @@ class WaveformDiscriminatorBlock(nn.Module):
         return [self.final_activation(x)] + feats
 
     def forward(self, x: Tensor):
+        if needs_grad(x, self) and all(isinstance(l[1], nn.LeakyReLU) for l in self.layers if isinstance(l, nn.Sequential)):
+            flat = _WaveBlockNative.apply(self, x, *list(self.parameters()))
+            return flat[0], list(flat[1:])
         outs, feats = _run_bridged(self, x, self._hip, self._aten, 1)
         return outs[0], feats
 
@@ -361,6 +388,66 @@ class STFTDiscriminator(nn.Module):
             return [flat[0]], list(flat[1:])
         outs, feats = _run_bridged(self, x, self._hip, self._aten, 1)
         return outs, feats
+
+
+class _WaveBlockNative(torch.autograd.Function):
+    """WaveformDiscriminatorBlock forward + hand-written backward on the HIP kernels (same scheme as
+    _STFTDiscNative: per layer one dW call and one bwd-data call with the feature gradient and the LeakyReLU
+    gradient of the layer below fused in)."""
+
+    @staticmethod
+    def forward(ctx, blk, x: Tensor, *params: Tensor):
+        pool = blk.layers[0]
+        one = lambda t: t[0] if isinstance(t, tuple) else t  # noqa: E731
+        ctx.pool = (one(pool.kernel_size), one(pool.stride), one(pool.padding))
+        with torch.no_grad():
+            h = ops.avgpool1d(x.detach(), *ctx.pool)
+            feats, convs, slopes, tapes = [h], [], [], []
+            for layer in list(blk.layers)[1:]:
+                conv, act = (layer[0], layer[1]) if isinstance(layer, nn.Sequential) else (layer, None)
+                sl = None if act is None else _slope(act)
+                h = conv.run1d(h, sl)
+                tapes.append(conv._tape)
+                convs.append(conv)
+                slopes.append(sl)
+                feats.append(h)
+            sig = isinstance(blk.final_activation, nn.Sigmoid)
+            out = ops.sigmoid(h) if sig else h.clone()
+        ctx.convs, ctx.slopes, ctx.tapes, ctx.sig, ctx.params, ctx.l_in = convs, slopes, tapes, sig, params, x.shape[-1]
+        ctx.save_for_backward(out, *feats)
+        return (out, *feats)
+
+    @staticmethod
+    def backward(ctx, g_out: Optional[Tensor], *g_feats: Optional[Tensor]):
+        saved = ctx.saved_tensors
+        out, feats = saved[0], saved[1:]
+        convs, slopes, tapes = ctx.convs, ctx.slopes, ctx.tapes
+        gf = [None if g is None else g.contiguous() for g in g_feats]
+        grads = {}
+        # gradient w.r.t. the last conv's output (a feature too): from the sigmoid output and from the feature loss
+        dz = None
+        if g_out is not None:
+            dz = ops.sigmoid_backward(g_out.contiguous(), out) if ctx.sig else g_out.contiguous()
+        if gf[-1] is not None:
+            dz = gf[-1] if dz is None else dz + gf[-1]
+        for i in range(len(convs) - 1, -1, -1):
+            x_in = feats[i]                      # input of conv i (= feature i: pooled input or the layer below)
+            if dz is None:
+                dz = gf[i]                       # nothing from above: the feature gradient, if any, starts the chain
+                if dz is not None and i > 0 and slopes[i - 1] is not None:
+                    dz = torch.where(x_in > 0, dz, dz * slopes[i - 1])
+                continue
+            below = slopes[i - 1] if i > 0 else None      # activation that produced x_in
+            need_dx = i > 0 or ctx.needs_input_grad[1]
+            dxl, gl = convs[i].bwd1d(x_in, dz, tapes[i], need_dx=need_dx, add=gf[i],
+                                     mask=x_in if below is not None else None, slope=below or 0.0)
+            for p_, g_ in zip(convs[i].grad_params(), gl):
+                grads[p_] = g_
+            dz = dxl
+        dx = None
+        if ctx.needs_input_grad[1] and dz is not None:
+            dx = ops.avgpool1d_backward(dz, ctx.l_in, *ctx.pool)
+        return (None, dx, *[grads.get(p_) for p_ in ctx.params])
 
 
 class _STFTDiscNative(torch.autograd.Function):

@@ -368,6 +368,47 @@ def conv_pack_sigma(desc: ConvDesc, w: Tensor, sigma: Tensor) -> Tensor:
     return packed
 
 
+def conv_pack_bwd_sigma(desc: ConvDesc, w: Tensor, sigma: Tensor) -> Tensor:
+    lib = _lib.load()
+    _need_gpu(w, sigma)
+    n = lib.agx_conv_bwd_packed_floats(ctypes.byref(desc))
+    if n < 0:
+        _lib.check(int(n), "agx_conv_bwd_packed_floats")
+    w = _f32c(w)
+    packed = torch.empty(int(n), dtype=torch.float32, device=w.device)
+    _lib.check(lib.agx_conv_pack_bwd_sigma(ctypes.byref(desc), _ptr(w), _ptr(sigma), _ptr(packed), _stream()),
+               "agx_conv_pack_bwd_sigma")
+    return packed
+
+
+def conv_grouped_bwd_data(desc: ConvDesc, dz: Tensor, w: Tensor, sigma: Optional[Tensor] = None,
+                          add: Optional[Tensor] = None, mask: Optional[Tensor] = None, slope: float = 0.2) -> Tensor:
+    lib = _lib.load()
+    _need_gpu(dz, w, sigma, add, mask)
+    dz, w = _f32c(dz), _f32c(w)
+    add = None if add is None else _f32c(add)
+    mask = None if mask is None else _f32c(mask)
+    dx = torch.empty(desc.batch, desc.c_in, desc.l_in, dtype=torch.float32, device=dz.device)
+    _lib.check(lib.agx_conv_grouped_bwd_data(ctypes.byref(desc), _ptr(dz), _ptr(w), _ptr(sigma), _ptr(add), _ptr(mask),
+                                             slope, _ptr(dx), _stream()), "agx_conv_grouped_bwd_data")
+    return dx
+
+
+def conv_grouped_bwd_weight(desc: ConvDesc, x: Tensor, dz: Tensor, want_bias: bool = True):
+    """Plain (dw, dbias) of a grouped AGX_CONV_PADDED layer; dw has the torch layout (c_out, c_in / groups, K)."""
+    lib = _lib.load()
+    _need_gpu(x, dz)
+    x, dz = _f32c(x), _f32c(dz)
+    g = max(desc.groups, 1)
+    dw = torch.empty(desc.c_out, desc.c_in // g, desc.kernel, dtype=torch.float32, device=x.device)
+    db = torch.empty(desc.c_out, dtype=torch.float32, device=x.device) if want_bias else None
+    nbytes = int(lib.agx_conv_grouped_bwd_weight_workspace_bytes(ctypes.byref(desc)))
+    ws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=x.device)
+    _lib.check(lib.agx_conv_grouped_bwd_weight(ctypes.byref(desc), _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), _ptr(ws),
+                                               nbytes, _stream()), "agx_conv_grouped_bwd_weight")
+    return dw, db
+
+
 def avgpool1d(x: Tensor, kernel: int, stride: int, padding: int) -> Tensor:
     lib = _lib.load()
     _need_gpu(x)

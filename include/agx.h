@@ -259,6 +259,17 @@ int agx_spectral_sigma(const float *w, int32_t rows, int32_t cols, float *u, flo
 int agx_conv_pack_sigma(const agx_conv_desc *d, const float *w, const float *sigma, float *packed,
                         void *stream);
 
+/* Backward of grouped AGX_CONV_PADDED layers (dilation 1), VALU kernels on the torch weight layout
+ * w (c_out, c_in / groups, K); sigma (device scalar, may be NULL) divides w.  add / mask / slope as in
+ * agx_conv_bwd_data.  bwd_weight returns the PLAIN weight gradient (apply agx_spectral_grad afterwards). */
+int agx_conv_grouped_bwd_data(const agx_conv_desc *d, const float *dz, const float *w, const float *sigma,
+                              const float *add, const float *mask, float slope, float *dx, void *stream);
+size_t agx_conv_grouped_bwd_weight_workspace_bytes(const agx_conv_desc *d);
+int agx_conv_grouped_bwd_weight(const agx_conv_desc *d, const float *x, const float *dz, float *dw, float *dbias,
+                                void *workspace, size_t workspace_bytes, void *stream);
+/* agx_conv_pack_bwd for a spectrally normalised dense layer (rows scaled by 1 / sigma[0]). */
+int agx_conv_pack_bwd_sigma(const agx_conv_desc *d, const float *w, const float *sigma, float *packed, void *stream);
+
 /* torch.nn.AvgPool1d(kernel, stride, padding) with count_include_pad=True (discriminator.py:32) over
  * `rows` independent rows of length l_in; returns the output length via agx_avgpool1d_out_len. */
 int64_t agx_avgpool1d_out_len(int32_t l_in, int32_t kernel, int32_t stride, int32_t padding);

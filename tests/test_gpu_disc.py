@@ -381,3 +381,41 @@ def test_stft_discriminator_backward_runs_on_the_native_kernels(monkeypatch):
     (gl + dl).backward()
     assert calls["bridge"] == 0 and calls["dw"] == 3 * 14 and calls["dx"] == 3 * 14
     assert rec.grad is not None and all(p.grad is not None for p in d.parameters())
+
+
+@pytest.mark.parametrize("cin,cout,k,s,g,pad,length", [(16, 64, 41, 4, 4, 0, 3000), (64, 256, 41, 4, 16, 0, 900),
+                                                         (512, 1024, 41, 4, 256, 0, 200), (6, 9, 4, 3, 3, 2, 50),
+                                                         (8, 8, 5, 1, 2, 1, 33)])
+def test_grouped_conv1d_backward(cin, cout, k, s, g, pad, length):
+    torch.manual_seed(cin + k)
+    pre = torch.randn(2, cin, length)
+    x = F.leaky_relu(pre, 0.2).detach().requires_grad_(True)
+    w = (torch.randn(cout, cin // g, k) / (cin // g * k) ** 0.5).requires_grad_(True)
+    b = torch.randn(cout, requires_grad=True)
+    sigma = torch.tensor([0.37])
+    y = F.conv1d(x, w / sigma, b, stride=s, padding=pad, groups=g)
+    dz = torch.randn_like(y)
+    y.backward(dz)
+    d = ops.conv_desc(CONV_PADDED, 2, cin, cout, length, k, s, 1, 0, 0.2, 0, groups=g, padding=pad)
+    extra = torch.randn(2, cin, length)
+    dx = ops.conv_grouped_bwd_data(d, dz.to(DEV), w.detach().to(DEV), sigma.to(DEV), extra.to(DEV), x.detach().to(DEV), 0.2)
+    close(dx, (x.grad + extra) * torch.where(x.detach() > 0, 1.0, 0.2), 2e-5)
+    dw, db = ops.conv_grouped_bwd_weight(d, x.detach().to(DEV), dz.to(DEV))
+    close(dw, w.grad * sigma, 1e-4)          # plain gradient (w.r.t. w / sigma)
+    close(db, b.grad, 2e-5)
+
+
+def test_waveform_discriminator_backward_runs_on_the_native_kernels(monkeypatch):
+    torch.manual_seed(6)
+    d = ad.WaveFormDiscriminator(1, n_blocks=2).to(DEV).train()
+    calls = {"bridge": 0, "grouped": 0}
+    real_b = ad._MultiOutBridge.apply
+    monkeypatch.setattr(ad._MultiOutBridge, "apply", lambda *a, **k: (calls.__setitem__("bridge", calls["bridge"] + 1), real_b(*a, **k))[1])
+    real_g = ops.conv_grouped_bwd_weight
+    monkeypatch.setattr(ops, "conv_grouped_bwd_weight", lambda *a, **k: (calls.__setitem__("grouped", calls["grouped"] + 1), real_g(*a, **k))[1])
+    orig = 0.3 * torch.randn(2, 1, 16384, device=DEV)
+    rec = (orig + 0.05 * torch.randn_like(orig)).requires_grad_(True)
+    gl, dl = ad.discriminator_generator_loss(orig, rec, d)
+    (gl + dl).backward()
+    assert calls["bridge"] == 0 and calls["grouped"] == 3 * 2 * 4
+    assert rec.grad is not None and all(p.grad is not None for p in d.parameters())
