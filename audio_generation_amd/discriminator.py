@@ -552,9 +552,13 @@ def discriminator_generator_loss(original: Tensor, reconstruction: Tensor, discr
                                  feature_multipier: float = 100, scale_feature_loss: bool = True):
     """discriminator.py:204-246 (argument spelling kept): three passes through the discriminator, hinge
     GAN terms averaged over its outputs, L1 feature matching."""
-    original_d, original_features = discriminator(original.clone().requires_grad_())
+    # The reference feeds ``original.clone().requires_grad_()`` and ``reconstruction.detach().clone().requires_grad_()``
+    # to the real / detached-fake passes; those clones are local leaves nobody reads, so their input gradients
+    # (first-conv backward-data + STFT adjoint, per discriminator) are simply not requested here.  Parameter
+    # gradients are unaffected.
+    original_d, original_features = discriminator(original.detach())
     reconstruction_d, reconstruction_features = discriminator(reconstruction)
-    reconstruction_d2, _ = discriminator(reconstruction.detach().clone().requires_grad_())
+    reconstruction_d2, _ = discriminator(reconstruction.detach())
     k = len(original_d)
     discriminator_loss, generation_loss = 0, 0
     for x, y, y_disc in zip(original_d, reconstruction_d, reconstruction_d2):

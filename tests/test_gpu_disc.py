@@ -366,7 +366,7 @@ def test_small_backward_kernels():
 
 def test_stft_discriminator_backward_runs_on_the_native_kernels(monkeypatch):
     """No ATen bridge on the STFT discriminator: 14 layers x 3 passes of dW calls, bwd-data everywhere but the
-    first conv of the passes whose input needs no gradient."""
+    first conv of the two passes whose input needs no gradient (real, detached fake)."""
     torch.manual_seed(5)
     d = ad.STFTDiscriminator(first_channel_size=16, win_length=256).to(DEV).train()
     calls = {"dw": 0, "dx": 0, "bridge": 0}
@@ -379,7 +379,7 @@ def test_stft_discriminator_backward_runs_on_the_native_kernels(monkeypatch):
     rec = (orig + 0.05 * torch.randn_like(orig)).requires_grad_(True)
     gl, dl = ad.discriminator_generator_loss(orig, rec, d)
     (gl + dl).backward()
-    assert calls["bridge"] == 0 and calls["dw"] == 3 * 14 and calls["dx"] == 3 * 14
+    assert calls["bridge"] == 0 and calls["dw"] == 3 * 14 and calls["dx"] == 14 + 2 * 13
     assert rec.grad is not None and all(p.grad is not None for p in d.parameters())
 
 
