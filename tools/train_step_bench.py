@@ -7,8 +7,8 @@ same code on a box with fewer GPUs than ranks).
 AGX_GAN=1 adds the reference's six training discriminators (training.py:570-576) and runs the step as
 Trainer.mini_epoch does (training.py:363-385): discriminator_generator_loss per discriminator, the
 discriminator loss backward, the generator loss backward, one Adam step each -- BASELINE config 5 without the
-mel / pre-emphasis terms (torchaudio).  Discriminator forwards run on the HIP kernels; their
-backward is still the ATen bridge (discriminator.py), so this number is a starting point, not a roofline.
+mel / pre-emphasis terms (torchaudio).  Discriminator forward AND backward run on the HIP kernels
+(discriminator.py: _STFTDiscNative / _WaveBlockNative); the all-reduce then covers generator + discriminator grads.
 usage: [torchrun --nproc-per-node N] train_step_bench.py [batch_per_gpu] [steps]"""
 import json
 import os
@@ -94,7 +94,7 @@ def main():
     same = abs(agx_dist.max_over_ranks(chk, device=dev if backend == "nccl" else "cpu") - chk) < 1e-9 * max(1.0, abs(chk))
     if rank == 0:
         print(json.dumps({"what": "train step (fwd + native bwd + grad all-reduce + Adam), config S" +
-                          (f" + {len(discs)} discriminators (HIP forward, bridged backward)" if gan else ""),
+                          (f" + {len(discs)} discriminators (native forward + backward)" if gan else ""),
                           "n_gpus": world, "batch_per_gpu": batch, "ms_per_step": ms, "replicas_in_sync": same,
                           "samples_per_s": world * batch * 72000 / ms * 1e3, "losses": losses,
                           "approx_tflops_at_3x_forward": world * 3 * fwd_flop / ms * 1e-9,
