@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libagx.so")
 # constants mirrored from include/agx.h
 CONV_CAUSAL, CONV_TRANSPOSED, CONV_UPSAMPLE, CONV_SAME, CONV_PADDED = 0, 1, 2, 3, 4
 IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA = 0, 1, 2
-EPI_LEAKY_PRE, EPI_RESIDUAL, EPI_LEAKY_POST, EPI_GELU_PRE, EPI_MASK = 1, 2, 4, 8, 16
+EPI_LEAKY_PRE, EPI_RESIDUAL, EPI_LEAKY_POST, EPI_GELU_PRE, EPI_MASK, EPI_GELU_GRAD = 1, 2, 4, 8, 16, 32
 
 
 class ConvDesc(Structure):
@@ -72,6 +72,11 @@ SIGNATURES = {
                                  c_void_p]),
     "agx_attention_alibi": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float,
                                     c_void_p]),
+    "agx_layernorm_ct_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p]),
+    "agx_attention_alibi_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                                             c_int32, c_float, c_void_p]),
+    "agx_conv_bwd_data_gelu": (c_int, [_PD, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "agx_multires_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                      c_int32, c_int32, c_void_p]),
     "agx_wavelet_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32,

@@ -1,7 +1,8 @@
-"""Interim trainability: HIP forward, ATen backward.
+"""Fallback trainability: HIP forward, ATen backward.
 
-SURVEY 8(f1) -- hand-written backward kernels -- is the next row, not built
-yet.  Until then a module that must be differentiated runs
+Every default path has hand-written backward kernels now (native_backward.py, transformers.py,
+discriminator.py); this bridge is what remains for the shapes they do not cover (attention head_dim > 64,
+discriminators with an activation other than LeakyReLU, encoder stacks with norm != Identity).  Such a module runs
 
 * **forward** through libagx exactly as in inference (no autograd graph), and
 * **backward** by re-evaluating an ATen restatement of the same module

@@ -177,9 +177,259 @@ static int launch_attn(const float *qkv, const float *slopes, float *out, int B,
     return check_launch("attention_alibi");
 }
 
+// ---------------------------------------------------------------------- LayerNorm backward
+// Same decomposition as the forward (block = 64 time steps x all channels).  Per column:
+//   dxhat_c = dy_c w_c,  dx_c = rstd (dxhat_c - mean_c(dxhat) - xhat_c mean_c(dxhat xhat)) [+ add]
+// and per block the partial sums of dy xhat / dy over its 64 columns (reduced by ln_param_reduce_kernel).
+__global__ __launch_bounds__(256) void layernorm_ct_bwd_kernel(const float *__restrict__ x,
+                                                               const float *__restrict__ weight,
+                                                               const float *__restrict__ dy,
+                                                               const float *__restrict__ add, float *__restrict__ dx,
+                                                               float *__restrict__ part, int C, int T, float eps) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + lane;
+    const bool live = t < T;
+    const int tc = min(t, T - 1);
+    const size_t base = size_t(blockIdx.y) * C * T + tc;
+    auto colsum = [&](float v) -> float {
+        __syncthreads();
+        red[wave][lane] = v;
+        __syncthreads();
+        return (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    };
+    float s = 0.f;
+    for (int c = wave; c < C; c += 4) s += x[base + size_t(c) * T];
+    const float mean = colsum(s) / float(C);
+    float v = 0.f;
+    for (int c = wave; c < C; c += 4) {
+        const float d = x[base + size_t(c) * T] - mean;
+        v = fmaf(d, d, v);
+    }
+    const float rstd = 1.f / sqrtf(colsum(v) / float(C) + eps);
+    const int blk = blockIdx.y * gridDim.x + blockIdx.x, nblk = gridDim.x * gridDim.y;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = wave; c < C; c += 4) {
+        const float xh = (x[base + size_t(c) * T] - mean) * rstd;
+        const float g = live ? dy[base + size_t(c) * T] : 0.f;
+        const float dxh = g * (weight ? weight[c] : 1.f);
+        s1 += dxh;
+        s2 = fmaf(dxh, xh, s2);
+        float pg = g * xh, pb = g;          // parameter gradients: sum over this block's columns
+        for (int off = 32; off > 0; off >>= 1) {
+            pg += __shfl_xor(pg, off);
+            pb += __shfl_xor(pb, off);
+        }
+        if (lane == 0) {
+            part[size_t(blk) * C + c] = pg;
+            part[(size_t(nblk) + blk) * C + c] = pb;
+        }
+    }
+    const float m1 = colsum(s1) / float(C);
+    const float m2 = colsum(s2) / float(C);
+    if (!live) return;
+    for (int c = wave; c < C; c += 4) {
+        const size_t e = base + size_t(c) * T;
+        const float xh = (x[e] - mean) * rstd;
+        const float dxh = dy[e] * (weight ? weight[c] : 1.f);
+        dx[e] = rstd * (dxh - m1 - xh * m2) + (add ? add[e] : 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float *__restrict__ part, int nblk, int C,
+                                                              float *__restrict__ dweight, float *__restrict__ dbias) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float g = 0.f, b = 0.f;
+    for (int k = 0; k < nblk; ++k) {
+        g += part[size_t(k) * C + c];
+        b += part[(size_t(nblk) + k) * C + c];
+    }
+    if (dweight) dweight[c] = g;
+    if (dbias) dbias[c] = b;
+}
+
+// ---------------------------------------------------------------------- attention backward
+// One workgroup per (head, batch item); K and V (Dh x T each) stay in LDS, the queries are walked in blocks
+// of QB.  Config 3 is 225 frames x 8 heads x 64: 8 GFLOP per batch -- a VALU kernel (the forward's
+// register-resident MFMA formulation does not carry over: dK / dV accumulate across query blocks).
+//   P = softmax(Q^T K / scale + alibi),  dP = dO^T V,  dS = P (dP - rowsum(dP P)),
+//   dQ = dS K^T / scale,  dK = dS^T Q / scale,  dV = P^T dO
+template <int QB>
+__global__ __launch_bounds__(256) void attention_alibi_bwd_kernel(const float *__restrict__ qkv,
+                                                                  const float *__restrict__ slopes,
+                                                                  const float *__restrict__ dout,
+                                                                  float *__restrict__ dqkv, int H, int Dh, int T,
+                                                                  float scale_div) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *Ks = sm;                   // [Dh][T]
+    float *Vs = Ks + Dh * T;          // [Dh][T]
+    float *Qs = Vs + Dh * T;          // [Dh][QB]
+    float *Os = Qs + Dh * QB;         // [Dh][QB]   (dO block)
+    float *Ps = Os + Dh * QB;         // [QB][T]
+    float *Ss = Ps + QB * T;          // [QB][T]    (dS / scale)
+    __shared__ float rowa[QB][16], rowb[QB][16];
+    const int tid = threadIdx.x;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int HD = H * Dh;
+    const float *qg = qkv + (size_t(b) * 3 * HD + h * Dh) * T;
+    const float *kg = qg + size_t(HD) * T, *vg = kg + size_t(HD) * T;
+    const float *og = dout + (size_t(b) * HD + h * Dh) * T;
+    float *dqg = dqkv + (size_t(b) * 3 * HD + h * Dh) * T;
+    float *dkg = dqg + size_t(HD) * T, *dvg = dkg + size_t(HD) * T;
+    const float slope = slopes[h], inv = 1.f / scale_div;
+    for (int e = tid; e < Dh * T; e += 256) {
+        Ks[e] = kg[e];
+        Vs[e] = vg[e];
+    }
+    constexpr int MAXE = 64;          // dK / dV elements per thread: Dh * T <= 64 * 256
+    float dk[MAXE], dv[MAXE];
+#pragma unroll
+    for (int u = 0; u < MAXE; ++u) dk[u] = dv[u] = 0.f;
+    const int rq = tid / 16, rl = tid % 16;  // softmax: 16 threads per query row (QB <= 16)
+    for (int i0 = 0; i0 < T; i0 += QB) {
+        __syncthreads();
+        for (int e = tid; e < Dh * QB; e += 256) {
+            const int d = e / QB, q = e - d * QB, i = min(i0 + q, T - 1);
+            Qs[e] = qg[size_t(d) * T + i];
+            Os[e] = (i0 + q < T) ? og[size_t(d) * T + i] : 0.f;
+        }
+        __syncthreads();
+        // scores and dP
+        for (int e = tid; e < QB * T; e += 256) {
+            const int q = e / T, j = e - q * T;
+            float sacc = 0.f, pacc = 0.f;
+            for (int d = 0; d < Dh; ++d) {
+                sacc = fmaf(Qs[d * QB + q], Ks[d * T + j], sacc);
+                pacc = fmaf(Os[d * QB + q], Vs[d * T + j], pacc);
+            }
+            Ps[e] = sacc * inv - fabsf(float(i0 + q - j)) * slope;
+            Ss[e] = pacc;
+        }
+        __syncthreads();
+        // row softmax + delta = sum_j dP P
+        if (rq < QB) {
+            float mx = -3.0e38f;
+            for (int j = rl; j < T; j += 16) mx = fmaxf(mx, Ps[rq * T + j]);
+            rowa[rq][rl] = mx;
+        }
+        __syncthreads();
+        if (rq < QB) {
+            float mx = rowa[rq][0];
+            for (int k = 1; k < 16; ++k) mx = fmaxf(mx, rowa[rq][k]);
+            float sum = 0.f;
+            for (int j = rl; j < T; j += 16) {
+                const float pe = expf(Ps[rq * T + j] - mx);
+                Ps[rq * T + j] = pe;
+                sum += pe;
+            }
+            rowb[rq][rl] = sum;
+        }
+        __syncthreads();
+        if (rq < QB) {
+            float sum = 0.f;
+            for (int k = 0; k < 16; ++k) sum += rowb[rq][k];
+            const float rs = 1.f / sum;
+            float dl = 0.f;
+            for (int j = rl; j < T; j += 16) {
+                const float pn = Ps[rq * T + j] * rs;
+                Ps[rq * T + j] = pn;
+                dl = fmaf(pn, Ss[rq * T + j], dl);
+            }
+            rowa[rq][rl] = dl;     // rowa (the row maxima) was last read before the previous barrier
+        }
+        __syncthreads();
+        if (rq < QB) {
+            float dl = 0.f;
+            for (int k = 0; k < 16; ++k) dl += rowa[rq][k];
+            const bool qlive = i0 + rq < T;
+            for (int j = rl; j < T; j += 16) {
+                const float pn = qlive ? Ps[rq * T + j] : 0.f;
+                Ps[rq * T + j] = pn;                                   // rows past T contribute nothing
+                Ss[rq * T + j] = pn * (Ss[rq * T + j] - dl) * inv;     // dS / scale
+            }
+        }
+        __syncthreads();
+        // dQ[d][q] = sum_j dS[q][j] K[d][j]
+        for (int e = tid; e < Dh * QB; e += 256) {
+            const int d = e / QB, q = e - d * QB;
+            if (i0 + q >= T) continue;
+            float acc = 0.f;
+            for (int j = 0; j < T; ++j) acc = fmaf(Ss[q * T + j], Ks[d * T + j], acc);
+            dqg[size_t(d) * T + i0 + q] = acc;
+        }
+        // dK[d][j] += sum_q dS[q][j] Q[d][q],  dV[d][j] += sum_q P[q][j] dO[d][q]
+#pragma unroll
+        for (int u = 0; u < MAXE; ++u) {
+            const int e = tid + u * 256;
+            if (e < Dh * T) {
+                const int d = e / T, j = e - d * T;
+                float ak = dk[u], av = dv[u];
+#pragma unroll
+                for (int q = 0; q < QB; ++q) {
+                    ak = fmaf(Ss[q * T + j], Qs[d * QB + q], ak);
+                    av = fmaf(Ps[q * T + j], Os[d * QB + q], av);
+                }
+                dk[u] = ak;
+                dv[u] = av;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < MAXE; ++u) {
+        const int e = tid + u * 256;
+        if (e < Dh * T) {
+            dkg[e] = dk[u];
+            dvg[e] = dv[u];
+        }
+    }
+}
+
 }  // namespace agx
 
 extern "C" {
+
+int agx_layernorm_ct_backward(const float *x, const float *weight, const float *dy, const float *add, float *dx,
+                              float *dweight, float *dbias, float *workspace, int32_t batch, int32_t channels,
+                              int32_t t, float eps, void *stream) {
+    using namespace agx;
+    if (batch <= 0 || channels <= 0 || t <= 0) return fail(AGX_ERR_BAD_SHAPE, "layernorm_ct_backward: bad shape");
+    if (!x || !dy || !dx || !workspace) return fail(AGX_ERR_NULL_POINTER, "layernorm_ct_backward: NULL pointer");
+    if (batch > 65535) return fail(AGX_ERR_BAD_SHAPE, "layernorm_ct_backward: grid too large");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(ceil_div(t, 64), batch);
+    hipLaunchKernelGGL(layernorm_ct_bwd_kernel, grid, dim3(256), 0, st, x, weight, dy, add, dx, workspace, channels, t,
+                       eps);
+    if (dweight || dbias)
+        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(ceil_div(channels, 256)), dim3(256), 0, st, workspace,
+                           int(grid.x * grid.y), channels, dweight, dbias);
+    return check_launch("agx_layernorm_ct_backward");
+}
+
+int agx_attention_alibi_backward(const float *qkv, const float *slopes, const float *dout, float *dqkv, int32_t batch,
+                                 int32_t heads, int32_t head_dim, int32_t t, float scale_div, void *stream) {
+    using namespace agx;
+    if (batch <= 0 || heads <= 0 || head_dim <= 0 || t <= 0)
+        return fail(AGX_ERR_BAD_SHAPE, "attention_alibi_backward: bad shape");
+    if (!qkv || !slopes || !dout || !dqkv) return fail(AGX_ERR_NULL_POINTER, "attention_alibi_backward: NULL pointer");
+    if (t > 256 || head_dim > 64) return fail(AGX_ERR_UNSUPPORTED, "attention_alibi_backward: T <= 256, head_dim <= 64");
+    if (heads > 65535 || batch > 65535) return fail(AGX_ERR_BAD_SHAPE, "attention_alibi_backward: grid too large");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    auto lds_of = [&](int qb) { return size_t(2 * head_dim * t + 2 * head_dim * qb + 2 * qb * t) * sizeof(float); };
+    const dim3 grid(heads, batch);
+    // the kernel also holds 2 KB of static LDS (row reductions): ask for 156 KB of dynamic space at most
+    constexpr size_t kDynMax = 156 * 1024;
+    auto run = [&](auto kern, int qb) -> int {
+        if (lds_of(qb) > kDynMax) return fail(AGX_ERR_UNSUPPORTED, "attention_alibi_backward: needs %zu B of LDS", lds_of(qb));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(kDynMax));
+        if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds_of(qb), st, qkv, slopes, dout, dqkv, heads, head_dim, t, scale_div);
+        return check_launch("agx_attention_alibi_backward");
+    };
+    return lds_of(16) <= 150 * 1024 ? run(attention_alibi_bwd_kernel<16>, 16) : run(attention_alibi_bwd_kernel<8>, 8);
+}
+
 
 int agx_layernorm_ct(const float *x, const float *weight, const float *bias, float *y, int32_t batch,
                      int32_t channels, int32_t t, float eps, void *stream) {

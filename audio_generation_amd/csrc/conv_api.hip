@@ -50,6 +50,18 @@ int agx_conv_bwd_data(const agx_conv_desc *d, const float *dy, const float *pack
     return run_conv(p, d->impl, dy, packed_bwd, nullptr, add, dx, static_cast<hipStream_t>(stream));
 }
 
+int agx_conv_bwd_data_gelu(const agx_conv_desc *d, const float *dy, const float *packed_bwd, const float *add,
+                           const float *pre, float *dx, void *stream) {
+    using namespace agx;
+    ConvPlan p;
+    int rc = lower_conv_bwd_data(d, &p);
+    if (rc != AGX_OK) return rc;
+    if (!dy || !packed_bwd || !dx || !pre) return fail(AGX_ERR_NULL_POINTER, "agx_conv_bwd_data_gelu: NULL pointer");
+    p.epilogue = (add ? AGX_EPI_RESIDUAL : 0) | AGX_EPI_GELU_GRAD;
+    p.mask = pre;
+    return run_conv(p, d->impl, dy, packed_bwd, nullptr, add, dx, static_cast<hipStream_t>(stream));
+}
+
 int agx_conv_kernel_name(const agx_conv_desc *d, char *buf, size_t buf_len) {
     using namespace agx;
     ConvPlan p;

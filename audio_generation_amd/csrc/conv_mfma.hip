@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
 
     // ---- epilogue.  All loads (bias, residual, mask) are issued on clamped addresses before
     // any use so they overlap; only the stores are predicated.
-    const bool has_res = (p.epilogue & AGX_EPI_RESIDUAL) != 0, has_mask = (p.epilogue & AGX_EPI_MASK) != 0;
+    const bool has_res = (p.epilogue & AGX_EPI_RESIDUAL) != 0;
+    const bool ggrad = (p.epilogue & AGX_EPI_GELU_GRAD) != 0, has_mask = (p.epilogue & AGX_EPI_MASK) != 0 || ggrad;
     const bool pre = (p.epilogue & AGX_EPI_LEAKY_PRE) != 0, post = (p.epilogue & AGX_EPI_LEAKY_POST) != 0;
     const bool gelu = (p.epilogue & AGX_EPI_GELU_PRE) != 0;
 #pragma unroll
@@ -164,7 +165,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
                 if (gelu) v = gelu_erf(v);
                 if (has_res) v += rv[r];
                 if (post) v = leaky(v, p.slope);
-                if (has_mask) v = mv[r] > 0.f ? v : v * p.slope;
+                if (ggrad) v *= gelu_grad(mv[r]);
+                else if (has_mask) v = mv[r] > 0.f ? v : v * p.slope;
                 const int u = t * p.q + ph[r] - p.oshift;
                 const bool ok = col_ok && row_ok[r] && (m0 + i * 32 + acc_row(r, lh)) < p.M && u >= 0 && u < p.Lout;
                 if (ok) y[off[r]] = v;

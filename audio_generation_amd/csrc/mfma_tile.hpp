@@ -45,6 +45,11 @@ __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? 
 // torch.nn.GELU() default (approximate='none'): 0.5 x (1 + erf(x / sqrt 2))
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
 
+// d/dx of the exact GELU
+__device__ __forceinline__ float gelu_grad(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // k-step mapping inside a CC-channel chunk: MFMA step ks multiplies channel

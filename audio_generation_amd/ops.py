@@ -294,6 +294,49 @@ def attention_alibi(qkv: Tensor, slopes: Tensor, heads: int, head_dim: int, scal
     return out
 
 
+def layernorm_ct_backward(x: Tensor, weight: Optional[Tensor], dy: Tensor, eps: float = 1e-5,
+                          add: Optional[Tensor] = None):
+    """(dx [+ add], dweight, dbias) of ``layernorm_ct``."""
+    lib = _lib.load()
+    _need_gpu(x, weight, dy, add)
+    x, dy = _f32c(x), _f32c(dy)
+    add = None if add is None else _f32c(add)
+    b, c, t = x.shape
+    dx = torch.empty_like(x)
+    dw = torch.empty(c, dtype=torch.float32, device=x.device)
+    db = torch.empty(c, dtype=torch.float32, device=x.device)
+    ws = torch.empty(2 * b * ((t + 63) // 64) * c, dtype=torch.float32, device=x.device)
+    _lib.check(lib.agx_layernorm_ct_backward(_ptr(x), _ptr(None if weight is None else _f32c(weight)), _ptr(dy),
+                                             _ptr(add), _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws), b, c, t, float(eps),
+                                             _stream()), "agx_layernorm_ct_backward")
+    return dx, dw, db
+
+
+def attention_alibi_backward(qkv: Tensor, slopes: Tensor, dout: Tensor, heads: int, head_dim: int,
+                             scale_div: float) -> Tensor:
+    lib = _lib.load()
+    _need_gpu(qkv, slopes, dout)
+    qkv, dout = _f32c(qkv), _f32c(dout)
+    b, _, t = qkv.shape
+    dqkv = torch.empty_like(qkv)
+    _lib.check(lib.agx_attention_alibi_backward(_ptr(qkv), _ptr(_f32c(slopes)), _ptr(dout), _ptr(dqkv), b, heads,
+                                                head_dim, t, float(scale_div), _stream()),
+               "agx_attention_alibi_backward")
+    return dqkv
+
+
+def conv_bwd_data_gelu(desc: ConvDesc, dy: Tensor, packed_bwd: Tensor, pre: Tensor, add: Optional[Tensor] = None) -> Tensor:
+    """``conv_bwd_data`` followed (in the epilogue) by the exact-GELU gradient at the pre-activation ``pre``."""
+    lib = _lib.load()
+    _need_gpu(dy, packed_bwd, pre, add)
+    dy, pre = _f32c(dy), _f32c(pre)
+    add = None if add is None else _f32c(add)
+    dx = torch.empty(desc.batch, desc.c_in, desc.l_in, dtype=torch.float32, device=dy.device)
+    _lib.check(lib.agx_conv_bwd_data_gelu(ctypes.byref(desc), _ptr(dy), _ptr(packed_bwd), _ptr(add), _ptr(pre), _ptr(dx),
+                                          _stream()), "agx_conv_bwd_data_gelu")
+    return dx
+
+
 # ------------------------------------------------------------------ wavelet layers
 def multires_forward(x: Tensor, h0: Tensor, h1: Tensor, w: Tensor, depth: int) -> Tensor:
     lib = _lib.load()

@@ -65,6 +65,7 @@ class _PackedLinear:
         self.key = None
         self.packed = None
         self.bias = None
+        self.w3d = None
 
     def get(self, linears):
         key = tuple((l.weight.data_ptr(), l.weight._version,
@@ -73,7 +74,8 @@ class _PackedLinear:
             w = torch.cat([l.weight.detach() for l in linears], dim=0)
             c_out, c_in = w.shape
             desc = ops.conv_desc(CONV_CAUSAL, 1, c_in, c_out, 1 << 20, 1)
-            self.packed = ops.conv_pack(desc, w.reshape(c_out, c_in, 1).contiguous())
+            self.w3d = w.reshape(c_out, c_in, 1).contiguous()      # the native backward reads it
+            self.packed = ops.conv_pack(desc, self.w3d)
             if any(l.bias is not None for l in linears):
                 self.bias = torch.cat([l.bias.detach() if l.bias is not None
                                        else torch.zeros(l.out_features, device=w.device) for l in linears])
@@ -163,6 +165,91 @@ class FeedForward(nn.Module):
         return self.run_bct(x.transpose(1, 2).contiguous()).transpose(1, 2).contiguous()
 
 
+def _lin_bwd(pl: "_PackedLinear", x_in: Tensor, dy: Tensor, c_out: int, pre: Optional[Tensor] = None,
+             need_dx: bool = True):
+    """Backward of ``_linear_ct`` (k=1 conv): (dx or None, dW (c_out, c_in), dbias or None); with ``pre`` the
+    GELU gradient of the layer BELOW (at its pre-activation) is fused into the bwd-data epilogue."""
+    b, c_in, t = x_in.shape
+    desc = ops.conv_desc(CONV_CAUSAL, b, c_in, c_out, t, 1)
+    dw, _, db = ops.conv_bwd_weight(desc, x_in, dy, pl.w3d, None, want_bias=pl.bias is not None)
+    dx = None
+    if need_dx:
+        pk = ops.conv_pack_bwd(desc, pl.w3d)
+        dx = ops.conv_bwd_data(desc, dy, pk) if pre is None else ops.conv_bwd_data_gelu(desc, dy, pk, pre)
+    return dx, dw.reshape(c_out, c_in), db
+
+
+class _TransformerNative(torch.autograd.Function):
+    """Transformer forward + hand-written backward on the HIP kernels: k=1 conv backward for every Linear,
+    ``agx_attention_alibi_backward``, ``agx_layernorm_ct_backward`` (residual adds fused as ``add``), the GELU
+    gradient in a bwd-data epilogue (the pre-activation is recomputed with one conv launch)."""
+
+    @staticmethod
+    def forward(ctx, tf, x: Tensor, *params: Tensor):
+        saved = []
+        with torch.no_grad():
+            h = x.detach()
+            for attention, ff in tf.layers:
+                ln1 = attention.norm
+                xn1 = ops.layernorm_ct(h, ln1.weight.detach(), ln1.bias.detach(), ln1.eps)
+                wqkv, bqkv = attention._qkv.get([attention.W_q, attention.W_k, attention.W_v])
+                qkv = _linear_ct(xn1, wqkv, bqkv, 3 * attention.inner_dim)
+                o = ops.attention_alibi(qkv, attention.alibi_obj.head_scalars, attention.n_heads, attention.dim_head,
+                                        attention.dim_head ** 0.5)
+                wo, bo = attention._o.get([attention.W_o])
+                x1 = _linear_ct(o, wo, bo, attention.dim, EPI_RESIDUAL, h)
+                ln2, l1, l2 = ff.net[0], ff.net[1], ff.net[4]
+                xn2 = ops.layernorm_ct(x1, ln2.weight.detach(), ln2.bias.detach(), ln2.eps)
+                w1, b1 = ff._l1.get([l1])
+                hid = _linear_ct(xn2, w1, b1, l1.out_features, EPI_GELU_PRE)
+                w2, b2 = ff._l2.get([l2])
+                x2 = _linear_ct(hid, w2, b2, l2.out_features, EPI_RESIDUAL, x1)
+                saved += [h, xn1, qkv, o, x1, xn2, hid]
+                h = x2
+        ctx.tf, ctx.params = tf, params
+        ctx.save_for_backward(*saved)
+        return h
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        tf, saved = ctx.tf, ctx.saved_tensors
+        g = g.contiguous()
+        grads = {}
+        for li in range(len(tf.layers) - 1, -1, -1):
+            attention, ff = tf.layers[li]
+            h, xn1, qkv, o, x1, xn2, hid = saved[7 * li:7 * li + 7]
+            ln2, l1, l2 = ff.net[0], ff.net[1], ff.net[4]
+            # x2 = x1 + W2 gelu(W1 LN2(x1) + b1) + b2
+            w1, b1 = ff._l1.get([l1])
+            pre = _linear_ct(xn2, w1, b1, l1.out_features)                 # pre-activation, recomputed
+            dpre, dw2, db2 = _lin_bwd(ff._l2, hid, g, l2.out_features, pre=pre)
+            dxn2, dw1, db1 = _lin_bwd(ff._l1, xn2, dpre, l1.out_features)
+            dx1, dg2, dbt2 = ops.layernorm_ct_backward(x1, ln2.weight.detach(), dxn2, ln2.eps, add=g)
+            grads[l2.weight], grads[l1.weight], grads[ln2.weight], grads[ln2.bias] = dw2, dw1, dg2, dbt2
+            if l2.bias is not None:
+                grads[l2.bias] = db2
+            if l1.bias is not None:
+                grads[l1.bias] = db1
+            # x1 = h + W_o attn(W_qkv LN1(h))
+            ln1, inner = attention.norm, attention.inner_dim
+            do, dwo, dbo = _lin_bwd(attention._o, o, dx1, attention.dim)
+            dqkv = ops.attention_alibi_backward(qkv, attention.alibi_obj.head_scalars, do, attention.n_heads,
+                                                attention.dim_head, attention.dim_head ** 0.5)
+            need_dx = li > 0 or ctx.needs_input_grad[1]
+            dxn1, dwqkv, dbqkv = _lin_bwd(attention._qkv, xn1, dqkv, 3 * inner)
+            dx, dg1, dbt1 = ops.layernorm_ct_backward(h, ln1.weight.detach(), dxn1, ln1.eps, add=dx1)
+            grads[attention.W_o.weight], grads[ln1.weight], grads[ln1.bias] = dwo, dg1, dbt1
+            for k, lin in enumerate((attention.W_q, attention.W_k, attention.W_v)):
+                grads[lin.weight] = dwqkv[k * inner:(k + 1) * inner]
+                if lin.bias is not None:
+                    grads[lin.bias] = dbqkv[k * inner:(k + 1) * inner]
+            if attention.W_o.bias is not None:
+                grads[attention.W_o.bias] = dbo
+            g = dx
+            del need_dx
+        return (None, g if ctx.needs_input_grad[1] else None, *[grads.get(p_) for p_ in ctx.params])
+
+
 class Transformer(nn.Module):
     """transformers.py:225-279: ``x += attn(x); x += ff(x)`` per layer."""
 
@@ -200,8 +287,11 @@ class Transformer(nn.Module):
 
     def run_bct(self, x: Tensor) -> Tensor:
         """Channel-major (B, dim, T) in and out: 7 launches per layer, both residual adds fused into
-        the W_o / FFN-out conv epilogues.  With autograd on, the backward is bridged through ATen."""
+        the W_o / FFN-out conv epilogues.  With autograd on, the backward runs on the HIP kernels too
+        (_TransformerNative; head_dim > 64 falls back to the ATen bridge)."""
         if needs_grad(x, self):
+            if all(a.dim_head <= 64 for a, _ in self.layers):
+                return _TransformerNative.apply(self, x, *list(self.parameters()))
             return hip_forward_aten_backward(self._hip_bct, self._aten_bct, x, list(self.parameters()))
         return self._hip_bct(x)
 

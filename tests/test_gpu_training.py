@@ -108,3 +108,53 @@ def test_transformer_bottleneck_gradients():
     for name, p in tf.named_parameters():
         w = leaves[name].grad
         assert float((p.grad.cpu() - w).abs().max()) <= 2e-3 * float(w.abs().max()) + 1e-9, name
+
+
+def test_transformer_backward_kernels_against_autograd():
+    """LayerNorm backward (with the fused add), attention backward and the GELU-gradient epilogue, each against
+    autograd on the oracle's formulas; config-3 sizes (225 frames, 8 heads x 64)."""
+    import torch.nn.functional as F
+    from audio_generation_amd._lib import CONV_CAUSAL
+    torch.manual_seed(4)
+    # LayerNorm over channels of (B, C, T)
+    x = torch.randn(3, 96, 70, requires_grad=True)
+    w, b = (1 + 0.1 * torch.randn(96)).requires_grad_(True), torch.randn(96, requires_grad=True)
+    y = F.layer_norm(x.transpose(1, 2), (96,), w, b, 1e-5).transpose(1, 2)
+    dy, extra = torch.randn_like(y), torch.randn_like(y)
+    y.backward(dy)
+    dx, dw, db = ops.layernorm_ct_backward(x.detach().to(DEV), w.detach().to(DEV), dy.to(DEV), 1e-5, add=extra.to(DEV))
+    assert float((dx.cpu() - (x.grad + extra)).abs().max()) < 2e-5
+    assert float((dw.cpu() - w.grad).abs().max()) < 1e-4 and float((db.cpu() - b.grad).abs().max()) < 1e-4
+    # attention core
+    for (bsz, heads, dh, t) in ((2, 8, 64, 225), (1, 4, 16, 40), (2, 2, 64, 256)):
+        qkv = (0.5 * torch.randn(bsz, 3 * heads * dh, t)).requires_grad_(True)
+        slopes = oattn.alibi_slopes(heads)
+        q, k, v = (z.reshape(bsz, heads, dh, t) for z in qkv.chunk(3, dim=1))
+        s = torch.einsum("bhdi,bhdj->bhij", q, k) / dh ** 0.5 + oattn.alibi_bias(heads, t, t)
+        o = torch.einsum("bhij,bhdj->bhdi", s.softmax(-1), v).reshape(bsz, heads * dh, t)
+        do = torch.randn_like(o)
+        o.backward(do)
+        got_o = ops.attention_alibi(qkv.detach().to(DEV), slopes.to(DEV), heads, dh, dh ** 0.5)
+        assert float((got_o.cpu() - o.detach()).abs().max()) < 2e-5
+        got = ops.attention_alibi_backward(qkv.detach().to(DEV), slopes.to(DEV), do.to(DEV), heads, dh, dh ** 0.5)
+        assert float((got.cpu() - qkv.grad).abs().max()) < 5e-5 * max(1.0, float(qkv.grad.abs().max()))
+    # k = 1 conv bwd-data with the GELU gradient fused
+    xin = torch.randn(2, 64, 50)
+    wt = torch.randn(32, 64, 1) / 8
+    pre = torch.randn(2, 64, 50, requires_grad=True)
+    (F.conv1d(F.gelu(pre), wt) * (dyc := torch.randn(2, 32, 50))).sum().backward()
+    d = ops.conv_desc(CONV_CAUSAL, 2, 64, 32, 50, 1)
+    got = ops.conv_bwd_data_gelu(d, dyc.to(DEV), ops.conv_pack_bwd(d, wt.to(DEV)), pre.detach().to(DEV))
+    assert float((got.cpu() - pre.grad).abs().max()) < 2e-5
+    del xin
+
+
+def test_transformer_backward_is_native(monkeypatch):
+    from audio_generation_amd import transformers as atf
+    calls = {"bridge": 0}
+    real = atf.hip_forward_aten_backward
+    monkeypatch.setattr(atf, "hip_forward_aten_backward", lambda *a, **k: (calls.__setitem__("bridge", 1), real(*a, **k))[1])
+    tf = Transformer(128, depth=2, heads=2, head_dim=64, context_x=64).to(DEV).train()
+    x = torch.randn(2, 128, 50, device=DEV, requires_grad=True)
+    tf.run_bct(x).pow(2).mean().backward()
+    assert calls["bridge"] == 0 and x.grad is not None and all(p.grad is not None for p in tf.parameters())
