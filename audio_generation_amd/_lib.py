@@ -119,6 +119,20 @@ SIGNATURES = {
     "agx_reduce_mean": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "agx_reduce_mean_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "agx_sigmoid": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "agx_fdft_frames": (c_int64, [c_int32, c_int32, c_int32]),
+    "agx_fdft_rows": (c_int64, [c_int32, c_int32]),
+    "agx_fdft_packed_floats": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "agx_fdft_pack": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "agx_fdft_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32]),
+    "agx_fdft_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                 c_int32, c_void_p]),
+    "agx_fdft_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                  c_int32, c_void_p]),
+    "agx_melpower": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "agx_melpower_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                      c_void_p]),
+    "agx_preemphasis": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_int32, c_void_p]),
+    "agx_lowpass_biquad": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_float, c_float, c_void_p]),
     "agx_codes_packed_bytes": (c_int64, [c_int64, c_int32]),
     "agx_codes_pack": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "agx_codes_unpack": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void avgpool1d_kernel(const float *__restrict_
 //   Y[c, f, t] = sum_{p < H} sum_{j < 4} D_c[f, j H + p] xp[(t + j) H + p]
 // = an unpadded K = 4 conv over H channels xc[p][tau] = xp[tau H + p] (xp = reflect-padded input).
 __global__ __launch_bounds__(256) void stft_prep_kernel(const float *__restrict__ x, float *__restrict__ xc,
-                                                        int L, int N, int H, int Ttau) {
+                                                        int L, int N, int H, int Ttau, int chs) {
     // one block per (tau-tile of 64, batch); thread -> (p fastest over reads, tau fastest over writes)
     __shared__ float tile[64][65];
     const int b = blockIdx.z, tau0 = blockIdx.x * 64, p0 = blockIdx.y * 64;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void stft_prep_kernel(const float *__restrict_
     for (int e = threadIdx.x; e < 64 * 64; e += 256) {
         const int pp = e >> 6, tt = e & 63;
         const int tau = tau0 + tt, p = p0 + pp;
-        if (tau < Ttau && p < H) xc[(size_t(b) * H + p) * Ttau + tau] = tile[tt][pp];
+        if (tau < Ttau && p < H) xc[(size_t(b) * chs + p) * Ttau + tau] = tile[tt][pp];
     }
 }
 
@@ -157,14 +157,14 @@ __global__ __launch_bounds__(256) void stft_untranspose_kernel(const float *__re
 // (i = n + N/2 always; the reflected copies i = N/2 - n for 1 <= n <= N/2 and
 //  i = N/2 + 2(L-1) - n for L-1-N/2 <= n <= L-2), with dxc[p][tau] = dxp[tau H + p]
 __global__ __launch_bounds__(256) void stft_unprep_kernel(const float *__restrict__ dxc, float *__restrict__ dx, int L,
-                                                          int N, int H, int Ttau) {
+                                                          int N, int H, int Ttau, int chs) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= L) return;
     const int b = blockIdx.y, Lp = L + N, half = N / 2;
     auto at = [&](int i) -> float {
         if (i < 0 || i >= Lp) return 0.f;
         const int tau = i / H, p = i - tau * H;
-        return tau < Ttau ? dxc[(size_t(b) * H + p) * Ttau + tau] : 0.f;
+        return tau < Ttau ? dxc[(size_t(b) * chs + p) * Ttau + tau] : 0.f;
     };
     float acc = at(n + half);
     if (n >= 1 && n <= half) acc += at(half - n);
@@ -262,6 +262,7 @@ __device__ __forceinline__ float loss_term(int mode, float a, float b) {
         case 1: return fminf(a - 1.f, 0.f);
         case 2: return fminf(-a - 1.f, 0.f);
         case 3: return fabsf(a - b);
+        case 5: { const float t = logf(a + 1e-8f) - logf(b + 1e-8f); return t * t; }
         default: return fabsf(a + 1e-3f);
     }
 }
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256) void reduce_partial_kernel(const float *__rest
     __shared__ float sh[4];
     float acc = 0.f;
     for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256)
-        acc += loss_term(mode, x[i], mode == 3 ? y[i] : 0.f);
+        acc += loss_term(mode, x[i], (mode == 3 || mode == 5) ? y[i] : 0.f);
     const float tot = block_sum_256(acc, sh);
     if (threadIdx.x == 0) part[blockIdx.x] = tot;
 }
@@ -304,7 +305,13 @@ __global__ __launch_bounds__(256) void reduce_mean_bwd_kernel(const float *__res
             case 1: d = (a - 1.f < 0.f) ? 1.f : 0.f; break;       // torch.minimum(a - 1, 0): gradient to a where smaller
             case 2: d = (-a - 1.f < 0.f) ? -1.f : 0.f; break;
             case 3: { const float t = a - y[i]; d = t > 0.f ? 1.f : (t < 0.f ? -1.f : 0.f); break; }
+            case 5: d = 2.f * (logf(a + 1e-8f) - logf(y[i] + 1e-8f)); break;   // times 1/(a+eps) resp. -1/(y+eps) below
             default: { const float t = a + 1e-3f; d = t > 0.f ? 1.f : (t < 0.f ? -1.f : 0.f); break; }
+        }
+        if (mode == 5) {
+            dx[i] = d * gs / (a + 1e-8f);
+            if (dy) dy[i] = -d * gs / (y[i] + 1e-8f);
+            continue;
         }
         dx[i] = d * gs;
         if (mode == 3 && dy) dy[i] = -d * gs;
@@ -314,6 +321,17 @@ __global__ __launch_bounds__(256) void reduce_mean_bwd_kernel(const float *__res
 __global__ __launch_bounds__(256) void sigmoid_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t n) {
     const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (i < n) y[i] = 1.f / (1.f + expf(-x[i]));
+}
+
+void launch_stft_prep(const float *x, float *xc, int batch, int L, int N, int H, int Ttau, int ch_stride, hipStream_t st) {
+    hipLaunchKernelGGL(stft_prep_kernel, dim3(ceil_div(Ttau, 64), ceil_div(H, 64), batch), dim3(256), 0, st, x, xc, L, N,
+                       H, Ttau, ch_stride);
+}
+
+void launch_stft_unprep(const float *dxc, float *dx, int batch, int L, int N, int H, int Ttau, int ch_stride,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(stft_unprep_kernel, dim3(ceil_div(L, 256), batch), dim3(256), 0, st, dxc, dx, L, N, H, Ttau,
+                       ch_stride);
 }
 
 }  // namespace agx
@@ -402,8 +420,7 @@ int agx_stft_forward(const float *x, const float *packed, float *y, void *worksp
     const int N = n_fft, H = N / 4, T = int(T64), Ttau = T + 3;
     float *xc = static_cast<float *>(workspace);
     float *cv = xc + size_t(batch) * H * Ttau;
-    hipLaunchKernelGGL(stft_prep_kernel, dim3(ceil_div(Ttau, 64), ceil_div(H, 64), batch), dim3(256), 0, st, x, xc,
-                       length, N, H, Ttau);
+    launch_stft_prep(x, xc, batch, length, N, H, Ttau, H, st);
     agx_conv_desc d{AGX_CONV_PADDED, batch, H, 2 * N, Ttau, 4, 1, 1, 0, 0.f, AGX_IMPL_MFMA, 1, 0};
     ConvPlan p;
     int rc = lower_conv(&d, &p);
@@ -418,8 +435,8 @@ int agx_stft_forward(const float *x, const float *packed, float *y, void *worksp
 int agx_reduce_mean(const float *x, const float *y, int64_t n, int32_t mode, float *out, float *workspace,
                     void *stream) {
     using namespace agx;
-    if (n <= 0 || mode < 0 || mode > 4) return fail(AGX_ERR_BAD_SHAPE, "reduce_mean: bad n / mode");
-    if (!x || !out || !workspace || (mode == 3 && !y)) return fail(AGX_ERR_NULL_POINTER, "reduce_mean: NULL pointer");
+    if (n <= 0 || mode < 0 || mode > 5) return fail(AGX_ERR_BAD_SHAPE, "reduce_mean: bad n / mode");
+    if (!x || !out || !workspace || ((mode == 3 || mode == 5) && !y)) return fail(AGX_ERR_NULL_POINTER, "reduce_mean: NULL pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nb = int(ceil_div64(n, 256) < 1024 ? ceil_div64(n, 256) : 1024);
     hipLaunchKernelGGL(reduce_partial_kernel, dim3(nb), dim3(256), 0, st, x, y, n, mode, workspace);
@@ -430,8 +447,8 @@ int agx_reduce_mean(const float *x, const float *y, int64_t n, int32_t mode, flo
 int agx_reduce_mean_backward(const float *x, const float *y, int64_t n, int32_t mode, const float *grad, float *dx,
                              float *dy, void *stream) {
     using namespace agx;
-    if (n <= 0 || mode < 0 || mode > 4) return fail(AGX_ERR_BAD_SHAPE, "reduce_mean_backward: bad n / mode");
-    if (!x || !grad || !dx || (mode == 3 && !y)) return fail(AGX_ERR_NULL_POINTER, "reduce_mean_backward: NULL pointer");
+    if (n <= 0 || mode < 0 || mode > 5) return fail(AGX_ERR_BAD_SHAPE, "reduce_mean_backward: bad n / mode");
+    if (!x || !grad || !dx || ((mode == 3 || mode == 5) && !y)) return fail(AGX_ERR_NULL_POINTER, "reduce_mean_backward: NULL pointer");
     const int nb = int(ceil_div64(n, 256) < 4096 ? ceil_div64(n, 256) : 4096);
     hipLaunchKernelGGL(reduce_mean_bwd_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, n, mode,
                        grad, float(1.0 / double(n)), dx, dy);
@@ -484,8 +501,7 @@ int agx_stft_backward(const float *dy, const float *packed_bwd, float *dx, void 
     rc = conv_mfma_supported(p) ? launch_conv_mfma(p, cv, packed_bwd, nullptr, nullptr, dxc, st)
                                 : launch_conv_direct(p, cv, packed_bwd, nullptr, nullptr, dxc, st);  // n_fft = 64: 16 rows
     if (rc != AGX_OK) return rc;
-    hipLaunchKernelGGL(stft_unprep_kernel, dim3(ceil_div(length, 256), batch), dim3(256), 0, st, dxc, dx, length, N, H,
-                       Ttau);
+    launch_stft_unprep(dxc, dx, batch, length, N, H, Ttau, H, st);
     return check_launch("agx_stft_backward");
 }
 

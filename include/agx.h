@@ -352,7 +352,8 @@ int agx_spectral_grad(float *g, const float *w, const float *sigma, const float 
 
 /* Reductions of discriminator_generator_loss (discriminator.py:204-246), one launch each, result in
  * out[0] (device):  mode 0 mean(x) | 1 mean(min(x - 1, 0)) | 2 mean(min(-x - 1, 0)) |
- * 3 mean|x - y| | 4 mean|x + 1e-3|.   y only for mode 3.  workspace: 1024 floats. */
+ * 3 mean|x - y| | 4 mean|x + 1e-3| | 5 mean (log(x + 1e-8) - log(y + 1e-8))^2 (training.py:74).
+ * y only for modes 3 and 5.  workspace: 1024 floats. */
 int agx_reduce_mean(const float *x, const float *y, int64_t n, int32_t mode, float *out, float *workspace,
                     void *stream);
 /* Gradient of the above: dx = grad[0] * d mean(term) / dx (and dy = -dx for the L1 term; dy may be NULL). */
@@ -360,6 +361,38 @@ int agx_reduce_mean_backward(const float *x, const float *y, int64_t n, int32_t 
                              float *dy, void *stream);
 /* final_activation of the discriminators (torch.nn.Sigmoid, discriminator.py:46, 173). */
 int agx_sigmoid(const float *x, float *y, int64_t n, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Training-loop signal ops: torchaudio in the reference -- parity unpinned (torchaudio is not
+ * installed in the build container; restated from its documented behaviour, oracle/signal.py)
+ * ------------------------------------------------------------------------- */
+
+/* Framed DFT: windowed STFT with hop | n_fft as a polyphase conv on the MFMA conv kernel.
+ *   window_kind 0 rectangular | 1 periodic Hann (win_length <= n_fft, centred as torch.stft does)
+ *   norm_kind   0 none | 1 n_fft^-1/2 | 2 (sum window^2)^-1/2  (torchaudio Spectrogram(normalized=True))
+ * x (B, L) -> y (B, 2 R, T): R = agx_fdft_rows() real rows then R imaginary rows (bins >= F are zero padding),
+ * T = 1 + L / hop, reflect-centred.  backward: the adjoint.  workspace: agx_fdft_workspace_bytes. */
+int64_t agx_fdft_frames(int32_t length, int32_t n_fft, int32_t hop);
+int64_t agx_fdft_rows(int32_t n_fft, int32_t onesided);
+int64_t agx_fdft_packed_floats(int32_t n_fft, int32_t win_length, int32_t hop, int32_t onesided, int32_t backward);
+int agx_fdft_pack(int32_t n_fft, int32_t win_length, int32_t hop, int32_t onesided, int32_t window_kind,
+                  int32_t norm_kind, int32_t backward, float *packed, void *stream);
+int64_t agx_fdft_workspace_bytes(int32_t batch, int32_t length, int32_t n_fft, int32_t hop);
+int agx_fdft_forward(const float *x, const float *packed, float *y, void *workspace, int32_t batch, int32_t length,
+                     int32_t n_fft, int32_t win_length, int32_t hop, int32_t onesided, void *stream);
+int agx_fdft_backward(const float *dy, const float *packed_bwd, float *dx, void *workspace, int32_t batch,
+                      int32_t length, int32_t n_fft, int32_t win_length, int32_t hop, int32_t onesided, void *stream);
+/* mel[b, m, t] = sum_{f < bins} fb[f, m] (re^2 + im^2) on the fdft layout; fb (bins, n_mels) row-major. */
+int agx_melpower(const float *cv, const float *fb, float *mel, int32_t batch, int32_t bins, int32_t frames,
+                 int32_t n_mels, void *stream);
+int agx_melpower_backward(const float *cv, const float *fb, const float *dmel, float *dcv, int32_t batch, int32_t bins,
+                          int32_t frames, int32_t n_mels, void *stream);
+/* torchaudio.functional.preemphasis (training.py:333-334): y[n] = x[n] - coeff x[n-1]; adjoint != 0: its transpose. */
+int agx_preemphasis(const float *x, float *y, int64_t rows, int32_t length, float coeff, int32_t adjoint,
+                    void *stream);
+/* torchaudio.functional.lowpass_biquad (training.py:316-318): RBJ low-pass, direct form I, output clamped to [-1, 1]. */
+int agx_lowpass_biquad(const float *x, float *y, int64_t rows, int32_t length, float sample_rate, float cutoff_freq,
+                       float q, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Codec bitstream (wire size per utils.py:137-147)               *

@@ -1,0 +1,84 @@
+"""Training-loop signal ops against the oracle's restatement of torchaudio (parity unpinned:
+torchaudio is absent, see oracle/signal.py)."""
+import pytest
+import torch
+
+from audio_generation_amd import signal_ops as sg
+from oracle import signal as osg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def close(a, b, tol):
+    a, b = a.detach().cpu(), b.detach().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = float(b.abs().max()) + 1e-12
+    assert float((a - b).abs().max()) <= tol * scale + 1e-9, float((a - b).abs().max()) / scale
+
+
+def test_preemphasis_and_its_gradient():
+    x = torch.randn(3, 1, 1000, requires_grad=True)
+    y = osg.preemphasis(x, 0.97)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    yd = sg.preemphasis(xd, 0.97)
+    close(yd, y, 1e-6)
+    yd.backward(dy.to(DEV))
+    close(xd.grad, x.grad, 1e-6)
+
+
+def test_lowpass_biquad():
+    torch.manual_seed(0)
+    x = (0.5 * torch.randn(4, 1, 3000)).clamp(-1, 1)
+    for cutoff in (5000.0, 800.0, 11000.0):
+        close(sg.lowpass_biquad(x.to(DEV), 24000, cutoff), osg.lowpass_biquad(x, 24000, cutoff), 2e-5)
+    big = 3.0 * torch.randn(2, 500)                       # the clamp of lfilter(clamp=True)
+    got = sg.lowpass_biquad(big.to(DEV), 24000, 11000.0)
+    assert float(got.abs().max()) <= 1.0
+    close(got, osg.lowpass_biquad(big, 24000, 11000.0), 2e-5)
+
+
+def test_mel_filterbank_matches_the_restatement():
+    for n_fft in (512, 2048):
+        assert torch.equal(sg.melscale_fbanks(n_fft // 2 + 1, 24000, 64), osg.mel_fbanks(n_fft // 2 + 1, 24000, 64))
+
+
+@pytest.mark.parametrize("window", [32, 64, 128, 256, 512, 1024, 2048])
+def test_mel_spectrogram(window):
+    torch.manual_seed(window)
+    x = 0.2 * torch.randn(2, 1, 6000)
+    want = osg.mel_spectrogram(x.squeeze(1), 24000, window).unsqueeze(1)
+    spec = sg.MelSpectrogram(sample_rate=24000, n_fft=max(window, 512), win_length=window, hop_length=window // 4,
+                             n_mels=64, normalized=True).to(DEV)
+    got = spec(x.to(DEV))
+    assert got.shape == want.shape == (2, 1, 64, 1 + 6000 // (window // 4))
+    close(got, want, 5e-5)
+
+
+def test_multispectral_loss_and_gradient():
+    torch.manual_seed(1)
+    orig = 0.2 * torch.randn(2, 1, 8000)
+    rec = (orig + 0.02 * torch.randn_like(orig)).requires_grad_(True)
+    windows = [2 ** i for i in range(5, 12)]
+    want = osg.multispectral_reconstruction_loss(orig.squeeze(1), rec.squeeze(1), 24000, windows, spec_loss_weight=0.01)
+    want.backward()
+    specs = [sg.MelSpectrogram(24000, max(w, 512), w, w // 4, 64, True).to(DEV) for w in windows]
+    rec_d = rec.detach().to(DEV).requires_grad_(True)
+    got = sg.multispectral_reconstruction_loss(orig.to(DEV), rec_d, specs, windows, spec_loss_weight=0.01)
+    assert abs(float(got) - float(want)) <= 2e-4 * abs(float(want))
+    got.backward()
+    close(rec_d.grad, rec.grad, 2e-3)
+
+
+def test_full_size_mel_loss_runs():
+    """Config-5 shapes: batch 8 x 72 000; finite, positive, differentiable."""
+    torch.manual_seed(2)
+    orig = (0.1 * torch.randn(8, 1, 72000)).to(DEV)
+    rec = (orig + 0.01 * torch.randn_like(orig)).requires_grad_(True)
+    windows = [2 ** i for i in range(5, 12)]
+    specs = [sg.MelSpectrogram(24000, max(w, 512), w, w // 4, 64, True).to(DEV) for w in windows]
+    loss = sg.multispectral_reconstruction_loss(orig, rec, specs, windows)
+    loss.backward()
+    assert torch.isfinite(loss) and float(loss) > 0 and torch.isfinite(rec.grad).all() and float(rec.grad.abs().max()) > 0

@@ -48,6 +48,13 @@ def main():
         discs = [WaveFormDiscriminator(1)] + [STFTDiscriminator(win_length=w) for w in wins]
         discs = [d.to(dev).train() for d in discs]
         opt_d = [torch.optim.Adam(d.parameters(), lr=8e-4) for d in discs]
+    # the reconstruction-side terms of Trainer.mini_epoch (training.py:313-359): low-pass of the input batch,
+    # pre-emphasis before the MSE, the 7-window mel loss  (AGX_SIGNAL=0 switches them off)
+    signal = gan and os.environ.get("AGX_SIGNAL", "1") == "1"
+    if signal:
+        from audio_generation_amd import signal_ops as sg
+        windows = [2 ** i for i in range(5, 12)]
+        specs = [sg.MelSpectrogram(24000, max(w, 512), w, w // 4, 64, True).to(dev) for w in windows]
 
     def all_params():
         return list(model.parameters()) + [p for d in discs for p in d.parameters()]
@@ -56,12 +63,19 @@ def main():
         opt.zero_grad(set_to_none=True)
         for o in opt_d:
             o.zero_grad(set_to_none=True)
-        y, commit, _ = model(x)
-        loss = ((y - x) ** 2).mean() + commit
+        if signal:
+            xin = sg.lowpass_biquad(x, 24000, 5000.0)
+            y, commit, _ = model(xin)
+            loss = ((sg.preemphasis(y, 0.97) - sg.preemphasis(xin, 0.97)) ** 2).mean() + commit
+            loss = loss + sg.multispectral_reconstruction_loss(xin, y, specs, windows, spec_loss_weight=0.01)
+        else:
+            xin = x
+            y, commit, _ = model(xin)
+            loss = ((y - xin) ** 2).mean() + commit
         if gan:                                 # training.py:363-376
             d_loss = 0
             for d in discs:
-                g_loss, d_loss_i = discriminator_generator_loss(x, y, d)
+                g_loss, d_loss_i = discriminator_generator_loss(xin, y, d)
                 loss = loss + g_loss
                 d_loss = d_loss + d_loss_i
             d_loss.backward(retain_graph=True)
@@ -94,7 +108,8 @@ def main():
     same = abs(agx_dist.max_over_ranks(chk, device=dev if backend == "nccl" else "cpu") - chk) < 1e-9 * max(1.0, abs(chk))
     if rank == 0:
         print(json.dumps({"what": "train step (fwd + native bwd + grad all-reduce + Adam), config S" +
-                          (f" + {len(discs)} discriminators (native forward + backward)" if gan else ""),
+                          (f" + {len(discs)} discriminators (native forward + backward)" if gan else "") +
+                          (" + low-pass, pre-emphasis, 7-window mel loss" if signal else ""),
                           "n_gpus": world, "batch_per_gpu": batch, "ms_per_step": ms, "replicas_in_sync": same,
                           "samples_per_s": world * batch * 72000 / ms * 1e3, "losses": losses,
                           "approx_tflops_at_3x_forward": world * 3 * fwd_flop / ms * 1e-9,
