@@ -289,6 +289,10 @@ class Transformer(nn.Module):
         """Channel-major (B, dim, T) in and out: 7 launches per layer, both residual adds fused into
         the W_o / FFN-out conv epilogues.  With autograd on, the backward runs on the HIP kernels too
         (_TransformerNative; head_dim > 64 falls back to the ATen bridge)."""
+        for attention, _ in self.layers:
+            if x.shape[-1] > attention.context:
+                raise AgxError(f"sequence length {x.shape[-1]} exceeds the ALiBi context {attention.context} "
+                               "(the reference fails here too, transformers.py:88-93)")
         if needs_grad(x, self):
             if all(a.dim_head <= 64 for a, _ in self.layers):
                 return _TransformerNative.apply(self, x, *list(self.parameters()))
