@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libagx.so")
 # constants mirrored from include/agx.h
 CONV_CAUSAL, CONV_TRANSPOSED, CONV_UPSAMPLE, CONV_SAME, CONV_PADDED = 0, 1, 2, 3, 4
 IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA = 0, 1, 2
-EPI_LEAKY_PRE, EPI_RESIDUAL, EPI_LEAKY_POST, EPI_GELU_PRE, EPI_MASK, EPI_GELU_GRAD = 1, 2, 4, 8, 16, 32
+EPI_LEAKY_PRE, EPI_RESIDUAL, EPI_LEAKY_POST, EPI_GELU_PRE, EPI_MASK = 1, 2, 4, 8, 16
 
 
 class ConvDesc(Structure):

@@ -14,6 +14,14 @@ int launch_resblock_fused(const ConvPlan &p, const float *x, const float *w1, co
 bool resblock_fused_supported(const ConvPlan &p);
 const char *resblock_variant(const ConvPlan &p);
 
+// dx *= gelu'(pre)  (exact erf GELU)
+__global__ __launch_bounds__(256) void gelu_grad_mul_kernel(float *__restrict__ dx, const float *__restrict__ pre, int64_t n) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = pre[i];
+    dx[i] *= 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}
+
 static int run_conv(const ConvPlan &p, int impl, const float *x, const float *wp, const float *bias,
                     const float *res, float *y, hipStream_t st) {
     if (impl == AGX_IMPL_AUTO) impl = conv_mfma_supported(p) ? AGX_IMPL_MFMA : AGX_IMPL_DIRECT;
@@ -57,9 +65,15 @@ int agx_conv_bwd_data_gelu(const agx_conv_desc *d, const float *dy, const float 
     int rc = lower_conv_bwd_data(d, &p);
     if (rc != AGX_OK) return rc;
     if (!dy || !packed_bwd || !dx || !pre) return fail(AGX_ERR_NULL_POINTER, "agx_conv_bwd_data_gelu: NULL pointer");
-    p.epilogue = (add ? AGX_EPI_RESIDUAL : 0) | AGX_EPI_GELU_GRAD;
-    p.mask = pre;
-    return run_conv(p, d->impl, dy, packed_bwd, nullptr, add, dx, static_cast<hipStream_t>(stream));
+    p.epilogue = add ? AGX_EPI_RESIDUAL : 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = run_conv(p, d->impl, dy, packed_bwd, nullptr, add, dx, st);
+    if (rc != AGX_OK) return rc;
+    // the GELU gradient as a second (elementwise) launch: erf + exp in the conv epilogue cost the MFMA kernels
+    // their register budget (spills in every instantiation), and this op only exists on the 225-frame bottleneck
+    const int64_t n = int64_t(p.B) * p.Cout * p.Lout;
+    hipLaunchKernelGGL(gelu_grad_mul_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, st, dx, pre, n);
+    return check_launch("agx_conv_bwd_data_gelu");
 }
 
 int agx_conv_kernel_name(const agx_conv_desc *d, char *buf, size_t buf_len) {

@@ -94,10 +94,6 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvPlan p, int ci_til
         if (p.epilogue & AGX_EPI_RESIDUAL) v += res[o];
         if (p.epilogue & AGX_EPI_LEAKY_POST) v = v > 0.f ? v : v * p.slope;
         if (p.epilogue & AGX_EPI_MASK) v = p.mask[o] > 0.f ? v : v * p.slope;
-        if (p.epilogue & AGX_EPI_GELU_GRAD) {
-            const float xg = p.mask[o];
-            v *= 0.5f * (1.f + erff(xg * 0.70710678118654752f)) + xg * 0.3989422804014327f * expf(-0.5f * xg * xg);
-        }
         y[o] = v;
     }
 }
@@ -111,7 +107,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvPlan p, int ci_til
 constexpr int kNarrowJ = 7, kNarrowP = 6;
 
 static inline bool narrow_ok(const ConvPlan &p) {
-    return p.G == 1 && p.kh == 1 && p.Tout == 1 && !(p.epilogue & AGX_EPI_GELU_GRAD) && p.J == kNarrowJ && p.P == kNarrowP && p.s == 1 && p.d == 1 && p.q == 1 && p.oshift == 0 &&
+    return p.G == 1 && p.kh == 1 && p.Tout == 1 && p.J == kNarrowJ && p.P == kNarrowP && p.s == 1 && p.d == 1 && p.q == 1 && p.oshift == 0 &&
            p.Lin % 4 == 0 && p.Lvalid % 4 == 0 && p.Lout % 4 == 0 && p.Lt == p.Lout && p.Lvalid >= 4 &&
            (p.M == 1 || p.M == 2 || p.M == 32);
 }

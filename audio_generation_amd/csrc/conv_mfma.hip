@@ -108,8 +108,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
 
     // ---- epilogue.  All loads (bias, residual, mask) are issued on clamped addresses before
     // any use so they overlap; only the stores are predicated.
-    const bool has_res = (p.epilogue & AGX_EPI_RESIDUAL) != 0;
-    const bool ggrad = (p.epilogue & AGX_EPI_GELU_GRAD) != 0, has_mask = (p.epilogue & AGX_EPI_MASK) != 0 || ggrad;
+    const bool has_res = (p.epilogue & AGX_EPI_RESIDUAL) != 0, has_mask = (p.epilogue & AGX_EPI_MASK) != 0;
     const bool pre = (p.epilogue & AGX_EPI_LEAKY_PRE) != 0, post = (p.epilogue & AGX_EPI_LEAKY_POST) != 0;
     const bool gelu = (p.epilogue & AGX_EPI_GELU_PRE) != 0;
 #pragma unroll
@@ -138,38 +137,45 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
             const int orow = MODE == 2 ? trow + prow[k] : trow;
             const bool col_ok = MODE == 2 ? (prow[k] < p.pm_R && orow < p.Tt && t < p.Lt) : t < p.Lt;
             const int tc = min(t, p.Lt - 1);
-            size_t off[16];
-            float rv[16], mv[16];
-            bool row_ok[16];
+            // elements in groups of EG: 16 for the 1-D kernels (all loads in flight at once), 8 for the 2-D
+            // modes, whose row / phase bookkeeping would otherwise spill
+            constexpr int EG = MODE == 0 ? 16 : 8;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int u = min(max(tc * p.q + ph[r] - p.oshift, 0), p.Lout - 1);
-                const int orr = MODE == 2 ? orow * p.qh + pa[r] - p.oshift_h : orow;  // output row of this element
-                row_ok[r] = !TWO_D || (orr >= 0 && orr < p.Tout);
-                const int orc = TWO_D ? min(max(orr, 0), p.Tout - 1) : 0;
-                off[r] = TWO_D ? (size_t(b) * p.Cout + co[r]) * p.y_cstride + size_t(orc) * p.Lout + u
-                               : (size_t(b) * p.Cout + co[r]) * p.Lout + u;
-            }
-            if (has_res) {
+            for (int r0 = 0; r0 < 16; r0 += EG) {
+                size_t off[EG];
+                float rv[EG], mv[EG];
+                bool row_ok[EG];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) rv[r] = res[off[r]];
-            }
-            if (has_mask) {
+                for (int e = 0; e < EG; ++e) {
+                    const int r = r0 + e;
+                    const int u = min(max(tc * p.q + ph[r] - p.oshift, 0), p.Lout - 1);
+                    const int orr = MODE == 2 ? orow * p.qh + pa[r] - p.oshift_h : orow;  // output row of this element
+                    row_ok[e] = !TWO_D || (orr >= 0 && orr < p.Tout);
+                    const int orc = TWO_D ? min(max(orr, 0), p.Tout - 1) : 0;
+                    off[e] = TWO_D ? (size_t(b) * p.Cout + co[r]) * p.y_cstride + size_t(orc) * p.Lout + u
+                                   : (size_t(b) * p.Cout + co[r]) * p.Lout + u;
+                }
+                if (has_res) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mv[r] = p.mask[off[r]];
-            }
+                    for (int e = 0; e < EG; ++e) rv[e] = res[off[e]];
+                }
+                if (has_mask) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[i][k][r] + bv[r];
-                if (pre) v = leaky(v, p.slope);
-                if (gelu) v = gelu_erf(v);
-                if (has_res) v += rv[r];
-                if (post) v = leaky(v, p.slope);
-                if (ggrad) v *= gelu_grad(mv[r]);
-                else if (has_mask) v = mv[r] > 0.f ? v : v * p.slope;
-                const int u = t * p.q + ph[r] - p.oshift;
-                const bool ok = col_ok && row_ok[r] && (m0 + i * 32 + acc_row(r, lh)) < p.M && u >= 0 && u < p.Lout;
-                if (ok) y[off[r]] = v;
+                    for (int e = 0; e < EG; ++e) mv[e] = p.mask[off[e]];
+                }
+#pragma unroll
+                for (int e = 0; e < EG; ++e) {
+                    const int r = r0 + e;
+                    float v = acc[i][k][r] + bv[r];
+                    if (pre) v = leaky(v, p.slope);
+                    if (gelu) v = gelu_erf(v);
+                    if (has_res) v += rv[e];
+                    if (post) v = leaky(v, p.slope);
+                    if (has_mask) v = mv[e] > 0.f ? v : v * p.slope;
+                    const int u = t * p.q + ph[r] - p.oshift;
+                    const bool ok = col_ok && row_ok[e] && (m0 + i * 32 + acc_row(r, lh)) < p.M && u >= 0 && u < p.Lout;
+                    if (ok) y[off[e]] = v;
+                }
             }
         }
     }

@@ -72,7 +72,6 @@ int agx_get_tuning(const char *name);
 #define AGX_EPI_LEAKY_POST 4 /* LeakyReLU(slope) after the add     vae.py:131-134    */
 #define AGX_EPI_GELU_PRE 8   /* exact (erf) GELU on (acc + bias)   transformers.py:216, wavelets.py:96 */
 #define AGX_EPI_MASK 16      /* backward only: v *= (mask[o] > 0 ? 1 : slope), the LeakyReLU gradient     */
-#define AGX_EPI_GELU_GRAD 32 /* backward only: v *= gelu'(mask[o]), mask = the PRE-activation (exact erf GELU) */
 
 typedef struct agx_conv_desc {
     int32_t kind;      /* AGX_CONV_*                                              */
@@ -252,7 +251,7 @@ int agx_layernorm_ct_backward(const float *x, const float *weight, const float *
 /* Backward of agx_attention_alibi: dqkv (B, 3*H*Dh, T) from qkv and dout (B, H*Dh, T).  head_dim <= 64, T <= 256. */
 int agx_attention_alibi_backward(const float *qkv, const float *slopes, const float *dout, float *dqkv, int32_t batch,
                                  int32_t heads, int32_t head_dim, int32_t t, float scale_div, void *stream);
-/* agx_conv_bwd_data with the GELU gradient in the epilogue: dx = (W^T dy [+ add]) * gelu'(pre). */
+/* agx_conv_bwd_data followed by the exact-GELU gradient: dx = (W^T dy [+ add]) * gelu'(pre)  (two launches). */
 int agx_conv_bwd_data_gelu(const agx_conv_desc *d, const float *dy, const float *packed_bwd, const float *add,
                            const float *pre, float *dx, void *stream);
 
