@@ -184,10 +184,25 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
 // LDS floats per staged channel for a BN-column tile (patch mode also fixes the tile's rows x columns).
 static int tile_span(const ConvPlan &p, int BN, int *R, int *WF) {
     if (!p.pm_R) return (BN - 1) * p.s + (p.J - 1) * p.d + 1;
-    // tile = R output rows x WF output columns (R * WF <= BN): a whole output row when it fits
-    int wf = p.Lt < BN ? p.Lt : BN;
-    int r = BN / wf;
+    // tile = R output rows x WF output columns (R * WF <= BN).  WF = the whole row when it fits; otherwise the
+    // power-of-two split of BN that wastes the fewest base positions (backward-data of strided layers has
+    // 2^k + 1 columns: 128-wide tiles would be one third empty)
+    int wf = p.Lt, r = BN / (p.Lt < 1 ? 1 : p.Lt);
+    if (p.Lt >= BN) {
+        long best = -1;
+        for (int cand = BN; cand >= 8; cand /= 2) {
+            int rr = BN / cand;
+            if (rr > p.Tt) rr = p.Tt;
+            const long area = long(ceil_div(p.Lt, cand)) * cand * (long(ceil_div(p.Tt, rr)) * rr);
+            if (best < 0 || area < best) {
+                best = area;
+                wf = cand;
+                r = rr;
+            }
+        }
+    }
     if (r > p.Tt) r = p.Tt;
+    if (r < 1) r = 1;
     if (R) *R = r;
     if (WF) *WF = wf;
     return ((r - 1) * p.sh + p.kh) * ((wf - 1) * p.s + p.J / p.kh);
