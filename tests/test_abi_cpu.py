@@ -110,3 +110,28 @@ def test_quantizer_surface():
     assert tuple_checker(3, 2) == [3, 3]
     ema = ResidualQuantizer(num_quantizers=2, dim=4, quantizer_class="ema", codebook_sizes=4)
     assert len(list(ema.parameters())) == 0 and "codebooks" in ema.state_dict()
+
+
+def test_descriptor_structs_match_the_header_layout(tmp_path):
+    """sizeof / offsetof of the two descriptor structs as gcc lays them out from include/agx.h against the
+    ctypes mirrors in _lib.py (ABI drift would silently scramble every conv call)."""
+    import ctypes
+    import subprocess
+    from audio_generation_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "layout.c"
+    fields1 = [f for f, _ in _lib.ConvDesc._fields_]
+    fields2 = [f for f, _ in _lib.Conv2dDesc._fields_]
+    body = ['#include <stdio.h>', '#include <stddef.h>', '#include "agx.h"', 'int main(void) {',
+            'printf("%zu\\n", sizeof(agx_conv_desc));']
+    body += [f'printf("%zu\\n", offsetof(agx_conv_desc, {f}));' for f in fields1]
+    body += ['printf("%zu\\n", sizeof(agx_conv2d_desc));']
+    body += [f'printf("%zu\\n", offsetof(agx_conv2d_desc, {f}));' for f in fields2]
+    body += ['return 0; }']
+    src.write_text("\n".join(body))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    nums = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    want = [ctypes.sizeof(_lib.ConvDesc)] + [getattr(_lib.ConvDesc, f).offset for f in fields1]
+    want += [ctypes.sizeof(_lib.Conv2dDesc)] + [getattr(_lib.Conv2dDesc, f).offset for f in fields2]
+    assert nums == want
