@@ -457,7 +457,7 @@ static int bw2d_geometry(const agx_conv2d_desc *d, Bw2dGeom *g, int *cfg, int *b
     *bm = *cfg == 0 ? 128 : (*cfg == 1 ? 64 : 32);
     const int nt = ceil_div(g->Cin * KK, 128), mt = ceil_div(g->Cout, *bm);
     const int64_t items = int64_t(g->B) * ceil_div(g->Hout, g->R) * ceil_div(g->Wout, g->WF);
-    int64_t ns = ceil_div(768, nt * mt);
+    int64_t ns = ceil_div(tuning().dw_wgs, nt * mt);   // default 1536: +5..15 % over 768 on the 3x3 layers
     if (ns > items) ns = items;
     if (ns < 1) ns = 1;
     if (ns > 65535) ns = 65535;
