@@ -20,6 +20,8 @@ const char *last_error();
 struct Tuning {
     int rb_cc = 16;   // channels per LDS chunk of the fused residual block (16 or 32)
     int rb_wgs = 0;   // 1..3: cap resident workgroups per CU of the fused residual block (0 = natural)
+    int dw_dma = 0;     // 1: LDS-DMA double-buffered conv2d weight-gradient kernel (experimental: 48-53 TFLOP/s with 8 waves
+                        // per workgroup, 40 with 4 -- the per-item DMA latency is not hidden yet), 0: the synchronous one (53-61)
     int dw_wgs = 1536;  // workgroups the conv2d weight-gradient kernel aims for (slices = dw_wgs / tiles)
     int conv_cc = 0;    // diagnostic: force the LDS chunk (8/16/32 channels) of the MFMA conv; 0 = table
     int conv_shape = 0; // diagnostic: 1 = 128x128 conv tiles as 4 row-waves x (1x4) fragments

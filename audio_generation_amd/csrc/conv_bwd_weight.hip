@@ -399,6 +399,164 @@ __global__ __launch_bounds__(256) void conv2d_bwd_weight_kernel(Bw2dGeom g, cons
     }
 }
 
+// Pipelined version of conv2d_bwd_weight_kernel: the dy tile and the x patches of item n+1 stream into a second
+// LDS buffer by LDS-DMA (no registers) while the MFMAs of item n run, operand fragments are read one k-step
+// ahead, and one workgroup owns a CU (2 x (dy tile + patches) of LDS).  Measured on the synchronous kernel:
+// staging and MFMA time simply add up (removing either leaves the other's time), hence this form.  Status:
+// correct (same tests) but not yet faster -- one workgroup per CU leaves the item too short (1.7 us with 8 waves)
+// to cover the DMA latency; it needs a third buffer with counted waits.  Off by default (agx_set_tuning "dw_dma").
+template <int MW, int NW, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void conv2d_bwd_weight_dma_kernel(Bw2dGeom g, const float *__restrict__ x,
+                                                                    const float *__restrict__ dy,
+                                                                    float *__restrict__ part,
+                                                                    float *__restrict__ bias_part) {
+    constexpr int NWV = WM * WN, NT = 64 * NWV;   // waves / threads per workgroup (4 or 8 waves)
+    constexpr int BM = 32 * MW * WM, BN = 32 * NW * WN;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int xtotal = g.n_chan * g.span;
+    const int bufsz = BM * BW_TS + ((xtotal + 63) & ~63);       // floats per buffer
+    int *kofft = reinterpret_cast<int *>(sm + 2 * bufsz);      // [BW_T]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int KK = g.kh * g.kw, NK = g.Cin * KK, M = g.Cout;
+    const int n_base = blockIdx.x * BN, m_base = blockIdx.y * BM, slice = blockIdx.z;
+    const int ci_first = n_base / KK;
+    const int npos = g.R * g.WF;
+    if (tid < BW_T) {
+        const int r = tid / g.WF, fc = tid - r * g.WF;
+        kofft[tid] = tid < npos ? (r * g.sh) * g.SW + fc * g.sw : 0;
+    }
+    const int my_rr = lane / g.WF, my_fc = lane - my_rr * g.WF;   // dy-tile column of this lane (k = lane)
+    const float inv_span = 1.f / float(g.span), inv_sw = 1.f / float(g.SW);
+    int boff[NW];
+    bool nvalid[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const int n = n_base + (wn * NW + k) * 32 + li;
+        nvalid[k] = n < NK;
+        const int nc = min(n, NK - 1);
+        const int ci = nc / KK, rem = nc - ci * KK;
+        const int dh = rem / g.kw, dw = rem - dh * g.kw;
+        boff[k] = (ci - ci_first) * g.span + dh * g.SW + dw;
+    }
+    int arow[MW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i) arow[i] = ((wm * MW + i) * 32 + li) * BW_TS;
+    f32x16 acc[MW][NW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
+    constexpr int TPR = NT / BM, CPT = BW_T / TPR;
+    float bsum = 0.f;
+    const bool do_bias = bias_part != nullptr && blockIdx.x == 0;
+    const int nft = (g.Wout + g.WF - 1) / g.WF, nrg = (g.Hout + g.R - 1) / g.R;
+    const int items = g.B * nrg * nft;
+    const size_t plane = size_t(g.Hout) * g.Wout;
+
+    // issue the DMA of one item into buffer `buf`; lanes with nothing to fetch write the zero themselves
+    auto stage = [&](int item, float *buf) {
+        int it = item;
+        const int ft = it % nft;
+        it /= nft;
+        const int rg = it % nrg, b = it / nrg;
+        const int trow0 = rg * g.R, f0 = ft * g.WF;
+        float *dysb = buf, *xsb = buf + BM * BW_TS;
+        {   // dy tile: one 64-lane row per instruction
+            const int t = trow0 + my_rr, f = f0 + my_fc;
+            const bool pos_ok = lane < npos && t < g.Hout && f < g.Wout;
+            const float *src0 = dy + size_t(b) * g.Cout * plane + size_t(min(t, g.Hout - 1)) * g.Wout + min(f, g.Wout - 1);
+            for (int r = wave; r < BM; r += NWV) {
+                const int co = m_base + r;
+                if (pos_ok && co < M) glds_dword(src0 + size_t(co) * plane, dysb + r * BW_TS);
+                else dysb[r * BW_TS + lane] = 0.f;
+            }
+        }
+        {   // x patches, flat over (channel, patch row, patch column)
+            const int row0 = trow0 * g.sh - g.ph, col0 = f0 * g.sw - g.pw;
+            const float *xb = x + size_t(b) * g.Cin * g.Hin * g.Win;
+            for (int e0 = wave * 64; e0 < xtotal; e0 += NT) {
+                const int e = e0 + lane;
+                const int ec = min(e, xtotal - 1);
+                const int c = int((float(ec) + 0.5f) * inv_span), i = ec - c * g.span;   // exact: e < 2^20
+                const int rr = int((float(i) + 0.5f) * inv_sw), cc = i - rr * g.SW;
+                const int ch = ci_first + c, gr = row0 + rr, gc = col0 + cc;
+                const bool ok = e < xtotal && ch < g.Cin && gr >= 0 && gr < g.Hin && gc >= 0 && gc < g.Win;
+                if (ok) glds_dword(xb + (size_t(ch) * g.Hin + gr) * g.Win + gc, xsb + e0);
+                else if (e < xtotal) xsb[e] = 0.f;
+            }
+        }
+    };
+
+    float *cur = sm, *nxt = sm + bufsz;
+    if (slice < items) stage(slice, cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int item = slice; item < items; item += g.n_slices) {
+        if (item + g.n_slices < items) stage(item + g.n_slices, nxt);
+        const float *dys = cur, *xs = cur + BM * BW_TS;
+        if (do_bias) {
+            const float *row = dys + (tid / TPR) * BW_TS + (tid % TPR) * CPT;
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) bsum += row[c];
+        }
+        // contraction over the 64 positions, fragments read one k-step ahead
+        float a_c[MW], b_c[NW], a_n[MW], b_n[NW];
+        {
+            const int ko = kofft[lh];
+#pragma unroll
+            for (int i = 0; i < MW; ++i) a_c[i] = dys[arow[i] + lh];
+#pragma unroll
+            for (int k = 0; k < NW; ++k) b_c[k] = nvalid[k] ? xs[boff[k] + ko] : 0.f;
+        }
+#pragma unroll 8
+        for (int ks = 0; ks < BW_T / 2; ++ks) {
+            const int tn = min(2 * (ks + 1) + lh, BW_T - 1);
+            const int ko = kofft[tn];
+#pragma unroll
+            for (int i = 0; i < MW; ++i) a_n[i] = dys[arow[i] + tn];
+#pragma unroll
+            for (int k = 0; k < NW; ++k) b_n[k] = nvalid[k] ? xs[boff[k] + ko] : 0.f;
+#pragma unroll
+            for (int i = 0; i < MW; ++i)
+#pragma unroll
+                for (int k = 0; k < NW; ++k)
+                    acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[i], b_c[k], acc[i][k], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MW; ++i) a_c[i] = a_n[i];
+#pragma unroll
+            for (int k = 0; k < NW; ++k) b_c[k] = b_n[k];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of the next item has landed
+        __syncthreads();                                     // everyone's has; everyone is done with cur
+        float *tmp = cur;
+        cur = nxt;
+        nxt = tmp;
+    }
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const int n = n_base + (wn * NW + k) * 32 + li;
+        if (n >= NK) continue;
+        float *dst = part + (size_t(slice) * NK + n) * M;
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m_base + (wm * MW + i) * 32 + acc_row(r, lh);
+                if (m < M) dst[m] = acc[i][k][r];
+            }
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int off = 1; off < TPR; off <<= 1) bsum += __shfl_xor(bsum, off);
+        const int m = m_base + tid / TPR;
+        if (tid % TPR == 0 && m < M) bias_part[size_t(slice) * M + m] = bsum;
+    }
+}
+
 // Gradient w.r.t. the normalised weight G[co][n] = dwp[n][co] -> dw (torch layout), and per-row <G, W>.
 __global__ __launch_bounds__(256) void bwd2d_unpack_kernel(const float *__restrict__ dwp, const float *__restrict__ w,
                                                            float *__restrict__ dw, float *__restrict__ rowdot, int NK,
@@ -592,9 +750,25 @@ int agx_conv2d_bwd_weight(const agx_conv2d_desc *d, const float *x, const float 
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, x, dy, part, dbias ? bias_part : nullptr);
         return AGX_OK;
     };
-    rc = cfg == 0 ? launch(conv2d_bwd_weight_kernel<2, 2, 2, 2>)
-       : cfg == 1 ? launch(conv2d_bwd_weight_kernel<1, 2, 2, 2>)
-                  : launch(conv2d_bwd_weight_kernel<1, 1, 1, 4>);
+    const size_t lds_dma = (2 * (size_t(bm) * BW_TS + ((size_t(g.n_chan) * g.span + 63) & ~size_t(63))) + BW_T) * sizeof(float);
+    if (tuning().dw_dma && lds_dma <= 160 * 1024) {
+        lds = lds_dma;
+        // 8 waves per workgroup (one workgroup per CU: two waves per SIMD hide the LDS -> MFMA latency)
+        auto launch8 = [&](auto kern) -> int {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+            hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, g, x, dy, part, dbias ? bias_part : nullptr);
+            return AGX_OK;
+        };
+        rc = cfg == 0 ? launch8(conv2d_bwd_weight_dma_kernel<1, 2, 4, 2>)
+           : cfg == 1 ? launch8(conv2d_bwd_weight_dma_kernel<1, 1, 2, 4>)
+                      : launch(conv2d_bwd_weight_dma_kernel<1, 1, 1, 4>);
+    } else {
+        rc = cfg == 0 ? launch(conv2d_bwd_weight_kernel<2, 2, 2, 2>)
+           : cfg == 1 ? launch(conv2d_bwd_weight_kernel<1, 2, 2, 2>)
+                      : launch(conv2d_bwd_weight_kernel<1, 1, 1, 4>);
+    }
     if (rc != AGX_OK) return rc;
     hipLaunchKernelGGL(bwd_slice_reduce_kernel, dim3((unsigned)ceil_div64(nw, 64)), dim3(256), 0, st, part, g.n_slices,
                        nw, dwp);

@@ -218,6 +218,7 @@ int agx_set_tuning(const char *name, int32_t value) {
     else if (!strcmp(name, "rb_wgs")) agx::tuning().rb_wgs = value;
     else if (!strcmp(name, "rb_sched")) agx::tuning().rb_sched = value;
     else if (!strcmp(name, "rb_occ")) agx::tuning().rb_occ = value;
+    else if (!strcmp(name, "dw_dma")) agx::tuning().dw_dma = value;
     else if (!strcmp(name, "dw_wgs")) agx::tuning().dw_wgs = value;
     else if (!strcmp(name, "conv_cc")) agx::tuning().conv_cc = value;
     else if (!strcmp(name, "conv_shape")) agx::tuning().conv_shape = value;
@@ -232,6 +233,7 @@ int agx_get_tuning(const char *name) {
     if (!strcmp(name, "rb_wgs")) return agx::tuning().rb_wgs;
     if (!strcmp(name, "rb_sched")) return agx::tuning().rb_sched;
     if (!strcmp(name, "rb_occ")) return agx::tuning().rb_occ;
+    if (!strcmp(name, "dw_dma")) return agx::tuning().dw_dma;
     if (!strcmp(name, "dw_wgs")) return agx::tuning().dw_wgs;
     if (!strcmp(name, "conv_cc")) return agx::tuning().conv_cc;
     if (!strcmp(name, "conv_shape")) return agx::tuning().conv_shape;

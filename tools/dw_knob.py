@@ -12,7 +12,8 @@ def timeit(fn, reps=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-vals = [int(v) for v in sys.argv[2:]] or [768, 512, 1024, 1536, 2048]
+knob = (sys.argv[2] if len(sys.argv) > 2 else "dw_wgs").encode()
+vals = [int(v) for v in sys.argv[3:]] or [768, 512, 1024, 1536, 2048]
 for (cin, cout, kh, kw, sh, sw, h, w) in [(32, 32, 3, 3, 1, 1, 282, 1024), (64, 64, 3, 3, 1, 1, 282, 512), (128, 128, 3, 3, 1, 1, 141, 256), (64, 128, 4, 4, 2, 2, 282, 512), (256, 256, 3, 3, 1, 1, 70, 64)]:
     x = torch.randn(B, cin, h, w, device="cuda")
     pad = ((kh - 1) // 2, (kw - 1) // 2)
@@ -22,8 +23,8 @@ for (cin, cout, kh, kw, sh, sw, h, w) in [(32, 32, 3, 3, 1, 1, 282, 1024), (64, 
     fl = 2.0 * dy.numel() * cin * kh * kw
     out = []
     for a in vals:
-        lib.agx_set_tuning(b"dw_wgs", a)
+        lib.agx_set_tuning(knob, a)
         t = timeit(lambda: ops.conv2d_bwd_weight(d, x, dy))
         out.append(f"{a}: {t:.3f} ms ({fl/t*1e-9:.1f} TF)")
-    lib.agx_set_tuning(b"dw_wgs", 768)
+    lib.agx_set_tuning(knob, vals[0] if knob != b"dw_dma" else 1)
     print(f"{cin}->{cout} k{kh}x{kw} s{sh}: " + "  ".join(out))
