@@ -64,7 +64,7 @@ def build_units(stack: nn.ModuleList) -> Optional[List[_Unit]]:
         slope = _leaky_slope(act) if act is not None else None
         if isinstance(layer, CausalResidualBlock1d):
             inner = _leaky_slope(layer.activation)
-            if inner is None:
+            if inner is None or getattr(layer, "depthwise", False):   # depthwise variant: ATen bridge
                 return False
             units.append(_Unit("res", [layer.conv1, layer.conv2], slope, inner))
             return True

@@ -24,7 +24,7 @@ from torch import nn
 
 from . import ops
 from .autograd_bridge import hip_forward_aten_backward, needs_grad
-from ._lib import (CONV_CAUSAL, CONV_TRANSPOSED, CONV_UPSAMPLE, EPI_LEAKY_POST, EPI_LEAKY_PRE,
+from ._lib import (CONV_CAUSAL, CONV_PADDED, CONV_TRANSPOSED, CONV_UPSAMPLE, EPI_LEAKY_POST, EPI_LEAKY_PRE,
                    IMPL_AUTO, AgxError)
 
 Tensor = torch.Tensor
@@ -61,12 +61,13 @@ class _ConvParams(nn.Module):
     """
 
     def __init__(self, c_in: int, c_out: int, kernel: int, stride: int, dilation: int, bias: bool,
-                 transposed: bool, norm: str = "weight"):
+                 transposed: bool, norm: str = "weight", groups: int = 1):
         super().__init__()
         self.in_channels, self.out_channels = c_in, c_out
         self.kernel_size, self.stride, self.dilation = (kernel,), (stride,), (dilation,)
         self.transposed = transposed
-        shape = (c_in, c_out, kernel) if transposed else (c_out, c_in, kernel)
+        self.groups = groups
+        shape = (c_in, c_out, kernel) if transposed else (c_out, c_in // groups, kernel)
         w = torch.empty(shape)
         nn.init.kaiming_uniform_(w, a=math.sqrt(5))
         fan_in = shape[1] * kernel
@@ -119,7 +120,7 @@ class _ConvParams(nn.Module):
             key = (kind, v.data_ptr(), v._version)
         if self._packed is None or self._packed_key != key:
             desc = ops.conv_desc(kind, 1, self.in_channels, self.out_channels, 1 << 20,
-                                 self.kernel_size[0], self.stride[0], self.dilation[0])
+                                 self.kernel_size[0], self.stride[0], self.dilation[0], groups=self.groups)
             self._packed = ops.conv_pack(desc, v.detach(), None if g is None else g.detach())
             self._packed_key = key
         return self._packed
@@ -134,7 +135,8 @@ class _ConvBase(nn.Module):
         if x.dim() != 3 or x.shape[1] != c.in_channels:
             raise AgxError(f"{type(self).__name__}: expected (B,{c.in_channels},L), got {tuple(x.shape)}")
         desc = ops.conv_desc(self.kind, x.shape[0], c.in_channels, c.out_channels, x.shape[2],
-                             c.kernel_size[0], c.stride[0], c.dilation[0], epilogue, slope, self.impl)
+                             c.kernel_size[0], c.stride[0], c.dilation[0], epilogue, slope, self.impl,
+                             groups=getattr(c, "groups", 1))
         bias = None if c.bias is None else c.bias.detach()
         return ops.conv_forward(desc, x, c.packed(self.kind), bias, res)
 
@@ -155,14 +157,19 @@ class CausalConv1d(_ConvBase):
         k, s, d = c.kernel_size[0], c.stride[0], c.dilation[0]
         nxt = (x.shape[-1] - k + self.pad) / s + 1
         extra = (math.ceil(nxt) - 1) * s + k - self.pad - x.shape[-1]
-        return F.conv1d(F.pad(x, (self.pad, extra)), c.aten_weight(), c.bias, stride=s, dilation=d)
+        return F.conv1d(F.pad(x, (self.pad, extra)), c.aten_weight(), c.bias, stride=s, dilation=d,
+                        groups=getattr(c, "groups", 1))
 
     def __init__(self, in_channels, out_channels, kernel_size, dilation=1, stride=1, bias=True,
                  groups=1, norm="weight"):
         super().__init__()
         if groups != 1:
-            raise NotImplementedError("grouped causal convs (depthwise=True) have no HIP kernel yet")
-        self.conv = _ConvParams(in_channels, out_channels, kernel_size, stride, dilation, bias, False, norm)
+            # the one grouped use in the reference: the k = 1 depthwise conv of vae.py:103 -- no padding at all,
+            # so it is the grouped AGX_CONV_PADDED layer (direct kernel)
+            if kernel_size != 1 or stride != 1 or dilation != 1:
+                raise NotImplementedError("grouped causal convs are wired for kernel 1 / stride 1 only (vae.py:103)")
+            self.kind = CONV_PADDED
+        self.conv = _ConvParams(in_channels, out_channels, kernel_size, stride, dilation, bias, False, norm, groups)
         self.dilation = dilation
         self.pad = dilation * (kernel_size - 1) - stride + 1  # vae.py:32
 
@@ -206,15 +213,18 @@ class CausalResidualBlock1d(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size=7, dilation=1, bias=True,
                  activation=None, dropout=0.0, depthwise=False):
         super().__init__()
-        if depthwise:
-            raise NotImplementedError("depthwise residual blocks have no HIP kernel yet")
         if dropout != 0.0:
             raise NotImplementedError("dropout > 0 is training-only and not on the forward path")
         if in_channels != out_channels:
             raise AgxError("residual block needs in_channels == out_channels (as the reference's add does)")
-        self.conv1 = CausalConv1d(in_channels, out_channels, kernel_size, dilation=dilation, bias=bias)
+        self.depthwise = depthwise
+        if depthwise:   # vae.py:103-105: a per-channel k = 1 conv in front of the dilated conv (three launches, unfused)
+            self.conv1 = nn.Sequential(CausalConv1d(in_channels, in_channels, 1, bias=bias, groups=in_channels),
+                                       CausalConv1d(in_channels, out_channels, kernel_size, dilation=dilation, bias=bias))
+        else:
+            self.conv1 = CausalConv1d(in_channels, out_channels, kernel_size, dilation=dilation, bias=bias)
+            object.__setattr__(self.conv1, "_parent_block", self)   # plain attribute: no module cycle
         self.conv2 = CausalConv1d(out_channels, out_channels, 1, bias=bias)
-        object.__setattr__(self.conv1, "_parent_block", self)   # plain attribute: no module cycle
         self.activation = nn.LeakyReLU(0.1) if activation is None else activation
         self.dropout = nn.Dropout(dropout)
 
@@ -222,6 +232,12 @@ class CausalResidualBlock1d(nn.Module):
         """Whole block (+ the activation that follows it in the enclosing
         ``Sequential`` when ``post_slope`` is given) through ``agx_resblock_forward``."""
         slope = _leaky_slope(self.activation)
+        if self.depthwise:
+            h = self.conv1[1].run(self.conv1[0].run(x), EPI_LEAKY_PRE if slope is not None else 0, slope or 0.0)
+            if slope is None:
+                h = self.activation(h)
+            epi = ops.EPI_RESIDUAL | (EPI_LEAKY_POST if post_slope is not None else 0)
+            return self.conv2.run(h, epi, post_slope or 0.0, res=x)
         c1, c2 = self.conv1.conv, self.conv2.conv
         if self.split_launches or slope is None or (post_slope is not None and post_slope != slope):
             # exotic activation mix: two convs with separate epilogues
@@ -236,7 +252,8 @@ class CausalResidualBlock1d(nn.Module):
                                     post_act=post_slope is not None)
 
     def _aten(self, x: Tensor) -> Tensor:  # backward bridge only
-        return x + self.conv2._aten(_act_aten(self.conv1._aten(x), _leaky_slope(self.activation)))
+        h = self.conv1[1]._aten(self.conv1[0]._aten(x)) if self.depthwise else self.conv1._aten(x)
+        return x + self.conv2._aten(_act_aten(h, _leaky_slope(self.activation)))
 
     def forward(self, x: Tensor) -> Tensor:
         return self.run(x, None)

@@ -85,11 +85,17 @@ def leaky(x: Tensor) -> Tensor:
 
 
 def residual_block(x: Tensor, sd: Dict[str, Tensor], prefix: str, dilation: int) -> Tensor:
-    """vae.py:113-117 (``depthwise=False``, dropout p=0)."""
-    w1, b1 = conv_params(sd, prefix + "conv1.conv.")
+    """vae.py:113-117 (dropout p=0); the ``depthwise=True`` variant (vae.py:103-105: a per-channel k = 1 conv
+    in front of the dilated conv) is recognised by its state-dict keys ``conv1.0.* / conv1.1.*``."""
     w2, b2 = conv_params(sd, prefix + "conv2.conv.")
-    h = leaky(causal_conv1d(x, w1, b1, dilation=dilation))
-    return x + causal_conv1d(h, w2, b2)
+    if prefix + "conv1.0.conv.weight_v" in sd or prefix + "conv1.0.conv.weight" in sd:
+        wd, bd = conv_params(sd, prefix + "conv1.0.conv.")
+        w1, b1 = conv_params(sd, prefix + "conv1.1.conv.")
+        h = causal_conv1d(causal_conv1d(x, wd, bd, groups=x.shape[1]), w1, b1, dilation=dilation)
+    else:
+        w1, b1 = conv_params(sd, prefix + "conv1.conv.")
+        h = causal_conv1d(x, w1, b1, dilation=dilation)
+    return x + causal_conv1d(leaky(h), w2, b2)
 
 
 # --------------------------------------------------------------------------- #

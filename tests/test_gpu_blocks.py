@@ -173,3 +173,27 @@ def test_wavelet_vqae_config4_topology():
         y = model.decode(zg)
     assert rms(zg.cpu().transpose(1, 2), z) < 1e-5
     assert rms(y.cpu(), want) < 1e-4
+
+
+def test_depthwise_residual_variant_matches_the_reference_goldens():
+    """CausalResidualBlock1d / encoder / decoder blocks with depthwise=True (vae.py:103-105; golden G8): the
+    per-channel k = 1 conv runs as a grouped AGX_CONV_PADDED layer in front of the dilated conv."""
+    from audio_generation_amd.vae import CausalDecoderBlock, CausalEncoderBlock, CausalResidualBlock1d
+    from tests.helpers import load_npz, sub_sd
+    blob = load_npz("g8_depthwise.npz")
+    mods = {"res_d3": CausalResidualBlock1d(6, 6, dilation=3, depthwise=True),
+            "res_d9": CausalResidualBlock1d(16, 16, dilation=9, depthwise=True),
+            "encblock": CausalEncoderBlock(4, 8, 4, depthwise=True),
+            "decblock": CausalDecoderBlock(8, 4, 5, depthwise=True)}
+    for name, m in mods.items():
+        m.load_state_dict(sub_sd(blob, f"{name}/sd/"), strict=True)
+        m = m.to(DEV).eval()
+        with torch.no_grad():
+            y = m(torch.from_numpy(blob[f"{name}/x"]).to(DEV))
+        assert max_abs(y.cpu(), blob[f"{name}/y"]) < 2e-5, name
+    # trainable through the bridge
+    m = mods["res_d9"].train()
+    x = torch.randn(2, 16, 50, device=DEV, requires_grad=True)
+    from audio_generation_amd.autograd_bridge import hip_forward_aten_backward
+    hip_forward_aten_backward(m.forward, m._aten, x, list(m.parameters())).pow(2).mean().backward()
+    assert x.grad is not None and all(p.grad is not None for p in m.parameters())

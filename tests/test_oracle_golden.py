@@ -151,3 +151,38 @@ def test_shape_table_known_answers():
     enc_macs = sum(r["macs"] for r in g6["layers"] if r["name"].startswith("encoders"))
     dec_macs = sum(r["macs"] for r in g6["layers"] if r["name"].startswith("decoders"))
     assert abs(enc_macs / 72000 - 195194) < 1 and abs(dec_macs / 72000 - 316026) < 1
+
+
+def _depthwise_cases():
+    blob = load_npz("g8_depthwise.npz")
+    for name, dil in (("res_d3", 3), ("res_d9", 9)):
+        yield name, blob, lambda x, sd, d=dil: codec.residual_block(x, sd, "", d)
+
+    def enc(x, sd):
+        y = x
+        for j, d in enumerate((1, 3, 9)):
+            y = codec.leaky(codec.residual_block(y, sd, f"layers.{j}.0.", d))
+        w, b = codec.conv_params(sd, "layers.3.0.conv.")
+        return codec.leaky(codec.causal_conv1d(y, w, b, stride=4))
+
+    def dec(x, sd):
+        w, b = codec.conv_params(sd, "in_conv.0.conv.")
+        y = codec.leaky(codec.upsample_conv1d(x, w, b, 5))
+        for j, d in enumerate((1, 3, 9)):
+            y = codec.leaky(codec.residual_block(y, sd, f"layers.{j}.0.", d))
+        return y
+
+    yield "encblock", blob, enc
+    yield "decblock", blob, dec
+
+
+def test_depthwise_variant_matches_the_reference():
+    """depthwise=True residual blocks (vae.py:103-105), alone and inside encoder / decoder blocks (golden G8)."""
+    n = 0
+    for name, blob, fn in _depthwise_cases():
+        sd = sub_sd(blob, f"{name}/sd/")
+        assert any(k.startswith("conv1.0.") or ".conv1.0." in k for k in sd)
+        y = fn(torch.from_numpy(blob[f"{name}/x"]), sd)
+        assert max_abs(y, blob[f"{name}/y"]) < TOL, name
+        n += 1
+    assert n == 4
