@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libagx.so")
 
 # constants mirrored from include/agx.h
 CONV_CAUSAL, CONV_TRANSPOSED, CONV_UPSAMPLE, CONV_SAME, CONV_PADDED = 0, 1, 2, 3, 4
-IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA = 0, 1, 2
+IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA, IMPL_MFMA_BF16X3 = 0, 1, 2, 3
 EPI_LEAKY_PRE, EPI_RESIDUAL, EPI_LEAKY_POST, EPI_GELU_PRE, EPI_MASK = 1, 2, 4, 8, 16
 
 

@@ -73,6 +73,7 @@ struct ConvPlan {
     // patch mode, backward-data of strided layers: qh output-row phases per base row (rows m = (co*qh + a)*q + c),
     // output row = qh * base row + a - oshift_h; Tt base rows (forward: qh = 1, oshift_h = 0, Tt = Tout)
     int qh, oshift_h, Tt;
+    int prec;   // 0: fp32 MFMA (exact fp32 FMA chain); 1: bf16x3 on the bf16 MFMA (mfma_tile.hpp), 1-D MFMA kernels only
 };
 
 // Packed weight image ("group-K-major"): channels in groups of 16,
@@ -82,6 +83,10 @@ struct ConvPlan {
 constexpr int kWG = 16;  // channels per weight group
 __host__ __device__ inline int64_t packed_weight_floats(int Cin, int J, int M) {
     return int64_t((Cin + kWG - 1) / kWG) * J * M * kWG;
+}
+// bf16x3 image (mfma_tile.hpp): three bf16 planes per 16-channel group = 48 bf16 = 24 floats per (group, tap, row)
+__host__ __device__ inline int64_t packed_weight_floats_bf(int Cin, int J, int M) {
+    return int64_t((Cin + kWG - 1) / kWG) * J * M * 24;
 }
 __host__ __device__ inline size_t packed_weight_index(int ci, int j, int m, int J, int M) {
     return (size_t(ci / kWG) * J + j) * M * kWG + size_t(m) * kWG + (ci % kWG);

@@ -61,6 +61,7 @@ int lower_conv2d(const agx_conv2d_desc *d, ConvPlan *p) {
     p->qh = 1;
     p->oshift_h = 0;
     p->Tt = p->Tout;
+    p->prec = 0;
     if (int64_t(p->B) * p->Tout > (int64_t(1) << 30)) return fail(AGX_ERR_BAD_SHAPE, "conv2d: batch * output rows too large");
     return AGX_OK;
 }

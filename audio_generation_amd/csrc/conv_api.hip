@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void gelu_grad_mul_kernel(float *__restrict__ 
 static int run_conv(const ConvPlan &p, int impl, const float *x, const float *wp, const float *bias,
                     const float *res, float *y, hipStream_t st) {
     if (impl == AGX_IMPL_AUTO) impl = conv_mfma_supported(p) ? AGX_IMPL_MFMA : AGX_IMPL_DIRECT;
-    if (impl == AGX_IMPL_MFMA) return launch_conv_mfma(p, x, wp, bias, res, y, st);
+    if (impl == AGX_IMPL_MFMA || impl == AGX_IMPL_MFMA_BF16X3) return launch_conv_mfma(p, x, wp, bias, res, y, st);
     if (impl == AGX_IMPL_DIRECT) return launch_conv_direct(p, x, wp, bias, res, y, st);
     return fail(AGX_ERR_BAD_SHAPE, "conv: unknown impl %d", impl);
 }

@@ -24,7 +24,7 @@
 
 namespace agx {
 
-template <int MW, int NW, int WM, int WN, int CC, int MODE = 0>  // 0: 1-D  1: 2-D row-folded  2: 2-D patches
+template <int MW, int NW, int WM, int WN, int CC, int MODE = 0, int PREC = 0>  // MODE 0: 1-D  1: 2-D row-folded  2: 2-D patches
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
                                                         const float *__restrict__ x,
                                                         const float *__restrict__ wp,
@@ -101,6 +101,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
                                                 trow * p.sh - p.ph, p.Tin, p.ncv},
                                        p.Lvalid, in0, p.d};
         conv_gemm_rows<MW, NW, CC, kSchedDefault>(acc, xs, stg, wp, p, p.M, span, arow, bcol, wave, lane);
+    } else if (PREC == 1) {
+        const StagerRows<RowMap1D> stg{RowMap1D{x + size_t(b) * p.Cin * p.Lin, p.Lin}, p.Lvalid, in0, p.d};
+        conv_gemm_rows_bf<MW, NW, (CC < 16 ? 16 : CC)>(acc, xs, stg, reinterpret_cast<const __bf16 *>(wp), p, p.M, span,
+                                                       arow, bcol, wave, lane);
     } else {
         const float *xb = x + size_t(b) * p.Cin * p.Lin;
         conv_gemm<MW, NW, CC>(acc, xs, xb, wp, p, p.M, span, in0, arow, bcol, wave, lane);
@@ -208,7 +212,7 @@ static int tile_span(const ConvPlan &p, int BN, int *R, int *WF) {
     return ((r - 1) * p.sh + p.kh) * ((wf - 1) * p.s + p.J / p.kh);
 }
 
-template <int MW, int NW, int WM, int WN, int CC, int MODE = 0>
+template <int MW, int NW, int WM, int WN, int CC, int MODE = 0, int PREC = 0>
 static int launch_variant(const ConvPlan &p0, const float *x, const float *wp, const float *bias,
                           const float *res, float *y, hipStream_t st) {
     constexpr int BM = 32 * MW * WM, BN = 32 * NW * WN;
@@ -216,7 +220,7 @@ static int launch_variant(const ConvPlan &p0, const float *x, const float *wp, c
     const int span = tile_span(p0, BN, &p.pm_R, &p.pm_WF);
     const size_t lds = size_t(2) * CC * span * sizeof(float);  // double-buffered input tile
     if (lds > 160 * 1024) return fail(AGX_ERR_UNSUPPORTED, "conv_mfma: tile needs %zu B of LDS", lds);
-    auto kern = conv_mfma_kernel<MW, NW, WM, WN, CC, MODE>;
+    auto kern = conv_mfma_kernel<MW, NW, WM, WN, CC, MODE, PREC>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -245,22 +249,27 @@ struct Variant {
                     hipStream_t);  // row-folded 2-D; nullptr: no 2-D instantiation of this tile
     int (*launch_patch)(const ConvPlan &, const float *, const float *, const float *, const float *, float *,
                         hipStream_t);  // patch 2-D
+    int (*launch_bf)(const ConvPlan &, const float *, const float *, const float *, const float *, float *,
+                     hipStream_t);     // 1-D bf16x3 (16-channel chunks only)
 };
 
 #define AGX_VARIANT(MW, NW, WM, WN, CC) \
-    { MW, NW, WM, WN, CC, "conv_mfma<" #MW "," #NW "," #WM "," #WN "," #CC ">", launch_variant<MW, NW, WM, WN, CC>, nullptr, nullptr }
+    { MW, NW, WM, WN, CC, "conv_mfma<" #MW "," #NW "," #WM "," #WN "," #CC ">", launch_variant<MW, NW, WM, WN, CC>, nullptr, nullptr, nullptr }
 #define AGX_VARIANT2(MW, NW, WM, WN, CC) \
     { MW, NW, WM, WN, CC, "conv_mfma<" #MW "," #NW "," #WM "," #WN "," #CC ">", launch_variant<MW, NW, WM, WN, CC>, \
-      launch_variant<MW, NW, WM, WN, CC, 1>, launch_variant<MW, NW, WM, WN, CC, 2> }
+      launch_variant<MW, NW, WM, WN, CC, 1>, launch_variant<MW, NW, WM, WN, CC, 2>, nullptr }
+#define AGX_VARIANT3(MW, NW, WM, WN, CC) \
+    { MW, NW, WM, WN, CC, "conv_mfma<" #MW "," #NW "," #WM "," #WN "," #CC ">", launch_variant<MW, NW, WM, WN, CC>, \
+      launch_variant<MW, NW, WM, WN, CC, 1>, launch_variant<MW, NW, WM, WN, CC, 2>, launch_variant<MW, NW, WM, WN, CC, 0, 1> }
 
-static const Variant kWide[] = {AGX_VARIANT2(2, 2, 2, 2, 16), AGX_VARIANT2(2, 2, 2, 2, 8), AGX_VARIANT(2, 2, 2, 2, 32)};
+static const Variant kWide[] = {AGX_VARIANT3(2, 2, 2, 2, 16), AGX_VARIANT2(2, 2, 2, 2, 8), AGX_VARIANT(2, 2, 2, 2, 32)};
 // 128 x 64 tiles for short signals: twice the workgroups when the 128 x 128 grid would leave
 // a CU with a single resident workgroup (nothing to overlap staging / epilogue with).
-static const Variant kWideShort[] = {AGX_VARIANT2(1, 2, 4, 1, 16), AGX_VARIANT2(1, 2, 4, 1, 8), AGX_VARIANT(1, 2, 4, 1, 32)};
+static const Variant kWideShort[] = {AGX_VARIANT3(1, 2, 4, 1, 16), AGX_VARIANT2(1, 2, 4, 1, 8), AGX_VARIANT(1, 2, 4, 1, 32)};
 static const Variant kWideAlt[] = {AGX_VARIANT(1, 4, 4, 1, 16), AGX_VARIANT(1, 4, 4, 1, 8), AGX_VARIANT(1, 4, 4, 1, 32)};
-static const Variant kMid[] = {AGX_VARIANT2(2, 2, 1, 4, 16), AGX_VARIANT2(2, 2, 1, 4, 8), AGX_VARIANT2(2, 1, 1, 4, 16),
+static const Variant kMid[] = {AGX_VARIANT3(2, 2, 1, 4, 16), AGX_VARIANT2(2, 2, 1, 4, 8), AGX_VARIANT2(2, 1, 1, 4, 16),
                                AGX_VARIANT2(2, 1, 1, 4, 8),  AGX_VARIANT(2, 2, 1, 4, 32)};
-static const Variant kNarrow[] = {AGX_VARIANT2(1, 4, 1, 4, 16), AGX_VARIANT2(1, 4, 1, 4, 8), AGX_VARIANT2(1, 1, 1, 4, 16),
+static const Variant kNarrow[] = {AGX_VARIANT3(1, 4, 1, 4, 16), AGX_VARIANT2(1, 4, 1, 4, 8), AGX_VARIANT2(1, 1, 1, 4, 16),
                                   AGX_VARIANT2(1, 1, 1, 4, 8),  AGX_VARIANT(1, 4, 1, 4, 32)};
 
 static size_t variant_lds(const Variant &v, const ConvPlan &p) {
@@ -288,7 +297,7 @@ static const Variant *select_variant(const ConvPlan &p) {
     const Variant *list = p.M >= 128 ? kWide : (p.M >= 64 ? kMid : kNarrow);
     const int n = p.M >= 128 ? 3 : 5;
     if (p.M >= 128 && tuning().conv_shape == 1) list = kWideAlt;
-    const Variant *v = pick(list, n, p, tuning().conv_cc);
+    const Variant *v = pick(list, n, p, p.prec ? 16 : tuning().conv_cc);
     if (v && p.M >= 128 && tuning().conv_short && !p.pm_R) {
         // Short signals: the same channel chunk (= the same summation order, so results do not depend on
         // the batch size or the signal length) on 128 x 64 tiles.
@@ -315,6 +324,11 @@ int launch_conv_mfma(const ConvPlan &p, const float *x, const float *wp, const f
         return fail(AGX_ERR_UNSUPPORTED,
                     "conv_mfma: needs Cin %% 16 == 0, q*Cout >= 32 and an input tile that fits LDS (Cin=%d M=%d s=%d J=%d d=%d)",
                     p.Cin, p.M, p.s, p.J, p.d);
+    if (p.prec) {
+        if (!v->launch_bf || p.pm_R || p.kh > 1 || p.Tout > 1)
+            return fail(AGX_ERR_UNSUPPORTED, "conv_mfma: no bf16x3 instantiation for this layer (%s)", v->name);
+        return v->launch_bf(p, x, wp, bias, res, y, st);
+    }
     if (p.pm_R) {
         if (!v->launch_patch) return fail(AGX_ERR_UNSUPPORTED, "conv_mfma: no 2-D instantiation of %s", v->name);
         return v->launch_patch(p, x, wp, bias, res, y, st);

@@ -141,6 +141,7 @@ int lower_conv(const agx_conv_desc *d, ConvPlan *p) {
     p->qh = 1;
     p->oshift_h = 0;
     p->Tt = 1;
+    p->prec = d->impl == AGX_IMPL_MFMA_BF16X3 ? 1 : 0;
     p->x_cstride = p->Lin;
     p->y_cstride = p->Lout;
     return AGX_OK;
@@ -201,6 +202,7 @@ int lower_conv_bwd_data(const agx_conv_desc *d, ConvPlan *b) {
     b->qh = 1;
     b->oshift_h = 0;
     b->Tt = 1;
+    b->prec = 0;
     return AGX_OK;
 }
 
@@ -253,6 +255,7 @@ int64_t agx_conv_packed_floats(const agx_conv_desc *d) {
     if (rc != AGX_OK) return rc;
     // + dim0 floats of scratch at the tail for the weight-norm scales
     const int dim0 = (d->kind == AGX_CONV_TRANSPOSED) ? d->c_in : d->c_out;
+    if (p.prec) return agx::packed_weight_floats_bf(p.Cin, p.J, p.M) + dim0;
     return agx::packed_weight_floats(p.Cin / p.G, p.J, p.M) + dim0;
 }
 

@@ -326,6 +326,124 @@ __device__ __forceinline__ void conv_gemm_rows(f32x16 (&acc)[MW][NW], float *__r
     AGX_STAMP(2);
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16x3 form of the main loop (AGX_IMPL_MFMA_BF16X3).  Every fp32 operand is split into three bf16
+// pieces x = h + m + l (24 significant bits); a product block is the six bf16 MFMAs hh + hm + mh + hl + lh + mm
+// (fp32 accumulation, small terms first): 6 x 32 cycles for a 32 x 32 x 16 block against 8 x 64 on the fp32
+// MFMA, with fp32-class accuracy (tools/gemm_bf16x3.hip: 6.8e-7 vs 3.9e-7 of the fp32 chain over K = 1024) but
+// NOT the bitwise fp32 FMA chain -- used where only a float tolerance applies (the decoder), never where an
+// integer is decided (encoder -> RVQ indices).  Weights are split once by the pack kernel (three planes per
+// 16-channel group: 96 B per (group, tap, row)); the input is split in registers after its LDS read, one phase
+// ahead, in the shadow of the previous phase's MFMAs.  A K = 16 block = the 16 channels of a phase: lane half
+// lh holds channels 8 lh .. 8 lh + 7 -- the same channel assignment as the fp32 loop, so staging is shared.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3(const float (&x)[8], bf16x8 &h, bf16x8 &m, bf16x8 &l) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 hh = (__bf16)x[i];
+        const float r1 = x[i] - (float)hh;
+        const __bf16 mm = (__bf16)r1;
+        h[i] = hh;
+        m[i] = mm;
+        l[i] = (__bf16)(r1 - (float)mm);
+    }
+}
+
+template <int MW>
+__device__ __forceinline__ void load_a_phase_bf(bf16x8 (&a)[3][MW], const __bf16 *__restrict__ wpb, int c0, int j, int J,
+                                                int M, int lh, const int (&arow)[MW]) {
+    const __bf16 *slab = wpb + (size_t(c0 / kWG) * J + j) * M * 48 + lh * 8;
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+        const __bf16 *row = slab + size_t(arow[i]) * 48;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) a[pl][i] = *reinterpret_cast<const bf16x8 *>(row + pl * 16);
+    }
+}
+
+template <int MW, int NW>
+__device__ __forceinline__ void mfma_block_bf(f32x16 (&acc)[MW][NW], const bf16x8 (&a)[3][MW], const bf16x8 (&b)[3][NW]) {
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            f32x16 c = acc[i][k];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][k], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][k], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][k], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][k], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][k], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][k], c, 0, 0, 0);
+            acc[i][k] = c;
+        }
+}
+
+// Same pipeline as conv_gemm_rows (LDS-DMA double buffer per chunk, weights one phase ahead in registers,
+// input fragments read one phase ahead), CC a multiple of 16.
+template <int MW, int NW, int CC, class Stager>
+__device__ __forceinline__ void conv_gemm_rows_bf(f32x16 (&acc)[MW][NW], float *__restrict__ xs, const Stager &stg,
+                                                  const __bf16 *__restrict__ wpb, const ConvPlan &p, int M, int span,
+                                                  const int (&arow)[MW], const int (&bcol)[NW], int wave, int lane) {
+    static_assert(CC % 16 == 0, "bf16x3 phases are 16 channels deep");
+    constexpr int NH = CC / 16;
+    const int lh = lane >> 5;
+    const int tid = wave * 64 + lane;
+    float *buf0 = xs, *buf1 = xs + CC * span;
+    stg.zero_fill(xs, 2 * CC, span, tid);
+    bf16x8 a_cur[3][MW], a_nxt[3][MW], b_cur[3][NW];
+    float b_raw[8][NW];
+    load_a_phase_bf<MW>(a_cur, wpb, 0, 0, p.J, M, lh, arow);
+    __syncthreads();
+    stg.template issue<CC>(buf0, 0, span, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int it = 0;
+    for (int c0 = 0; c0 < p.Cin; c0 += CC, ++it) {
+        float *cur = (it & 1) ? buf1 : buf0;
+        float *nxt = (it & 1) ? buf0 : buf1;
+        load_b_phase<NW, 16>(b_raw, cur, span, bcol);
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            float x[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[q] = b_raw[q][k];
+            split3(x, b_cur[0][k], b_cur[1][k], b_cur[2][k]);
+        }
+        for (int h = 0; h < NH; ++h) {
+            for (int j = 0; j < p.J; ++j) {
+                int nj = j + 1, nh = h, nc0 = c0;
+                if (nj == p.J) {
+                    nj = 0;
+                    if (++nh == NH) {
+                        nh = 0;
+                        nc0 += CC;
+                    }
+                }
+                if (h == 0 && j == 0 && c0 + CC < p.Cin) stg.template issue<CC>(nxt, c0 + CC, span, wave, lane);
+                const bool last = nc0 >= p.Cin;
+                load_a_phase_bf<MW>(a_nxt, wpb, last ? 0 : nc0 + nh * 16, last ? 0 : nj, p.J, M, lh, arow);
+                load_b_phase<NW, 16>(b_raw, cur + (nc0 == c0 ? nh * 16 * span + stg.tapoff(nj) : 0), span, bcol);
+                mfma_block_bf<MW, NW>(acc, a_cur, b_cur);
+                // next phase's input: split while this phase's MFMAs drain
+#pragma unroll
+                for (int k = 0; k < NW; ++k) {
+                    float x[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) x[q] = b_raw[q][k];
+                    split3(x, b_cur[0][k], b_cur[1][k], b_cur[2][k]);
+                }
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int i = 0; i < MW; ++i) a_cur[pl][i] = a_nxt[pl][i];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}
+
 // 1-D entry point (rows = channels of one batch item at xb).
 template <int MW, int NW, int CC, int SCHED = kSchedDefault>
 __device__ __forceinline__ void conv_gemm(f32x16 (&acc)[MW][NW], float *__restrict__ xs,

@@ -78,6 +78,29 @@ __global__ __launch_bounds__(256) void pack_kernel(const float *__restrict__ v,
     packed[e] = fwd_weight(v, scale, kind, Cin, Cout, K, J, P, up, ci, j, m / q, m % q);
 }
 
+// bf16x3 image: [((g * J + j) * M + m) * 48 + plane * 16 + c16] bf16, w = h + m + l split with round-to-nearest
+__global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float *__restrict__ v, const float *__restrict__ scale,
+                                                          __bf16 *__restrict__ packed, int kind, int Cin, int Cout, int K,
+                                                          int q, int J, int P, int up) {
+    const int M = q * Cout;
+    const int64_t total = int64_t((Cin + kWG - 1) / kWG) * J * M * kWG;   // one thread per weight
+    const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int c16 = int(e % kWG);
+    const int m = int((e / kWG) % M);
+    const int gj = int(e / (int64_t(kWG) * M));
+    const int j = gj % J, ci = (gj / J) * kWG + c16;
+    const float w = ci < Cin ? fwd_weight(v, scale, kind, Cin, Cout, K, J, P, up, ci, j, m / q, m % q) : 0.f;
+    const __bf16 h = (__bf16)w;
+    const float r1 = w - (float)h;
+    const __bf16 mm = (__bf16)r1;
+    const __bf16 l = (__bf16)(r1 - (float)mm);
+    __bf16 *dst = packed + (size_t(gj) * M + m) * 48 + c16;
+    dst[0] = h;
+    dst[16] = mm;
+    dst[32] = l;
+}
+
 // Packed image of the BACKWARD-DATA op (core.hip: lower_conv_bwd_data).  (Cin, Cout, K, q, J, P, s) are
 // the FORWARD plan's; the image has fwd-Cout "input" channels and M_b = q_b * fwd-Cin rows.
 __global__ __launch_bounds__(256) void pack_bwd_kernel(const float *__restrict__ v,
@@ -176,14 +199,21 @@ static int pack_forward(const agx_conv_desc *d, const float *v, const float *g, 
     const int cpg = p.Cin / p.G;  // the weight tensor is (Cout, Cin / groups, K)
     const int dim0 = transposed ? d->c_in : d->c_out;
     const int inner = (transposed ? d->c_out : cpg) * d->kernel;
-    const int64_t n_w = packed_weight_floats(cpg, p.J, p.M);
+    const int64_t n_w = p.prec ? packed_weight_floats_bf(p.Cin, p.J, p.M) : packed_weight_floats(cpg, p.J, p.M);
     float *scale = packed + n_w;  // tail scratch reserved by agx_conv_packed_floats
+    if (p.prec && p.G != 1) return fail(AGX_ERR_UNSUPPORTED, "%s: bf16x3 images are for dense layers", who);
     if (g)
         hipLaunchKernelGGL(wn_scale_kernel, dim3(dim0), dim3(256), 0, st, v, g, scale, inner);
     else if (sigma)
         hipLaunchKernelGGL(fill_inv_sigma_kernel, dim3(ceil_div(dim0, 256)), dim3(256), 0, st, scale, dim0, sigma);
     else
         hipLaunchKernelGGL(fill_ones_kernel, dim3(ceil_div(dim0, 256)), dim3(256), 0, st, scale, dim0);
+    if (p.prec) {
+        const int64_t nthreads = int64_t(ceil_div(p.Cin, kWG)) * p.J * p.M * kWG;
+        hipLaunchKernelGGL(pack_bf16x3_kernel, dim3((unsigned)ceil_div64(nthreads, 256)), dim3(256), 0, st, v, scale,
+                           reinterpret_cast<__bf16 *>(packed), d->kind, p.Cin, p.Cout, d->kernel, p.q, p.J, p.P, d->stride);
+        return check_launch(who);
+    }
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)ceil_div64(n_w, 256)), dim3(256), 0, st, v, scale,
                        packed, d->kind, cpg, p.Cout, d->kernel, p.q, p.J, p.P, d->stride);
     return check_launch(who);

@@ -67,6 +67,9 @@ int agx_get_tuning(const char *name);
 #define AGX_IMPL_AUTO 0
 #define AGX_IMPL_DIRECT 1 /* fp32 VALU, any shape                            */
 #define AGX_IMPL_MFMA 2   /* fp32-input MFMA implicit GEMM (exact fp32 FMA chain) */
+#define AGX_IMPL_MFMA_BF16X3 3 /* operands split into 3 bf16 pieces, 6 bf16 MFMAs per product block: fp32-class
+                               * accuracy (~1e-7 rel.), not the bitwise fp32 chain; dense 1-D layers with
+                               * Cin % 16 == 0 and q*Cout >= 32; its own packed image (agx_conv_pack with this impl) */
 
 /* Epilogue flags (fused into the conv kernel; all optional). */
 #define AGX_EPI_LEAKY_PRE 1  /* LeakyReLU(slope) on (acc + bias)   vae.py:99,125,156 */
