@@ -20,7 +20,7 @@
 
 namespace agx {
 
-template <int MW, int NW, int CC, int SCHED = kSchedDefault, int OCC = (MW <= 4 ? 2 : 1)>
+template <int MW, int NW, int CC, int SCHED = kSchedDefault, int OCC = (MW <= 4 ? 2 : 1), int PREC = 0>
 __global__ __launch_bounds__(256, OCC) void resblock_mfma_kernel(ConvPlan p, int span, int post_act,
                                                             const float *__restrict__ x,
                                                             const float *__restrict__ w1,
@@ -55,7 +55,13 @@ __global__ __launch_bounds__(256, OCC) void resblock_mfma_kernel(ConvPlan p, int
     const float *xb = x + size_t(b) * C * p.Lin;
 
     // ---- GEMM1: h = W1 (*) x ------------------------------------------------------
-    conv_gemm<MW, NW, CC, SCHED>(acc, xs, xb, w1, p, C, span, in0, arow, bcol, wave, lane);
+    if (PREC == 1) {
+        const StagerRows<RowMap1D> stg{RowMap1D{xb, p.Lin}, p.Lvalid, in0, p.d};
+        conv_gemm_rows_bf<MW, NW, (CC < 16 ? 16 : CC)>(acc, xs, stg, reinterpret_cast<const __bf16 *>(w1), p, C, span, arow,
+                                                       bcol, wave, lane);
+    } else {
+        conv_gemm<MW, NW, CC, SCHED>(acc, xs, xb, w1, p, C, span, in0, arow, bcol, wave, lane);
+    }
 
     // ---- hidden activation, in registers --------------------------------------------
 #pragma unroll
@@ -80,6 +86,40 @@ __global__ __launch_bounds__(256, OCC) void resblock_mfma_kernel(ConvPlan p, int
 #pragma unroll
             for (int r = 0; r < 16; ++r) out[i][k][r] = 0.f;
 
+    if (PREC == 1) {
+        // bf16x3 GEMM2: a K = 16 block = accumulator registers 8 kb .. 8 kb + 7 of hidden subtile i, i.e. hidden
+        // channels 16 (2i + kb) + {4 lh + 0..3, 8 + 4 lh + 0..3}: the matching W2 pieces are two 8-byte runs of the
+        // standard bf16x3 image per plane (group 2i + kb, tap 0).
+        const __bf16 *w2b = reinterpret_cast<const __bf16 *>(w2);
+#pragma unroll
+        for (int i = 0; i < MW; ++i) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                bf16x8 bq[3][NW];
+#pragma unroll
+                for (int k = 0; k < NW; ++k) {
+                    float xq[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xq[e] = acc[i][k][8 * kb + e];
+                    split3(xq, bq[0][k], bq[1][k], bq[2][k]);
+                }
+                bf16x8 aq[3][MW];
+                const __bf16 *grp = w2b + size_t(2 * i + kb) * C * 48 + 4 * lh;
+#pragma unroll
+                for (int io = 0; io < MW; ++io) {
+                    const __bf16 *row = grp + size_t(io * 32 + li) * 48;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                        const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(row + pl * 16);
+                        const bf16x4 hi = *reinterpret_cast<const bf16x4 *>(row + pl * 16 + 8);
+                        aq[pl][io] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    }
+                }
+                mfma_block_bf<MW, NW>(out, aq, bq);
+            }
+        }
+    } else
 #pragma unroll
     for (int i = 0; i < MW; ++i) {       // hidden-channel subtile
 #pragma unroll
@@ -141,7 +181,7 @@ __global__ __launch_bounds__(256, OCC) void resblock_mfma_kernel(ConvPlan p, int
     AGX_STAMP(5);
 }
 
-template <int MW, int NW, int CC, int SCHED = kSchedDefault, int OCC = (MW <= 4 ? 2 : 1)>
+template <int MW, int NW, int CC, int SCHED = kSchedDefault, int OCC = (MW <= 4 ? 2 : 1), int PREC = 0>
 static int launch_rb(const ConvPlan &p, const float *x, const float *w1, const float *b1, const float *w2,
                      const float *b2, float *y, int post_act, hipStream_t st) {
     constexpr int BN = 32 * NW * 4;
@@ -150,7 +190,7 @@ static int launch_rb(const ConvPlan &p, const float *x, const float *w1, const f
     if (lds > 160 * 1024) return fail(AGX_ERR_UNSUPPORTED, "resblock: tile needs %zu B of LDS", lds);
     const int wgs = tuning().rb_wgs;  // diagnostic: cap workgroups per CU by requesting more LDS
     if (wgs >= 1 && wgs <= 3 && lds < size_t(160 * 1024) / wgs) lds = size_t(160 * 1024) / wgs;
-    auto kern = resblock_mfma_kernel<MW, NW, CC, SCHED, OCC>;
+    auto kern = resblock_mfma_kernel<MW, NW, CC, SCHED, OCC, PREC>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -201,6 +241,14 @@ int launch_resblock_fused(const ConvPlan &p, const float *x, const float *w1, co
          : sched == 0 ? launch_rb<MW, NW, 16, 0>(p, x, w1, b1, w2, b2, y, post_act, st)                 \
          : sched == 2 ? launch_rb<MW, NW, 16, 2>(p, x, w1, b1, w2, b2, y, post_act, st)                 \
                       : launch_rb<MW, NW, 16, 1>(p, x, w1, b1, w2, b2, y, post_act, st))
+    if (p.prec) {   // bf16x3 (AGX_IMPL_MFMA_BF16X3): both packed images are bf16x3 images
+        switch (p.Cin) {
+            case 32: return launch_rb<1, 4, 16, 1, 2, 1>(p, x, w1, b1, w2, b2, y, post_act, st);
+            case 64: return launch_rb<2, 2, 16, 1, 2, 1>(p, x, w1, b1, w2, b2, y, post_act, st);
+            case 128: return launch_rb<4, 1, 16, 1, 2, 1>(p, x, w1, b1, w2, b2, y, post_act, st);
+            default: return launch_rb<8, 1, 16, 1, 1, 1>(p, x, w1, b1, w2, b2, y, post_act, st);
+        }
+    }
     if (tuning().rb_occ == 3 && !c32) {  // diagnostic: cap VGPRs at 168 so that 3 waves/SIMD fit
         switch (p.Cin) {
             case 32: return launch_rb<1, 4, 16, 1, 3>(p, x, w1, b1, w2, b2, y, post_act, st);

@@ -25,7 +25,7 @@ from torch import nn
 from . import ops
 from .autograd_bridge import hip_forward_aten_backward, needs_grad
 from ._lib import (CONV_CAUSAL, CONV_PADDED, CONV_TRANSPOSED, CONV_UPSAMPLE, EPI_LEAKY_POST, EPI_LEAKY_PRE,
-                   IMPL_AUTO, AgxError)
+                   IMPL_AUTO, IMPL_MFMA_BF16X3, AgxError)
 
 Tensor = torch.Tensor
 
@@ -109,18 +109,20 @@ class _ConvParams(nn.Module):
             self._packed_bwd_key = key
         return self._packed_bwd
 
-    def packed(self, kind: int) -> Tensor:
+    def packed(self, kind: int, impl: int = IMPL_AUTO) -> Tensor:
         """Packed (weight-norm folded) image, rebuilt when the parameters change
-        (optimizer step, ``load_state_dict``, ``.to(device)``)."""
+        (optimizer step, ``load_state_dict``, ``.to(device)``).  The bf16x3 kernels have their own image."""
+        bf = impl == IMPL_MFMA_BF16X3
         if hasattr(self, "weight_v"):
             v, g = self.weight_v, self.weight_g
-            key = (kind, v.data_ptr(), v._version, g.data_ptr(), g._version)
+            key = (kind, bf, v.data_ptr(), v._version, g.data_ptr(), g._version)
         else:
             v, g = self.weight, None
-            key = (kind, v.data_ptr(), v._version)
+            key = (kind, bf, v.data_ptr(), v._version)
         if self._packed is None or self._packed_key != key:
             desc = ops.conv_desc(kind, 1, self.in_channels, self.out_channels, 1 << 20,
-                                 self.kernel_size[0], self.stride[0], self.dilation[0], groups=self.groups)
+                                 self.kernel_size[0], self.stride[0], self.dilation[0],
+                                 impl=IMPL_MFMA_BF16X3 if bf else IMPL_AUTO, groups=self.groups)
             self._packed = ops.conv_pack(desc, v.detach(), None if g is None else g.detach())
             self._packed_key = key
         return self._packed
@@ -138,7 +140,7 @@ class _ConvBase(nn.Module):
                              c.kernel_size[0], c.stride[0], c.dilation[0], epilogue, slope, self.impl,
                              groups=getattr(c, "groups", 1))
         bias = None if c.bias is None else c.bias.detach()
-        return ops.conv_forward(desc, x, c.packed(self.kind), bias, res)
+        return ops.conv_forward(desc, x, c.packed(self.kind, self.impl), bias, res)
 
     def forward(self, x: Tensor) -> Tensor:
         return self.run(x)
@@ -248,7 +250,8 @@ class CausalResidualBlock1d(nn.Module):
                              c1.kernel_size[0], 1, c1.dilation[0], 0, slope, self.conv1.impl)
         b1 = None if c1.bias is None else c1.bias.detach()
         b2 = None if c2.bias is None else c2.bias.detach()
-        return ops.resblock_forward(desc, x, c1.packed(CONV_CAUSAL), b1, c2.packed(CONV_CAUSAL), b2,
+        impl = self.conv1.impl
+        return ops.resblock_forward(desc, x, c1.packed(CONV_CAUSAL, impl), b1, c2.packed(CONV_CAUSAL, impl), b2,
                                     post_act=post_slope is not None)
 
     def _aten(self, x: Tensor) -> Tensor:  # backward bridge only
@@ -397,6 +400,24 @@ class CausalVQAE(nn.Module):
 
         self.encoders = nn.ModuleList(encoders)
         self.decoders = nn.ModuleList(decoders)
+
+    # -- arithmetic of the conv stacks (build-defined; the reference has fp32 only) ------------------
+    def set_conv_arithmetic(self, decoders: str = "fp32", encoders: str = "fp32") -> "CausalVQAE":
+        """``"fp32"``: the fp32-input MFMA kernels (bitwise an fp32 FMA chain).  ``"bf16x3"``: operands split into three
+        bf16 pieces on the bf16 MFMA -- the same error against fp64 as fp32 (tools/bf16x3_accuracy.py), 1.3-1.5x
+        faster, but not the bitwise fp32 chain.  The default keeps the ENCODER exact (it decides the RVQ indices)
+        and is what every parity statement refers to; ``bench.py`` reports which setting it ran."""
+        for stack, mode in ((self.decoders, decoders), (self.encoders, encoders)):
+            if mode not in ("fp32", "bf16x3"):
+                raise ValueError(f"unknown arithmetic {mode!r}")
+            for m in stack.modules():
+                if isinstance(m, _ConvBase):
+                    c = m.conv
+                    q = c.stride[0] if m.kind in (CONV_TRANSPOSED, CONV_UPSAMPLE) else 1
+                    ok = mode == "bf16x3" and c.in_channels % 16 == 0 and q * c.out_channels >= 32 and getattr(c, "groups", 1) == 1
+                    m.impl = IMPL_MFMA_BF16X3 if ok else IMPL_AUTO
+        self.__dict__.pop("_unit_cache", None)
+        return self
 
     # -- layout helpers (vae.py:283-288) ------------------------------------------------
     def rearrange_in(self, x: Tensor) -> Tensor:

@@ -119,3 +119,19 @@ def test_bitstream_round_trip_reproduces_the_forward(setup):
     assert stream.numel() == (4 * 225 * 8 * 10 + 7) // 8 and shape == (4, 225, 8)    # 9 000 bytes for 12 s of audio
     y2, idx2 = model.decompress(stream, shape)
     assert torch.equal(idx2, index[:4]) and torch.equal(y2, y[:4])
+
+
+def test_bf16x3_decoder_matches_fp32_and_oracle(setup):
+    """Decoder on the bf16x3 kernels (CausalVQAE.set_conv_arithmetic): same waveform as the fp32-MFMA decoder
+    to ~1e-6 of its scale, and within the 1e-4 RMS budget of the oracle; indices unchanged (encoder stays fp32)."""
+    model, x, z, y, commit, index = setup
+    model.set_conv_arithmetic(decoders="bf16x3")
+    try:
+        with torch.no_grad():
+            y2, _, index2 = model(x)
+    finally:
+        model.set_conv_arithmetic()
+    assert torch.equal(index2, index)
+    scale = float(y.abs().max())
+    assert float((y2 - y).abs().max()) <= 2e-5 * scale
+    assert float((y2 - y).pow(2).mean().sqrt()) <= 1e-6 * max(scale, 1.0)
