@@ -84,7 +84,8 @@ int agx_conv_kernel_name(const agx_conv_desc *d, char *buf, size_t buf_len) {
     if (!buf || buf_len == 0) return fail(AGX_ERR_NULL_POINTER, "agx_conv_kernel_name: NULL buffer");
     int impl = d->impl;
     if (impl == AGX_IMPL_AUTO) impl = conv_mfma_supported(p) ? AGX_IMPL_MFMA : AGX_IMPL_DIRECT;
-    snprintf(buf, buf_len, "%s", impl == AGX_IMPL_MFMA ? conv_mfma_variant(p) : conv_direct_variant(p));
+    if (impl == AGX_IMPL_MFMA_BF16X3) snprintf(buf, buf_len, "%s:bf16x3", conv_mfma_variant(p));
+    else snprintf(buf, buf_len, "%s", impl == AGX_IMPL_MFMA ? conv_mfma_variant(p) : conv_direct_variant(p));
     return AGX_OK;
 }
 
@@ -102,11 +103,12 @@ int agx_resblock_kernel_name(const agx_conv_desc *d, char *buf, size_t buf_len) 
     int rc = lower_conv(&d1, &p);
     if (rc != AGX_OK) return rc;
     if (d->impl != AGX_IMPL_DIRECT && resblock_fused_supported(p)) {
-        snprintf(buf, buf_len, "%s", resblock_variant(p));
+        snprintf(buf, buf_len, "%s%s", resblock_variant(p), p.prec ? ":bf16x3" : "");
     } else {
         int impl = d->impl;
         if (impl == AGX_IMPL_AUTO) impl = conv_mfma_supported(p) ? AGX_IMPL_MFMA : AGX_IMPL_DIRECT;
-        snprintf(buf, buf_len, "2x:%s", impl == AGX_IMPL_MFMA ? conv_mfma_variant(p) : conv_direct_variant(p));
+        snprintf(buf, buf_len, "2x:%s%s", impl == AGX_IMPL_DIRECT ? conv_direct_variant(p) : conv_mfma_variant(p),
+                 p.prec ? ":bf16x3" : "");
     }
     return AGX_OK;
 }

@@ -362,21 +362,18 @@ __device__ __forceinline__ void load_a_phase_bf(bf16x8 (&a)[3][MW], const __bf16
     }
 }
 
+// The six products of one K = 16 block, small terms first.  Product-major order: consecutive MFMAs go to
+// DIFFERENT accumulators (MW * NW independent chains), so none waits for its predecessor's result.
 template <int MW, int NW>
 __device__ __forceinline__ void mfma_block_bf(f32x16 (&acc)[MW][NW], const bf16x8 (&a)[3][MW], const bf16x8 (&b)[3][NW]) {
+    constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};   // (plane of a, plane of b): mm hl lh hm mh hh
 #pragma unroll
-    for (int i = 0; i < MW; ++i)
+    for (int t = 0; t < 6; ++t)
 #pragma unroll
-        for (int k = 0; k < NW; ++k) {
-            f32x16 c = acc[i][k];
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][k], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][k], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][k], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][k], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][k], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][k], c, 0, 0, 0);
-            acc[i][k] = c;
-        }
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int k = 0; k < NW; ++k)
+                acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]][i], b[PB[t]][k], acc[i][k], 0, 0, 0);
 }
 
 // Same pipeline as conv_gemm_rows (LDS-DMA double buffer per chunk, weights one phase ahead in registers,

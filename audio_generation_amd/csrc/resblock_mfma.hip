@@ -219,7 +219,7 @@ static bool rb_use_cc32(const ConvPlan &p) {
 }
 
 const char *resblock_variant(const ConvPlan &p) {
-    const bool c32 = rb_use_cc32(p);
+    const bool c32 = rb_use_cc32(p) && !p.prec;
     switch (p.Cin) {
         case 32: return c32 ? "resblock_mfma<1,4,32>" : "resblock_mfma<1,4,16>";
         case 64: return c32 ? "resblock_mfma<2,2,32>" : "resblock_mfma<2,2,16>";

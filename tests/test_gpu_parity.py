@@ -91,12 +91,12 @@ SHAPES = [  # (kind, cin, cout, k, stride, dilation, B, L) -- the layer shapes o
 ]
 
 
-@pytest.mark.parametrize("impl", ["direct", "mfma"])
+@pytest.mark.parametrize("impl", ["direct", "mfma", "bf16x3"])
 def test_conv_kernels_match_oracle(impl):
     gen = torch.Generator().manual_seed(11)
     checked = 0
     for (kind, cin, cout, k, s, d, b, length) in SHAPES:
-        if impl == "mfma" and (cin % 16 != 0 or (cout * (s if kind != "conv" else 1)) < 32):
+        if impl != "direct" and (cin % 16 != 0 or (cout * (s if kind != "conv" else 1)) < 32):
             continue
         wshape = (cin, cout, k) if kind == "convt" else (cout, cin, k)
         v = torch.randn(wshape, generator=gen) / (cin * k) ** 0.5
@@ -112,7 +112,9 @@ def test_conv_kernels_match_oracle(impl):
             want = codec.upsample_conv1d(x, w, bias, s)
         want = codec.leaky(want)
         desc = ops.conv_desc(KIND[kind], b, cin, cout, length, k, s, d, _lib.EPI_LEAKY_PRE, 0.1,
-                             _lib.IMPL_DIRECT if impl == "direct" else _lib.IMPL_MFMA)
+                             {"direct": _lib.IMPL_DIRECT, "mfma": _lib.IMPL_MFMA, "bf16x3": _lib.IMPL_MFMA_BF16X3}[impl])
+        if impl == "bf16x3":
+            assert ops.conv_kernel_name(desc).endswith(":bf16x3")
         packed = ops.conv_pack(desc, v.to(DEV), g.to(DEV))
         y = ops.conv_forward(desc, x.to(DEV), packed, bias.to(DEV))
         assert tuple(y.shape) == tuple(want.shape), (kind, cin, cout, k, s, d)
@@ -148,6 +150,19 @@ def test_residual_and_epilogues():
             CausalResidualBlock1d.split_launches = False
         assert max_abs(y_split.cpu(), codec.leaky(want)) < 3e-5, (c, d)
         assert max_abs(y_split, y_act) < 3e-5, (c, d)
+        # bf16x3 arithmetic (fused kernel for C in {32,64,128,256}): same tolerance as the fp32 kernels
+        if c % 16 == 0 and c >= 32:
+            for conv in (m.conv1, m.conv2):
+                conv.impl = _lib.IMPL_MFMA_BF16X3
+            try:
+                with torch.no_grad():
+                    y_bf = m.run(x.to(DEV), 0.1)
+                    y_bf_plain = m(x.to(DEV))
+            finally:
+                for conv in (m.conv1, m.conv2):
+                    conv.impl = _lib.IMPL_AUTO
+            assert max_abs(y_bf.cpu(), codec.leaky(want)) < 3e-5, (c, d)
+            assert max_abs(y_bf_plain.cpu(), want) < 3e-5, (c, d)
 
 
 # ------------------------------------------------------------------------------- RVQ
