@@ -61,7 +61,7 @@ int lower_conv2d(const agx_conv2d_desc *d, ConvPlan *p) {
     p->qh = 1;
     p->oshift_h = 0;
     p->Tt = p->Tout;
-    p->prec = 0;
+    p->prec = (patch && d->impl == AGX_IMPL_MFMA_BF16X3) ? 1 : 0;   // bf16x3: patch layers only
     if (int64_t(p->B) * p->Tout > (int64_t(1) << 30)) return fail(AGX_ERR_BAD_SHAPE, "conv2d: batch * output rows too large");
     return AGX_OK;
 }
@@ -89,6 +89,7 @@ int lower_conv2d_bwd_data(const agx_conv2d_desc *d, ConvPlan *b) {
     b->y_cstride = int64_t(d->h_in) * d->w_in;
     b->epilogue = 0;
     b->mask = nullptr;
+    b->prec = 0;
     b->d = 1;
     b->s = 1;
     b->sh = 1;
@@ -119,6 +120,7 @@ int lower_conv2d_bwd_data(const agx_conv2d_desc *d, ConvPlan *b) {
         }
         b->M = d->c_in * d->stride_h * d->stride_w;
         b->pm_R = 1;
+        b->prec = d->impl == AGX_IMPL_MFMA_BF16X3 ? 1 : 0;
     } else if (d->stride_h != 1 || d->stride_w != 1 || d->kh - 1 - d->pad_h < 0 || d->kw - 1 - d->pad_w < 0) {
         // odd shapes (strided layers with few / unaligned channels: the tiny test models): gather kernel below
         b->pm_R = -1;
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(256) void scale_copy_kernel(const float *__restrict
 // Packed image of the backward-data op (both lowerings above).
 __global__ __launch_bounds__(256) void pack_bwd2d_kernel(const float *__restrict__ w, const float *__restrict__ sigma,
                                                          float *__restrict__ packed, int Cin, int Cout, int kh, int kw,
-                                                         int sh, int sw, int patch, int nch, int J, int M) {
+                                                         int sh, int sw, int patch, int nch, int J, int M, int bf) {
     const int64_t total = packed_weight_floats(nch, J, M);
     const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (e >= total) return;
@@ -217,7 +219,18 @@ __global__ __launch_bounds__(256) void pack_bwd2d_kernel(const float *__restrict
         }
         if (dh < kh && dw < kw) out = w[((size_t(co) * Cin + ci) * kh + dh) * kw + dw] * (sigma ? 1.f / sigma[0] : 1.f);
     }
-    packed[e] = out;
+    if (!bf) {
+        packed[e] = out;
+        return;
+    }
+    // bf16x3 image (mfma_tile.hpp): three planes per 16-channel group
+    const __bf16 h = (__bf16)out;
+    const float r1 = out - (float)h;
+    const __bf16 mm = (__bf16)r1;
+    __bf16 *dst = reinterpret_cast<__bf16 *>(packed) + (size_t(gj) * M + m) * 48 + c16;
+    dst[0] = h;
+    dst[16] = mm;
+    dst[32] = (__bf16)(r1 - (float)mm);
 }
 }  // namespace agx
 
@@ -228,7 +241,7 @@ int64_t agx_conv2d_bwd_packed_floats(const agx_conv2d_desc *d) {
     int rc = agx::lower_conv2d_bwd_data(d, &b);
     if (rc != AGX_OK) return rc;
     if (b.pm_R < 0) return int64_t(d->c_out) * d->c_in * d->kh * d->kw;
-    return agx::packed_weight_floats(b.ncv, b.J, b.M);
+    return b.prec ? agx::packed_weight_floats_bf(b.ncv, b.J, b.M) : agx::packed_weight_floats(b.ncv, b.J, b.M);
 }
 
 int agx_conv2d_pack_bwd(const agx_conv2d_desc *d, const float *w, const float *sigma, float *packed, void *stream) {
@@ -246,7 +259,7 @@ int agx_conv2d_pack_bwd(const agx_conv2d_desc *d, const float *w, const float *s
     const int64_t n = packed_weight_floats(b.ncv, b.J, b.M);
     hipLaunchKernelGGL(pack_bwd2d_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), w, sigma, packed, d->c_in, d->c_out, d->kh, d->kw, d->stride_h,
-                       d->stride_w, b.pm_R ? 1 : 0, b.ncv, b.J, b.M);
+                       d->stride_w, b.pm_R ? 1 : 0, b.ncv, b.J, b.M, b.prec);
     return check_launch("agx_conv2d_pack_bwd");
 }
 
@@ -284,6 +297,7 @@ int agx_conv2d_out_shape(const agx_conv2d_desc *d, int32_t *h_out, int32_t *w_ou
 
 static int conv2d_impl(const agx_conv2d_desc *d, const agx::ConvPlan &p) {
     int impl = d->impl;
+    if (impl == AGX_IMPL_MFMA_BF16X3) impl = p.prec ? AGX_IMPL_MFMA : AGX_IMPL_AUTO;   // layers without a bf16x3 form run fp32
     if (impl == AGX_IMPL_AUTO) impl = agx::conv_mfma_supported(p) ? AGX_IMPL_MFMA : AGX_IMPL_DIRECT;
     return impl;
 }

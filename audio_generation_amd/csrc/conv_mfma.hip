@@ -95,7 +95,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
     if (MODE == 2) {
         const StagerPatch stg{x + size_t(b) * p.cin_real * p.x_cstride, p.x_cstride, p.Lin, p.Tin,
                               trow * p.sh - p.ph, f0 * p.s - p.P, SW, p.J / p.kh, p.cin_real, 1.f / float(SW)};
-        conv_gemm_rows<MW, NW, CC, kSchedDefault>(acc, xs, stg, wp, p, p.M, span, arow, bcol, wave, lane);
+        if (PREC == 1)
+            conv_gemm_rows_bf<MW, NW, (CC < 16 ? 16 : CC)>(acc, xs, stg, reinterpret_cast<const __bf16 *>(wp), p, p.M, span,
+                                                           arow, bcol, wave, lane);
+        else
+            conv_gemm_rows<MW, NW, CC, kSchedDefault>(acc, xs, stg, wp, p, p.M, span, arow, bcol, wave, lane);
     } else if (MODE == 1) {
         const StagerRows<RowMap2D> stg{RowMap2D{x + size_t(b) * p.cin_real * p.x_cstride, p.x_cstride, p.Lin, p.kh,
                                                 trow * p.sh - p.ph, p.Tin, p.ncv},
@@ -251,25 +255,28 @@ struct Variant {
                         hipStream_t);  // patch 2-D
     int (*launch_bf)(const ConvPlan &, const float *, const float *, const float *, const float *, float *,
                      hipStream_t);     // 1-D bf16x3 (16-channel chunks only)
+    int (*launch_patch_bf)(const ConvPlan &, const float *, const float *, const float *, const float *, float *,
+                           hipStream_t);   // patch 2-D bf16x3
 };
 
 #define AGX_VARIANT(MW, NW, WM, WN, CC) \
-    { MW, NW, WM, WN, CC, "conv_mfma<" #MW "," #NW "," #WM "," #WN "," #CC ">", launch_variant<MW, NW, WM, WN, CC>, nullptr, nullptr, nullptr }
+    { MW, NW, WM, WN, CC, "conv_mfma<" #MW "," #NW "," #WM "," #WN "," #CC ">", launch_variant<MW, NW, WM, WN, CC>, nullptr, nullptr, nullptr, nullptr }
 #define AGX_VARIANT2(MW, NW, WM, WN, CC) \
     { MW, NW, WM, WN, CC, "conv_mfma<" #MW "," #NW "," #WM "," #WN "," #CC ">", launch_variant<MW, NW, WM, WN, CC>, \
-      launch_variant<MW, NW, WM, WN, CC, 1>, launch_variant<MW, NW, WM, WN, CC, 2>, nullptr }
+      launch_variant<MW, NW, WM, WN, CC, 1>, launch_variant<MW, NW, WM, WN, CC, 2>, nullptr, nullptr }
 #define AGX_VARIANT3(MW, NW, WM, WN, CC) \
     { MW, NW, WM, WN, CC, "conv_mfma<" #MW "," #NW "," #WM "," #WN "," #CC ">", launch_variant<MW, NW, WM, WN, CC>, \
-      launch_variant<MW, NW, WM, WN, CC, 1>, launch_variant<MW, NW, WM, WN, CC, 2>, launch_variant<MW, NW, WM, WN, CC, 0, 1> }
+      launch_variant<MW, NW, WM, WN, CC, 1>, launch_variant<MW, NW, WM, WN, CC, 2>, launch_variant<MW, NW, WM, WN, CC, 0, 1>, \
+      launch_variant<MW, NW, WM, WN, CC, 2, 1> }
 
 static const Variant kWide[] = {AGX_VARIANT3(2, 2, 2, 2, 16), AGX_VARIANT2(2, 2, 2, 2, 8), AGX_VARIANT(2, 2, 2, 2, 32)};
 // 128 x 64 tiles for short signals: twice the workgroups when the 128 x 128 grid would leave
 // a CU with a single resident workgroup (nothing to overlap staging / epilogue with).
 static const Variant kWideShort[] = {AGX_VARIANT3(1, 2, 4, 1, 16), AGX_VARIANT2(1, 2, 4, 1, 8), AGX_VARIANT(1, 2, 4, 1, 32)};
 static const Variant kWideAlt[] = {AGX_VARIANT(1, 4, 4, 1, 16), AGX_VARIANT(1, 4, 4, 1, 8), AGX_VARIANT(1, 4, 4, 1, 32)};
-static const Variant kMid[] = {AGX_VARIANT3(2, 2, 1, 4, 16), AGX_VARIANT2(2, 2, 1, 4, 8), AGX_VARIANT2(2, 1, 1, 4, 16),
+static const Variant kMid[] = {AGX_VARIANT3(2, 2, 1, 4, 16), AGX_VARIANT2(2, 2, 1, 4, 8), AGX_VARIANT3(2, 1, 1, 4, 16),
                                AGX_VARIANT2(2, 1, 1, 4, 8),  AGX_VARIANT(2, 2, 1, 4, 32)};
-static const Variant kNarrow[] = {AGX_VARIANT3(1, 4, 1, 4, 16), AGX_VARIANT2(1, 4, 1, 4, 8), AGX_VARIANT2(1, 1, 1, 4, 16),
+static const Variant kNarrow[] = {AGX_VARIANT3(1, 4, 1, 4, 16), AGX_VARIANT2(1, 4, 1, 4, 8), AGX_VARIANT3(1, 1, 1, 4, 16),
                                   AGX_VARIANT2(1, 1, 1, 4, 8),  AGX_VARIANT(1, 4, 1, 4, 32)};
 
 static size_t variant_lds(const Variant &v, const ConvPlan &p) {
@@ -325,6 +332,7 @@ int launch_conv_mfma(const ConvPlan &p, const float *x, const float *wp, const f
                     "conv_mfma: needs Cin %% 16 == 0, q*Cout >= 32 and an input tile that fits LDS (Cin=%d M=%d s=%d J=%d d=%d)",
                     p.Cin, p.M, p.s, p.J, p.d);
     if (p.prec) {
+        if (p.pm_R && v->launch_patch_bf) return v->launch_patch_bf(p, x, wp, bias, res, y, st);
         if (!v->launch_bf || p.pm_R || p.kh > 1 || p.Tout > 1)
             return fail(AGX_ERR_UNSUPPORTED, "conv_mfma: no bf16x3 instantiation for this layer (%s)", v->name);
         return v->launch_bf(p, x, wp, bias, res, y, st);

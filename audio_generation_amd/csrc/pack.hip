@@ -236,7 +236,7 @@ extern "C" int64_t agx_conv2d_packed_floats(const agx_conv2d_desc *d) {
     agx::ConvPlan p;
     int rc = agx::lower_conv2d(d, &p);
     if (rc != AGX_OK) return rc;
-    return agx::packed_weight_floats(p.ncv, p.J, p.M) + p.Cout;
+    return (p.prec ? agx::packed_weight_floats_bf(p.ncv, p.J, p.M) : agx::packed_weight_floats(p.ncv, p.J, p.M)) + p.Cout;
 }
 
 extern "C" int agx_conv2d_pack(const agx_conv2d_desc *d, const float *w, const float *sigma, float *packed,
@@ -247,12 +247,18 @@ extern "C" int agx_conv2d_pack(const agx_conv2d_desc *d, const float *w, const f
     if (rc != AGX_OK) return rc;
     if (!w || !packed) return fail(AGX_ERR_NULL_POINTER, "agx_conv2d_pack: NULL pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int64_t n_w = packed_weight_floats(p.ncv, p.J, p.M);
+    const int64_t n_w = p.prec ? packed_weight_floats_bf(p.ncv, p.J, p.M) : packed_weight_floats(p.ncv, p.J, p.M);
     float *scale = packed + n_w;
     if (sigma)
         hipLaunchKernelGGL(fill_inv_sigma_kernel, dim3(ceil_div(p.Cout, 256)), dim3(256), 0, st, scale, p.Cout, sigma);
     else
         hipLaunchKernelGGL(fill_ones_kernel, dim3(ceil_div(p.Cout, 256)), dim3(256), 0, st, scale, p.Cout);
+    if (p.prec) {
+        const int64_t nthreads = int64_t(ceil_div(p.ncv, kWG)) * p.J * p.M * kWG;
+        hipLaunchKernelGGL(pack_bf16x3_kernel, dim3((unsigned)ceil_div64(nthreads, 256)), dim3(256), 0, st, w, scale,
+                           reinterpret_cast<__bf16 *>(packed), AGX_CONV_PADDED, p.ncv, p.Cout, p.J, 1, p.J, p.P, 1);
+        return check_launch("agx_conv2d_pack");
+    }
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)ceil_div64(n_w, 256)), dim3(256), 0, st, w, scale, packed,
                        AGX_CONV_PADDED, p.ncv, p.Cout, p.J, 1, p.J, p.P, 1);
     return check_launch("agx_conv2d_pack");

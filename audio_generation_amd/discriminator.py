@@ -30,7 +30,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import ops
-from ._lib import CONV_PADDED, EPI_LEAKY_PRE
+from ._lib import CONV_PADDED, EPI_LEAKY_PRE, IMPL_AUTO, IMPL_MFMA_BF16X3
 from .autograd_bridge import needs_grad
 from .quantizer import tuple_checker
 
@@ -68,6 +68,7 @@ class _SNConv(nn.Module):
         else:
             self.bias, self.weight = conv.bias, conv.weight
         self._key, self._packed, self._iter = None, None, 0
+        self.impl = IMPL_AUTO      # IMPL_MFMA_BF16X3: Conv2d layers with a bf16x3 form run on it (set_arithmetic)
         self._uv_override = None   # (u, v) of the forward being differentiated (backward bridge only)
         self._tape = None          # (sigma, u, v) of the latest forward (native backward)
 
@@ -86,7 +87,7 @@ class _SNConv(nn.Module):
         """Packed image; rebuilt when the weight, the buffers or the mode changed (always in training mode:
         the power iteration moves sigma)."""
         w = self.raw_weight
-        key = (w.data_ptr(), w._version, self.training, self._iter,
+        key = (w.data_ptr(), w._version, self.training, self._iter, self.impl,
                None if self.norm != "spectral" else (self.weight_u._version, self.weight_v._version))
         if self.training or key != self._key:
             sigma = self._sigma()
@@ -94,7 +95,7 @@ class _SNConv(nn.Module):
             self._tape = None if sigma is None else (sigma, self.weight_u.clone(), self.weight_v.clone())
             desc = make_desc()
             self._packed = pack_plain(desc, w.detach()) if sigma is None else pack_sigma(desc, w.detach(), sigma)
-            self._key = (w.data_ptr(), w._version, self.training, self._iter,
+            self._key = (w.data_ptr(), w._version, self.training, self._iter, self.impl,
                          None if self.norm != "spectral" else (self.weight_u._version, self.weight_v._version))
         return self._packed
 
@@ -126,7 +127,7 @@ class _SNConv(nn.Module):
         def desc(batch=b, hh=h, ww=w):
             return ops.conv2d_desc(batch, self.in_channels, self.out_channels, hh, ww, self.kernel_size[0],
                                    self.kernel_size[1], self.stride, self.padding,
-                                   EPI_LEAKY_PRE if slope is not None else 0, slope or 0.0)
+                                   EPI_LEAKY_PRE if slope is not None else 0, slope or 0.0, self.impl)
 
         packed = self.packed(lambda: desc(1, 64, 64), ops.conv2d_pack, ops.conv2d_pack)
         return ops.conv2d_forward(desc(), x, packed, None if self.bias is None else self.bias.detach())
@@ -135,7 +136,8 @@ class _SNConv(nn.Module):
     def desc2d(self, x: Tensor, slope: Optional[float] = None):
         b, _, h, w = x.shape
         return ops.conv2d_desc(b, self.in_channels, self.out_channels, h, w, self.kernel_size[0], self.kernel_size[1],
-                               self.stride, self.padding, EPI_LEAKY_PRE if slope is not None else 0, slope or 0.0)
+                               self.stride, self.padding, EPI_LEAKY_PRE if slope is not None else 0, slope or 0.0,
+                               self.impl)
 
     def bwd2d(self, x: Tensor, dy: Tensor, tape, need_dx: bool = True, add: Optional[Tensor] = None,
               mask: Optional[Tensor] = None, slope: float = 0.2):
@@ -175,6 +177,18 @@ class _SNConv(nn.Module):
 
     def grad_params(self):
         return ([self.bias] if self.bias is not None else []) + [self.raw_weight]
+
+
+def set_arithmetic(module: nn.Module, mode: str = "fp32") -> nn.Module:
+    """``"bf16x3"``: the Conv2d layers of the STFT discriminators that have a bf16x3 form (Cin % 16 == 0, Cout >= 32)
+    run forward and backward-data on the bf16x3 kernels (fp32-class accuracy on the bf16 MFMA); the
+    weight gradient stays on the fp32 kernel.  Default ``"fp32"``."""
+    if mode not in ("fp32", "bf16x3"):
+        raise ValueError(f"unknown arithmetic {mode!r}")
+    for m in module.modules():
+        if isinstance(m, _SNConv):
+            m.impl = IMPL_MFMA_BF16X3 if (mode == "bf16x3" and m.nd == 2) else IMPL_AUTO
+    return module
 
 
 class _MultiOutBridge(torch.autograd.Function):

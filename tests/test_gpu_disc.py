@@ -118,6 +118,10 @@ def test_conv2d(cin, cout, kh, kw, sh, sw, ph, pw, h, w, impl):
     d = ops.conv2d_desc(2, cin, cout, h, w, kh, kw, (sh, sw), (ph, pw), EPI_LEAKY_PRE, 0.2, impl)
     got = ops.conv2d_forward(d, x.to(DEV), ops.conv2d_pack(d, wt.to(DEV)), b.to(DEV))
     close(got, want, 1e-5)
+    if impl == 0:   # the bf16x3 arithmetic (layers without a bf16x3 form fall back to fp32 inside the library)
+        from audio_generation_amd._lib import IMPL_MFMA_BF16X3
+        d3 = ops.conv2d_desc(2, cin, cout, h, w, kh, kw, (sh, sw), (ph, pw), EPI_LEAKY_PRE, 0.2, IMPL_MFMA_BF16X3)
+        close(ops.conv2d_forward(d3, x.to(DEV), ops.conv2d_pack(d3, wt.to(DEV)), b.to(DEV)), want, 1e-5)
     name = ops.conv2d_kernel_name(d)
     if impl == IMPL_MFMA or (impl == 0 and cout >= 32):
         assert name.startswith("conv_mfma"), name
@@ -300,6 +304,9 @@ def test_conv2d_backward_data(cin, cout, kh, kw, sh, sw, ph, pw, h, w):
     extra = torch.randn(2, cin, h, w)
     close(ops.conv2d_bwd_data(d, dy.to(DEV), pk, xin.detach().to(DEV), 0.2, add=extra.to(DEV)),
           (want_plain + extra) * torch.where(xin.detach() > 0, 1.0, 0.2), 2e-5)
+    from audio_generation_amd._lib import IMPL_MFMA_BF16X3
+    d3 = ops.conv2d_desc(2, cin, cout, h, w, kh, kw, (sh, sw), (ph, pw), 0, 0.2, IMPL_MFMA_BF16X3)
+    close(ops.conv2d_bwd_data(d3, dy.to(DEV), ops.conv2d_pack_bwd(d3, wt.to(DEV))), want_plain, 2e-5)
 
 
 @pytest.mark.parametrize("cin,cout,kh,kw,sh,sw,ph,pw,h,w", [
@@ -419,3 +426,39 @@ def test_waveform_discriminator_backward_runs_on_the_native_kernels(monkeypatch)
     (gl + dl).backward()
     assert calls["bridge"] == 0 and calls["grouped"] == 3 * 2 * 4
     assert rec.grad is not None and all(p.grad is not None for p in d.parameters())
+
+
+def test_bf16x3_stft_discriminator_matches_fp32():
+    """STFT discriminator with its Conv2d layers on the bf16x3 kernels: outputs, features, loss and gradients agree
+    with the fp32 run to fp32-class tolerances (full widths, win 512)."""
+    torch.manual_seed(9)
+    d = ad.STFTDiscriminator(win_length=512).to(DEV).train()
+    orig = 0.3 * torch.randn(2, 1, 12000, device=DEV)
+    with torch.no_grad():          # let the power iteration converge: a fresh sigma = u.Wv is tiny, the activations
+        for _ in range(12):        # huge, the sigmoid saturated and the gradients ill-conditioned
+            d(orig)
+    sd = {k: v.clone() for k, v in d.state_dict().items()}
+    rec0 = orig + 0.05 * torch.randn_like(orig)
+    res = {}
+    for mode in ("fp32", "bf16x3"):
+        d.load_state_dict(sd)
+        ad.set_arithmetic(d, mode)
+        rec = rec0.clone().requires_grad_(True)
+        for p_ in d.parameters():
+            p_.grad = None
+        gl, dl = ad.discriminator_generator_loss(orig, rec, d)
+        (gl + dl).backward()
+        res[mode] = (float(gl), float(dl), rec.grad.clone(), [p_.grad.clone() for p_ in d.parameters()])
+    ad.set_arithmetic(d, "fp32")
+    a, b = res["fp32"], res["bf16x3"]
+    assert abs(a[0] - b[0]) <= 1e-4 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-5 * abs(a[1])
+    # The kernels themselves agree with autograd to ~1e-6 in both arithmetics (test_conv2d / test_conv2d_backward_data
+    # run both); the gradient of a GAN discriminator through 14 layers, LeakyReLU masks and the hinge is
+    # ill-conditioned, so whole-model gradients are compared by direction (cosine) and a loose max-norm.
+    for ga, gb in [(a[2], b[2])] + list(zip(a[3], b[3])):
+        cos = float((ga * gb).sum() / (ga.norm() * gb.norm() + 1e-30))
+        assert cos > 0.9999, cos
+        close(gb, ga, 5e-2)
+    names = {ops.conv2d_kernel_name(m.desc2d(torch.empty(2, m.in_channels, 20, 64))) for m in d.modules()
+             if isinstance(m, ad._SNConv)}
+    assert names
