@@ -158,3 +158,30 @@ def test_transformer_backward_is_native(monkeypatch):
     x = torch.randn(2, 128, 50, device=DEV, requires_grad=True)
     tf.run_bct(x).pow(2).mean().backward()
     assert calls["bridge"] == 0 and x.grad is not None and all(p.grad is not None for p in tf.parameters())
+
+
+def test_training_step_with_bf16x3_decoder_matches_fp32():
+    """Forward on the bf16x3 decoder kernels, backward on the fp32 kernels: loss and gradients stay within
+    fp32-class distance of the all-fp32 step."""
+    torch.manual_seed(3)
+    kw = dict(in_channels=1, n_blocks=4, strides=(2, 4, 5, 8), first_block_channels=32, num_quantizers=3,
+              codebook_size=64, codebook_dim=64, input_format="n c l", wavelet_decoders=False)
+    model = CausalVQAE(**kw).to(DEV).train()
+    x = 0.1 * torch.randn(2, 1, 3200, device=DEV)
+    with torch.no_grad():
+        model.quantizer.init_from_latents(model._run_encoders(x).transpose(1, 2))
+    res = {}
+    for mode in ("fp32", "bf16x3"):
+        model.set_conv_arithmetic(decoders=mode)
+        for p in model.parameters():
+            p.grad = None
+        y, commit, index = model(x)
+        loss = ((y - x) ** 2).mean() + commit
+        loss.backward()
+        res[mode] = (float(loss.detach()), index.clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    model.set_conv_arithmetic()
+    assert torch.equal(res["fp32"][1], res["bf16x3"][1])
+    assert abs(res["fp32"][0] - res["bf16x3"][0]) <= 1e-6 * abs(res["fp32"][0])
+    for n, g in res["fp32"][2].items():
+        d = float((g - res["bf16x3"][2][n]).abs().max())
+        assert d <= 1e-4 * float(g.abs().max()) + 1e-10, (n, d)
