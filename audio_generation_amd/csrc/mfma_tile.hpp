@@ -378,7 +378,7 @@ __device__ __forceinline__ void mfma_block_bf(f32x16 (&acc)[MW][NW], const bf16x
 
 // Same pipeline as conv_gemm_rows (LDS-DMA double buffer per chunk, weights one phase ahead in registers,
 // input fragments read one phase ahead), CC a multiple of 16.
-template <int MW, int NW, int CC, class Stager>
+template <int MW, int NW, int CC, class Stager, int BSCHED = 0>
 __device__ __forceinline__ void conv_gemm_rows_bf(f32x16 (&acc)[MW][NW], float *__restrict__ xs, const Stager &stg,
                                                   const __bf16 *__restrict__ wpb, const ConvPlan &p, int M, int span,
                                                   const int (&arow)[MW], const int (&bcol)[NW], int wave, int lane) {
@@ -421,19 +421,40 @@ __device__ __forceinline__ void conv_gemm_rows_bf(f32x16 (&acc)[MW][NW], float *
                 const bool last = nc0 >= p.Cin;
                 load_a_phase_bf<MW>(a_nxt, wpb, last ? 0 : nc0 + nh * 16, last ? 0 : nj, p.J, M, lh, arow);
                 load_b_phase<NW, 16>(b_raw, cur + (nc0 == c0 ? nh * 16 * span + stg.tapoff(nj) : 0), span, bcol);
+                bf16x8 b_new[3][NW];
+                if (BSCHED == 2) {   // split the next phase's input BEFORE this phase's MFMAs (it then only waits for LDS)
+#pragma unroll
+                    for (int k = 0; k < NW; ++k) {
+                        float x[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) x[q] = b_raw[q][k];
+                        split3(x, b_new[0][k], b_new[1][k], b_new[2][k]);
+                    }
+                }
                 mfma_block_bf<MW, NW>(acc, a_cur, b_cur);
-                // next phase's input: split while this phase's MFMAs drain
+                if (BSCHED != 2) {   // ... or while this phase's MFMAs drain
 #pragma unroll
-                for (int k = 0; k < NW; ++k) {
-                    float x[8];
+                    for (int k = 0; k < NW; ++k) {
+                        float x[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) x[q] = b_raw[q][k];
-                    split3(x, b_cur[0][k], b_cur[1][k], b_cur[2][k]);
+                        for (int q = 0; q < 8; ++q) x[q] = b_raw[q][k];
+                        split3(x, b_new[0][k], b_new[1][k], b_new[2][k]);
+                    }
+                }
+                if (BSCHED == 1) {   // thread the VALU work between the MFMAs: 1 MFMA : 3 VALU
+#pragma unroll
+                    for (int gidx = 0; gidx < 6 * MW * NW; ++gidx) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    }
                 }
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
+                for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                    for (int k = 0; k < NW; ++k) b_cur[pl][k] = b_new[pl][k];
 #pragma unroll
                     for (int i = 0; i < MW; ++i) a_cur[pl][i] = a_nxt[pl][i];
+                }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -20,7 +20,7 @@
 
 namespace agx {
 
-template <int MW, int NW, int CC, int SCHED = kSchedDefault, int OCC = (MW <= 4 ? 2 : 1), int PREC = 0>
+template <int MW, int NW, int CC, int SCHED = kSchedDefault, int OCC = (MW <= 4 ? 2 : 1), int PREC = 0>   // PREC 1: bf16x3 (SCHED = its schedule)
 __global__ __launch_bounds__(256, OCC) void resblock_mfma_kernel(ConvPlan p, int span, int post_act,
                                                             const float *__restrict__ x,
                                                             const float *__restrict__ w1,
@@ -57,8 +57,8 @@ __global__ __launch_bounds__(256, OCC) void resblock_mfma_kernel(ConvPlan p, int
     // ---- GEMM1: h = W1 (*) x ------------------------------------------------------
     if (PREC == 1) {
         const StagerRows<RowMap1D> stg{RowMap1D{xb, p.Lin}, p.Lvalid, in0, p.d};
-        conv_gemm_rows_bf<MW, NW, (CC < 16 ? 16 : CC)>(acc, xs, stg, reinterpret_cast<const __bf16 *>(w1), p, C, span, arow,
-                                                       bcol, wave, lane);
+        conv_gemm_rows_bf<MW, NW, (CC < 16 ? 16 : CC), StagerRows<RowMap1D>, SCHED>(
+            acc, xs, stg, reinterpret_cast<const __bf16 *>(w1), p, C, span, arow, bcol, wave, lane);
     } else {
         conv_gemm<MW, NW, CC, SCHED>(acc, xs, xb, w1, p, C, span, in0, arow, bcol, wave, lane);
     }
@@ -242,12 +242,21 @@ int launch_resblock_fused(const ConvPlan &p, const float *x, const float *w1, co
          : sched == 2 ? launch_rb<MW, NW, 16, 2>(p, x, w1, b1, w2, b2, y, post_act, st)                 \
                       : launch_rb<MW, NW, 16, 1>(p, x, w1, b1, w2, b2, y, post_act, st))
     if (p.prec) {   // bf16x3 (AGX_IMPL_MFMA_BF16X3): both packed images are bf16x3 images
+        // measured per shape (AGX_BF16X3=1 tools/ab_bench.py bf_sched 0 1 2): C=32: 0, C=64: 2 (-5 %), C=128: 1 (-12 %),
+        // C=256: 1 (-6 %); knob -1 = this table
+        int bs = tuning().bf_sched;
+        if (bs < 0) bs = p.Cin == 64 ? 2 : (p.Cin >= 128 ? 1 : 0);
+#define AGX_RBF(MW, NW, OCC)                                                                        \
+    (bs == 1 ? launch_rb<MW, NW, 16, 1, OCC, 1>(p, x, w1, b1, w2, b2, y, post_act, st)             \
+     : bs == 2 ? launch_rb<MW, NW, 16, 2, OCC, 1>(p, x, w1, b1, w2, b2, y, post_act, st)           \
+               : launch_rb<MW, NW, 16, 0, OCC, 1>(p, x, w1, b1, w2, b2, y, post_act, st))
         switch (p.Cin) {
-            case 32: return launch_rb<1, 4, 16, 1, 2, 1>(p, x, w1, b1, w2, b2, y, post_act, st);
-            case 64: return launch_rb<2, 2, 16, 1, 2, 1>(p, x, w1, b1, w2, b2, y, post_act, st);
-            case 128: return launch_rb<4, 1, 16, 1, 2, 1>(p, x, w1, b1, w2, b2, y, post_act, st);
-            default: return launch_rb<8, 1, 16, 1, 1, 1>(p, x, w1, b1, w2, b2, y, post_act, st);
+            case 32: return AGX_RBF(1, 4, 2);
+            case 64: return AGX_RBF(2, 2, 2);
+            case 128: return AGX_RBF(4, 1, 2);
+            default: return AGX_RBF(8, 1, 1);
         }
+#undef AGX_RBF
     }
     if (tuning().rb_occ == 3 && !c32) {  // diagnostic: cap VGPRs at 168 so that 3 waves/SIMD fit
         switch (p.Cin) {

@@ -46,6 +46,7 @@ const char *agx_last_error(void);
  *   "rb_occ" 2|3       3: fused residual block built under a 168-VGPR cap (3 waves/SIMD); no gain measured
  *   "conv_short" 0|1   128x64 MFMA conv tiles when the 128x128 grid is under two workgroups per CU (default 1)
  *   "conv_cc" 0|8|16|32  force the LDS channel chunk of the MFMA conv (0 = table)
+ *   "bf_sched" -1|0|1|2  schedule of the bf16x3 main loop of the fused residual block (-1 = per-shape table)
  *   "dw_dma" 0|1       1: experimental LDS-DMA double-buffered conv2d weight-gradient kernel (default 0)
  *   "dw_wgs" n         workgroups the conv2d weight-gradient kernel aims for (default 1536)
  *   "conv_shape" 0|1   1: 128x128 conv tiles as four row-waves of 1x4 fragments                    */
