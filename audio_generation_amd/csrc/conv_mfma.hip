@@ -24,6 +24,11 @@
 
 namespace agx {
 
+#ifndef AGX_BF_CONV_SCHED
+#define AGX_BF_CONV_SCHED 0
+#endif
+constexpr int kBfConvSched = AGX_BF_CONV_SCHED;   // schedule of the bf16x3 loop in the plain 1-D convs (mfma_tile.hpp)
+
 template <int MW, int NW, int WM, int WN, int CC, int MODE = 0, int PREC = 0>  // MODE 0: 1-D  1: 2-D row-folded  2: 2-D patches
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
                                                         const float *__restrict__ x,
@@ -107,8 +112,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
         conv_gemm_rows<MW, NW, CC, kSchedDefault>(acc, xs, stg, wp, p, p.M, span, arow, bcol, wave, lane);
     } else if (PREC == 1) {
         const StagerRows<RowMap1D> stg{RowMap1D{x + size_t(b) * p.Cin * p.Lin, p.Lin}, p.Lvalid, in0, p.d};
-        conv_gemm_rows_bf<MW, NW, (CC < 16 ? 16 : CC)>(acc, xs, stg, reinterpret_cast<const __bf16 *>(wp), p, p.M, span,
-                                                       arow, bcol, wave, lane);
+        conv_gemm_rows_bf<MW, NW, (CC < 16 ? 16 : CC), StagerRows<RowMap1D>, kBfConvSched>(
+            acc, xs, stg, reinterpret_cast<const __bf16 *>(wp), p, p.M, span, arow, bcol, wave, lane);
     } else {
         const float *xb = x + size_t(b) * p.Cin * p.Lin;
         conv_gemm<MW, NW, CC>(acc, xs, xb, wp, p, p.M, span, in0, arow, bcol, wave, lane);
