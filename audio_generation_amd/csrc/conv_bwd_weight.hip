@@ -246,9 +246,10 @@ __global__ __launch_bounds__(256) void bwd_bias_fold_kernel(const float *__restr
 struct Bw2dGeom {
     int B, Cin, Cout, Hin, Win, Hout, Wout, kh, kw, sh, sw, ph, pw;
     int R, WF, RH, SW, span, n_chan, n_slices;
+    int prec;   // 1: bf16x3 contraction (AGX_IMPL_MFMA_BF16X3)
 };
 
-template <int MW, int NW, int WM, int WN>
+template <int MW, int NW, int WM, int WN, int PREC = 0>   // PREC 1: bf16x3 contraction (mfma_tile.hpp), both operands split in registers
 __global__ __launch_bounds__(256) void conv2d_bwd_weight_kernel(Bw2dGeom g, const float *__restrict__ x,
                                                                 const float *__restrict__ dy,
                                                                 float *__restrict__ part,
@@ -362,6 +363,31 @@ __global__ __launch_bounds__(256) void conv2d_bwd_weight_kernel(Bw2dGeom g, cons
 #pragma unroll
             for (int c = 0; c < CPT; ++c) bsum += row[c];
         }
+        if (PREC == 1) {
+#pragma unroll
+            for (int kb = 0; kb < BW_T / 16; ++kb) {     // K = 16 blocks: this lane's positions 16 kb + 8 lh + 0..7
+                const int k0 = 16 * kb + 8 * lh;
+                int ko[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ko[e] = kofft[k0 + e];
+                bf16x8 aq[3][MW], bq[3][NW];
+#pragma unroll
+                for (int i = 0; i < MW; ++i) {
+                    float xq[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xq[e] = dys[arow[i] + k0 + e];
+                    split3(xq, aq[0][i], aq[1][i], aq[2][i]);
+                }
+#pragma unroll
+                for (int k = 0; k < NW; ++k) {
+                    float xq[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xq[e] = nvalid[k] ? xs[boff[k] + ko[e]] : 0.f;
+                    split3(xq, bq[0][k], bq[1][k], bq[2][k]);
+                }
+                mfma_block_bf<MW, NW>(acc, aq, bq);
+            }
+        } else
 #pragma unroll 4
         for (int ks = 0; ks < BW_T / 2; ++ks) {
             const int tt = 2 * ks + lh;
@@ -611,6 +637,7 @@ static int bw2d_geometry(const agx_conv2d_desc *d, Bw2dGeom *g, int *cfg, int *b
     g->span = g->RH * g->SW;
     const int KK = g->kh * g->kw;
     g->n_chan = 127 / KK + 2;
+    g->prec = d->impl == AGX_IMPL_MFMA_BF16X3 ? 1 : 0;
     *cfg = g->Cout >= 128 ? 0 : (g->Cout >= 64 ? 1 : 2);
     *bm = *cfg == 0 ? 128 : (*cfg == 1 ? 64 : 32);
     const int nt = ceil_div(g->Cin * KK, 128), mt = ceil_div(g->Cout, *bm);
@@ -764,6 +791,10 @@ int agx_conv2d_bwd_weight(const agx_conv2d_desc *d, const float *x, const float 
         rc = cfg == 0 ? launch8(conv2d_bwd_weight_dma_kernel<1, 2, 4, 2>)
            : cfg == 1 ? launch8(conv2d_bwd_weight_dma_kernel<1, 1, 2, 4>)
                       : launch(conv2d_bwd_weight_dma_kernel<1, 1, 1, 4>);
+    } else if (g.prec) {
+        rc = cfg == 0 ? launch(conv2d_bwd_weight_kernel<2, 2, 2, 2, 1>)
+           : cfg == 1 ? launch(conv2d_bwd_weight_kernel<1, 2, 2, 2, 1>)
+                      : launch(conv2d_bwd_weight_kernel<1, 1, 1, 4, 1>);
     } else {
         rc = cfg == 0 ? launch(conv2d_bwd_weight_kernel<2, 2, 2, 2>)
            : cfg == 1 ? launch(conv2d_bwd_weight_kernel<1, 2, 2, 2>)

@@ -336,6 +336,12 @@ def test_conv2d_backward_weight(cin, cout, kh, kw, sh, sw, ph, pw, h, w, spectra
         dw, db = ops.conv2d_bwd_weight(d, x.to(DEV), dy.to(DEV))
     close(dw, wt.grad, 1e-4)
     close(db, b.grad, 2e-5)
+    if not spectral:   # the bf16x3 contraction
+        from audio_generation_amd._lib import IMPL_MFMA_BF16X3
+        d3 = ops.conv2d_desc(3, cin, cout, h, w, kh, kw, (sh, sw), (ph, pw), 0, 0.2, IMPL_MFMA_BF16X3)
+        dw3, db3 = ops.conv2d_bwd_weight(d3, x.to(DEV), dy.to(DEV))
+        close(dw3, wt.grad, 1e-4)
+        close(db3, b.grad, 2e-5)
 
 
 @pytest.mark.parametrize("win,length", [(64, 500), (256, 1024), (1024, 24000)])

@@ -1,6 +1,7 @@
 import sys, torch
 sys.path.insert(0, "/root/repo")
 from audio_generation_amd import ops
+IMPL = int(sys.argv[1]) if len(sys.argv) > 1 else 0   # 3 = bf16x3
 def timeit(fn, reps=5):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -14,7 +15,7 @@ for (cin, cout, kh, kw, sh, sw, h, w) in [(64, 64, 3, 3, 1, 1, 282, 512), (128, 
     wt = torch.randn(cout, cin, kh, kw, device="cuda") * 0.05
     bias = torch.randn(cout, device="cuda")
     pad = ((kh - 1) // 2, (kw - 1) // 2)
-    d = ops.conv2d_desc(B, cin, cout, h, w, kh, kw, (sh, sw), pad)
+    d = ops.conv2d_desc(B, cin, cout, h, w, kh, kw, (sh, sw), pad, 0, 0.2, IMPL)
     pk = ops.conv2d_pack(d, wt)
     y = ops.conv2d_forward(d, x, pk, bias)
     dy = torch.randn_like(y)

@@ -39,6 +39,9 @@ def main():
     with torch.no_grad():
         model.quantizer.init_from_latents(model._run_encoders(x[:4]))
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    bf = os.environ.get("AGX_BF16X3", "0") == "1"     # decoder + discriminator Conv2d layers on the bf16x3 kernels
+    if bf:
+        model.set_conv_arithmetic(decoders="bf16x3")
     gan = os.environ.get("AGX_GAN", "0") == "1"
     discs, opt_d = [], []
     if gan:
@@ -47,6 +50,10 @@ def main():
         wins = [int(w) for w in os.environ.get("AGX_GAN_WINS", "2048,1024,512,256,128").split(",") if w]
         discs = [WaveFormDiscriminator(1)] + [STFTDiscriminator(win_length=w) for w in wins]
         discs = [d.to(dev).train() for d in discs]
+        if bf:
+            from audio_generation_amd.discriminator import set_arithmetic
+            for d in discs:
+                set_arithmetic(d, "bf16x3")
         opt_d = [torch.optim.Adam(d.parameters(), lr=8e-4) for d in discs]
     # the reconstruction-side terms of Trainer.mini_epoch (training.py:313-359): low-pass of the input batch,
     # pre-emphasis before the MSE, the 7-window mel loss  (AGX_SIGNAL=0 switches them off)
@@ -109,7 +116,8 @@ def main():
     if rank == 0:
         print(json.dumps({"what": "train step (fwd + native bwd + grad all-reduce + Adam), config S" +
                           (f" + {len(discs)} discriminators (native forward + backward)" if gan else "") +
-                          (" + low-pass, pre-emphasis, 7-window mel loss" if signal else ""),
+                          (" + low-pass, pre-emphasis, 7-window mel loss" if signal else "") +
+                          (" [bf16x3: decoder forward, discriminator Conv2d forward + backward-data]" if bf else ""),
                           "n_gpus": world, "batch_per_gpu": batch, "ms_per_step": ms, "replicas_in_sync": same,
                           "samples_per_s": world * batch * 72000 / ms * 1e3, "losses": losses,
                           "approx_tflops_at_3x_forward": world * 3 * fwd_flop / ms * 1e-9,
