@@ -18,7 +18,7 @@ constexpr int BW_TS = BW_T + 1; // dyS row stride (odd: conflict-free column rea
 
 // Workgroup tile = (32*MW*WM) rows of m x (32*NW*WN) columns of n; 4 waves as WM x WN.
 // The n-tile-0 workgroups also accumulate the bias gradient (row sums of the staged dy tile).
-template <int MW, int NW, int WM, int WN>
+template <int MW, int NW, int WM, int WN, int PREC = 0>   // PREC 1: bf16x3 contraction
 __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(ConvPlan p, int span, int n_chan, int n_slices,
                                                               const float *__restrict__ x,
                                                               const float *__restrict__ dy,
@@ -118,6 +118,28 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(ConvPlan p, int sp
 #pragma unroll
             for (int c = 0; c < CPT; ++c) bsum += row[c];
         }
+        if (PREC == 1) {
+#pragma unroll
+            for (int kb = 0; kb < BW_T / 16; ++kb) {     // K = 16 blocks: this lane's positions 16 kb + 8 lh + 0..7
+                const int k0 = 16 * kb + 8 * lh;
+                bf16x8 aq[3][MW], bq[3][NW];
+#pragma unroll
+                for (int i = 0; i < MW; ++i) {
+                    float xq[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xq[e] = dys[arow[i] + k0 + e];
+                    split3(xq, aq[0][i], aq[1][i], aq[2][i]);
+                }
+#pragma unroll
+                for (int k = 0; k < NW; ++k) {
+                    float xq[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xq[e] = nvalid[k] ? xs[boff[k] + (k0 + e) * p.s] : 0.f;
+                    split3(xq, bq[0][k], bq[1][k], bq[2][k]);
+                }
+                mfma_block_bf<MW, NW>(acc, aq, bq);
+            }
+        } else
 #pragma unroll 4
         for (int ks = 0; ks < BW_T / 2; ++ks) {
             const int tt = 2 * ks + lh;
@@ -716,9 +738,14 @@ int agx_conv_bwd_weight(const agx_conv_desc *d, const float *x, const float *dy,
                            bias_part);
         return AGX_OK;
     };
-    rc = geo.cfg == 0 ? launch(conv_bwd_weight_kernel<2, 2, 2, 2>)
-       : geo.cfg == 1 ? launch(conv_bwd_weight_kernel<1, 2, 2, 2>)
-                      : launch(conv_bwd_weight_kernel<1, 1, 1, 4>);
+    if (d->impl == AGX_IMPL_MFMA_BF16X3)
+        rc = geo.cfg == 0 ? launch(conv_bwd_weight_kernel<2, 2, 2, 2, 1>)
+           : geo.cfg == 1 ? launch(conv_bwd_weight_kernel<1, 2, 2, 2, 1>)
+                          : launch(conv_bwd_weight_kernel<1, 1, 1, 4, 1>);
+    else
+        rc = geo.cfg == 0 ? launch(conv_bwd_weight_kernel<2, 2, 2, 2>)
+           : geo.cfg == 1 ? launch(conv_bwd_weight_kernel<1, 2, 2, 2>)
+                          : launch(conv_bwd_weight_kernel<1, 1, 1, 4>);
     if (rc != AGX_OK) return rc;
     hipLaunchKernelGGL(bwd_slice_reduce_kernel, dim3((unsigned)ceil_div64(nw, 64)), dim3(256), 0, st, part,
                        geo.n_slices, nw, dwp);

@@ -88,6 +88,10 @@ def test_backward_weight_bias_and_weight_norm_match_autograd():
                                                  want_bias=False)
         assert none_g is None and none_b is None
         assert max_abs(dw.cpu(), want_w) < 2e-4 * max(1.0, float(want_w.abs().max())), (kind, cin, cout, k, s, d)
+        # the bf16x3 contraction (descriptor impl = AGX_IMPL_MFMA_BF16X3)
+        desc3 = ops.conv_desc(KIND[kind], b, cin, cout, length, k, s, d, impl=_lib.IMPL_MFMA_BF16X3)
+        dw3, _, _ = ops.conv_bwd_weight(desc3, x.to(DEV), dy.to(DEV), w_plain.detach().to(DEV), None, want_bias=False)
+        assert max_abs(dw3.cpu(), want_w) < 2e-4 * max(1.0, float(want_w.abs().max())), (kind, cin, cout, k, s, d)
         checked += 1
     assert checked == len(SHAPES)
 
