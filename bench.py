@@ -324,26 +324,33 @@ def main():
         result["speedup_vs_cpu_baseline"] = result["value"] / base["value"]
 
     if rank == 0 and world == 1 and not args.no_extra:
-        # secondary measurement, outside the timed region and NOT the headline value: the other arithmetic
-        other = "mixed" if args.arith == "fp32" else "fp32"
-        model.set_conv_arithmetic(decoders="bf16x3" if other == "mixed" else "fp32")
-        with torch.no_grad():
-            for _ in range(3):
-                y2, _, index2 = model(x)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            n2 = max(5, min(args.steps, 20))
-            for _ in range(n2):
-                y2, _, index2 = model(x)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t1) / n2
+        # secondary measurements, outside the timed region and NOT the headline value: the other arithmetics
+        def measure(dec, enc):
+            model.set_conv_arithmetic(decoders=dec, encoders=enc)
+            with torch.no_grad():
+                for _ in range(3):
+                    y2, _, index2 = model(x)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                n2 = max(5, min(args.steps, 20))
+                for _ in range(n2):
+                    y2, _, index2 = model(x)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t1) / n2
+            return {"value": bsz * CLIP / dt, "unit": "samples/s", "ms_per_step": 1e3 * dt, "launch": "eager",
+                    "index_agreement_with_measured_run": float((index2 == index).float().mean()),
+                    "waveform_rms_vs_measured_run": float((y2 - y).double().pow(2).mean().sqrt())}
+
+        others = []
+        if args.arith == "fp32":
+            others.append(dict(arithmetic="mixed: encoder + RVQ fp32, decoder bf16x3 (fp32-class accuracy, not the bitwise "
+                                          "fp32 chain; the supported opt-in)", **measure("bf16x3", "fp32")))
+        else:
+            others.append(dict(arithmetic="fp32: fp32-input MFMA everywhere", **measure("fp32", "fp32")))
+        others.append(dict(arithmetic="all bf16x3 (encoder too): shown for the trade-off only -- near-tie indices can flip, so "
+                                      "it is NOT a supported configuration", **measure("bf16x3", "bf16x3")))
         model.set_conv_arithmetic(decoders="bf16x3" if args.arith == "mixed" else "fp32")
-        result["other_arithmetic"] = {
-            "arithmetic": other + (" (encoder + RVQ fp32, decoder bf16x3: fp32-class accuracy, not the bitwise fp32 chain)"
-                                   if other == "mixed" else " (fp32-input MFMA everywhere)"),
-            "value": bsz * CLIP / dt, "unit": "samples/s", "ms_per_step": 1e3 * dt, "launch": "eager",
-            "indices_equal_to_measured_run": bool(torch.equal(index2, index)),
-            "waveform_rms_vs_measured_run": float((y2 - y).double().pow(2).mean().sqrt())}
+        result["other_arithmetic"] = others
 
     if rank == 0:
         print(json.dumps(result), flush=True)
