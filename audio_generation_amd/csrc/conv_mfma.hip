@@ -140,7 +140,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
                 co[r] = mq;
                 pa[r] = 0;
             }
-            bv[r] = bias ? bias[co[r]] : 0.f;
+            const float bl = (bias ? bias : wp)[co[r]];   // unconditional load, masked below (no branch per element)
+            bv[r] = bias ? bl : 0.f;
         }
 #pragma unroll
         for (int k = 0; k < NW; ++k) {

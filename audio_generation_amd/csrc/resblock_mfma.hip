@@ -64,11 +64,16 @@ __global__ __launch_bounds__(256, OCC) void resblock_mfma_kernel(ConvPlan p, int
     }
 
     // ---- hidden activation, in registers --------------------------------------------
+    // Bias loads are unconditional (a NULL bias reads the weight image instead and is masked by a select):
+    // behind `b1 ? b1[..] : 0` hipcc emits one branch + one waited load per element.
+    const bool has_b1 = b1 != nullptr, has_b2 = b2 != nullptr;
+    const float *b1p = has_b1 ? b1 : w1, *b2p = has_b2 ? b2 : w1;
 #pragma unroll
     for (int i = 0; i < MW; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float bv = b1 ? b1[i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] : 0.f;
+            const float bl = b1p[i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+            const float bv = has_b1 ? bl : 0.f;
 #pragma unroll
             for (int k = 0; k < NW; ++k) {
                 const float v = acc[i][k][r] + bv;
@@ -165,7 +170,10 @@ __global__ __launch_bounds__(256, OCC) void resblock_mfma_kernel(ConvPlan p, int
             const int io = g0 + ig;
             float bv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) bv[r] = b2 ? b2[io * 32 + acc_row(r, lh)] : 0.f;
+            for (int r = 0; r < 16; ++r) {
+                const float bl = b2p[io * 32 + acc_row(r, lh)];
+                bv[r] = has_b2 ? bl : 0.f;
+            }
 #pragma unroll
             for (int k = 0; k < NW; ++k) {
                 const int t = t0 + n0 + k * 32 + li;
