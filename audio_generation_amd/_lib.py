@@ -104,6 +104,8 @@ SIGNATURES = {
     "agx_conv2d_bwd_weight_workspace_bytes": (c_size_t, [_P2]),
     "agx_conv2d_bwd_weight": (c_int, [_P2, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_size_t, c_void_p]),
+    "agx_conv2d_colsplit_weights": (c_int, [_P2, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "agx_conv2d_colsum": (c_int, [_P2, c_void_p, c_void_p, c_void_p, c_void_p]),
     "agx_stft_frames": (c_int64, [c_int32, c_int32]),
     "agx_stft_packed_floats": (c_int64, [c_int32]),
     "agx_stft_pack": (c_int, [c_int32, c_int32, c_void_p, c_void_p]),

@@ -20,6 +20,8 @@ const char *last_error();
 struct Tuning {
     int rb_cc = 16;   // channels per LDS chunk of the fused residual block (16 or 32)
     int rb_wgs = 0;   // 1..3: cap resident workgroups per CU of the fused residual block (0 = natural)
+    int patch_tie = 1;  // 2-D patch tiles: 1 = among the R x WF splits with the same padded area take the one that stages the fewest
+                        // input elements (tall tiles share the row halo), 0 = always the widest
     int bf_sched = -1;  // (-1 = per-shape table) schedule of the bf16x3 main loop in the fused residual block: 0 split after the MFMAs,
                         // 1 the same with MFMA / VALU interleave hints, 2 split before the MFMAs
     int dw_dma = 0;     // 1: LDS-DMA double-buffered conv2d weight-gradient kernel (experimental: 48-53 TFLOP/s with 8 waves

@@ -30,7 +30,7 @@ int lower_conv2d(const agx_conv2d_desc *d, ConvPlan *p) {
     //                 several output rows x columns staged as one 2-D input patch per channel;
     //  * row-folded -- everything else (the 2-channel 7x7 first conv, the 1-channel final conv, the direct
     //                 kernel): virtual channels c' = ci * kh + dh, one output row per tile.
-    const bool patch = d->impl != AGX_IMPL_DIRECT && d->c_in % kWG == 0 && d->c_out >= 32;
+    const bool patch = d->impl != AGX_IMPL_DIRECT && d->c_in % kWG == 0 && d->c_out >= 8;   // rows >= M are clamped / masked
     p->B = d->batch;
     p->cin_real = d->c_in;
     p->ncv = patch ? d->c_in : d->c_in * d->kh;
@@ -189,6 +189,36 @@ __global__ __launch_bounds__(256) void scale_copy_kernel(const float *__restrict
     if (e < n) out[e] = w[e] * (sigma ? 1.f / sigma[0] : 1.f);
 }
 
+// Backward-data of a layer with very few input channels (the 2-channel 7x7 first conv of the STFT discriminators):
+// M = Cin would waste the MFMA tile (and the direct kernel manages 4 TFLOP/s), so the kernel's column axis is
+// peeled off:   P[(c, dw)][i][j'] = sum_{co, dh} W[co, c, dh, dw] dy[co][i - dh + ph][j']     (a (kh x 1) Conv2d with
+// kw * Cin output rows -- on the patch tiles)    then    dx[c][i][j] = sum_dw P[(c, dw)][i][j - dw + pw].
+__global__ __launch_bounds__(256) void colsplit_weights_kernel(const float *__restrict__ w, const float *__restrict__ sigma,
+                                                               float *__restrict__ wp, int Cin, int Cout, int kh, int kw) {
+    // wp (Cin*kw, Cout, kh, 1):  wp[(c*kw + dw)][co][a] = w[co][c][kh-1-a][dw] / sigma
+    const int64_t total = int64_t(Cin) * kw * Cout * kh;
+    const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int a = int(e % kh), co = int((e / kh) % Cout), m = int(e / (int64_t(kh) * Cout));
+    const int c = m / kw, dw = m - c * kw;
+    wp[e] = w[((size_t(co) * Cin + c) * kh + (kh - 1 - a)) * kw + dw] * (sigma ? 1.f / sigma[0] : 1.f);
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ pbuf, const float *__restrict__ add,
+                                                     float *__restrict__ dx, int C, int kw, int H, int Wp, int Wx, int pw) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y, bc = blockIdx.z;   // bc = b * C + c
+    if (j >= Wx) return;
+    const int b = bc / C, c = bc - b * C;
+    float acc = 0.f;
+    for (int dw = 0; dw < kw; ++dw) {
+        const int jp = j - dw + pw;
+        if (jp >= 0 && jp < Wp) acc += pbuf[((size_t(b) * C * kw + c * kw + dw) * H + i) * Wp + jp];
+    }
+    const size_t e = (size_t(bc) * H + i) * Wx + j;
+    dx[e] = acc + (add ? add[e] : 0.f);
+}
+
 // Packed image of the backward-data op (both lowerings above).
 __global__ __launch_bounds__(256) void pack_bwd2d_kernel(const float *__restrict__ w, const float *__restrict__ sigma,
                                                          float *__restrict__ packed, int Cin, int Cout, int kh, int kw,
@@ -284,6 +314,28 @@ int agx_conv2d_bwd_data(const agx_conv2d_desc *d, const float *dy, const float *
     if (b.pm_R || (d->impl != AGX_IMPL_DIRECT && conv_mfma_supported(b)))
         return launch_conv_mfma(b, dy, packed_bwd, nullptr, add, dx, st);
     return launch_conv_direct(b, dy, packed_bwd, nullptr, add, dx, st);
+}
+
+int agx_conv2d_colsplit_weights(const agx_conv2d_desc *d, const float *w, const float *sigma, float *wp, void *stream) {
+    using namespace agx;
+    if (!d || !w || !wp) return fail(AGX_ERR_NULL_POINTER, "agx_conv2d_colsplit_weights: NULL pointer");
+    const int64_t total = int64_t(d->c_in) * d->kw * d->c_out * d->kh;
+    hipLaunchKernelGGL(colsplit_weights_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), w, sigma, wp, d->c_in, d->c_out, d->kh, d->kw);
+    return check_launch("agx_conv2d_colsplit_weights");
+}
+
+int agx_conv2d_colsum(const agx_conv2d_desc *d, const float *pbuf, const float *add, float *dx, void *stream) {
+    using namespace agx;
+    ConvPlan f;
+    int rc = lower_conv2d(d, &f);
+    if (rc != AGX_OK) return rc;
+    if (d->stride_h != 1 || d->stride_w != 1) return fail(AGX_ERR_UNSUPPORTED, "agx_conv2d_colsum: stride-1 layers only");
+    if (!pbuf || !dx) return fail(AGX_ERR_NULL_POINTER, "agx_conv2d_colsum: NULL pointer");
+    if (d->h_in > 65535 || int64_t(d->batch) * d->c_in > 65535) return fail(AGX_ERR_BAD_SHAPE, "agx_conv2d_colsum: grid too large");
+    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(d->w_in, 256), d->h_in, d->batch * d->c_in), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), pbuf, add, dx, d->c_in, d->kw, d->h_in, f.Lout, d->w_in, d->pad_w);
+    return check_launch("agx_conv2d_colsum");
 }
 
 int agx_conv2d_out_shape(const agx_conv2d_desc *d, int32_t *h_out, int32_t *w_out) {

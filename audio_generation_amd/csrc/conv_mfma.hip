@@ -203,13 +203,17 @@ static int tile_span(const ConvPlan &p, int BN, int *R, int *WF) {
     // 2^k + 1 columns: 128-wide tiles would be one third empty)
     int wf = p.Lt, r = BN / (p.Lt < 1 ? 1 : p.Lt);
     if (p.Lt >= BN) {
-        long best = -1;
+        long best = -1, best_staged = 0;
+        const int kwt = p.J / p.kh;
         for (int cand = BN; cand >= 8; cand /= 2) {
             int rr = BN / cand;
             if (rr > p.Tt) rr = p.Tt;
-            const long area = long(ceil_div(p.Lt, cand)) * cand * (long(ceil_div(p.Tt, rr)) * rr);
-            if (best < 0 || area < best) {
+            const long tiles = long(ceil_div(p.Lt, cand)) * ceil_div(p.Tt, rr);
+            const long area = tiles * cand * rr;
+            const long staged = tiles * ((rr - 1) * p.sh + p.kh) * ((cand - 1) * p.s + kwt);
+            if (best < 0 || area < best || (tuning().patch_tie && area == best && cand >= 16 && staged < best_staged)) {
                 best = area;
+                best_staged = staged;
                 wf = cand;
                 r = rr;
             }
@@ -306,7 +310,7 @@ static const Variant *pick(const Variant *list, int n, const ConvPlan &p, int wa
 }
 
 static const Variant *select_variant(const ConvPlan &p) {
-    if (p.Cin % 16 != 0 || p.M < 32 || p.G != 1) return nullptr;
+    if (p.Cin % 16 != 0 || p.M < (p.pm_R ? 8 : 32) || p.G != 1) return nullptr;   // patch tiles tolerate few rows (clamped)
     const Variant *list = p.M >= 128 ? kWide : (p.M >= 64 ? kMid : kNarrow);
     const int n = p.M >= 128 ? 3 : 5;
     if (p.M >= 128 && tuning().conv_shape == 1) list = kWideAlt;

@@ -221,6 +221,7 @@ int agx_set_tuning(const char *name, int32_t value) {
     else if (!strcmp(name, "rb_sched")) agx::tuning().rb_sched = value;
     else if (!strcmp(name, "rb_occ")) agx::tuning().rb_occ = value;
     else if (!strcmp(name, "bf_sched")) agx::tuning().bf_sched = value;
+    else if (!strcmp(name, "patch_tie")) agx::tuning().patch_tie = value;
     else if (!strcmp(name, "dw_dma")) agx::tuning().dw_dma = value;
     else if (!strcmp(name, "dw_wgs")) agx::tuning().dw_wgs = value;
     else if (!strcmp(name, "conv_cc")) agx::tuning().conv_cc = value;
@@ -237,6 +238,7 @@ int agx_get_tuning(const char *name) {
     if (!strcmp(name, "rb_sched")) return agx::tuning().rb_sched;
     if (!strcmp(name, "rb_occ")) return agx::tuning().rb_occ;
     if (!strcmp(name, "bf_sched")) return agx::tuning().bf_sched;
+    if (!strcmp(name, "patch_tie")) return agx::tuning().patch_tie;
     if (!strcmp(name, "dw_dma")) return agx::tuning().dw_dma;
     if (!strcmp(name, "dw_wgs")) return agx::tuning().dw_wgs;
     if (!strcmp(name, "conv_cc")) return agx::tuning().conv_cc;

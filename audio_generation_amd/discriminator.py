@@ -148,7 +148,13 @@ class _SNConv(nn.Module):
         dw, db = ops.conv2d_bwd_weight(desc, x, dy, w, sigma, u, v, want_bias=self.bias is not None)
         dx = None
         if need_dx:
-            dx = ops.conv2d_bwd_data(desc, dy, ops.conv2d_pack_bwd(desc, w, sigma), mask, slope, add)
+            few = (self.in_channels * self.stride[0] * self.stride[1] < 32 and self.stride == (1, 1) and mask is None
+                   and self.out_channels % 16 == 0 and self.in_channels * self.kernel_size[1] >= 8
+                   and self.kernel_size[0] - 1 - self.padding[0] >= 0)
+            if few:    # the 2-channel first conv: kw * Cin rows on the MFMA tiles instead of Cin on the direct kernel
+                dx = ops.conv2d_bwd_data_fewchannels(desc, dy, w, sigma, add)
+            else:
+                dx = ops.conv2d_bwd_data(desc, dy, ops.conv2d_pack_bwd(desc, w, sigma), mask, slope, add)
         return dx, ([db, dw] if self.bias is not None else [dw])
 
     def desc1d(self, x: Tensor, slope: Optional[float] = None):

@@ -545,6 +545,25 @@ def conv2d_bwd_weight(desc, x: Tensor, dy: Tensor, w: Optional[Tensor] = None, s
     return dw, db
 
 
+def conv2d_bwd_data_fewchannels(desc, dy: Tensor, w: Tensor, sigma: Optional[Tensor] = None,
+                                add: Optional[Tensor] = None) -> Tensor:
+    """Backward-data of a stride-1 Conv2d with very few input channels (c_in * kw >= 8 rows on the MFMA tiles instead
+    of c_in): auxiliary (kh x 1) conv over dy, then a column fold (include/agx.h: agx_conv2d_colsplit_weights)."""
+    lib = _lib.load()
+    _need_gpu(dy, w, sigma, add)
+    dy, w = _f32c(dy), _f32c(w)
+    add = None if add is None else _f32c(add)
+    wp = torch.empty(desc.c_in * desc.kw, desc.c_out, desc.kh, 1, dtype=torch.float32, device=dy.device)
+    _lib.check(lib.agx_conv2d_colsplit_weights(ctypes.byref(desc), _ptr(w), _ptr(sigma), _ptr(wp), _stream()),
+               "agx_conv2d_colsplit_weights")
+    aux = conv2d_desc(desc.batch, desc.c_out, desc.c_in * desc.kw, dy.shape[2], dy.shape[3], desc.kh, 1, (1, 1),
+                      (desc.kh - 1 - desc.pad_h, 0))
+    pbuf = conv2d_forward(aux, dy, conv2d_pack(aux, wp), None)
+    dx = torch.empty(desc.batch, desc.c_in, desc.h_in, desc.w_in, dtype=torch.float32, device=dy.device)
+    _lib.check(lib.agx_conv2d_colsum(ctypes.byref(desc), _ptr(pbuf), _ptr(add), _ptr(dx), _stream()), "agx_conv2d_colsum")
+    return dx
+
+
 def conv2d_kernel_name(desc) -> str:
     buf = ctypes.create_string_buffer(96)
     _lib.check(_lib.load().agx_conv2d_kernel_name(ctypes.byref(desc), buf, 96), "agx_conv2d_kernel_name")

@@ -46,6 +46,7 @@ const char *agx_last_error(void);
  *   "rb_occ" 2|3       3: fused residual block built under a 168-VGPR cap (3 waves/SIMD); no gain measured
  *   "conv_short" 0|1   128x64 MFMA conv tiles when the 128x128 grid is under two workgroups per CU (default 1)
  *   "conv_cc" 0|8|16|32  force the LDS channel chunk of the MFMA conv (0 = table)
+ *   "patch_tie" 0|1      2-D patch tiles: tie between equally padded R x WF splits goes to the fewest staged elements (1) or the widest (0)
  *   "bf_sched" -1|0|1|2  schedule of the bf16x3 main loop of the fused residual block (-1 = per-shape table)
  *   "dw_dma" 0|1       1: experimental LDS-DMA double-buffered conv2d weight-gradient kernel (default 0)
  *   "dw_wgs" n         workgroups the conv2d weight-gradient kernel aims for (default 1536)
@@ -320,6 +321,12 @@ int64_t agx_conv2d_bwd_packed_floats(const agx_conv2d_desc *d);
 int agx_conv2d_pack_bwd(const agx_conv2d_desc *d, const float *w, const float *sigma, float *packed, void *stream);
 int agx_conv2d_bwd_data(const agx_conv2d_desc *d, const float *dy, const float *packed_bwd, const float *add,
                         const float *mask, float slope, float *dx, void *stream);
+/* Backward-data of a stride-1 layer with very few input channels (the 2-channel first conv), in two steps:
+ * agx_conv2d_colsplit_weights writes the weights of the auxiliary (kh x 1) layer with c_in*kw output rows
+ * (wp: c_in*kw x c_out x kh floats; run it with agx_conv2d_forward on dy, padding (kh-1-pad_h, 0)); its output
+ * P (B, c_in*kw, h_in, w_out) is folded by agx_conv2d_colsum: dx[c][i][j] = sum_dw P[c*kw+dw][i][j-dw+pad_w] (+ add). */
+int agx_conv2d_colsplit_weights(const agx_conv2d_desc *d, const float *w, const float *sigma, float *wp, void *stream);
+int agx_conv2d_colsum(const agx_conv2d_desc *d, const float *pbuf, const float *add, float *dx, void *stream);
 /* dW (c_out, c_in, kh, kw) and dbias (c_out, may be NULL) of the layer.  With sigma != NULL the layer is
  * spectrally normalised: w is weight_orig, u / v the vectors sigma was computed with, and dw is the
  * gradient w.r.t. weight_orig:  G / sigma - (<G, W> / sigma^2) u v^T  (G = gradient w.r.t. W / sigma). */

@@ -383,7 +383,9 @@ def test_stft_discriminator_backward_runs_on_the_native_kernels(monkeypatch):
     torch.manual_seed(5)
     d = ad.STFTDiscriminator(first_channel_size=16, win_length=256).to(DEV).train()
     calls = {"dw": 0, "dx": 0, "bridge": 0}
-    real_w, real_x = ops.conv2d_bwd_weight, ops.conv2d_bwd_data
+    real_w, real_x, real_f = ops.conv2d_bwd_weight, ops.conv2d_bwd_data, ops.conv2d_bwd_data_fewchannels
+    monkeypatch.setattr(ops, "conv2d_bwd_data_fewchannels",
+                        lambda *a, **k: (calls.__setitem__("dx", calls["dx"] + 1), real_f(*a, **k))[1])
     monkeypatch.setattr(ops, "conv2d_bwd_weight", lambda *a, **k: (calls.__setitem__("dw", calls["dw"] + 1), real_w(*a, **k))[1])
     monkeypatch.setattr(ops, "conv2d_bwd_data", lambda *a, **k: (calls.__setitem__("dx", calls["dx"] + 1), real_x(*a, **k))[1])
     real_b = ad._MultiOutBridge.apply
@@ -468,3 +470,19 @@ def test_bf16x3_stft_discriminator_matches_fp32():
     names = {ops.conv2d_kernel_name(m.desc2d(torch.empty(2, m.in_channels, 20, 64))) for m in d.modules()
              if isinstance(m, ad._SNConv)}
     assert names
+
+
+@pytest.mark.parametrize("cin,cout,kh,kw,ph,pw,h,w", [(2, 32, 7, 7, 3, 3, 21, 70), (3, 48, 5, 5, 2, 2, 9, 33), (2, 32, 7, 7, 3, 3, 40, 1024),
+                                                      (1, 16, 3, 9, 1, 4, 6, 20)])
+def test_conv2d_backward_data_few_input_channels(cin, cout, kh, kw, ph, pw, h, w):
+    """The column-split backward-data of the first (2-channel) conv against autograd, with the fused add."""
+    torch.manual_seed(cin + cout)
+    x = torch.randn(2, cin, h, w, requires_grad=True)
+    wt = torch.randn(cout, cin, kh, kw) / (cin * kh * kw) ** 0.5
+    sigma = torch.tensor([1.7])
+    y = F.conv2d(x, wt / sigma, None, padding=(ph, pw))
+    dy, extra = torch.randn_like(y), torch.randn(2, cin, h, w)
+    y.backward(dy)
+    d = ops.conv2d_desc(2, cin, cout, h, w, kh, kw, (1, 1), (ph, pw))
+    got = ops.conv2d_bwd_data_fewchannels(d, dy.to(DEV), wt.to(DEV), sigma.to(DEV), extra.to(DEV))
+    close(got, x.grad + extra, 2e-5)

@@ -26,6 +26,10 @@ def main():
     win = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     b = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     dev = "cuda"
+    for kv in os.environ.get("AGX_KNOBS", "").split(","):     # e.g. AGX_KNOBS=patch_tie=0
+        if kv:
+            from audio_generation_amd import _lib
+            _lib.load().agx_set_tuning(kv.split("=")[0].encode(), int(kv.split("=")[1]))
     d = ad.STFTDiscriminator(win_length=win).to(dev).train()
     x = 0.1 * torch.randn(b, 1, 72000, device=dev)
     with torch.no_grad():
@@ -43,6 +47,10 @@ def main():
             hh = h
             tf = timeit(lambda: c.run2d(hh, None))
             tx = timeit(lambda: ops.conv2d_bwd_data(desc, dy, pk))
+            if c is d.first_conv:    # what _SNConv.bwd2d runs for the 2-channel layer
+                tx2 = timeit(lambda: ops.conv2d_bwd_data_fewchannels(desc, dy, w, tape[0]))
+                print(f"   first conv dx: direct {tx:.3f} ms, column-split {tx2:.3f} ms")
+                tx = tx2
             tw = timeit(lambda: ops.conv2d_bwd_weight(desc, hh, dy, w, *tape))
             fl = 2.0 * y.numel() * c.in_channels * c.kernel_size[0] * c.kernel_size[1]
             print(f"{c.in_channels:4d}->{c.out_channels:4d} k{tuple(c.kernel_size)} s{tuple(c.stride)} in {tuple(h.shape[2:])}: "
