@@ -135,6 +135,8 @@ SIGNATURES = {
                                       c_void_p]),
     "agx_preemphasis": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_int32, c_void_p]),
     "agx_lowpass_biquad": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_float, c_float, c_void_p]),
+    "agx_resample_out_len": (c_int64, [c_int64, c_int32, c_int32]),
+    "agx_resample": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "agx_codes_packed_bytes": (c_int64, [c_int64, c_int32]),
     "agx_codes_pack": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "agx_codes_unpack": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),

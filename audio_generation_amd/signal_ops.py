@@ -1,6 +1,7 @@
 """The training loop's signal ops on HIP kernels -- what ``networks/training.py`` takes from
 torchaudio: ``MelSpectrogram`` (:151-156), ``multispectral_reconstruction_loss`` (:51-78),
-``functional.lowpass_biquad`` (:316-318) and ``functional.preemphasis`` (:333-334).
+``functional.lowpass_biquad`` (:316-318), ``functional.preemphasis`` (:333-334) and ``transforms.Resample`` (:554,
+applied per clip by ``utils.collator``, utils.py:157-158).
 
 **Parity unpinned**: torchaudio is not installed in the build container and the reference holds no fixture
 for these ops; behaviour is restated from torchaudio's documentation (``oracle/signal.py``) and the kernels
@@ -64,6 +65,73 @@ def lowpass_biquad(waveform: Tensor, sample_rate: int, cutoff_freq: float, Q: fl
     _lib.check(lib.agx_lowpass_biquad(_ptr(x), _ptr(y), _rows(x), x.shape[-1], float(sample_rate), float(cutoff_freq),
                                       float(Q), _stream()), "agx_lowpass_biquad")
     return y
+
+
+class Resample(nn.Module):
+    """torchaudio.transforms.Resample(orig_freq, new_freq) with its defaults (sinc_interp_hann,
+    lowpass_filter_width 6, rolloff 0.99): the reference's ``resampler`` (training.py:554).  The windowed-sinc
+    table (new_freq / gcd phases x 2 width + orig_freq / gcd taps) is built once in float64 and kept in float32;
+    the interpolation runs on ``agx_resample`` (csrc/spectral.hip)."""
+
+    def __init__(self, orig_freq: int = 16000, new_freq: int = 16000, resampling_method: str = "sinc_interp_hann",
+                 lowpass_filter_width: int = 6, rolloff: float = 0.99):
+        super().__init__()
+        if resampling_method != "sinc_interp_hann":
+            raise NotImplementedError("Resample: only torchaudio's default sinc_interp_hann window")
+        if int(orig_freq) != orig_freq or int(new_freq) != new_freq or orig_freq <= 0 or new_freq <= 0:
+            raise ValueError("Resample: frequencies must be positive integers")
+        if lowpass_filter_width <= 0:
+            raise ValueError("Low pass filter width should be positive.")
+        self.orig_freq, self.new_freq = int(orig_freq), int(new_freq)
+        g = math.gcd(self.orig_freq, self.new_freq)
+        self.of, self.nf = self.orig_freq // g, self.new_freq // g
+        base = min(self.of, self.nf) * rolloff
+        self.width = math.ceil(lowpass_filter_width * self.of / base)
+        taps = torch.arange(-self.width, self.width + self.of, dtype=torch.float64) / self.of          # (K,)
+        phase = -torch.arange(self.nf, dtype=torch.float64) / self.nf                                  # (nf,)
+        t = ((phase[:, None] + taps[None, :]) * base).clamp(-lowpass_filter_width, lowpass_filter_width)
+        window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+        t = t * math.pi
+        sinc = torch.where(t == 0, torch.ones_like(t), torch.sin(t) / torch.where(t == 0, torch.ones_like(t), t))
+        self.register_buffer("kernel", (sinc * window * (base / self.of)).to(torch.float32), persistent=False)
+
+    def forward(self, waveform: Tensor) -> Tensor:
+        if self.orig_freq == self.new_freq:
+            return waveform
+        lib = _lib.load()
+        _need_gpu(waveform, self.kernel)
+        x = _f32c(waveform)
+        rows, length = _rows(x), x.shape[-1]
+        out_len = int(lib.agx_resample_out_len(length, self.of, self.nf))
+        y = torch.empty(*x.shape[:-1], out_len, dtype=torch.float32, device=x.device)
+        for r0 in range(0, rows, 65535):            # the row index rides on grid.y
+            r1 = min(rows, r0 + 65535)
+            _lib.check(lib.agx_resample(_ptr(x.view(rows, length)[r0:r1]), _ptr(self.kernel), _ptr(y.view(rows, out_len)[r0:r1]),
+                                        r1 - r0, length, self.of, self.nf, self.width, _stream()), "agx_resample")
+        return y
+
+
+def collator(batch, size: int = 72000, resampler: Optional[nn.Module] = None):
+    """``utils.collator`` (utils.py:149-175): per clip ``x = item[0]`` (the label is dropped), resample, then zero-pad
+    at a random split or crop at a random offset to ``size`` samples.  As in the reference a clip whose length
+    already equals ``size`` is left out of the returned list (its ``if / elif`` has no branch for it), and the
+    random offsets come from ``torch.randint`` on the default generator.  Clips are moved to the GPU for the
+    resampler (``Resample`` has no CPU path) and come back on the device they arrived on."""
+    out = []
+    for item in batch:
+        x = item[0]
+        if resampler is not None:
+            dev = x.device
+            x = resampler(x.cuda() if not x.is_cuda else x).to(dev)
+        n = x.shape[-1]
+        if n < size:
+            diff = size - n
+            split = int(torch.randint(0, diff, (1,)).item())
+            out.append(torch.cat([x.new_zeros((x.shape[0], split)), x, x.new_zeros((x.shape[0], diff - split))], dim=-1))
+        elif n > size:
+            start = int(torch.randint(0, n - size, (1,)).item())
+            out.append(x[:, start:start + size])
+    return out
 
 
 def melscale_fbanks(n_freqs: int, sample_rate: int, n_mels: int) -> Tensor:

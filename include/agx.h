@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AGX_VERSION 110 /* 0.1.1: agx_conv_desc gained groups / padding (zero = old behaviour) */
+#define AGX_VERSION 111 /* 0.1.1: agx_conv_desc gained groups / padding (zero = old behaviour); 111: resample, conv2d column split */
 
 #define AGX_OK 0
 #define AGX_ERR_BAD_SHAPE (-1)
@@ -405,6 +405,12 @@ int agx_preemphasis(const float *x, float *y, int64_t rows, int32_t length, floa
 /* torchaudio.functional.lowpass_biquad (training.py:316-318): RBJ low-pass, direct form I, output clamped to [-1, 1]. */
 int agx_lowpass_biquad(const float *x, float *y, int64_t rows, int32_t length, float sample_rate, float cutoff_freq,
                        float q, void *stream);
+/* torchaudio.transforms.Resample (training.py:554, applied per clip by utils.collator utils.py:157-158): y (rows,
+ * agx_resample_out_len(length)) = polyphase sinc interpolation of x (rows, length) with the caller's table
+ * (new_freq, 2 width + orig_freq) -- orig_freq / new_freq already divided by their gcd. */
+int64_t agx_resample_out_len(int64_t length, int32_t orig_freq, int32_t new_freq);
+int agx_resample(const float *x, const float *table, float *y, int64_t rows, int32_t length, int32_t orig_freq,
+                 int32_t new_freq, int32_t width, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Codec bitstream (wire size per utils.py:137-147)               *

@@ -11,6 +11,7 @@ norm=None)) as the reference calls them:
 * ``training.py:51-78``    multispectral_reconstruction_loss
 * ``training.py:316-318``  lowpass_biquad(x, sample_rate, cutoff_freq)
 * ``training.py:333-334``  preemphasis(x, 0.97)
+* ``training.py:554``      transforms.Resample(data_sample_rate, sample_rate) (applied per clip by utils.collator)
 """
 from __future__ import annotations
 
@@ -95,3 +96,37 @@ def multispectral_reconstruction_loss(original: Tensor, reconstruction: Tensor, 
         else:
             loss = loss + alpha * F.mse_loss(so, sr)
     return spec_loss_weight * loss
+
+
+def resample_kernel(orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99):
+    """torchaudio.functional.resample's windowed-sinc table (sinc_interp_hann), entry by entry in float64:
+    table[p][k] = scale * sinc(pi t) * cos^2(pi t / (2 lpw)),  t = clamp(base * ((k - width) / of - p / nf), +-lpw),
+    base = min(of, nf) * rolloff, scale = base / of, width = ceil(lpw * of / base), K = 2 width + of.
+    Returns (table float32 (nf, K), width, of, nf)."""
+    g = math.gcd(int(orig_freq), int(new_freq))
+    of, nf = int(orig_freq) // g, int(new_freq) // g
+    base = min(of, nf) * rolloff
+    width = math.ceil(lowpass_filter_width * of / base)
+    K = 2 * width + of
+    table = torch.zeros(nf, K, dtype=torch.float64)
+    for p in range(nf):
+        for k in range(K):
+            t = base * ((k - width) / of - p / nf)
+            t = max(-lowpass_filter_width, min(lowpass_filter_width, t))
+            w = math.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+            table[p, k] = (1.0 if t == 0 else math.sin(math.pi * t) / (math.pi * t)) * w * base / of
+    return table.to(torch.float32), width, of, nf
+
+
+def resample(x: Tensor, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99) -> Tensor:
+    """transforms.Resample(orig_freq, new_freq)(x): pad (width, width + of), conv1d with the (nf, 1, K) table at
+    stride of, interleave the nf phases, crop to ceil(nf * length / of)."""
+    if orig_freq == new_freq:
+        return x
+    table, width, of, nf = resample_kernel(orig_freq, new_freq, lowpass_filter_width, rolloff)
+    shape, length = x.shape, x.shape[-1]
+    xs = F.pad(x.reshape(-1, length).to(torch.float32), (width, width + of))
+    y = F.conv1d(xs[:, None], table[:, None], stride=of)                 # (rows, nf, n)
+    y = y.transpose(1, 2).reshape(xs.shape[0], -1)
+    target = -(-nf * length // of)
+    return y[:, :target].reshape(*shape[:-1], target)

@@ -82,3 +82,53 @@ def test_full_size_mel_loss_runs():
     loss = sg.multispectral_reconstruction_loss(orig, rec, specs, windows)
     loss.backward()
     assert torch.isfinite(loss) and float(loss) > 0 and torch.isfinite(rec.grad).all() and float(rec.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("orig,new,length", [(48000, 24000, 5000), (44100, 24000, 33075), (16000, 24000, 1234),
+                                              (22050, 24000, 900), (24000, 24000, 100), (8000, 24000, 7)])
+def test_resample(orig, new, length):
+    """transforms.Resample (the collator's resampler) against the restatement; parity unpinned (torchaudio absent)."""
+    torch.manual_seed(length)
+    x = torch.randn(2, 1, length)
+    mod = sg.Resample(orig, new).to(DEV)
+    got = mod(x.to(DEV))
+    want = osg.resample(x, orig, new)
+    assert got.shape == want.shape
+    close(got, want, 2e-6)
+    if orig != new:
+        table, width, of, nf = osg.resample_kernel(orig, new)
+        assert (mod.of, mod.nf, mod.width) == (of, nf, width)
+        assert float((mod.kernel.cpu() - table).abs().max()) < 1e-7
+
+
+def test_resample_rejects_what_torchaudio_rejects():
+    with pytest.raises(ValueError):
+        sg.Resample(44100.5, 24000)
+    with pytest.raises(ValueError):
+        sg.Resample(44100, 24000, lowpass_filter_width=0)
+
+
+def test_collator_pads_crops_and_resamples_like_the_reference():
+    """utils.collator (utils.py:149-175): same torch.randint draws as the reference's loop, so the crops / pads
+    land where its own would with the same seed; equal-length clips are dropped (reference quirk)."""
+    torch.manual_seed(3)
+    clips = [(torch.randn(1, 3000), 0), (torch.randn(1, 500), 1), (torch.randn(1, 1000), 2)]
+    rs = sg.Resample(48000, 24000).to(DEV)
+    torch.manual_seed(11)
+    got = sg.collator(clips, size=1000, resampler=rs)
+    torch.manual_seed(11)
+    want = []
+    for x, _ in clips:                          # the reference's loop on the oracle's resampler
+        x = osg.resample(x, 48000, 24000)
+        n = x.shape[-1]
+        if n < 1000:
+            split = torch.randint(0, 1000 - n, (1,)).item()
+            want.append(torch.cat([torch.zeros(1, split), x, torch.zeros(1, 1000 - n - split)], dim=-1))
+        elif n > 1000:
+            start = torch.randint(0, n - 1000, (1,)).item()
+            want.append(x[:, start:start + 1000])
+    assert len(got) == len(want) == 3
+    for g, w in zip(got, want):
+        assert g.shape == (1, 1000) and not g.is_cuda
+        close(g, w, 2e-6)
+    assert sg.collator([(torch.zeros(1, 1000), 0)], size=1000) == []

@@ -53,3 +53,30 @@ def test_biquad_equals_scipy_lfilter():
 def test_preemphasis_definition():
     x = torch.arange(6.0).reshape(1, 6)
     assert torch.allclose(osg.preemphasis(x, 0.5), torch.tensor([[0.0, 1.0, 1.5, 2.0, 2.5, 3.0]]))
+
+
+@pytest.mark.parametrize("orig,new", [(48000, 24000), (44100, 24000), (16000, 24000), (22050, 24000)])
+def test_resample_restatement(orig, new):
+    """Parity unpinned (torchaudio absent).  The conv form against the interpolation written sample by sample in
+    float64, y[i] = sum_j x[j] h(i / nf - j / of), and a band-limited sine against its analytic resampling."""
+    torch.manual_seed(orig % 97)
+    x = torch.randn(2, 700)
+    y = osg.resample(x, orig, new)
+    table, width, of, nf = osg.resample_kernel(orig, new)
+    assert y.shape == (2, math.ceil(700 * nf / of))
+    base, lpw = min(of, nf) * 0.99, 6
+    for i in [0, 1, 5, y.shape[1] // 2, y.shape[1] - 2, y.shape[1] - 1]:
+        acc = 0.0
+        for j in range(700):
+            t = base * (j / of - i / nf)
+            if abs(t) >= lpw:
+                continue                      # the Hann window is zero from there on
+            h = (1.0 if t == 0 else math.sin(math.pi * t) / (math.pi * t)) * math.cos(t * math.pi / lpw / 2) ** 2
+            acc += float(x[1, j]) * h * base / of
+        assert abs(acc - float(y[1, i])) < 2e-5, (i, acc, float(y[1, i]))
+    n = torch.arange(4000, dtype=torch.float64)
+    f0 = 0.05 * min(orig, new)                # well inside both bands
+    got = osg.resample(torch.sin(2 * math.pi * f0 * n / orig).float()[None], orig, new)[0]
+    m = torch.arange(got.shape[0], dtype=torch.float64)
+    want = torch.sin(2 * math.pi * f0 * m / new)
+    assert float((got.double() - want)[200:-200].abs().max()) < 5e-3
