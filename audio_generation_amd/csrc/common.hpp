@@ -26,8 +26,6 @@ struct Tuning {
                         // 1 the same with MFMA / VALU interleave hints, 2 split before the MFMAs
     int dw_dma = 0;     // 1: LDS-DMA double-buffered conv2d weight-gradient kernel (experimental: 48-53 TFLOP/s with 8 waves
                         // per workgroup, 40 with 4 -- the per-item DMA latency is not hidden yet), 0: the synchronous one (53-61)
-    int dw_prio = 0;    // conv2d weight-gradient kernel: wave priority by workgroup id (0 off, 1 (id/256)%4, 2 id%4, 3 (id/32)%4, 4 (id/8)%4): co-resident
-                        // workgroups otherwise run their staging / MFMA phases in lock-step
     int dw_wgs = 1536;  // workgroups the conv2d weight-gradient kernel aims for (slices = dw_wgs / tiles)
     int conv_cc = 0;    // diagnostic: force the LDS chunk (8/16/32 channels) of the MFMA conv; 0 = table
     int conv_shape = 0; // diagnostic: 1 = 128x128 conv tiles as 4 row-waves x (1x4) fragments

@@ -269,7 +269,6 @@ struct Bw2dGeom {
     int B, Cin, Cout, Hin, Win, Hout, Wout, kh, kw, sh, sw, ph, pw;
     int R, WF, RH, SW, span, n_chan, n_slices;
     int prec;   // 1: bf16x3 contraction (AGX_IMPL_MFMA_BF16X3)
-    int prio;   // tuning().dw_prio
 };
 
 template <int MW, int NW, int WM, int WN, int PREC = 0>   // PREC 1: bf16x3 contraction (mfma_tile.hpp), both operands split in registers
@@ -290,14 +289,6 @@ __global__ __launch_bounds__(256) void conv2d_bwd_weight_kernel(Bw2dGeom g, cons
     const int n_base = blockIdx.x * BN, m_base = blockIdx.y * BM, slice = blockIdx.z;
     const int ci_first = n_base / KK;
     const int npos = g.R * g.WF;              // contraction positions per tile (<= BW_T)
-    if (g.prio) {
-        const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const int pr = (g.prio == 1 ? lin >> 8 : g.prio == 2 ? lin : g.prio == 3 ? lin >> 5 : lin >> 3) & 3;
-        if (pr == 1) __builtin_amdgcn_s_setprio(1);
-        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
-        else if (pr == 3) __builtin_amdgcn_s_setprio(3);
-    }
-
     if (tid < BW_T) {
         const int r = tid / g.WF, fc = tid - r * g.WF;
         kofft[tid] = tid < npos ? (r * g.sh) * g.SW + fc * g.sw : 0;
@@ -668,7 +659,6 @@ static int bw2d_geometry(const agx_conv2d_desc *d, Bw2dGeom *g, int *cfg, int *b
     const int KK = g->kh * g->kw;
     g->n_chan = 127 / KK + 2;
     g->prec = d->impl == AGX_IMPL_MFMA_BF16X3 ? 1 : 0;
-    g->prio = tuning().dw_prio;
     *cfg = g->Cout >= 128 ? 0 : (g->Cout >= 64 ? 1 : 2);
     *bm = *cfg == 0 ? 128 : (*cfg == 1 ? 64 : 32);
     const int nt = ceil_div(g->Cin * KK, 128), mt = ceil_div(g->Cout, *bm);

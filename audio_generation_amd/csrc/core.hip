@@ -224,7 +224,6 @@ int agx_set_tuning(const char *name, int32_t value) {
     else if (!strcmp(name, "patch_tie")) agx::tuning().patch_tie = value;
     else if (!strcmp(name, "dw_dma")) agx::tuning().dw_dma = value;
     else if (!strcmp(name, "dw_wgs")) agx::tuning().dw_wgs = value;
-    else if (!strcmp(name, "dw_prio")) agx::tuning().dw_prio = value;
     else if (!strcmp(name, "conv_cc")) agx::tuning().conv_cc = value;
     else if (!strcmp(name, "conv_shape")) agx::tuning().conv_shape = value;
     else if (!strcmp(name, "conv_short")) agx::tuning().conv_short = value;
@@ -242,7 +241,6 @@ int agx_get_tuning(const char *name) {
     if (!strcmp(name, "patch_tie")) return agx::tuning().patch_tie;
     if (!strcmp(name, "dw_dma")) return agx::tuning().dw_dma;
     if (!strcmp(name, "dw_wgs")) return agx::tuning().dw_wgs;
-    if (!strcmp(name, "dw_prio")) return agx::tuning().dw_prio;
     if (!strcmp(name, "conv_cc")) return agx::tuning().conv_cc;
     if (!strcmp(name, "conv_shape")) return agx::tuning().conv_shape;
     if (!strcmp(name, "conv_short")) return agx::tuning().conv_short;

@@ -28,6 +28,8 @@ constexpr int NWV = 8;    // waves per workgroup (2 per SIMD: one computes while
 constexpr int NT = 64 * NWV;
 constexpr int RS = 33;    // LDS row stride of R / O (conflict-free in both access patterns)
 constexpr int CAND = 8;   // candidate slots per frame
+constexpr int TLMAX = 8;  // |c'|^2, |c'| table entries a thread carries to the next stage: 2 K <= TLMAX * NT for the LDS copy
+constexpr int MUMAX = 2;  // same for the mean codeword: Dp <= MUMAX * NT
 
 __host__ __device__ inline int rvq_dp(int dim) { return (dim + 7) & ~7; }  // D rounded up to the 8-deep k block
 // stage image, all on CENTRED codewords c' = fl(c - mu), mu = the stage's mean codeword:
@@ -150,7 +152,7 @@ struct RvqArgs {
     double *sq_err;  // (Q)
 };
 
-template <int MT>
+template <int MT, bool TAIL_LDS>   // TAIL_LDS: the stage's |c'|^2 and |c'| tables are copied to LDS (they fit beside R / O)
 __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Dp = rvq_dp(a.D);
@@ -165,6 +167,9 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
     int *ccode = best + FT;                                // [FT][CAND]
     float *cscore = reinterpret_cast<float *>(ccode + FT * CAND);  // [FT][CAND]
     double *cdist = reinterpret_cast<double *>(cscore + FT * CAND);  // [FT][CAND] (8-byte aligned: offsets are even)
+    int *work = reinterpret_cast<int *>(cdist + FT * CAND);  // [FT * CAND] (frame, candidate) pairs that need the exact distance
+    int *flags = work + FT * CAND;                            // [0] number of pairs, [1] any frame in candidate overflow
+    float *tails = reinterpret_cast<float *>(flags + 2);     // [2 K] c2 | cn of the current stage (TAIL_LDS)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -204,21 +209,40 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
         const float *cn = c2 + K;
         const float *cbq = a.cb + size_t(q) * K * D;
 
-        if (tid < FT) cnt[tid] = 0;
-        const float *mu_g = c2 + 2 * size_t(K) + 4;
-        for (int d = tid; d < Dp; d += NT) mus[d] = mu_g[d];
-        __syncthreads();
-        // ||r - mu||^2 per frame (wave w owns frames w, w+NWV, ...)
-        for (int f = wave; f < FT; f += NWV) {
-            float part = 0.f;
-            for (int d = lane; d < D; d += 64) {
-                const float v = R[d * RS + f] - mus[d];
-                part = fmaf(v, v, part);
+        if (q == 0) {   // later stages: all of this is prepared by the previous stage's update phase (C)
+            if (tid < FT) cnt[tid] = 0;
+            if (tid < 2) flags[tid] = 0;
+            if (TAIL_LDS)
+                for (int e = tid; e < 2 * K; e += NT) tails[e] = c2[e];   // c2 and cn are adjacent in the image
+            const float *mu_g = c2 + 2 * size_t(K) + 4;
+            for (int d = tid; d < Dp; d += NT) mus[d] = mu_g[d];
+            __syncthreads();
+            // ||r - mu||^2 per frame (wave w owns frames w, w+NWV, ...)
+            for (int f = wave; f < FT; f += NWV) {
+                float part = 0.f;
+                for (int d = lane; d < D; d += 64) {
+                    const float v = R[d * RS + f] - mus[d];
+                    part = fmaf(v, v, part);
+                }
+                for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+                if (lane == 0) rn2[f] = part;
             }
-            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-            if (lane == 0) rn2[f] = part;
+            __syncthreads();
         }
-        __syncthreads();
+        // The next stage's mean and |c'|^2 / |c'| tables are requested now and sit in registers until this stage's
+        // search is over (their latency hides behind the score GEMM).
+        float tl_next[TLMAX], mu_next[MUMAX];
+        const bool more = q + 1 < a.Q;
+        {
+            const float *c2n = c2 + (more ? rvq_stage_floats(K, D) : 0);
+            if (TAIL_LDS) {
+#pragma unroll
+                for (int u = 0; u < TLMAX; ++u) tl_next[u] = c2n[min(tid + u * NT, 2 * K - 1)];
+            }
+            const float *mun = c2n + 2 * size_t(K) + 4;
+#pragma unroll
+            for (int u = 0; u < MUMAX; ++u) mu_next[u] = mun[min(tid + u * NT, Dp - 1)];
+        }
         // Error bound of one computed score: |s_k + |r'|^2 - |r - c_k|^2| <= E_k = eu (|r'| + |c'_k|)^2
         // (fp32 MFMA chain and |c'|^2: (D+2) u (c'^2 + 2 r'c'); the two centring roundings: 2 u (r'+c')^2).
         // Per CODEWORD, not per codebook: one far-away outlier codeword must not widen the margin of
@@ -245,38 +269,54 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
             // one block ahead; B operands are conflict-free ds_read_b32 of the residual tile.
             const float *rb = R + (4 * lh) * RS + li;
             const float *ab = img + size_t(lh) * K * 4;
-            f32x4 a_cur[MT], a_nxt[MT];
+            // The codeword operands come straight from L2 (~1 us under load) while one 8-deep block is only
+            // 4 MT MFMAs (0.2 us): they are requested three blocks ahead into a ring of four register sets
+            // (the loop is unrolled by four so that the ring is addressed statically: a register move would
+            // have to wait for its load).
+            constexpr int NB = 4;
+            f32x4 a_r[NB][MT];
             float b_cur[4], b_nxt[4];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) a_cur[i] = *reinterpret_cast<const f32x4 *>(ab + size_t(acol[i]) * 4);
+            for (int p = 0; p < NB - 1; ++p) {
+                const int dp = 8 * p < Dp ? 8 * p : 0;
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    a_r[p][i] = *reinterpret_cast<const f32x4 *>(ab + size_t(dp >> 2) * K * 4 + size_t(acol[i]) * 4);
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) b_cur[ks] = rb[ks * RS] - mus[4 * lh + ks];
             __builtin_amdgcn_s_waitcnt(0xC07F);  // retire the LDS reads here, not in front of every block's MFMAs
-            for (int d8 = 0; d8 < Dp; d8 += 8) {
-                // operands of the NEXT 8-deep block are requested while this block's MFMAs issue
-                // (threaded between them by the scheduler); past the end the prefetch re-reads block 0
-                const int dn = d8 + 8 < Dp ? d8 + 8 : 0;
-                const float *an = ab + size_t(dn >> 2) * K * 4;
+            for (int d0 = 0; d0 < Dp; d0 += 8 * NB) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i) a_nxt[i] = *reinterpret_cast<const f32x4 *>(an + size_t(acol[i]) * 4);
+                for (int u = 0; u < NB; ++u) {
+                    const int d8 = d0 + 8 * u;
+                    if (d8 < Dp) {      // wave-uniform
+                        // operands of later blocks are requested while this block's MFMAs issue (threaded
+                        // between them by the scheduler); past the end the prefetch re-reads block 0
+                        const int dn = d8 + 8 < Dp ? d8 + 8 : 0;
+                        const int df = d8 + 8 * (NB - 1) < Dp ? d8 + 8 * (NB - 1) : 0;
+                        const float *an = ab + size_t(df >> 2) * K * 4;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) b_nxt[ks] = rb[(dn + ks) * RS] - mus[dn + 4 * lh + ks];
+                        for (int i = 0; i < MT; ++i)
+                            a_r[(u + NB - 1) % NB][i] = *reinterpret_cast<const f32x4 *>(an + size_t(acol[i]) * 4);
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
+                        for (int ks = 0; ks < 4; ++ks) b_nxt[ks] = rb[(dn + ks) * RS] - mus[dn + 4 * lh + ks];
 #pragma unroll
-                    for (int i = 0; i < MT; ++i)
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i][ks], b_cur[ks], acc[i], 0, 0, 0);
+                        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int gidx = 0; gidx < 4; ++gidx) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);  // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read (residual + mean)
+                            for (int i = 0; i < MT; ++i)
+                                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_r[u][i][ks], b_cur[ks], acc[i], 0, 0, 0);
+#pragma unroll
+                        for (int gidx = 0; gidx < 4; ++gidx) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);  // MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read (residual + mean)
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) b_cur[ks] = b_nxt[ks];
+                    }
                 }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < MT; ++i) a_cur[i] = a_nxt[i];
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) b_cur[ks] = b_nxt[ks];
             }
             // lower bounds in place; rows of register r: (r&3) + 8*(r>>2) + 4*lh.  One subtile at a
             // time (the sched_barrier keeps hipcc from hoisting all 2*16*MT table loads at once,
@@ -288,8 +328,8 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
                 for (int r = 0; r < 16; ++r) {
                     const int code = code0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     const int cc = min(code, K - 1);
-                    const float s = (code < K) ? (c2[cc] - 2.f * acc[i][r]) : INFINITY;
-                    const float rc = rnorm + cn[cc];
+                    const float s = (code < K) ? ((TAIL_LDS ? tails[cc] : c2[cc]) - 2.f * acc[i][r]) : INFINITY;
+                    const float rc = rnorm + (TAIL_LDS ? tails[K + cc] : cn[cc]);
                     const float e = eu * rc * rc;
                     acc[i][r] = s - e;          // keep the lower bound
                     m = fminf(m, s + e);        // reduce the upper bound
@@ -320,13 +360,13 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
                 }
             __syncthreads();
         }
-
         // ---- B: decide ----
         if (tid < FT) {  // wave 0, lane == li == frame
             const int f = tid;
             const int n = cnt[f];
             if (n > CAND) {
                 state[f] = 2;
+                flags[1] = 1;
             } else {
                 const float thr = running;
                 int kept = 0;
@@ -347,16 +387,16 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
                     state[f] = 0;
                 } else {
                     state[f] = 1;
+                    const int slot = atomicAdd(&flags[0], kept);
+                    for (int c = 0; c < kept; ++c) work[slot + c] = f * CAND + c;
                 }
             }
         }
         __syncthreads();
-        for (int fc = wave; fc < FT * CAND; fc += NWV) {  // one (frame, candidate) pair per wave at a time
-            const int f = fc >> 3, c = fc & 7;
-            if (state[f] == 1 && c < cnt[f]) {             // wave-uniform (LDS values)
-                const double dist = exact_dist_wave(R + f, cbq + size_t(ccode[fc]) * D, D, lane);
-                if (lane == 0) cdist[fc] = dist;
-            }
+        for (int w = wave; w < flags[0]; w += NWV) {  // one listed (frame, candidate) pair per wave at a time
+            const int fc = work[w], f = fc >> 3;
+            const double dist = exact_dist_wave(R + f, cbq + size_t(ccode[fc]) * D, D, lane);
+            if (lane == 0) cdist[fc] = dist;
         }
         __syncthreads();
         if (tid < FT && state[tid] == 1) {
@@ -373,9 +413,19 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
             }
             best[f] = bc;
         }
+        // this stage's search is over: the next stage's tables replace the current ones
+        if (TAIL_LDS) {
+#pragma unroll
+            for (int u = 0; u < TLMAX; ++u)
+                if (tid + u * NT < 2 * K) tails[tid + u * NT] = tl_next[u];
+        }
+#pragma unroll
+        for (int u = 0; u < MUMAX; ++u)
+            if (tid + u * NT < Dp) mus[tid + u * NT] = mu_next[u];
         __syncthreads();
         // candidate overflow (degenerate codebooks): full defining search, whole block per frame
-        for (int f = 0; f < FT; ++f) {
+        const int any_overflow = flags[1];
+        for (int f = 0; f < (any_overflow ? FT : 0); ++f) {
             if (state[f] != 2) continue;  // uniform across the block (LDS value)
             double bd = INFINITY;
             int bc = 0x7fffffff;
@@ -402,34 +452,72 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
             }
             __syncthreads();
         }
-
         // ---- C: r -= c, out += c, index, squared residual ----
+        // (the codeword rows of all of a wave's frames are requested together: one L2 latency, not one per frame)
+        constexpr int FPW = FT / NWV;
+        if (D <= 512) {
+            float cv[FPW][8];
+#pragma unroll
+            for (int j = 0; j < FPW; ++j) {
+                const float *c = cbq + size_t(best[wave + j * NWV]) * D;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) cv[j][u] = lane + 64 * u < D ? c[lane + 64 * u] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < FPW; ++j) {
+                const int f = wave + j * NWV;
+                float part = 0.f, pnext = 0.f;    // pnext: ||r - mu||^2 of the NEXT stage, same order as at q == 0
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int d = lane + 64 * u;
+                    if (d < D) {
+                        const float rv = R[d * RS + f] - cv[j][u];
+                        R[d * RS + f] = rv;
+                        O[d * RS + f] = O[d * RS + f] + cv[j][u];
+                        part = fmaf(rv, rv, part);
+                        const float v = rv - mus[d];
+                        pnext = fmaf(v, v, pnext);
+                    }
+                }
+                for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+                for (int off = 32; off > 0; off >>= 1) pnext += __shfl_xor(pnext, off);
+                if (lane == 0) {
+                    wmin[f] = part;  // squared residual of this frame (wmin row 0 is free between score passes)
+                    rn2[f] = pnext;
+                    if (n0 + f < N) a.index[(n0 + f) * a.Q + q] = best[f];
+                }
+            }
+        } else
         for (int f = wave; f < FT; f += NWV) {
             const int idx = best[f];
             const float *c = cbq + size_t(idx) * D;
-            float part = 0.f;
+            float part = 0.f, pnext = 0.f;
             for (int d = lane; d < D; d += 64) {
                 const float cv = c[d];
                 const float rv = R[d * RS + f] - cv;
                 R[d * RS + f] = rv;
                 O[d * RS + f] = O[d * RS + f] + cv;
                 part = fmaf(rv, rv, part);
+                const float v = rv - mus[d];
+                pnext = fmaf(v, v, pnext);
             }
             for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            for (int off = 32; off > 0; off >>= 1) pnext += __shfl_xor(pnext, off);
             if (lane == 0) {
-                wmin[f] = part;  // squared residual of this frame (wmin row 0 is free between score passes)
+                wmin[f] = part;
+                rn2[f] = pnext;
                 if (n0 + f < N) a.index[(n0 + f) * a.Q + q] = idx;
             }
         }
+        if (tid < FT) cnt[tid] = 0;       // (read last by the decide step)
+        if (tid < 2) flags[tid] = 0;
         __syncthreads();
-        if (tid == 0) {
-            double s = 0.0;
-            for (int f = 0; f < FT; ++f)
-                if (n0 + f < N) s += double(wmin[f]);
-            atomicAdd(&a.sq_err[q], s);
+        if (wave == 0) {                  // the stage's squared error: 32 frames, pairwise in double
+            double s = (lane < FT && n0 + lane < N) ? double(wmin[lane]) : 0.0;
+            for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off);
+            if (lane == 0) atomicAdd(&a.sq_err[q], s);
         }
     }
-
     // ---- write x_q ----
     if (a.q_st == 1 || a.q_sd != 1) {
         for (int e = tid; e < D * FT; e += NT) {
@@ -451,12 +539,15 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
     }
 }
 
-static size_t rvq_lds_bytes(int dim) {
+static size_t rvq_lds_bytes(int dim, int k, bool *tail_in_lds) {
     const int Dp = rvq_dp(dim);
     size_t floats = size_t(2) * Dp * RS + NWV * FT + FT /*rn2*/ + Dp /*mus*/ + 3 * FT /*cnt,state,best*/ +
                     FT * CAND /*ccode*/ + FT * CAND /*cscore*/;
     floats = (floats + 1) & ~size_t(1);
-    return floats * 4 + size_t(FT) * CAND * 8;
+    const size_t base = floats * 4 + size_t(FT) * CAND * 8 + (size_t(FT) * CAND + 2) * 4 /*work, flags*/;
+    const bool fits = base + size_t(2) * k * 4 <= 160 * 1024 && 2 * k <= TLMAX * NT;
+    if (tail_in_lds) *tail_in_lds = fits;
+    return fits ? base + size_t(2) * k * 4 : base;
 }
 
 // ------------------------------------------------------------------------ dequantize
@@ -509,7 +600,8 @@ int agx_rvq_forward(const float *x, int64_t x_sb, int64_t x_st, int64_t x_sd, co
         return fail(AGX_ERR_BAD_SHAPE, "rvq_forward: bad shape B=%d T=%d D=%d K=%d Q=%d", batch, t, dim, k, q_used);
     if (!x || !codebooks || !packed || !xq || (q_used > 0 && (!index || !sq_err)))
         return fail(AGX_ERR_NULL_POINTER, "rvq_forward: NULL pointer");
-    const size_t lds = rvq_lds_bytes(dim);
+    bool tail_lds = false;
+    const size_t lds = rvq_lds_bytes(dim, k, &tail_lds);
     if (lds > 160 * 1024) return fail(AGX_ERR_UNSUPPORTED, "rvq_forward: D=%d needs %zu B of LDS", dim, lds);
     RvqArgs a{x, x_sb, x_st, x_sd, codebooks, packed, batch, t, dim, k, q_used, xq, q_sb, q_st, q_sd, index, sq_err};
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -524,8 +616,8 @@ int agx_rvq_forward(const float *x, int64_t x_sb, int64_t x_st, int64_t x_sd, co
     };
     // codewords per pass = 8 waves x MT x 32.  MT = 4 (one pass for K = 1024) spills at the 256-VGPR cap
     // of 2 waves/SIMD, so K > 512 runs as passes of 512 codewords with the running-bound candidate rule.
-    if (k > 256) return launch(rvq_forward_kernel<2>);
-    return launch(rvq_forward_kernel<1>);
+    if (k > 256) return tail_lds ? launch(rvq_forward_kernel<2, true>) : launch(rvq_forward_kernel<2, false>);
+    return tail_lds ? launch(rvq_forward_kernel<1, true>) : launch(rvq_forward_kernel<1, false>);
 }
 
 int agx_rvq_dequantize(const float *codebook, const int64_t *idx, int64_t n, int32_t k, int32_t dim,

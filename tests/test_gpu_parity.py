@@ -205,6 +205,13 @@ def test_rvq_bit_exact_ragged_and_small():
     _rvq_case(1, 1, 8, 1, 2, seed=7)                        # single frame, single codeword
 
 
+def test_rvq_large_codebook_and_wide_frames():
+    """K > 2048: the |c'|^2 / |c'| tables stay in global memory (no LDS copy); D > 512: the sequential forms of
+    the exact distance and of the update phase."""
+    _rvq_case(1, 40, 64, 2304, 3, seed=21)
+    _rvq_case(1, 33, 544, 96, 2, seed=22)
+
+
 def test_rvq_ties_duplicates_and_truncation():
     _rvq_case(2, 40, 64, 128, 4, seed=8, dup=True)
     _rvq_case(2, 40, 64, 128, 4, seed=9, q_used=2)
