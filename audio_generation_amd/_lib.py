@@ -163,6 +163,10 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError if the ABI and the header drifted apart
         fn.restype = res
         fn.argtypes = args
+    for kv in filter(None, os.environ.get("AGX_TUNING", "").split(",")):     # measurement knobs, e.g. AGX_TUNING=dw_wgs=768
+        name, _, value = kv.partition("=")
+        if lib.agx_set_tuning(name.strip().encode(), int(value)) != 0:
+            raise AgxError(f"AGX_TUNING: unknown knob {name!r}")
     _lib = lib
     return lib
 

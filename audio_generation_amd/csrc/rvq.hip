@@ -615,7 +615,8 @@ int agx_rvq_forward(const float *x, int64_t x_sb, int64_t x_st, int64_t x_sd, co
         return check_launch("rvq_forward");
     };
     // codewords per pass = 8 waves x MT x 32.  MT = 4 (one pass for K = 1024) spills at the 256-VGPR cap
-    // of 2 waves/SIMD, so K > 512 runs as passes of 512 codewords with the running-bound candidate rule.
+    // of 2 waves/SIMD (measured again with the operand ring: 903 us against 807), so K > 512 runs as passes of
+    // 512 codewords with the running-bound candidate rule.
     if (k > 256) return tail_lds ? launch(rvq_forward_kernel<2, true>) : launch(rvq_forward_kernel<2, false>);
     return tail_lds ? launch(rvq_forward_kernel<1, true>) : launch(rvq_forward_kernel<1, false>);
 }
