@@ -26,6 +26,8 @@ struct Tuning {
                         // 1 the same with MFMA / VALU interleave hints, 2 split before the MFMAs
     int dw_dma = 0;     // 1: LDS-DMA double-buffered conv2d weight-gradient kernel (experimental: 48-53 TFLOP/s with 8 waves
                         // per workgroup, 40 with 4 -- the per-item DMA latency is not hidden yet), 0: the synchronous one (53-61)
+    int dw_direct = 2;  // 1-D weight gradient on the LDS-free kernel: 2 = every stride-1 layer, 1 = the k = 1 layers only, 0 = none
+    int dw1_wgs = 768;  // workgroups the 1-D LDS-free weight-gradient kernel aims for
     int dw_wgs = 1536;  // workgroups the conv2d weight-gradient kernel aims for (slices = dw_wgs / tiles)
     int conv_cc = 0;    // diagnostic: force the LDS chunk (8/16/32 channels) of the MFMA conv; 0 = table
     int conv_shape = 0; // diagnostic: 1 = 128x128 conv tiles as 4 row-waves x (1x4) fragments

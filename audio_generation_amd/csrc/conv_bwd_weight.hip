@@ -19,7 +19,7 @@ constexpr int BW_TS = BW_T + 1; // dyS row stride (odd: conflict-free column rea
 // Workgroup tile = (32*MW*WM) rows of m x (32*NW*WN) columns of n; 4 waves as WM x WN.
 // The n-tile-0 workgroups also accumulate the bias gradient (row sums of the staged dy tile).
 template <int MW, int NW, int WM, int WN, int PREC = 0>   // PREC 1: bf16x3 contraction
-__global__ __launch_bounds__(256) void conv_bwd_weight_kernel(ConvPlan p, int span, int n_chan, int n_slices,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void conv_bwd_weight_kernel(ConvPlan p, int span, int n_chan, int n_slices,
                                                               const float *__restrict__ x,
                                                               const float *__restrict__ dy,
                                                               float *__restrict__ part,
@@ -64,6 +64,10 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(ConvPlan p, int sp
 
     const int chunks = (p.Lt + BW_T - 1) / BW_T;
     const int items = p.B * chunks;
+    constexpr int NB = BM * BW_T / 256;       // dy-tile elements per thread (rows tid / 64 + 4 u, column tid % 64)
+    const int tt = tid & 63;
+    const int total = n_chan * span;
+    const float inv_span = 1.f / float(span);
     for (int item = slice; item < items; item += n_slices) {
         const int b = item / chunks, t0 = (item - b * chunks) * BW_T;
         __syncthreads();
@@ -72,8 +76,7 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(ConvPlan p, int sp
         // dy tile: row r <-> m = m_base + r = co*q + ph, column tt <-> dy[b, co, q*(t0+tt) + ph];
         // a thread's column tt = tid % 64 is the same for all its elements
         {
-            const int tt = tid & 63, t = t0 + tt;
-            constexpr int NB = BM * BW_T / 256;
+            const int t = t0 + tt;
 #pragma unroll
             for (int u0 = 0; u0 < NB; u0 += 8) {
                 float v[8];
@@ -94,8 +97,6 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(ConvPlan p, int sp
         {
             const int in0 = t0 * p.s - p.P;
             const float *xb = x + size_t(b) * p.Cin * p.Lin;
-            const int total = n_chan * span;
-            const float inv_span = 1.f / float(span);
             for (int e0 = tid; e0 < total; e0 += 256 * 8) {
                 float v[8];
                 bool ok[8];
@@ -174,6 +175,237 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(ConvPlan p, int sp
         for (int off = 1; off < TPR; off <<= 1) bsum += __shfl_xor(bsum, off);
         const int m = m_base + tid / TPR;
         if (tid % TPR == 0 && m < p.M) bias_part[size_t(slice) * p.M + m] = bsum;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stride-1 layers (every residual-block conv: 48 of the 60 weight gradients of config S): no staging phase and no
+// workgroup barrier.  The contraction order of an MFMA is free as long as both operands agree, so lane (li, lh)
+// takes the 16 CONSECUTIVE positions t0 + 16 lh + 0..15 of "its" row (A: dy[co = row li]; B: x[ci] shifted by the
+// tap) and k-step ks pairs position 16 lh + ks of both.  Every wave runs its own stream over a contiguous range of
+// 32-position items: the 32 rows x 128 bytes of an operand block travel global -> LDS by LDS-DMA (dwordx4, 8 lanes
+// per row = whole cache lines; loading "row per lane" straight into registers costs one TA cycle per lane and was
+// TA-bound at 62-82 TFLOP/s), into a wave-private buffer whose 16-byte chunks are XOR-swizzled (chunk c of row r
+// at slot c ^ (r & 7)) so that the four ds_read_b128 per block that fetch the MFMA operands are conflict-free.
+// The DMA of item n+1 is in flight during the 16 MW NW MFMAs of item n (operands already in registers).
+// Waves left over by a small tile (WK = 4 / (WM WN)) take different slices of the contraction and are added
+// through LDS at the end.
+struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
+
+template <int MW, int NW, int WM, int WN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void conv_bwd_weight_direct_kernel(ConvPlan p, const float *__restrict__ x,
+                                                                     const float *__restrict__ dy,
+                                                                     float *__restrict__ part,
+                                                                     float *__restrict__ bias_part) {
+    constexpr int WK = 4 / (WM * WN), BM = 32 * MW * WM, BN = 32 * NW * WN, T = 32;
+    static_assert(WK * WM * WN == 4, "4 waves");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the item loop's branches are wave-uniform
+    const int li = lane & 31, lh = lane >> 5;
+    const int wk = wave / (WM * WN), wr = wave % (WM * WN), wm = wr / WN, wn = wr % WN;
+    const int NK = p.Cin * p.J;
+    const int n_base = blockIdx.x * BN, m_base = blockIdx.y * BM;
+    const int slice = blockIdx.z * WK + wk, n_slices = gridDim.z * WK;   // contraction slices (waves); one partial tile per workgroup
+
+    int aoff[MW], brow[NW], bshift[NW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i) aoff[i] = min(m_base + (wm * MW + i) * 32 + li, p.M - 1) * p.Lout;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const int n = min(n_base + (wn * NW + k) * 32 + li, NK - 1);
+        const int ci = n / p.J, j = n - ci * p.J;
+        brow[k] = ci * p.Lin;
+        bshift[k] = j * p.d - p.P;
+    }
+    f32x16 acc[MW][NW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
+    float bsum[MW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i) bsum[i] = 0.f;
+    const bool do_bias = bias_part != nullptr && blockIdx.x == 0 && wn == 0;
+
+    const int chunks = (p.Lt + T - 1) / T;
+    const int items = p.B * chunks;
+    const int tmax_shift = (p.J - 1) * p.d - p.P;   // largest tap shift (0 for a causal layer)
+
+    // interior chunks (all 32 positions and all taps inside the row) go through the wave's LDS buffer:
+    // DMA instruction i of a block carries rows 8 i .. 8 i + 7, lane l -> row 8 i + (l >> 3), slot l & 7
+    extern __shared__ __attribute__((aligned(16))) float dma_buf[];
+    float *wbuf = dma_buf + wave * ((MW + NW) * 1024);          // (MW + NW) blocks of 32 rows x 32 floats
+    const int dr = lane >> 3, dchunk = (lane & 7) ^ dr;          // this lane's row within an instruction, global chunk
+    int adma[MW][4], bdma[NW][4];
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            adma[i][v] = min(m_base + (wm * MW + i) * 32 + 8 * v + dr, p.M - 1) * p.Lout + 4 * dchunk;
+#pragma unroll
+    for (int k = 0; k < NW; ++k)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int n = min(n_base + (wn * NW + k) * 32 + 8 * v + dr, NK - 1);
+            const int ci = n / p.J, j = n - ci * p.J;
+            bdma[k][v] = ci * p.Lin + j * p.d - p.P + 4 * dchunk;
+        }
+    const int rd_off = (li >> 3) * 256 + (li & 7) * 32;          // floats: this lane's row in a block
+    auto dma = [&](int item) {
+        const int b = item / chunks, tw = (item - b * chunks) * T;
+        const float *dyb = dy + size_t(b) * p.Cout * p.Lout + tw;
+        const float *xb = x + size_t(b) * p.Cin * p.Lin + tw;
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(dyb + adma[i][v]),
+                                                 (__attribute__((address_space(3))) void *)(wbuf + i * 1024 + v * 256), 16, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xb + bdma[k][v]),
+                                                 (__attribute__((address_space(3))) void *)(wbuf + (MW + k) * 1024 + v * 256), 16, 0, 0);
+    };
+    auto read_lds = [&](f32x4 (&A)[MW][4], f32x4 (&Bv)[NW][4]) {
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                A[i][e] = *reinterpret_cast<const f32x4 *>(wbuf + i * 1024 + rd_off + 4 * ((4 * lh + e) ^ (li & 7)));
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                Bv[k][e] = *reinterpret_cast<const f32x4 *>(wbuf + (MW + k) * 1024 + rd_off + 4 * ((4 * lh + e) ^ (li & 7)));
+    };
+    // first / last chunks of a row: element by element on clamped addresses, masked to zero afterwards
+    // (bitwise AND: a select would be turned back into predicated loads, each with its own wait)
+    auto load_edge = [&](f32x4 (&A)[MW][4], f32x4 (&Bv)[NW][4], int item) {
+        const int b = item / chunks, t0 = (item - b * chunks) * T + 16 * lh;
+        const float *dyb = dy + size_t(b) * p.Cout * p.Lout;
+        const float *xb = x + size_t(b) * p.Cin * p.Lin;
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int t = t0 + e;
+                const unsigned v = __float_as_uint(dyb[aoff[i] + min(t, p.Lt - 1)]);
+                A[i][e >> 2][e & 3] = __uint_as_float(v & (t < p.Lt ? ~0u : 0u));
+            }
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int xi = t0 + e + bshift[k];
+                const unsigned v = __float_as_uint(xb[brow[k] + min(max(xi, 0), p.Lvalid - 1)]);
+                Bv[k][e >> 2][e & 3] = __uint_as_float(v & ((xi >= 0 && xi < p.Lvalid) ? ~0u : 0u));
+            }
+    };
+    auto compute = [&](const f32x4 (&A)[MW][4], const f32x4 (&Bv)[NW][4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int i = 0; i < MW; ++i)
+#pragma unroll
+                    for (int k = 0; k < NW; ++k)
+                        acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[i][e][c], Bv[k][e][c], acc[i][k], 0, 0, 0);
+        if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < MW; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bsum[i] += (A[i][e][0] + A[i][e][1]) + (A[i][e][2] + A[i][e][3]);
+        }
+    };
+
+    // A slice owns a CONTIGUOUS range of items (every row is streamed front to back).  Runs of interior chunks:
+    // wait for the DMA of item n, pull its operands into registers, start the DMA of item n+1 (unconditional, the
+    // index is clamped to the run), then the MFMAs of item n.  (Sending the edge chunks through the DMA as well and
+    // masking them in registers costs more in the common path -- registers, a branch in the loop -- than it saves.)
+    f32x4 A0[MW][4], B0[NW][4];
+    const int per = (items + n_slices - 1) / n_slices;
+    int item = slice * per;
+    const int end = min(items, item + per);
+    const int c_lo = (p.P + T - 1) / T;                                                    // first interior chunk of a row
+    const int c_hi = max(0, min(p.Lt / T, (p.Lvalid - max(tmax_shift, 0)) / T));            // one past the last
+    while (item < end) {
+        const int c = item % chunks;
+        if (c < c_lo || c >= c_hi) {
+            load_edge(A0, B0, item);
+            compute(A0, B0);
+            ++item;
+            continue;
+        }
+        const int run = min(end - item, c_hi - c), last = item + run - 1;
+        dma(item);
+        for (int n = 0; n < run; ++n) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA has landed (wave-private buffer: no barrier)
+            read_lds(A0, B0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // operands are in registers: the buffer may be overwritten
+            dma(min(item + n + 1, last));
+            compute(A0, B0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (the clamped extra DMA of the last step)
+        item += run;
+    }
+    // the WK waves that shared a tile add their partials through LDS in a fixed order (wave 1, 2, 3 onto wave 0)
+    if constexpr (WK > 1) {
+        constexpr int PER = (MW * NW * 16 + MW) * 64;
+        static_assert((WK - 1) * WM * WN * PER <= 4 * (MW + NW) * 1024, "the exchange reuses the DMA buffers");
+        float *red = dma_buf;
+        __syncthreads();      // every wave is done with its DMA buffer
+        float *mine = red + ((wk > 0 ? wk - 1 : 0) * WM * WN + wr) * PER + lane;
+        if (wk > 0) {
+#pragma unroll
+            for (int i = 0; i < MW; ++i) {
+#pragma unroll
+                for (int k = 0; k < NW; ++k)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mine[((i * NW + k) * 16 + r) * 64] = acc[i][k][r];
+                mine[(MW * NW * 16 + i) * 64] = bsum[i];
+            }
+        }
+        __syncthreads();
+        if (wk > 0) return;
+#pragma unroll
+        for (int w = 1; w < WK; ++w) {
+            const float *src = red + ((w - 1) * WM * WN + wr) * PER + lane;
+#pragma unroll
+            for (int i = 0; i < MW; ++i) {
+#pragma unroll
+                for (int k = 0; k < NW; ++k)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][k][r] += src[((i * NW + k) * 16 + r) * 64];
+                bsum[i] += src[(MW * NW * 16 + i) * 64];
+            }
+        }
+    }
+    const int oslice = blockIdx.z;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const int n = n_base + (wn * NW + k) * 32 + li;
+        if (n >= NK) continue;
+        float *dst = part + (size_t(oslice) * NK + n) * p.M;
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m_base + (wm * MW + i) * 32 + acc_row(r, lh);
+                if (m < p.M) dst[m] = acc[i][k][r];
+            }
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < MW; ++i) {
+            const float tot = bsum[i] + __shfl_xor(bsum[i], 32);
+            const int m = m_base + (wm * MW + i) * 32 + li;
+            if (lh == 0 && m < p.M) bias_part[size_t(oslice) * p.M + m] = tot;
+        }
     }
 }
 
@@ -674,14 +906,36 @@ static int bw2d_geometry(const agx_conv2d_desc *d, Bw2dGeom *g, int *cfg, int *b
 }
 
 struct BwGeom {
-    int cfg;  // 0: 128x128 tile, 1: 64x128, 2: 32x128
+    int cfg;  // 0: 128x128 tile, 1: 64x128, 2: 32x128;  direct kernel: 10..14 (see bw_geometry)
     int bm, span, n_chan, n_slices;
+    bool direct;
     dim3 grid;
     size_t lds;
 };
 
-static BwGeom bw_geometry(const ConvPlan &p) {
+static BwGeom bw_geometry(const ConvPlan &p, bool bf16x3) {
     BwGeom g;
+    g.direct = !bf16x3 && p.s == 1 && p.q == 1 && p.G == 1 && (tuning().dw_direct == 2 || (tuning().dw_direct == 1 && p.J == 1));
+    if (g.direct) {   // conv_bwd_weight_direct_kernel: tile and the waves left for the contraction (WK)
+        const int NK = p.Cin * p.J;
+        int bn, wk;
+        if (p.M > 64)      { g.cfg = 10; g.bm = 128; bn = 128; wk = 1; }   // <2,2,2,2>
+        else if (p.M > 32) { if (NK > 64) { g.cfg = 11; g.bm = 64; bn = 128; wk = 2; }    // <2,2,1,2>
+                             else         { g.cfg = 12; g.bm = 64; bn = 64; wk = 4; } }   // <2,2,1,1>
+        else               { if (NK > 32) { g.cfg = 13; g.bm = 32; bn = 256; wk = 1; }    // <1,2,1,4>
+                             else         { g.cfg = 14; g.bm = 32; bn = 32; wk = 4; } }   // <1,1,1,1>
+        const int nt = ceil_div(NK, bn), mt = ceil_div(p.M, g.bm);
+        const int items = p.B * ceil_div(p.Lt, 32);
+        int gz = ceil_div(tuning().dw1_wgs, nt * mt);
+        if (gz * wk > items) gz = ceil_div(items, wk);
+        if (gz < 1) gz = 1;
+        if (gz > 65535) gz = 65535;
+        g.n_slices = gz;     // partial tiles in the workspace (the WK waves of a workgroup are added in LDS)
+        g.grid = dim3(nt, mt, gz);
+        g.span = g.n_chan = 0;
+        g.lds = 0;
+        return g;
+    }
     g.cfg = p.M >= 128 ? 0 : (p.M >= 64 ? 1 : 2);
     g.bm = g.cfg == 0 ? 128 : (g.cfg == 1 ? 64 : 32);
     g.span = (BW_T - 1) * p.s + (p.J - 1) * p.d + 1;
@@ -706,7 +960,7 @@ size_t agx_conv_bwd_weight_workspace_bytes(const agx_conv_desc *d) {
     using namespace agx;
     ConvPlan p;
     if (lower_conv(d, &p) != AGX_OK) return 0;
-    const BwGeom g = bw_geometry(p);
+    const BwGeom g = bw_geometry(p, d->impl == AGX_IMPL_MFMA_BF16X3);
     // slices of dWp + the reduced dWp + slices of the bias row sums
     return ((size_t(g.n_slices) + 1) * p.Cin * p.J * p.M + (size_t(g.n_slices) + 1) * p.M) * sizeof(float);
 }
@@ -723,7 +977,7 @@ int agx_conv_bwd_weight(const agx_conv_desc *d, const float *x, const float *dy,
         return fail(AGX_ERR_WORKSPACE, "agx_conv_bwd_weight: workspace too small (%zu < %zu)", workspace_bytes,
                     agx_conv_bwd_weight_workspace_bytes(d));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const BwGeom geo = bw_geometry(p);
+    const BwGeom geo = bw_geometry(p, d->impl == AGX_IMPL_MFMA_BF16X3);
     if (geo.lds > 160 * 1024) return fail(AGX_ERR_UNSUPPORTED, "agx_conv_bwd_weight: tile needs %zu B of LDS", geo.lds);
     float *part = static_cast<float *>(workspace);
     const int64_t nw = int64_t(p.Cin) * p.J * p.M;
@@ -737,7 +991,20 @@ int agx_conv_bwd_weight(const agx_conv_desc *d, const float *x, const float *dy,
                            bias_part);
         return AGX_OK;
     };
-    if (d->impl == AGX_IMPL_MFMA_BF16X3)
+    auto launch_direct = [&](auto kern, int blocks_per_wave) -> int {   // 4 waves x (MW + NW) operand blocks of 4 KB
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(kern, geo.grid, dim3(256), size_t(4) * blocks_per_wave * 4096, st, p, x, dy, part, bias_part);
+        return AGX_OK;
+    };
+    if (geo.direct)
+        rc = geo.cfg == 10 ? launch_direct(conv_bwd_weight_direct_kernel<2, 2, 2, 2>, 4)
+           : geo.cfg == 11 ? launch_direct(conv_bwd_weight_direct_kernel<2, 2, 1, 2>, 4)
+           : geo.cfg == 12 ? launch_direct(conv_bwd_weight_direct_kernel<2, 2, 1, 1>, 4)
+           : geo.cfg == 13 ? launch_direct(conv_bwd_weight_direct_kernel<1, 2, 1, 4>, 3)
+                           : launch_direct(conv_bwd_weight_direct_kernel<1, 1, 1, 1>, 2);
+    else if (d->impl == AGX_IMPL_MFMA_BF16X3)
         rc = geo.cfg == 0 ? launch(conv_bwd_weight_kernel<2, 2, 2, 2, 1>)
            : geo.cfg == 1 ? launch(conv_bwd_weight_kernel<1, 2, 2, 2, 1>)
                           : launch(conv_bwd_weight_kernel<1, 1, 1, 4, 1>);

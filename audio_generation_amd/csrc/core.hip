@@ -224,6 +224,8 @@ int agx_set_tuning(const char *name, int32_t value) {
     else if (!strcmp(name, "patch_tie")) agx::tuning().patch_tie = value;
     else if (!strcmp(name, "dw_dma")) agx::tuning().dw_dma = value;
     else if (!strcmp(name, "dw_wgs")) agx::tuning().dw_wgs = value;
+    else if (!strcmp(name, "dw_direct")) agx::tuning().dw_direct = value;
+    else if (!strcmp(name, "dw1_wgs")) agx::tuning().dw1_wgs = value;
     else if (!strcmp(name, "conv_cc")) agx::tuning().conv_cc = value;
     else if (!strcmp(name, "conv_shape")) agx::tuning().conv_shape = value;
     else if (!strcmp(name, "conv_short")) agx::tuning().conv_short = value;
@@ -241,6 +243,8 @@ int agx_get_tuning(const char *name) {
     if (!strcmp(name, "patch_tie")) return agx::tuning().patch_tie;
     if (!strcmp(name, "dw_dma")) return agx::tuning().dw_dma;
     if (!strcmp(name, "dw_wgs")) return agx::tuning().dw_wgs;
+    if (!strcmp(name, "dw_direct")) return agx::tuning().dw_direct;
+    if (!strcmp(name, "dw1_wgs")) return agx::tuning().dw1_wgs;
     if (!strcmp(name, "conv_cc")) return agx::tuning().conv_cc;
     if (!strcmp(name, "conv_shape")) return agx::tuning().conv_shape;
     if (!strcmp(name, "conv_short")) return agx::tuning().conv_short;
