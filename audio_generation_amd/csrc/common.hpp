@@ -24,8 +24,7 @@ struct Tuning {
                         // input elements (tall tiles share the row halo), 0 = always the widest
     int bf_sched = -1;  // (-1 = per-shape table) schedule of the bf16x3 main loop in the fused residual block: 0 split after the MFMAs,
                         // 1 the same with MFMA / VALU interleave hints, 2 split before the MFMAs
-    int dw_dma = 0;     // 1: LDS-DMA double-buffered conv2d weight-gradient kernel (experimental: 48-53 TFLOP/s with 8 waves
-                        // per workgroup, 40 with 4 -- the per-item DMA latency is not hidden yet), 0: the synchronous one (53-61)
+    int dw2_direct = 1; // conv2d weight gradient of stride-1 "same" layers on the barrier-free LDS-DMA kernel (0: the staged one)
     int dw_direct = 2;  // 1-D weight gradient on the LDS-free kernel: 2 = every stride-1 layer, 1 = the k = 1 layers only, 0 = none
     int dw1_wgs = 768;  // workgroups the 1-D LDS-free weight-gradient kernel aims for
     int dw_wgs = 1536;  // workgroups the conv2d weight-gradient kernel aims for (slices = dw_wgs / tiles)

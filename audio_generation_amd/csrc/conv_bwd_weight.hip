@@ -678,50 +678,66 @@ __global__ __launch_bounds__(256) void conv2d_bwd_weight_kernel(Bw2dGeom g, cons
     }
 }
 
-// Pipelined version of conv2d_bwd_weight_kernel: the dy tile and the x patches of item n+1 stream into a second
-// LDS buffer by LDS-DMA (no registers) while the MFMAs of item n run, operand fragments are read one k-step
-// ahead, and one workgroup owns a CU (2 x (dy tile + patches) of LDS).  Measured on the synchronous kernel:
-// staging and MFMA time simply add up (removing either leaves the other's time), hence this form.  Status:
-// correct (same tests) but not yet faster -- one workgroup per CU leaves the item too short (1.7 us with 8 waves)
-// to cover the DMA latency; it needs a third buffer with counted waits.  Off by default (agx_set_tuning "dw_dma").
+// Stride-1 "same" layers (the 3x3 convs and the 7x7 first conv of the STFT discriminators): the 2-D form of
+// conv_bwd_weight_direct_kernel -- no staging phase, no workgroup barrier, wave-private LDS-DMA buffers with
+// XOR-swizzled 16-byte chunks.  An item is 32 consecutive columns of one output row; B row n = (ci, dh, dw) is
+// the window x[ci, t + dh - ph, f0 + dw - pw + 0..31].  Rows in the vertical padding are DMA'd from a page of
+// zeros (an address select, no branch); a window may run up to pw elements over the end of its image row, into
+// the neighbouring row of the same tensor -- those elements are masked in registers, and only where the DMA could
+// leave the tensor itself (first rows of batch element 0, last rows of element B - 1) the operands are loaded
+// element by element.
+__device__ float bw_zero_page[64];
+
 template <int MW, int NW, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void conv2d_bwd_weight_dma_kernel(Bw2dGeom g, const float *__restrict__ x,
-                                                                    const float *__restrict__ dy,
-                                                                    float *__restrict__ part,
-                                                                    float *__restrict__ bias_part) {
-    constexpr int NWV = WM * WN, NT = 64 * NWV;   // waves / threads per workgroup (4 or 8 waves)
-    constexpr int BM = 32 * MW * WM, BN = 32 * NW * WN;
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int xtotal = g.n_chan * g.span;
-    const int bufsz = BM * BW_TS + ((xtotal + 63) & ~63);       // floats per buffer
-    int *kofft = reinterpret_cast<int *>(sm + 2 * bufsz);      // [BW_T]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void conv2d_bwd_weight_direct_kernel(
+    Bw2dGeom g, const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ part,
+    float *__restrict__ bias_part) {
+    constexpr int WK = 4 / (WM * WN), BM = 32 * MW * WM, BN = 32 * NW * WN, T = 32;
+    static_assert(WK * WM * WN == 4, "4 waves");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
-    const int wm = wave / WN, wn = wave % WN;
+    const int wk = wave / (WM * WN), wr = wave % (WM * WN), wm = wr / WN, wn = wr % WN;
     const int KK = g.kh * g.kw, NK = g.Cin * KK, M = g.Cout;
-    const int n_base = blockIdx.x * BN, m_base = blockIdx.y * BM, slice = blockIdx.z;
-    const int ci_first = n_base / KK;
-    const int npos = g.R * g.WF;
-    if (tid < BW_T) {
-        const int r = tid / g.WF, fc = tid - r * g.WF;
-        kofft[tid] = tid < npos ? (r * g.sh) * g.SW + fc * g.sw : 0;
-    }
-    const int my_rr = lane / g.WF, my_fc = lane - my_rr * g.WF;   // dy-tile column of this lane (k = lane)
-    const float inv_span = 1.f / float(g.span), inv_sw = 1.f / float(g.SW);
-    int boff[NW];
-    bool nvalid[NW];
+    const int HWo = g.Hout * g.Wout, HWi = g.Hin * g.Win, FC = g.Wout / T;
+    const int n_base = blockIdx.x * BN, m_base = blockIdx.y * BM;
+    const int slice = blockIdx.z * WK + wk, n_slices = gridDim.z * WK;
+
+    // the MFMA rows of this lane (edge path, masks)
+    int aoff[MW], brow[NW], bdh[NW], bdw[NW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i) aoff[i] = min(m_base + (wm * MW + i) * 32 + li, M - 1) * HWo;
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
-        const int n = n_base + (wn * NW + k) * 32 + li;
-        nvalid[k] = n < NK;
-        const int nc = min(n, NK - 1);
-        const int ci = nc / KK, rem = nc - ci * KK;
-        const int dh = rem / g.kw, dw = rem - dh * g.kw;
-        boff[k] = (ci - ci_first) * g.span + dh * g.SW + dw;
+        const int n = min(n_base + (wn * NW + k) * 32 + li, NK - 1);
+        const int ci = n / KK, rem = n - ci * KK, dh = rem / g.kw;
+        brow[k] = ci * HWi;
+        bdh[k] = dh - g.ph;
+        bdw[k] = rem - dh * g.kw - g.pw;
     }
-    int arow[MW];
+    // the DMA rows of this lane: instruction v of a block carries rows 8 v .. 8 v + 7, lane l -> row 8 v + (l >> 3)
+    extern __shared__ __attribute__((aligned(16))) float dma_buf[];
+    float *wbuf = dma_buf + wave * ((MW + NW) * 1024);
+    const int dr = lane >> 3, dchunk = (lane & 7) ^ dr;
+    int adma[MW][4], bdma[NW][4], bdmah[NW];        // bdmah: the four dh - ph of a block, one byte each (+ 64)
 #pragma unroll
-    for (int i = 0; i < MW; ++i) arow[i] = ((wm * MW + i) * 32 + li) * BW_TS;
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) adma[i][v] = min(m_base + (wm * MW + i) * 32 + 8 * v + dr, M - 1) * HWo + 4 * dchunk;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        bdmah[k] = 0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int n = min(n_base + (wn * NW + k) * 32 + 8 * v + dr, NK - 1);
+            const int ci = n / KK, rem = n - ci * KK, dh = rem / g.kw, dw = rem - dh * g.kw;
+            bdma[k][v] = ci * HWi + (dh - g.ph) * g.Win + (dw - g.pw) + 4 * dchunk;
+            bdmah[k] |= (dh - g.ph + 64) << (8 * v);
+        }
+    }
+    const int rd_off = (li >> 3) * 256 + (li & 7) * 32;
+    const float *zsrc = bw_zero_page + 4 * (lane & 7);
+
     f32x16 acc[MW][NW];
 #pragma unroll
     for (int i = 0; i < MW; ++i)
@@ -729,97 +745,164 @@ __global__ __launch_bounds__(64 * WM * WN) void conv2d_bwd_weight_dma_kernel(Bw2
         for (int k = 0; k < NW; ++k)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
-    constexpr int TPR = NT / BM, CPT = BW_T / TPR;
-    float bsum = 0.f;
-    const bool do_bias = bias_part != nullptr && blockIdx.x == 0;
-    const int nft = (g.Wout + g.WF - 1) / g.WF, nrg = (g.Hout + g.R - 1) / g.R;
-    const int items = g.B * nrg * nft;
-    const size_t plane = size_t(g.Hout) * g.Wout;
+    float bsum[MW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i) bsum[i] = 0.f;
+    const bool do_bias = bias_part != nullptr && blockIdx.x == 0 && wn == 0;
 
-    // issue the DMA of one item into buffer `buf`; lanes with nothing to fetch write the zero themselves
-    auto stage = [&](int item, float *buf) {
-        int it = item;
-        const int ft = it % nft;
-        it /= nft;
-        const int rg = it % nrg, b = it / nrg;
-        const int trow0 = rg * g.R, f0 = ft * g.WF;
-        float *dysb = buf, *xsb = buf + BM * BW_TS;
-        {   // dy tile: one 64-lane row per instruction
-            const int t = trow0 + my_rr, f = f0 + my_fc;
-            const bool pos_ok = lane < npos && t < g.Hout && f < g.Wout;
-            const float *src0 = dy + size_t(b) * g.Cout * plane + size_t(min(t, g.Hout - 1)) * g.Wout + min(f, g.Wout - 1);
-            for (int r = wave; r < BM; r += NWV) {
-                const int co = m_base + r;
-                if (pos_ok && co < M) glds_dword(src0 + size_t(co) * plane, dysb + r * BW_TS);
-                else dysb[r * BW_TS + lane] = 0.f;
+    const int rows = g.B * g.Hout, items = rows * FC;
+    auto dma = [&](int item) {
+        const int row = item / FC, fc = item - row * FC, b = row / g.Hout, t = row - b * g.Hout;
+        const float *dyb = dy + size_t(b) * M * HWo + t * g.Wout + fc * T;
+        const float *xb = x + size_t(b) * g.Cin * HWi + t * g.Win + fc * T;
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(dyb + adma[i][v]),
+                                                 (__attribute__((address_space(3))) void *)(wbuf + i * 1024 + v * 256), 16, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int r = t + ((bdmah[k] >> (8 * v)) & 255) - 64;
+                const float *src = (r >= 0 && r < g.Hin) ? xb + bdma[k][v] : zsrc;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(wbuf + (MW + k) * 1024 + v * 256), 16, 0, 0);
             }
-        }
-        {   // x patches, flat over (channel, patch row, patch column)
-            const int row0 = trow0 * g.sh - g.ph, col0 = f0 * g.sw - g.pw;
-            const float *xb = x + size_t(b) * g.Cin * g.Hin * g.Win;
-            for (int e0 = wave * 64; e0 < xtotal; e0 += NT) {
-                const int e = e0 + lane;
-                const int ec = min(e, xtotal - 1);
-                const int c = int((float(ec) + 0.5f) * inv_span), i = ec - c * g.span;   // exact: e < 2^20
-                const int rr = int((float(i) + 0.5f) * inv_sw), cc = i - rr * g.SW;
-                const int ch = ci_first + c, gr = row0 + rr, gc = col0 + cc;
-                const bool ok = e < xtotal && ch < g.Cin && gr >= 0 && gr < g.Hin && gc >= 0 && gc < g.Win;
-                if (ok) glds_dword(xb + (size_t(ch) * g.Hin + gr) * g.Win + gc, xsb + e0);
-                else if (e < xtotal) xsb[e] = 0.f;
+    };
+    auto read_lds = [&](f32x4 (&A)[MW][4], f32x4 (&Bv)[NW][4]) {
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                A[i][e] = *reinterpret_cast<const f32x4 *>(wbuf + i * 1024 + rd_off + 4 * ((4 * lh + e) ^ (li & 7)));
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                Bv[k][e] = *reinterpret_cast<const f32x4 *>(wbuf + (MW + k) * 1024 + rd_off + 4 * ((4 * lh + e) ^ (li & 7)));
+    };
+    // first / last chunk of an image row: the (at most 4) window elements in the horizontal padding
+    auto mask_cols = [&](f32x4 (&Bv)[NW][4], int fc) {
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int x0 = fc * T + 16 * lh + c + bdw[k], x1 = x0 + 12;
+                Bv[k][0][c] = __uint_as_float(__float_as_uint(Bv[k][0][c]) & ((x0 >= 0 && x0 < g.Win) ? ~0u : 0u));
+                Bv[k][3][c] = __uint_as_float(__float_as_uint(Bv[k][3][c]) & ((x1 >= 0 && x1 < g.Win) ? ~0u : 0u));
+            }
+    };
+    auto load_edge = [&](f32x4 (&A)[MW][4], f32x4 (&Bv)[NW][4], int item) {
+        const int row = item / FC, fc = item - row * FC, b = row / g.Hout, t = row - b * g.Hout;
+        const float *dyb = dy + size_t(b) * M * HWo + t * g.Wout + fc * T + 16 * lh;
+        const float *xb = x + size_t(b) * g.Cin * HWi;
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) A[i][e] = *reinterpret_cast<const f32x4 *>(dyb + aoff[i] + 4 * e);
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int r = t + bdh[k];
+            const bool rok = r >= 0 && r < g.Hin;
+            const float *xr = xb + brow[k] + min(max(r, 0), g.Hin - 1) * g.Win;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int xi = fc * T + 16 * lh + e + bdw[k];
+                const unsigned v = __float_as_uint(xr[min(max(xi, 0), g.Win - 1)]);
+                Bv[k][e >> 2][e & 3] = __uint_as_float(v & ((rok && xi >= 0 && xi < g.Win) ? ~0u : 0u));
             }
         }
     };
-
-    float *cur = sm, *nxt = sm + bufsz;
-    if (slice < items) stage(slice, cur);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int item = slice; item < items; item += g.n_slices) {
-        if (item + g.n_slices < items) stage(item + g.n_slices, nxt);
-        const float *dys = cur, *xs = cur + BM * BW_TS;
+    auto compute = [&](const f32x4 (&A)[MW][4], const f32x4 (&Bv)[NW][4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int i = 0; i < MW; ++i)
+#pragma unroll
+                    for (int k = 0; k < NW; ++k)
+                        acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[i][e][c], Bv[k][e][c], acc[i][k], 0, 0, 0);
         if (do_bias) {
-            const float *row = dys + (tid / TPR) * BW_TS + (tid % TPR) * CPT;
-#pragma unroll
-            for (int c = 0; c < CPT; ++c) bsum += row[c];
-        }
-        // contraction over the 64 positions, fragments read one k-step ahead
-        float a_c[MW], b_c[NW], a_n[MW], b_n[NW];
-        {
-            const int ko = kofft[lh];
-#pragma unroll
-            for (int i = 0; i < MW; ++i) a_c[i] = dys[arow[i] + lh];
-#pragma unroll
-            for (int k = 0; k < NW; ++k) b_c[k] = nvalid[k] ? xs[boff[k] + ko] : 0.f;
-        }
-#pragma unroll 8
-        for (int ks = 0; ks < BW_T / 2; ++ks) {
-            const int tn = min(2 * (ks + 1) + lh, BW_T - 1);
-            const int ko = kofft[tn];
-#pragma unroll
-            for (int i = 0; i < MW; ++i) a_n[i] = dys[arow[i] + tn];
-#pragma unroll
-            for (int k = 0; k < NW; ++k) b_n[k] = nvalid[k] ? xs[boff[k] + ko] : 0.f;
 #pragma unroll
             for (int i = 0; i < MW; ++i)
 #pragma unroll
-                for (int k = 0; k < NW; ++k)
-                    acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[i], b_c[k], acc[i][k], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < MW; ++i) a_c[i] = a_n[i];
-#pragma unroll
-            for (int k = 0; k < NW; ++k) b_c[k] = b_n[k];
+                for (int e = 0; e < 4; ++e) bsum[i] += (A[i][e][0] + A[i][e][1]) + (A[i][e][2] + A[i][e][3]);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of the next item has landed
-        __syncthreads();                                     // everyone's has; everyone is done with cur
-        float *tmp = cur;
-        cur = nxt;
-        nxt = tmp;
+    };
+
+    f32x4 A0[MW][4], B0[NW][4];
+    const int per = (items + n_slices - 1) / n_slices;
+    int item = slice * per;
+    const int end = min(items, item + per);
+    // where a DMA window could leave the tensor: chunk 0 of the first ph + 1 rows of batch element 0 (it starts pw
+    // elements before its row), the last chunk of the last kh - ph rows of element B - 1
+    const int head_rows = min(g.ph + 1, rows), tail_row0 = max(rows - (g.kh - g.ph), 0);
+    while (item < end) {
+        const int row = item / FC, fc = item - row * FC;
+        const bool head = row < head_rows, tail = row >= tail_row0;
+        const bool unsafe = (head && fc == 0) || (tail && fc == FC - 1);
+        const int run_end = tail ? row * FC + FC - 1 : (head ? (row + 1) * FC : tail_row0 * FC);
+        const int run = unsafe ? 0 : min(end, run_end) - item;
+        if (run <= 0) {
+            load_edge(A0, B0, item);
+            compute(A0, B0);
+            ++item;
+            continue;
+        }
+        const int last = item + run - 1;
+        dma(item);
+        for (int n = 0; n < run; ++n) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            read_lds(A0, B0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            dma(min(item + n + 1, last));
+            const int fcn = (item + n) % FC;
+            if (fcn == 0 || fcn == FC - 1) mask_cols(B0, fcn);
+            compute(A0, B0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        item += run;
     }
+    if constexpr (WK > 1) {
+        constexpr int PER = (MW * NW * 16 + MW) * 64;
+        static_assert((WK - 1) * WM * WN * PER <= 4 * (MW + NW) * 1024, "the exchange reuses the DMA buffers");
+        float *red = dma_buf;
+        __syncthreads();
+        float *mine = red + ((wk > 0 ? wk - 1 : 0) * WM * WN + wr) * PER + lane;
+        if (wk > 0) {
+#pragma unroll
+            for (int i = 0; i < MW; ++i) {
+#pragma unroll
+                for (int k = 0; k < NW; ++k)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mine[((i * NW + k) * 16 + r) * 64] = acc[i][k][r];
+                mine[(MW * NW * 16 + i) * 64] = bsum[i];
+            }
+        }
+        __syncthreads();
+        if (wk > 0) return;
+#pragma unroll
+        for (int w = 1; w < WK; ++w) {
+            const float *src = red + ((w - 1) * WM * WN + wr) * PER + lane;
+#pragma unroll
+            for (int i = 0; i < MW; ++i) {
+#pragma unroll
+                for (int k = 0; k < NW; ++k)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][k][r] += src[((i * NW + k) * 16 + r) * 64];
+                bsum[i] += src[(MW * NW * 16 + i) * 64];
+            }
+        }
+    }
+    const int oslice = blockIdx.z;
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
         const int n = n_base + (wn * NW + k) * 32 + li;
         if (n >= NK) continue;
-        float *dst = part + (size_t(slice) * NK + n) * M;
+        float *dst = part + (size_t(oslice) * NK + n) * M;
 #pragma unroll
         for (int i = 0; i < MW; ++i)
 #pragma unroll
@@ -830,9 +913,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv2d_bwd_weight_dma_kernel(Bw2
     }
     if (do_bias) {
 #pragma unroll
-        for (int off = 1; off < TPR; off <<= 1) bsum += __shfl_xor(bsum, off);
-        const int m = m_base + tid / TPR;
-        if (tid % TPR == 0 && m < M) bias_part[size_t(slice) * M + m] = bsum;
+        for (int i = 0; i < MW; ++i) {
+            const float tot = bsum[i] + __shfl_xor(bsum[i], 32);
+            const int m = m_base + (wm * MW + i) * 32 + li;
+            if (lh == 0 && m < M) bias_part[size_t(oslice) * M + m] = tot;
+        }
     }
 }
 
@@ -902,6 +987,28 @@ static int bw2d_geometry(const agx_conv2d_desc *d, Bw2dGeom *g, int *cfg, int *b
     g->n_slices = int(ns);
     *grid = dim3(nt, mt, g->n_slices);
     *lds = (size_t(*bm) * BW_TS + size_t(g->n_chan) * g->span + BW_T) * sizeof(float);
+    // conv2d_bwd_weight_direct_kernel: stride-1 "same" layers whose rows are whole 32-column items
+    if (!g->prec && tuning().dw2_direct && g->sh == 1 && g->sw == 1 && g->Hout == g->Hin && g->Wout == g->Win &&
+        g->Wout % 32 == 0 && g->pw <= 4 && g->kw - 1 - g->pw <= 4 && g->ph < 32 && g->kh - g->ph < 32 &&
+        (g->Cout > 32 || g->Cin * KK <= 32 || g->Cin * KK >= 192)) {   // (32 rows x 98 columns, the 7x7 first conv: the 256-wide tile loses to the staged kernel)
+        const int NK = g->Cin * KK;
+        int dbm, dbn, wk;
+        if (g->Cout > 64)      { *cfg = 10; dbm = 128; dbn = 128; wk = 1; }   // <2,2,2,2>
+        else if (g->Cout > 32) { if (NK > 64) { *cfg = 11; dbm = 64; dbn = 128; wk = 2; }    // <2,2,1,2>
+                                 else         { *cfg = 12; dbm = 64; dbn = 64; wk = 4; } }   // <2,2,1,1>
+        else                   { if (NK > 32) { *cfg = 13; dbm = 32; dbn = 256; wk = 1; }    // <1,2,1,4>
+                                 else         { *cfg = 14; dbm = 32; dbn = 32; wk = 4; } }   // <1,1,1,1>
+        const int dnt = ceil_div(NK, dbn), dmt = ceil_div(g->Cout, dbm);
+        const int64_t ditems = int64_t(g->B) * g->Hout * (g->Wout / 32);
+        int64_t gz = ceil_div(tuning().dw_wgs, dnt * dmt);
+        if (gz * wk > ditems) gz = ceil_div64(ditems, wk);
+        if (gz < 1) gz = 1;
+        if (gz > 65535) gz = 65535;
+        g->n_slices = int(gz);
+        *bm = dbm;
+        *grid = dim3(dnt, dmt, g->n_slices);
+        *lds = 0;
+    }
     return AGX_OK;
 }
 
@@ -1070,20 +1177,20 @@ int agx_conv2d_bwd_weight(const agx_conv2d_desc *d, const float *x, const float 
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, x, dy, part, dbias ? bias_part : nullptr);
         return AGX_OK;
     };
-    const size_t lds_dma = (2 * (size_t(bm) * BW_TS + ((size_t(g.n_chan) * g.span + 63) & ~size_t(63))) + BW_T) * sizeof(float);
-    if (tuning().dw_dma && lds_dma <= 160 * 1024) {
-        lds = lds_dma;
-        // 8 waves per workgroup (one workgroup per CU: two waves per SIMD hide the LDS -> MFMA latency)
-        auto launch8 = [&](auto kern) -> int {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-            hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, g, x, dy, part, dbias ? bias_part : nullptr);
-            return AGX_OK;
-        };
-        rc = cfg == 0 ? launch8(conv2d_bwd_weight_dma_kernel<1, 2, 4, 2>)
-           : cfg == 1 ? launch8(conv2d_bwd_weight_dma_kernel<1, 1, 2, 4>)
-                      : launch(conv2d_bwd_weight_dma_kernel<1, 1, 1, 4>);
+    auto launch_direct = [&](auto kern, int blocks_per_wave) -> int {   // 4 waves x (MW + NW) operand blocks of 4 KB
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(kern, grid, dim3(256), size_t(4) * blocks_per_wave * 4096, st, g, x, dy, part,
+                           dbias ? bias_part : nullptr);
+        return AGX_OK;
+    };
+    if (cfg >= 10) {
+        rc = cfg == 10 ? launch_direct(conv2d_bwd_weight_direct_kernel<2, 2, 2, 2>, 4)
+           : cfg == 11 ? launch_direct(conv2d_bwd_weight_direct_kernel<2, 2, 1, 2>, 4)
+           : cfg == 12 ? launch_direct(conv2d_bwd_weight_direct_kernel<2, 2, 1, 1>, 4)
+           : cfg == 13 ? launch_direct(conv2d_bwd_weight_direct_kernel<1, 2, 1, 4>, 3)
+                       : launch_direct(conv2d_bwd_weight_direct_kernel<1, 1, 1, 1>, 2);
     } else if (g.prec) {
         rc = cfg == 0 ? launch(conv2d_bwd_weight_kernel<2, 2, 2, 2, 1>)
            : cfg == 1 ? launch(conv2d_bwd_weight_kernel<1, 2, 2, 2, 1>)

@@ -48,7 +48,9 @@ const char *agx_last_error(void);
  *   "conv_cc" 0|8|16|32  force the LDS channel chunk of the MFMA conv (0 = table)
  *   "patch_tie" 0|1      2-D patch tiles: tie between equally padded R x WF splits goes to the fewest staged elements (1) or the widest (0)
  *   "bf_sched" -1|0|1|2  schedule of the bf16x3 main loop of the fused residual block (-1 = per-shape table)
- *   "dw_dma" 0|1       1: experimental LDS-DMA double-buffered conv2d weight-gradient kernel (default 0)
+ *   "dw_direct" 0|1|2  1-D weight gradient on the barrier-free LDS-DMA kernel: 2 every stride-1 layer (default), 1 the k = 1 layers, 0 none
+ *   "dw2_direct" 0|1   conv2d weight gradient of stride-1 "same" layers on the barrier-free LDS-DMA kernel (default 1)
+ *   "dw1_wgs" N        workgroups the 1-D barrier-free weight-gradient kernel aims for (default 768)
  *   "dw_wgs" n         workgroups the conv2d weight-gradient kernel aims for (default 1536)
  *   "conv_shape" 0|1   1: 128x128 conv tiles as four row-waves of 1x4 fragments                    */
 int agx_set_tuning(const char *name, int32_t value);

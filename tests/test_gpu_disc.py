@@ -312,7 +312,12 @@ def test_conv2d_backward_data(cin, cout, kh, kw, sh, sw, ph, pw, h, w):
 @pytest.mark.parametrize("cin,cout,kh,kw,sh,sw,ph,pw,h,w", [
     (32, 32, 3, 3, 1, 1, 1, 1, 17, 200), (32, 64, 3, 4, 1, 2, 1, 1, 17, 200), (64, 128, 4, 4, 2, 2, 1, 1, 19, 131),
     (128, 128, 3, 4, 1, 2, 1, 1, 9, 16), (256, 512, 4, 4, 2, 2, 1, 1, 6, 4), (2, 32, 7, 7, 1, 1, 3, 3, 21, 70),
-    (512, 1, 1, 8, 1, 1, 0, 3, 5, 16), (5, 7, 3, 2, 2, 1, 0, 1, 10, 9)])
+    (512, 1, 1, 8, 1, 1, 0, 3, 5, 16), (5, 7, 3, 2, 2, 1, 0, 1, 10, 9),
+    # stride-1 "same" layers with whole 32-column items: the barrier-free LDS-DMA kernel, one shape per tile config,
+    # one- and two-row images (every item on the element-by-element edge path or next to it)
+    (32, 32, 3, 3, 1, 1, 1, 1, 9, 64), (16, 64, 3, 3, 1, 1, 1, 1, 5, 32), (2, 32, 7, 7, 1, 1, 3, 3, 12, 96),
+    (128, 128, 3, 3, 1, 1, 1, 1, 6, 32), (3, 40, 3, 3, 1, 1, 1, 1, 2, 64), (160, 130, 3, 3, 1, 1, 1, 1, 1, 32),
+    (2, 20, 5, 5, 1, 1, 2, 2, 7, 128), (24, 200, 1, 1, 1, 1, 0, 0, 4, 64)])
 @pytest.mark.parametrize("spectral", [False, True])
 def test_conv2d_backward_weight(cin, cout, kh, kw, sh, sw, ph, pw, h, w, spectral):
     """dW / dbias against autograd; with spectral norm the gradient w.r.t. weight_orig (sigma = u.Wv, u / v fixed)."""

@@ -26,5 +26,5 @@ for (cin, cout, kh, kw, sh, sw, h, w) in [(32, 32, 3, 3, 1, 1, 282, 1024), (64, 
         lib.agx_set_tuning(knob, a)
         t = timeit(lambda: ops.conv2d_bwd_weight(d, x, dy))
         out.append(f"{a}: {t:.3f} ms ({fl/t*1e-9:.1f} TF)")
-    lib.agx_set_tuning(knob, vals[0] if knob != b"dw_dma" else 1)
+    lib.agx_set_tuning(knob, vals[0])
     print(f"{cin}->{cout} k{kh}x{kw} s{sh}: " + "  ".join(out))
