@@ -988,7 +988,8 @@ static int bw2d_geometry(const agx_conv2d_desc *d, Bw2dGeom *g, int *cfg, int *b
     *grid = dim3(nt, mt, g->n_slices);
     *lds = (size_t(*bm) * BW_TS + size_t(g->n_chan) * g->span + BW_T) * sizeof(float);
     // conv2d_bwd_weight_direct_kernel: stride-1 "same" layers whose rows are whole 32-column items
-    if (!g->prec && tuning().dw2_direct && g->sh == 1 && g->sw == 1 && g->Hout == g->Hin && g->Wout == g->Win &&
+    // (also for AGX_IMPL_MFMA_BF16X3 descriptors: fp32 on this kernel is faster than bf16x3 on the staged one, and exact)
+    if (tuning().dw2_direct && g->sh == 1 && g->sw == 1 && g->Hout == g->Hin && g->Wout == g->Win &&
         g->Wout % 32 == 0 && g->pw <= 4 && g->kw - 1 - g->pw <= 4 && g->ph < 32 && g->kh - g->ph < 32 &&
         (g->Cout > 32 || g->Cin * KK <= 32 || g->Cin * KK >= 192)) {   // (32 rows x 98 columns, the 7x7 first conv: the 256-wide tile loses to the staged kernel)
         const int NK = g->Cin * KK;
@@ -1022,7 +1023,9 @@ struct BwGeom {
 
 static BwGeom bw_geometry(const ConvPlan &p, bool bf16x3) {
     BwGeom g;
-    g.direct = !bf16x3 && p.s == 1 && p.q == 1 && p.G == 1 && (tuning().dw_direct == 2 || (tuning().dw_direct == 1 && p.J == 1));
+    // (also for AGX_IMPL_MFMA_BF16X3 descriptors: fp32 on this kernel is faster than bf16x3 on the staged one, and exact)
+    g.direct = p.s == 1 && p.q == 1 && p.G == 1 && (tuning().dw_direct == 2 || (tuning().dw_direct == 1 && p.J == 1));
+    (void)bf16x3;
     if (g.direct) {   // conv_bwd_weight_direct_kernel: tile and the waves left for the contraction (WK)
         const int NK = p.Cin * p.J;
         int bn, wk;
