@@ -14,7 +14,7 @@ units in reverse with three C-ABI ops per conv:
   (mask = the saved activation), so the gradient that travels between units is always the
   one w.r.t. the pre-activation;
 * ``agx_conv_bwd_weight`` -- dv / dg / dbias (weight-norm chain rule included);
-* one ``agx_conv_forward`` per residual unit to re-materialise the hidden activation the
+* (``SAVE_HIDDEN = False`` only) one ``agx_conv_forward`` per residual unit to re-materialise the hidden activation the
   fused forward kernel never wrote.
 
 Stacks containing a layer without native backward kernels (e.g. a non-LeakyReLU activation)
@@ -29,6 +29,11 @@ from torch import nn
 
 from . import ops
 from ._lib import CONV_CAUSAL, EPI_LEAKY_PRE
+
+# Training forward of a residual unit: True = conv1 and conv2 as two launches that leave the hidden activation in
+# HBM for the backward (one C x L tensor per block: +3.5 GB at config S, batch 32); False = the fused inference
+# kernel, and the backward re-materialises the hidden activation with one more conv launch (6 % slower step).
+SAVE_HIDDEN = True
 
 Tensor = torch.Tensor
 
@@ -116,18 +121,29 @@ class _NativeStack(torch.autograd.Function):
     def forward(ctx, units: List[_Unit], x: Tensor, *params: Tensor):
         from .vae import _run_unit_forward
         ctx.units = units
-        inputs = []
+        inputs, hidden = [], []
         with torch.no_grad():
             for u in units:
                 inputs.append(x)
-                x = _run_unit_forward(u, x)
-        ctx.save_for_backward(*inputs)
+                if u.kind == "res" and SAVE_HIDDEN:
+                    # conv1 and conv2 as two launches: the hidden activation the backward needs is written once
+                    # here instead of being re-materialised there (the fused inference kernel never writes it)
+                    c1, c2 = u.convs
+                    h = c1.run(x, EPI_LEAKY_PRE, u.inner_slope)
+                    epi = ops.EPI_RESIDUAL | (ops.EPI_LEAKY_POST if u.slope is not None else 0)
+                    x = c2.run(h, epi, u.slope or 0.0, res=x)
+                    hidden.append(h)
+                else:
+                    x = _run_unit_forward(u, x)
+        ctx.n_inputs = len(inputs)
+        ctx.save_for_backward(*inputs, *hidden)
         ctx.mark_non_differentiable()
         return x
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
-        units, inputs = ctx.units, ctx.saved_tensors
+        units, inputs = ctx.units, ctx.saved_tensors[:ctx.n_inputs]
+        hidden = list(ctx.saved_tensors[ctx.n_inputs:])
         if units[-1].slope is not None:
             raise NotImplementedError("a stack ending in an activation needs its output saved for the mask")
         dz = grad_out.contiguous()                    # gradient w.r.t. the last unit's linear output
@@ -146,7 +162,8 @@ class _NativeStack(torch.autograd.Function):
                                        prev_slope or 0.0)
             else:
                 c1, c2 = u.convs
-                h = c1.run(x, EPI_LEAKY_PRE, u.inner_slope)                       # re-materialise the hidden act.
+                # the hidden activation: saved by the forward, or re-materialised with one conv launch
+                h = hidden.pop() if hidden else c1.run(x, EPI_LEAKY_PRE, u.inner_slope)
                 g2 = _grads_of(c2, h, dz)
                 dh = ops.conv_bwd_data(_desc(c2, h), dz, c2.conv.packed_bwd(CONV_CAUSAL), None, h, u.inner_slope)
                 g1 = _grads_of(c1, x, dh)
