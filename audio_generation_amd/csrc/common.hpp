@@ -24,7 +24,8 @@ struct Tuning {
                         // input elements (tall tiles share the row halo), 0 = always the widest
     int bf_sched = -1;  // (-1 = per-shape table) schedule of the bf16x3 main loop in the fused residual block: 0 split after the MFMAs,
                         // 1 the same with MFMA / VALU interleave hints, 2 split before the MFMAs
-    int dw2_direct = 1; // conv2d weight gradient of stride-1 "same" layers on the barrier-free LDS-DMA kernel (0: the staged one)
+    int dw2_direct = 2; // conv2d weight gradient on the barrier-free LDS-DMA kernel: 1 = stride-1 "same" layers, 2 = also the column-strided
+                        // layers (x read through its column-phase planes), 0 = the staged kernel everywhere
     int dw_direct = 2;  // 1-D weight gradient on the LDS-free kernel: 2 = every stride-1 layer, 1 = the k = 1 layers only, 0 = none
     int dw1_wgs = 768;  // workgroups the 1-D LDS-free weight-gradient kernel aims for
     int dw_wgs = 1536;  // workgroups the conv2d weight-gradient kernel aims for (slices = dw_wgs / tiles)

@@ -501,6 +501,7 @@ struct Bw2dGeom {
     int B, Cin, Cout, Hin, Win, Hout, Wout, kh, kw, sh, sw, ph, pw;
     int R, WF, RH, SW, span, n_chan, n_slices;
     int prec;   // 1: bf16x3 contraction (AGX_IMPL_MFMA_BF16X3)
+    int Wp;     // direct kernel: width of a column-phase plane of x (= Win when sw == 1)
 };
 
 template <int MW, int NW, int WM, int WN, int PREC = 0>   // PREC 1: bf16x3 contraction (mfma_tile.hpp), both operands split in registers
@@ -686,7 +687,23 @@ __global__ __launch_bounds__(256) void conv2d_bwd_weight_kernel(Bw2dGeom g, cons
 // the neighbouring row of the same tensor -- those elements are masked in registers, and only where the DMA could
 // leave the tensor itself (first rows of batch element 0, last rows of element B - 1) the operands are loaded
 // element by element.
+// Column-strided layers (sw = 2: the (3,4)/(4,4) convs) read x through its sw column-phase planes
+// xs[rho][b, ci, r, f] = x[b, ci, r, f sw + rho] (deinterleave_cols_kernel, one pass over x): with dw - pw = a sw + rho the
+// window of B row (ci, dh, dw) is xs[rho][ci, t sh + dh - ph, f0 + a + 0..31] -- contiguous again; a row stride sh only
+// enters the row address.
 __device__ float bw_zero_page[64];
+
+__global__ __launch_bounds__(256) void deinterleave_cols_kernel(const float *__restrict__ x, float *__restrict__ xs,
+                                                                int64_t rows, int Win, int Wp, int sw) {
+    const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;      // one element of a plane row, all phases
+    if (e >= rows * Wp) return;
+    const int64_t row = e / Wp;
+    const int f = int(e - row * Wp);
+    for (int rho = 0; rho < sw; ++rho) {
+        const int xi = f * sw + rho;
+        xs[(int64_t(rho) * rows + row) * Wp + f] = xi < Win ? x[row * Win + xi] : 0.f;
+    }
+}
 
 template <int MW, int NW, int WM, int WN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void conv2d_bwd_weight_direct_kernel(
@@ -699,7 +716,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     const int li = lane & 31, lh = lane >> 5;
     const int wk = wave / (WM * WN), wr = wave % (WM * WN), wm = wr / WN, wn = wr % WN;
     const int KK = g.kh * g.kw, NK = g.Cin * KK, M = g.Cout;
-    const int HWo = g.Hout * g.Wout, HWi = g.Hin * g.Win, FC = g.Wout / T;
+    const int Wp = g.Wp, HWo = g.Hout * g.Wout, HWi = g.Hin * Wp, FC = g.Wout / T;
+    const int plane = g.B * g.Cin * HWi;          // floats per column-phase plane
     const int n_base = blockIdx.x * BN, m_base = blockIdx.y * BM;
     const int slice = blockIdx.z * WK + wk, n_slices = gridDim.z * WK;
 
@@ -711,9 +729,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     for (int k = 0; k < NW; ++k) {
         const int n = min(n_base + (wn * NW + k) * 32 + li, NK - 1);
         const int ci = n / KK, rem = n - ci * KK, dh = rem / g.kw;
-        brow[k] = ci * HWi;
+        const int dwp = rem - dh * g.kw - g.pw, a = floordiv_bw(dwp, g.sw);
+        brow[k] = (dwp - a * g.sw) * plane + ci * HWi;      // phase plane + channel
         bdh[k] = dh - g.ph;
-        bdw[k] = rem - dh * g.kw - g.pw;
+        bdw[k] = a;                                           // column shift inside the plane
     }
     // the DMA rows of this lane: instruction v of a block carries rows 8 v .. 8 v + 7, lane l -> row 8 v + (l >> 3)
     extern __shared__ __attribute__((aligned(16))) float dma_buf[];
@@ -730,8 +749,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int n = min(n_base + (wn * NW + k) * 32 + 8 * v + dr, NK - 1);
-            const int ci = n / KK, rem = n - ci * KK, dh = rem / g.kw, dw = rem - dh * g.kw;
-            bdma[k][v] = ci * HWi + (dh - g.ph) * g.Win + (dw - g.pw) + 4 * dchunk;
+            const int ci = n / KK, rem = n - ci * KK, dh = rem / g.kw, dwp = rem - dh * g.kw - g.pw;
+            const int a = floordiv_bw(dwp, g.sw);
+            bdma[k][v] = (dwp - a * g.sw) * plane + ci * HWi + (dh - g.ph) * Wp + a + 4 * dchunk;
             bdmah[k] |= (dh - g.ph + 64) << (8 * v);
         }
     }
@@ -754,7 +774,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     auto dma = [&](int item) {
         const int row = item / FC, fc = item - row * FC, b = row / g.Hout, t = row - b * g.Hout;
         const float *dyb = dy + size_t(b) * M * HWo + t * g.Wout + fc * T;
-        const float *xb = x + size_t(b) * g.Cin * HWi + t * g.Win + fc * T;
+        const float *xb = x + size_t(b) * g.Cin * HWi + t * g.sh * Wp + fc * T;
 #pragma unroll
         for (int i = 0; i < MW; ++i)
 #pragma unroll
@@ -765,7 +785,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         for (int k = 0; k < NW; ++k)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int r = t + ((bdmah[k] >> (8 * v)) & 255) - 64;
+                const int r = t * g.sh + ((bdmah[k] >> (8 * v)) & 255) - 64;
                 const float *src = (r >= 0 && r < g.Hin) ? xb + bdma[k][v] : zsrc;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)(wbuf + (MW + k) * 1024 + v * 256), 16, 0, 0);
@@ -790,8 +810,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int x0 = fc * T + 16 * lh + c + bdw[k], x1 = x0 + 12;
-                Bv[k][0][c] = __uint_as_float(__float_as_uint(Bv[k][0][c]) & ((x0 >= 0 && x0 < g.Win) ? ~0u : 0u));
-                Bv[k][3][c] = __uint_as_float(__float_as_uint(Bv[k][3][c]) & ((x1 >= 0 && x1 < g.Win) ? ~0u : 0u));
+                Bv[k][0][c] = __uint_as_float(__float_as_uint(Bv[k][0][c]) & ((x0 >= 0 && x0 < Wp) ? ~0u : 0u));
+                Bv[k][3][c] = __uint_as_float(__float_as_uint(Bv[k][3][c]) & ((x1 >= 0 && x1 < Wp) ? ~0u : 0u));
             }
     };
     auto load_edge = [&](f32x4 (&A)[MW][4], f32x4 (&Bv)[NW][4], int item) {
@@ -804,14 +824,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
             for (int e = 0; e < 4; ++e) A[i][e] = *reinterpret_cast<const f32x4 *>(dyb + aoff[i] + 4 * e);
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
-            const int r = t + bdh[k];
+            const int r = t * g.sh + bdh[k];
             const bool rok = r >= 0 && r < g.Hin;
-            const float *xr = xb + brow[k] + min(max(r, 0), g.Hin - 1) * g.Win;
+            const float *xr = xb + brow[k] + min(max(r, 0), g.Hin - 1) * Wp;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int xi = fc * T + 16 * lh + e + bdw[k];
-                const unsigned v = __float_as_uint(xr[min(max(xi, 0), g.Win - 1)]);
-                Bv[k][e >> 2][e & 3] = __uint_as_float(v & ((rok && xi >= 0 && xi < g.Win) ? ~0u : 0u));
+                const unsigned v = __float_as_uint(xr[min(max(xi, 0), Wp - 1)]);
+                Bv[k][e >> 2][e & 3] = __uint_as_float(v & ((rok && xi >= 0 && xi < Wp) ? ~0u : 0u));
             }
         }
     };
@@ -839,7 +859,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     const int end = min(items, item + per);
     // where a DMA window could leave the tensor: chunk 0 of the first ph + 1 rows of batch element 0 (it starts pw
     // elements before its row), the last chunk of the last kh - ph rows of element B - 1
-    const int head_rows = min(g.ph + 1, rows), tail_row0 = max(rows - (g.kh - g.ph), 0);
+    const int head_rows = min(g.ph + 1, rows), tail_row0 = max(rows - (g.kh - g.ph), 0);   // (supersets when sh > 1)
     while (item < end) {
         const int row = item / FC, fc = item - row * FC;
         const bool head = row < head_rows, tail = row >= tail_row0;
@@ -989,8 +1009,14 @@ static int bw2d_geometry(const agx_conv2d_desc *d, Bw2dGeom *g, int *cfg, int *b
     *lds = (size_t(*bm) * BW_TS + size_t(g->n_chan) * g->span + BW_T) * sizeof(float);
     // conv2d_bwd_weight_direct_kernel: stride-1 "same" layers whose rows are whole 32-column items
     // (also for AGX_IMPL_MFMA_BF16X3 descriptors: fp32 on this kernel is faster than bf16x3 on the staged one, and exact)
-    if (tuning().dw2_direct && g->sh == 1 && g->sw == 1 && g->Hout == g->Hin && g->Wout == g->Win &&
-        g->Wout % 32 == 0 && g->pw <= 4 && g->kw - 1 - g->pw <= 4 && g->ph < 32 && g->kh - g->ph < 32 &&
+    // or column-strided ones whose output row is as wide as a column-phase plane of x
+    g->Wp = ceil_div(g->Win, g->sw);
+    const int a_lo = -ceil_div(g->pw, g->sw), a_hi = (g->kw - 1 - g->pw) / g->sw;      // column shifts inside a plane
+    const bool same = g->sh == 1 && g->sw == 1 && g->Hout == g->Hin && g->Wout == g->Win;
+    const bool strided = tuning().dw2_direct >= 2 && g->sw > 1 && g->sw <= 4 && g->Win % g->sw == 0 && g->Wout == g->Wp &&
+                         int64_t(g->sw) * g->B * g->Cin * g->Hin * g->Wp < (int64_t(1) << 31);   // 32-bit plane offsets
+    if (tuning().dw2_direct && (same || strided) &&
+        g->Wout % 32 == 0 && -a_lo <= 4 && a_hi <= 4 && g->ph < 32 && g->kh - g->ph < 32 &&
         (g->Cout > 32 || g->Cin * KK <= 32 || g->Cin * KK >= 192)) {   // (32 rows x 98 columns, the 7x7 first conv: the 256-wide tile loses to the staged kernel)
         const int NK = g->Cin * KK;
         int dbm, dbn, wk;
@@ -1147,7 +1173,9 @@ size_t agx_conv2d_bwd_weight_workspace_bytes(const agx_conv2d_desc *d) {
     size_t lds;
     if (bw2d_geometry(d, &g, &cfg, &bm, &grid, &lds) != AGX_OK) return 0;
     const size_t nw = size_t(g.Cin) * g.kh * g.kw * g.Cout;
-    return ((size_t(g.n_slices) + 1) * nw + (size_t(g.n_slices) + 2) * g.Cout) * sizeof(float);
+    size_t floats = (size_t(g.n_slices) + 1) * nw + (size_t(g.n_slices) + 2) * g.Cout;
+    if (cfg >= 10 && g.sw > 1) floats += size_t(g.sw) * g.B * g.Cin * g.Hin * g.Wp + 128;   // column-phase planes of x (+ slack)
+    return floats * sizeof(float);
 }
 
 int agx_conv2d_bwd_weight(const agx_conv2d_desc *d, const float *x, const float *dy, const float *w,
@@ -1189,6 +1217,13 @@ int agx_conv2d_bwd_weight(const agx_conv2d_desc *d, const float *x, const float 
         return AGX_OK;
     };
     if (cfg >= 10) {
+        if (g.sw > 1) {   // column-strided layer: x through its sw column-phase planes
+            float *xs = rowdot + M + 64;
+            const int64_t xrows = int64_t(g.B) * g.Cin * g.Hin;
+            hipLaunchKernelGGL(deinterleave_cols_kernel, dim3((unsigned)ceil_div64(xrows * g.Wp, 256)), dim3(256), 0, st, x,
+                               xs, xrows, g.Win, g.Wp, g.sw);
+            x = xs;
+        }
         rc = cfg == 10 ? launch_direct(conv2d_bwd_weight_direct_kernel<2, 2, 2, 2>, 4)
            : cfg == 11 ? launch_direct(conv2d_bwd_weight_direct_kernel<2, 2, 1, 2>, 4)
            : cfg == 12 ? launch_direct(conv2d_bwd_weight_direct_kernel<2, 2, 1, 1>, 4)
