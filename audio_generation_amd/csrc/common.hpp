@@ -26,7 +26,8 @@ struct Tuning {
                         // 1 the same with MFMA / VALU interleave hints, 2 split before the MFMAs
     int dw2_direct = 2; // conv2d weight gradient on the barrier-free LDS-DMA kernel: 1 = stride-1 "same" layers, 2 = also the column-strided
                         // layers (x read through its column-phase planes), 0 = the staged kernel everywhere
-    int dw_direct = 2;  // 1-D weight gradient on the LDS-free kernel: 2 = every stride-1 layer, 1 = the k = 1 layers only, 0 = none
+    int dw_direct = 3;  // 1-D weight gradient on the barrier-free kernel: 3 = every dense layer (strided / transposed ones through a
+                        // phase-split copy of x / dy), 2 = the stride-1 layers, 1 = the k = 1 layers only, 0 = none
     int dw1_wgs = 768;  // workgroups the 1-D LDS-free weight-gradient kernel aims for
     int dw_wgs = 1536;  // workgroups the conv2d weight-gradient kernel aims for (slices = dw_wgs / tiles)
     int conv_cc = 0;    // diagnostic: force the LDS chunk (8/16/32 channels) of the MFMA conv; 0 = table

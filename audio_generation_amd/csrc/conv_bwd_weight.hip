@@ -190,15 +190,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
 // The DMA of item n+1 is in flight during the 16 MW NW MFMAs of item n (operands already in registers).
 // Waves left over by a small tile (WK = 4 / (WM WN)) take different slices of the contraction and are added
 // through LDS at the end.
-struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
+// Strided and transposed layers reach the same kernel through phase-split copies of one operand (one pass over it):
+//   stride s:  xs[b, ci s + rho, u] = x[b, ci, u s + rho]   -- with j d - P = a s + rho the window of B row (ci, j) is
+//              row ci s + rho of xs shifted by a: contiguous again (`sp` = s below, rows of length Lin' = ceil(Lin / s));
+//   q phases:  dys[b, co q + ph, t] = dy[b, co, q t + ph]    -- simply the (B, M, Lt) matrix of the polyphase GEMM.
+// The host passes a ConvPlan whose Lin / Lvalid / Lout / Cout describe these copies.
+__device__ __forceinline__ int floordiv_bw(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
-template <int MW, int NW, int WM, int WN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void conv_bwd_weight_direct_kernel(ConvPlan p, const float *__restrict__ x,
+__global__ __launch_bounds__(256) void phase_split_rows_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                               int64_t rows, int L, int valid, int Lp, int s) {
+    const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;      // one element of a phase row, all phases
+    if (e >= rows * Lp) return;
+    const int64_t row = e / Lp;
+    const int u = int(e - row * Lp);
+    for (int rho = 0; rho < s; ++rho) {
+        const int xi = u * s + rho;
+        dst[(row * s + rho) * Lp + u] = xi < valid ? src[row * L + xi] : 0.f;
+    }
+}
+
+template <int MW, int NW, int WM, int WN, bool PHASES = false>   // PHASES: x is a phase-split copy (sp_arg > 1)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void conv_bwd_weight_direct_kernel(ConvPlan p, int sp_arg, const float *__restrict__ x,
                                                                      const float *__restrict__ dy,
                                                                      float *__restrict__ part,
                                                                      float *__restrict__ bias_part) {
     constexpr int WK = 4 / (WM * WN), BM = 32 * MW * WM, BN = 32 * NW * WN, T = 32;
     static_assert(WK * WM * WN == 4, "4 waves");
+    const int sp = PHASES ? sp_arg : 1;   // (a compile-time 1 keeps the stride-1 instantiation's code as it was)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the item loop's branches are wave-uniform
     const int li = lane & 31, lh = lane >> 5;
@@ -213,9 +231,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
         const int n = min(n_base + (wn * NW + k) * 32 + li, NK - 1);
-        const int ci = n / p.J, j = n - ci * p.J;
-        brow[k] = ci * p.Lin;
-        bshift[k] = j * p.d - p.P;
+        const int ci = n / p.J, j = n - ci * p.J, a = floordiv_bw(j * p.d - p.P, sp);
+        brow[k] = (ci * sp + (j * p.d - p.P - a * sp)) * p.Lin;
+        bshift[k] = a;
     }
     f32x16 acc[MW][NW];
 #pragma unroll
@@ -231,7 +249,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
 
     const int chunks = (p.Lt + T - 1) / T;
     const int items = p.B * chunks;
-    const int tmax_shift = (p.J - 1) * p.d - p.P;   // largest tap shift (0 for a causal layer)
+    const int tmin_shift = floordiv_bw(-p.P, sp), tmax_shift = floordiv_bw((p.J - 1) * p.d - p.P, sp);   // extreme tap shifts
 
     // interior chunks (all 32 positions and all taps inside the row) go through the wave's LDS buffer:
     // DMA instruction i of a block carries rows 8 i .. 8 i + 7, lane l -> row 8 i + (l >> 3), slot l & 7
@@ -249,14 +267,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int n = min(n_base + (wn * NW + k) * 32 + 8 * v + dr, NK - 1);
-            const int ci = n / p.J, j = n - ci * p.J;
-            bdma[k][v] = ci * p.Lin + j * p.d - p.P + 4 * dchunk;
+            const int ci = n / p.J, j = n - ci * p.J, a = floordiv_bw(j * p.d - p.P, sp);
+            bdma[k][v] = (ci * sp + (j * p.d - p.P - a * sp)) * p.Lin + a + 4 * dchunk;
         }
     const int rd_off = (li >> 3) * 256 + (li & 7) * 32;          // floats: this lane's row in a block
     auto dma = [&](int item) {
         const int b = item / chunks, tw = (item - b * chunks) * T;
         const float *dyb = dy + size_t(b) * p.Cout * p.Lout + tw;
-        const float *xb = x + size_t(b) * p.Cin * p.Lin + tw;
+        const float *xb = x + size_t(b) * p.Cin * sp * p.Lin + tw;
 #pragma unroll
         for (int i = 0; i < MW; ++i)
 #pragma unroll
@@ -287,7 +305,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     auto load_edge = [&](f32x4 (&A)[MW][4], f32x4 (&Bv)[NW][4], int item) {
         const int b = item / chunks, t0 = (item - b * chunks) * T + 16 * lh;
         const float *dyb = dy + size_t(b) * p.Cout * p.Lout;
-        const float *xb = x + size_t(b) * p.Cin * p.Lin;
+        const float *xb = x + size_t(b) * p.Cin * sp * p.Lin;
 #pragma unroll
         for (int i = 0; i < MW; ++i)
 #pragma unroll
@@ -331,7 +349,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     const int per = (items + n_slices - 1) / n_slices;
     int item = slice * per;
     const int end = min(items, item + per);
-    const int c_lo = (p.P + T - 1) / T;                                                    // first interior chunk of a row
+    const int c_lo = (max(-tmin_shift, 0) + T - 1) / T;                                    // first interior chunk of a row
     const int c_hi = max(0, min(p.Lt / T, (p.Lvalid - max(tmax_shift, 0)) / T));            // one past the last
     while (item < end) {
         const int c = item % chunks;
@@ -424,8 +442,6 @@ __global__ __launch_bounds__(256) void bwd_slice_reduce_kernel(const float *__re
     __syncthreads();
     if (grp == 0 && e < n) out[e] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
-
-__device__ __forceinline__ int floordiv_bw(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
 // One block per dim-0 row r of the torch weight: fold dWp back to dw_r, then the weight-norm chain rule.
 __global__ __launch_bounds__(256) void bwd_weight_unpack_kernel(const float *__restrict__ dwp,
@@ -1050,7 +1066,11 @@ struct BwGeom {
 static BwGeom bw_geometry(const ConvPlan &p, bool bf16x3) {
     BwGeom g;
     // (also for AGX_IMPL_MFMA_BF16X3 descriptors: fp32 on this kernel is faster than bf16x3 on the staged one, and exact)
-    g.direct = p.s == 1 && p.q == 1 && p.G == 1 && (tuning().dw_direct == 2 || (tuning().dw_direct == 1 && p.J == 1));
+    // dw_direct: 1 = the k = 1 layers, 2 = + every stride-1 layer, 3 (default) = + strided / transposed layers through a
+    // phase-split copy of x / dy
+    const int dd = tuning().dw_direct;
+    g.direct = p.G == 1 && ((p.s == 1 && p.q == 1 && (dd >= 2 || (dd == 1 && p.J == 1))) ||
+                            (dd >= 3 && (p.s == 1 || p.q == 1) && p.s <= 16 && p.q <= 16));
     (void)bf16x3;
     if (g.direct) {   // conv_bwd_weight_direct_kernel: tile and the waves left for the contraction (WK)
         const int NK = p.Cin * p.J;
@@ -1097,8 +1117,11 @@ size_t agx_conv_bwd_weight_workspace_bytes(const agx_conv_desc *d) {
     ConvPlan p;
     if (lower_conv(d, &p) != AGX_OK) return 0;
     const BwGeom g = bw_geometry(p, d->impl == AGX_IMPL_MFMA_BF16X3);
-    // slices of dWp + the reduced dWp + slices of the bias row sums
-    return ((size_t(g.n_slices) + 1) * p.Cin * p.J * p.M + (size_t(g.n_slices) + 1) * p.M) * sizeof(float);
+    // slices of dWp + the reduced dWp + slices of the bias row sums (+ the phase-split copy of x or dy)
+    size_t floats = (size_t(g.n_slices) + 1) * p.Cin * p.J * p.M + (size_t(g.n_slices) + 1) * p.M;
+    if (g.direct && p.s > 1) floats += size_t(p.B) * p.Cin * p.s * ceil_div(p.Lin, p.s) + 128;
+    if (g.direct && p.q > 1) floats += size_t(p.B) * p.M * p.Lt + 128;
+    return floats * sizeof(float);
 }
 
 int agx_conv_bwd_weight(const agx_conv_desc *d, const float *x, const float *dy, const float *v, const float *g,
@@ -1127,14 +1150,42 @@ int agx_conv_bwd_weight(const agx_conv_desc *d, const float *x, const float *dy,
                            bias_part);
         return AGX_OK;
     };
+    ConvPlan pd = p;            // the plan as the direct kernel sees it (phase-split operands: see the kernel's header)
+    const float *xd = x, *dyd = dy;
+    int sp = 1;
+    if (geo.direct && (p.s > 1 || p.q > 1)) {
+        float *extra = part + (size_t(geo.n_slices) + 1) * nw + (size_t(geo.n_slices) + 1) * p.M + 64;
+        if (p.s > 1) {
+            const int Lp = ceil_div(p.Lin, p.s);
+            const int64_t rows = int64_t(p.B) * p.Cin;
+            hipLaunchKernelGGL(phase_split_rows_kernel, dim3((unsigned)ceil_div64(rows * Lp, 256)), dim3(256), 0, st, x, extra,
+                               rows, p.Lin, p.Lvalid, Lp, p.s);
+            xd = extra;
+            sp = p.s;
+            pd.Lin = pd.Lvalid = Lp;
+        } else {
+            const int64_t rows = int64_t(p.B) * p.Cout;
+            hipLaunchKernelGGL(phase_split_rows_kernel, dim3((unsigned)ceil_div64(rows * p.Lt, 256)), dim3(256), 0, st, dy, extra,
+                               rows, p.Lout, p.Lout, p.Lt, p.q);
+            dyd = extra;
+            pd.Lout = p.Lt;
+            pd.Cout = p.M;
+        }
+    }
     auto launch_direct = [&](auto kern, int blocks_per_wave) -> int {   // 4 waves x (MW + NW) operand blocks of 4 KB
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(kern, geo.grid, dim3(256), size_t(4) * blocks_per_wave * 4096, st, p, x, dy, part, bias_part);
+        hipLaunchKernelGGL(kern, geo.grid, dim3(256), size_t(4) * blocks_per_wave * 4096, st, pd, sp, xd, dyd, part, bias_part);
         return AGX_OK;
     };
-    if (geo.direct)
+    if (geo.direct && sp > 1)
+        rc = geo.cfg == 10 ? launch_direct(conv_bwd_weight_direct_kernel<2, 2, 2, 2, true>, 4)
+           : geo.cfg == 11 ? launch_direct(conv_bwd_weight_direct_kernel<2, 2, 1, 2, true>, 4)
+           : geo.cfg == 12 ? launch_direct(conv_bwd_weight_direct_kernel<2, 2, 1, 1, true>, 4)
+           : geo.cfg == 13 ? launch_direct(conv_bwd_weight_direct_kernel<1, 2, 1, 4, true>, 3)
+                           : launch_direct(conv_bwd_weight_direct_kernel<1, 1, 1, 1, true>, 2);
+    else if (geo.direct)
         rc = geo.cfg == 10 ? launch_direct(conv_bwd_weight_direct_kernel<2, 2, 2, 2>, 4)
            : geo.cfg == 11 ? launch_direct(conv_bwd_weight_direct_kernel<2, 2, 1, 2>, 4)
            : geo.cfg == 12 ? launch_direct(conv_bwd_weight_direct_kernel<2, 2, 1, 1>, 4)

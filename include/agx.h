@@ -48,8 +48,10 @@ const char *agx_last_error(void);
  *   "conv_cc" 0|8|16|32  force the LDS channel chunk of the MFMA conv (0 = table)
  *   "patch_tie" 0|1      2-D patch tiles: tie between equally padded R x WF splits goes to the fewest staged elements (1) or the widest (0)
  *   "bf_sched" -1|0|1|2  schedule of the bf16x3 main loop of the fused residual block (-1 = per-shape table)
- *   "dw_direct" 0|1|2  1-D weight gradient on the barrier-free LDS-DMA kernel: 2 every stride-1 layer (default), 1 the k = 1 layers, 0 none
- *   "dw2_direct" 0|1   conv2d weight gradient of stride-1 "same" layers on the barrier-free LDS-DMA kernel (default 1)
+ *   "dw_direct" 0..3   1-D weight gradient on the barrier-free LDS-DMA kernel: 3 every dense layer (default; strided / transposed
+ *                      ones through a phase-split copy of x / dy), 2 the stride-1 layers, 1 the k = 1 layers, 0 none
+ *   "dw2_direct" 0|1|2 conv2d weight gradient on the barrier-free LDS-DMA kernel: 1 stride-1 "same" layers, 2 (default) also the
+ *                      column-strided layers (x through its column-phase planes), 0 the staged kernel everywhere
  *   "dw1_wgs" N        workgroups the 1-D barrier-free weight-gradient kernel aims for (default 768)
  *   "dw_wgs" n         workgroups the conv2d weight-gradient kernel aims for (default 1536)
  *   "conv_shape" 0|1   1: 128x128 conv tiles as four row-waves of 1x4 fragments                    */
