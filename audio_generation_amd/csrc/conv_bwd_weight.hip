@@ -209,6 +209,107 @@ __global__ __launch_bounds__(256) void phase_split_rows_kernel(const float *__re
     }
 }
 
+// ---- pieces shared by the 1-D and the 2-D barrier-free kernels -----------------------------------------------
+// MFMA operands of one item out of the wave's swizzled DMA buffer: row li of every block, chunks 4 lh .. 4 lh + 3
+template <int MW, int NW>
+__device__ __forceinline__ void direct_read_lds(const float *wbuf, int li, int lh, f32x4 (&A)[MW][4], f32x4 (&Bv)[NW][4]) {
+    const int rd_off = (li >> 3) * 256 + (li & 7) * 32;          // floats: this lane's row in a block
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            A[i][e] = *reinterpret_cast<const f32x4 *>(wbuf + i * 1024 + rd_off + 4 * ((4 * lh + e) ^ (li & 7)));
+#pragma unroll
+    for (int k = 0; k < NW; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            Bv[k][e] = *reinterpret_cast<const f32x4 *>(wbuf + (MW + k) * 1024 + rd_off + 4 * ((4 * lh + e) ^ (li & 7)));
+}
+
+// the 16 MW NW MFMAs of one item (k-step = position 16 lh + 4 e + c of both operands) + the bias row sums
+template <int MW, int NW>
+__device__ __forceinline__ void direct_compute(f32x16 (&acc)[MW][NW], float (&bsum)[MW], const f32x4 (&A)[MW][4],
+                                               const f32x4 (&Bv)[NW][4], bool do_bias) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < MW; ++i)
+#pragma unroll
+                for (int k = 0; k < NW; ++k)
+                    acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[i][e][c], Bv[k][e][c], acc[i][k], 0, 0, 0);
+    if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bsum[i] += (A[i][e][0] + A[i][e][1]) + (A[i][e][2] + A[i][e][3]);
+    }
+}
+
+// End of a workgroup: the WK waves that shared a tile add their partials through LDS in a fixed order (wave 1, 2, 3
+// onto wave 0; the exchange reuses the DMA buffers), then the tile and the bias row sums go to the workspace.
+template <int MW, int NW, int WM, int WN>
+__device__ __forceinline__ void direct_finish(f32x16 (&acc)[MW][NW], float (&bsum)[MW], float *dma_buf, int wk, int wr,
+                                              int lane, int n_base, int m_base, int NK, int M, float *__restrict__ part,
+                                              float *__restrict__ bias_part, bool do_bias) {
+    constexpr int WK = 4 / (WM * WN);
+    const int li = lane & 31, lh = lane >> 5, wm = wr / WN, wn = wr % WN;
+    if constexpr (WK > 1) {
+        constexpr int PER = (MW * NW * 16 + MW) * 64;
+        static_assert((WK - 1) * WM * WN * PER <= 4 * (MW + NW) * 1024, "the exchange reuses the DMA buffers");
+        float *red = dma_buf;
+        __syncthreads();      // every wave is done with its DMA buffer
+        float *mine = red + ((wk > 0 ? wk - 1 : 0) * WM * WN + wr) * PER + lane;
+        if (wk > 0) {
+#pragma unroll
+            for (int i = 0; i < MW; ++i) {
+#pragma unroll
+                for (int k = 0; k < NW; ++k)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mine[((i * NW + k) * 16 + r) * 64] = acc[i][k][r];
+                mine[(MW * NW * 16 + i) * 64] = bsum[i];
+            }
+        }
+        __syncthreads();
+        if (wk > 0) return;
+#pragma unroll
+        for (int w = 1; w < WK; ++w) {
+            const float *src = red + ((w - 1) * WM * WN + wr) * PER + lane;
+#pragma unroll
+            for (int i = 0; i < MW; ++i) {
+#pragma unroll
+                for (int k = 0; k < NW; ++k)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][k][r] += src[((i * NW + k) * 16 + r) * 64];
+                bsum[i] += src[(MW * NW * 16 + i) * 64];
+            }
+        }
+    }
+    const int oslice = blockIdx.z;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const int n = n_base + (wn * NW + k) * 32 + li;
+        if (n >= NK) continue;
+        float *dst = part + (size_t(oslice) * NK + n) * M;
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m_base + (wm * MW + i) * 32 + acc_row(r, lh);
+                if (m < M) dst[m] = acc[i][k][r];
+            }
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < MW; ++i) {
+            const float tot = bsum[i] + __shfl_xor(bsum[i], 32);
+            const int m = m_base + (wm * MW + i) * 32 + li;
+            if (lh == 0 && m < M) bias_part[size_t(oslice) * M + m] = tot;
+        }
+    }
+}
+
 template <int MW, int NW, int WM, int WN, bool PHASES = false>   // PHASES: x is a phase-split copy (sp_arg > 1)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void conv_bwd_weight_direct_kernel(ConvPlan p, int sp_arg, const float *__restrict__ x,
                                                                      const float *__restrict__ dy,
@@ -270,7 +371,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
             const int ci = n / p.J, j = n - ci * p.J, a = floordiv_bw(j * p.d - p.P, sp);
             bdma[k][v] = (ci * sp + (j * p.d - p.P - a * sp)) * p.Lin + a + 4 * dchunk;
         }
-    const int rd_off = (li >> 3) * 256 + (li & 7) * 32;          // floats: this lane's row in a block
     auto dma = [&](int item) {
         const int b = item / chunks, tw = (item - b * chunks) * T;
         const float *dyb = dy + size_t(b) * p.Cout * p.Lout + tw;
@@ -287,18 +387,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
             for (int v = 0; v < 4; ++v)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xb + bdma[k][v]),
                                                  (__attribute__((address_space(3))) void *)(wbuf + (MW + k) * 1024 + v * 256), 16, 0, 0);
-    };
-    auto read_lds = [&](f32x4 (&A)[MW][4], f32x4 (&Bv)[NW][4]) {
-#pragma unroll
-        for (int i = 0; i < MW; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                A[i][e] = *reinterpret_cast<const f32x4 *>(wbuf + i * 1024 + rd_off + 4 * ((4 * lh + e) ^ (li & 7)));
-#pragma unroll
-        for (int k = 0; k < NW; ++k)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                Bv[k][e] = *reinterpret_cast<const f32x4 *>(wbuf + (MW + k) * 1024 + rd_off + 4 * ((4 * lh + e) ^ (li & 7)));
     };
     // first / last chunks of a row: element by element on clamped addresses, masked to zero afterwards
     // (bitwise AND: a select would be turned back into predicated loads, each with its own wait)
@@ -323,23 +411,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
                 Bv[k][e >> 2][e & 3] = __uint_as_float(v & ((xi >= 0 && xi < p.Lvalid) ? ~0u : 0u));
             }
     };
-    auto compute = [&](const f32x4 (&A)[MW][4], const f32x4 (&Bv)[NW][4]) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int i = 0; i < MW; ++i)
-#pragma unroll
-                    for (int k = 0; k < NW; ++k)
-                        acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[i][e][c], Bv[k][e][c], acc[i][k], 0, 0, 0);
-        if (do_bias) {
-#pragma unroll
-            for (int i = 0; i < MW; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) bsum[i] += (A[i][e][0] + A[i][e][1]) + (A[i][e][2] + A[i][e][3]);
-        }
-    };
+    auto compute = [&](const f32x4 (&A)[MW][4], const f32x4 (&Bv)[NW][4]) { direct_compute<MW, NW>(acc, bsum, A, Bv, do_bias); };
 
     // A slice owns a CONTIGUOUS range of items (every row is streamed front to back).  Runs of interior chunks:
     // wait for the DMA of item n, pull its operands into registers, start the DMA of item n+1 (unconditional, the
@@ -363,7 +435,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         dma(item);
         for (int n = 0; n < run; ++n) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA has landed (wave-private buffer: no barrier)
-            read_lds(A0, B0);
+            direct_read_lds<MW, NW>(wbuf, li, lh, A0, B0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // operands are in registers: the buffer may be overwritten
             dma(min(item + n + 1, last));
             compute(A0, B0);
@@ -371,60 +443,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (the clamped extra DMA of the last step)
         item += run;
     }
-    // the WK waves that shared a tile add their partials through LDS in a fixed order (wave 1, 2, 3 onto wave 0)
-    if constexpr (WK > 1) {
-        constexpr int PER = (MW * NW * 16 + MW) * 64;
-        static_assert((WK - 1) * WM * WN * PER <= 4 * (MW + NW) * 1024, "the exchange reuses the DMA buffers");
-        float *red = dma_buf;
-        __syncthreads();      // every wave is done with its DMA buffer
-        float *mine = red + ((wk > 0 ? wk - 1 : 0) * WM * WN + wr) * PER + lane;
-        if (wk > 0) {
-#pragma unroll
-            for (int i = 0; i < MW; ++i) {
-#pragma unroll
-                for (int k = 0; k < NW; ++k)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) mine[((i * NW + k) * 16 + r) * 64] = acc[i][k][r];
-                mine[(MW * NW * 16 + i) * 64] = bsum[i];
-            }
-        }
-        __syncthreads();
-        if (wk > 0) return;
-#pragma unroll
-        for (int w = 1; w < WK; ++w) {
-            const float *src = red + ((w - 1) * WM * WN + wr) * PER + lane;
-#pragma unroll
-            for (int i = 0; i < MW; ++i) {
-#pragma unroll
-                for (int k = 0; k < NW; ++k)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][k][r] += src[((i * NW + k) * 16 + r) * 64];
-                bsum[i] += src[(MW * NW * 16 + i) * 64];
-            }
-        }
-    }
-    const int oslice = blockIdx.z;
-#pragma unroll
-    for (int k = 0; k < NW; ++k) {
-        const int n = n_base + (wn * NW + k) * 32 + li;
-        if (n >= NK) continue;
-        float *dst = part + (size_t(oslice) * NK + n) * p.M;
-#pragma unroll
-        for (int i = 0; i < MW; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m_base + (wm * MW + i) * 32 + acc_row(r, lh);
-                if (m < p.M) dst[m] = acc[i][k][r];
-            }
-    }
-    if (do_bias) {
-#pragma unroll
-        for (int i = 0; i < MW; ++i) {
-            const float tot = bsum[i] + __shfl_xor(bsum[i], 32);
-            const int m = m_base + (wm * MW + i) * 32 + li;
-            if (lh == 0 && m < p.M) bias_part[size_t(oslice) * p.M + m] = tot;
-        }
-    }
+    direct_finish<MW, NW, WM, WN>(acc, bsum, dma_buf, wk, wr, lane, n_base, m_base, NK, p.M, part, bias_part, do_bias);
 }
 
 // out[e] = sum over slices of part[slice][e], in a fixed order: 4 slice groups (the 4 waves of a
@@ -771,7 +790,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
             bdmah[k] |= (dh - g.ph + 64) << (8 * v);
         }
     }
-    const int rd_off = (li >> 3) * 256 + (li & 7) * 32;
     const float *zsrc = bw_zero_page + 4 * (lane & 7);
 
     f32x16 acc[MW][NW];
@@ -807,18 +825,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
                                                  (__attribute__((address_space(3))) void *)(wbuf + (MW + k) * 1024 + v * 256), 16, 0, 0);
             }
     };
-    auto read_lds = [&](f32x4 (&A)[MW][4], f32x4 (&Bv)[NW][4]) {
-#pragma unroll
-        for (int i = 0; i < MW; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                A[i][e] = *reinterpret_cast<const f32x4 *>(wbuf + i * 1024 + rd_off + 4 * ((4 * lh + e) ^ (li & 7)));
-#pragma unroll
-        for (int k = 0; k < NW; ++k)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                Bv[k][e] = *reinterpret_cast<const f32x4 *>(wbuf + (MW + k) * 1024 + rd_off + 4 * ((4 * lh + e) ^ (li & 7)));
-    };
     // first / last chunk of an image row: the (at most 4) window elements in the horizontal padding
     auto mask_cols = [&](f32x4 (&Bv)[NW][4], int fc) {
 #pragma unroll
@@ -851,23 +857,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
             }
         }
     };
-    auto compute = [&](const f32x4 (&A)[MW][4], const f32x4 (&Bv)[NW][4]) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int i = 0; i < MW; ++i)
-#pragma unroll
-                    for (int k = 0; k < NW; ++k)
-                        acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[i][e][c], Bv[k][e][c], acc[i][k], 0, 0, 0);
-        if (do_bias) {
-#pragma unroll
-            for (int i = 0; i < MW; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) bsum[i] += (A[i][e][0] + A[i][e][1]) + (A[i][e][2] + A[i][e][3]);
-        }
-    };
+    auto compute = [&](const f32x4 (&A)[MW][4], const f32x4 (&Bv)[NW][4]) { direct_compute<MW, NW>(acc, bsum, A, Bv, do_bias); };
 
     f32x4 A0[MW][4], B0[NW][4];
     const int per = (items + n_slices - 1) / n_slices;
@@ -892,7 +882,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         dma(item);
         for (int n = 0; n < run; ++n) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            read_lds(A0, B0);
+            direct_read_lds<MW, NW>(wbuf, li, lh, A0, B0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             dma(min(item + n + 1, last));
             const int fcn = (item + n) % FC;
@@ -902,59 +892,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         item += run;
     }
-    if constexpr (WK > 1) {
-        constexpr int PER = (MW * NW * 16 + MW) * 64;
-        static_assert((WK - 1) * WM * WN * PER <= 4 * (MW + NW) * 1024, "the exchange reuses the DMA buffers");
-        float *red = dma_buf;
-        __syncthreads();
-        float *mine = red + ((wk > 0 ? wk - 1 : 0) * WM * WN + wr) * PER + lane;
-        if (wk > 0) {
-#pragma unroll
-            for (int i = 0; i < MW; ++i) {
-#pragma unroll
-                for (int k = 0; k < NW; ++k)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) mine[((i * NW + k) * 16 + r) * 64] = acc[i][k][r];
-                mine[(MW * NW * 16 + i) * 64] = bsum[i];
-            }
-        }
-        __syncthreads();
-        if (wk > 0) return;
-#pragma unroll
-        for (int w = 1; w < WK; ++w) {
-            const float *src = red + ((w - 1) * WM * WN + wr) * PER + lane;
-#pragma unroll
-            for (int i = 0; i < MW; ++i) {
-#pragma unroll
-                for (int k = 0; k < NW; ++k)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][k][r] += src[((i * NW + k) * 16 + r) * 64];
-                bsum[i] += src[(MW * NW * 16 + i) * 64];
-            }
-        }
-    }
-    const int oslice = blockIdx.z;
-#pragma unroll
-    for (int k = 0; k < NW; ++k) {
-        const int n = n_base + (wn * NW + k) * 32 + li;
-        if (n >= NK) continue;
-        float *dst = part + (size_t(oslice) * NK + n) * M;
-#pragma unroll
-        for (int i = 0; i < MW; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m_base + (wm * MW + i) * 32 + acc_row(r, lh);
-                if (m < M) dst[m] = acc[i][k][r];
-            }
-    }
-    if (do_bias) {
-#pragma unroll
-        for (int i = 0; i < MW; ++i) {
-            const float tot = bsum[i] + __shfl_xor(bsum[i], 32);
-            const int m = m_base + (wm * MW + i) * 32 + li;
-            if (lh == 0 && m < M) bias_part[size_t(oslice) * M + m] = tot;
-        }
-    }
+    direct_finish<MW, NW, WM, WN>(acc, bsum, dma_buf, wk, wr, lane, n_base, m_base, NK, M, part, bias_part, do_bias);
 }
 
 // Gradient w.r.t. the normalised weight G[co][n] = dwp[n][co] -> dw (torch layout), and per-row <G, W>.
