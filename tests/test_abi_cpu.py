@@ -135,3 +135,20 @@ def test_descriptor_structs_match_the_header_layout(tmp_path):
     want = [ctypes.sizeof(_lib.ConvDesc)] + [getattr(_lib.ConvDesc, f).offset for f in fields1]
     want += [ctypes.sizeof(_lib.Conv2dDesc)] + [getattr(_lib.Conv2dDesc, f).offset for f in fields2]
     assert nums == want
+
+
+def test_tuning_knobs_from_the_environment():
+    """AGX_TUNING=knob=value,... is applied once by _lib.load(); an unknown knob fails loudly (fresh interpreters:
+    the library handle of this process is already loaded)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("from audio_generation_amd import _lib; lib = _lib.load(); "
+            "print(lib.agx_get_tuning(b'dw_direct'), lib.agx_get_tuning(b'patch_tie'))")
+    env = dict(os.environ, AGX_TUNING="dw_direct=1, patch_tie=0")
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ["1", "0"]
+    bad = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, AGX_TUNING="no_such_knob=1"),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "no_such_knob" in bad.stderr
