@@ -198,21 +198,25 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvPlan p, int span,
 // LDS floats per staged channel for a BN-column tile (patch mode also fixes the tile's rows x columns).
 static int tile_span(const ConvPlan &p, int BN, int *R, int *WF) {
     if (!p.pm_R) return (BN - 1) * p.s + (p.J - 1) * p.d + 1;
-    // tile = R output rows x WF output columns (R * WF <= BN).  WF = the whole row when it fits; otherwise the
-    // power-of-two split of BN that wastes the fewest base positions (backward-data of strided layers has
-    // 2^k + 1 columns: 128-wide tiles would be one third empty)
-    int wf = p.Lt, r = BN / (p.Lt < 1 ? 1 : p.Lt);
-    if (p.Lt >= BN) {
-        long best = -1, best_staged = 0;
+    // tile = R output rows x WF output columns (R * WF <= BN); backward-data of strided layers has 2^k + 1 columns,
+    // so the widest tile is often not the best.
+    // candidates: the whole row (when it fits) and the power-of-two splits of BN; the cost of a split is the number
+    // of tiles (each costs BN columns of MFMA work whatever it covers) -- a 65-column base grid on "whole row" tiles
+    // of 128 was half empty (3.15 -> 2.0 ms on the 128 -> 256 strided layer's backward-data)
+    int wf = p.Lt < BN ? (p.Lt < 1 ? 1 : p.Lt) : BN, r = BN / wf;
+    if (r > p.Tt) r = p.Tt;
+    if (r < 1) r = 1;
+    long best = long(ceil_div(p.Lt, wf)) * ceil_div(p.Tt, r);
+    long best_staged = best * ((r - 1) * p.sh + p.kh) * ((wf - 1) * p.s + p.J / p.kh);
+    {
         const int kwt = p.J / p.kh;
         for (int cand = BN; cand >= 8; cand /= 2) {
             int rr = BN / cand;
             if (rr > p.Tt) rr = p.Tt;
             const long tiles = long(ceil_div(p.Lt, cand)) * ceil_div(p.Tt, rr);
-            const long area = tiles * cand * rr;
             const long staged = tiles * ((rr - 1) * p.sh + p.kh) * ((cand - 1) * p.s + kwt);
-            if (best < 0 || area < best || (tuning().patch_tie && area == best && cand >= 16 && staged < best_staged)) {
-                best = area;
+            if (tiles < best || (tuning().patch_tie && tiles == best && cand >= 16 && staged < best_staged)) {
+                best = tiles;
                 best_staged = staged;
                 wf = cand;
                 r = rr;
