@@ -61,6 +61,7 @@ SIGNATURES = {
                                      c_int32, c_void_p, c_size_t, c_void_p]),
     "agx_rvq_packed_floats": (c_int64, [c_int32, c_int32, c_int32]),
     "agx_rvq_pack": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "agx_rvq_pack_sized": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "agx_rvq_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32, c_int32]),
     "agx_rvq_forward": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
                                 c_int32, c_int32, c_int32, c_int32, c_int32,

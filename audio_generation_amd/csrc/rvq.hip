@@ -44,23 +44,30 @@ __host__ __device__ inline int64_t rvq_stage_floats(int k, int dim) {
 }
 
 // ------------------------------------------------------------------------- pack
+// Stages may have fewer than K codewords (the reference takes one codebook size per quantizer, vae.py:233): rows
+// kq .. K-1 of such a stage are padding -- excluded from the mean and from cmax2, |c'|^2 = +inf (never a candidate),
+// zero in the score image; the stage's count rides in the image's tail for the kernel's full-search fallback.
+struct RvqSizes { int n[64]; };
+
 // mu[d] = mean_k c[k][d]  (thread per d; fp32 sequential over k)
 __global__ __launch_bounds__(256) void rvq_mean_kernel(const float *__restrict__ cb, int k, int dim,
-                                                       float *__restrict__ packed) {
+                                                       float *__restrict__ packed, RvqSizes sizes) {
     const int q = blockIdx.y;
+    const int kq = sizes.n[q];
     const int d = blockIdx.x * 256 + threadIdx.x;
     const int dp = rvq_dp(dim);
     if (d >= dp) return;
     float *mu = packed + q * rvq_stage_floats(k, dim) + size_t(dp) * k + 2 * size_t(k) + 4;
     float acc = 0.f;
     if (d < dim)
-        for (int c = 0; c < k; ++c) acc += cb[(size_t(q) * k + c) * dim + d];
-    mu[d] = d < dim ? acc / float(k) : 0.f;
+        for (int c = 0; c < kq; ++c) acc += cb[(size_t(q) * k + c) * dim + d];
+    mu[d] = d < dim ? acc / float(kq) : 0.f;
 }
 
 __global__ __launch_bounds__(256) void rvq_pack_kernel(const float *__restrict__ cb, int n_q, int k,
-                                                       int dim, float *__restrict__ packed) {
+                                                       int dim, float *__restrict__ packed, RvqSizes sizes) {
     const int q = blockIdx.y;
+    const bool pad = blockIdx.x * 256 + threadIdx.x >= sizes.n[q];
     const int code = blockIdx.x * 256 + threadIdx.x;
     float *img = packed + q * rvq_stage_floats(k, dim);
     if (code >= k) return;
@@ -69,19 +76,20 @@ __global__ __launch_bounds__(256) void rvq_pack_kernel(const float *__restrict__
     const float *mu = img + size_t(dp) * k + 2 * size_t(k) + 4;
     float acc = 0.f;
     for (int d = 0; d < dp; ++d) {
-        const float v = d < dim ? row[d] - mu[d] : 0.f;
+        const float v = (d < dim && !pad) ? row[d] - mu[d] : 0.f;
         img[(size_t(d >> 2) * k + code) * 4 + (d & 3)] = v;
         acc = fmaf(v, v, acc);
     }
-    img[size_t(dp) * k + code] = acc;
-    img[size_t(dp) * k + k + code] = sqrtf(acc);
+    img[size_t(dp) * k + code] = pad ? INFINITY : acc;
+    img[size_t(dp) * k + k + code] = pad ? 0.f : sqrtf(acc);
 }
 
-__global__ __launch_bounds__(256) void rvq_cmax_kernel(int k, int dim, float *__restrict__ packed) {
+__global__ __launch_bounds__(256) void rvq_cmax_kernel(int k, int dim, float *__restrict__ packed, RvqSizes sizes) {
     float *img = packed + blockIdx.x * rvq_stage_floats(k, dim);
     const float *c2 = img + size_t(rvq_dp(dim)) * k;
+    const int kq = sizes.n[blockIdx.x];
     float m = 0.f;
-    for (int i = threadIdx.x; i < k; i += 256) m = fmaxf(m, c2[i]);
+    for (int i = threadIdx.x; i < kq; i += 256) m = fmaxf(m, c2[i]);
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
     __shared__ float part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
@@ -89,7 +97,8 @@ __global__ __launch_bounds__(256) void rvq_cmax_kernel(int k, int dim, float *__
     if (threadIdx.x == 0) {
         float *tail = img + size_t(rvq_dp(dim)) * k + 2 * size_t(k);
         tail[0] = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
-        tail[1] = tail[2] = tail[3] = 0.f;
+        tail[1] = __int_as_float(kq);      // codewords of this stage (an integer's bits)
+        tail[2] = tail[3] = 0.f;
     }
 }
 
@@ -425,11 +434,13 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
         __syncthreads();
         // candidate overflow (degenerate codebooks): full defining search, whole block per frame
         const int any_overflow = flags[1];
+        const int kq_bits = __float_as_int(c2[2 * size_t(K) + 1]);
+        const int Kq = kq_bits > 0 && kq_bits <= K ? kq_bits : K;     // this stage's codewords (rest of the K rows: padding)
         for (int f = 0; f < (any_overflow ? FT : 0); ++f) {
             if (state[f] != 2) continue;  // uniform across the block (LDS value)
             double bd = INFINITY;
             int bc = 0x7fffffff;
-            for (int code = wave; code < K; code += NWV) {  // every lane of the wave gets the same distance
+            for (int code = wave; code < Kq; code += NWV) {  // every lane of the wave gets the same distance
                 const double dc = exact_dist_wave(R + f, cbq + size_t(code) * D, D, lane);
                 if (dc < bd || (dc == bd && code < bc)) {
                     bd = dc;
@@ -576,15 +587,27 @@ int64_t agx_rvq_packed_floats(int32_t n_q, int32_t k, int32_t dim) {
     return int64_t(n_q) * agx::rvq_stage_floats(k, dim);
 }
 
-int agx_rvq_pack(const float *codebooks, int32_t n_q, int32_t k, int32_t dim, float *packed, void *stream) {
+int agx_rvq_pack_sized(const float *codebooks, const int32_t *sizes, int32_t n_q, int32_t k, int32_t dim, float *packed,
+                       void *stream) {
     using namespace agx;
     if (n_q <= 0 || k <= 0 || dim <= 0) return fail(AGX_ERR_BAD_SHAPE, "rvq_pack: bad shape Q=%d K=%d D=%d", n_q, k, dim);
     if (!codebooks || !packed) return fail(AGX_ERR_NULL_POINTER, "rvq_pack: NULL pointer");
+    if (n_q > 64) return fail(AGX_ERR_UNSUPPORTED, "rvq_pack: at most 64 stages (Q=%d)", n_q);
+    RvqSizes sz;
+    for (int q = 0; q < 64; ++q) sz.n[q] = k;
+    for (int q = 0; q < n_q && sizes; ++q) {
+        if (sizes[q] < 1 || sizes[q] > k) return fail(AGX_ERR_BAD_SHAPE, "rvq_pack: stage %d has %d codewords (K=%d)", q, sizes[q], k);
+        sz.n[q] = sizes[q];
+    }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(rvq_mean_kernel, dim3(ceil_div(rvq_dp(dim), 256), n_q), dim3(256), 0, st, codebooks, k, dim, packed);
-    hipLaunchKernelGGL(rvq_pack_kernel, dim3(ceil_div(k, 256), n_q), dim3(256), 0, st, codebooks, n_q, k, dim, packed);
-    hipLaunchKernelGGL(rvq_cmax_kernel, dim3(n_q), dim3(256), 0, st, k, dim, packed);
+    hipLaunchKernelGGL(rvq_mean_kernel, dim3(ceil_div(rvq_dp(dim), 256), n_q), dim3(256), 0, st, codebooks, k, dim, packed, sz);
+    hipLaunchKernelGGL(rvq_pack_kernel, dim3(ceil_div(k, 256), n_q), dim3(256), 0, st, codebooks, n_q, k, dim, packed, sz);
+    hipLaunchKernelGGL(rvq_cmax_kernel, dim3(n_q), dim3(256), 0, st, k, dim, packed, sz);
     return check_launch("agx_rvq_pack");
+}
+
+int agx_rvq_pack(const float *codebooks, int32_t n_q, int32_t k, int32_t dim, float *packed, void *stream) {
+    return agx_rvq_pack_sized(codebooks, nullptr, n_q, k, dim, packed, stream);
 }
 
 size_t agx_rvq_workspace_bytes(int32_t, int32_t, int32_t, int32_t, int32_t) { return 0; }

@@ -5,7 +5,7 @@ here (memory, streams); all arithmetic happens in the HIP kernels.
 from __future__ import annotations
 
 import ctypes
-from typing import Optional, Tuple
+from typing import Optional, Sequence, Tuple
 
 import torch
 
@@ -189,7 +189,9 @@ def resblock_forward(desc: ConvDesc, x: Tensor, packed1: Tensor, bias1: Optional
 
 
 # ---------------------------------------------------------------------------- rvq
-def rvq_pack(codebooks: Tensor) -> Tensor:
+def rvq_pack(codebooks: Tensor, sizes: Optional[Sequence[int]] = None) -> Tensor:
+    """Stage images of (Q, K, D) codebooks; ``sizes[q] <= K`` = real codewords of stage q (rows beyond are padding
+    the search can never select) for quantizers with one codebook size per stage."""
     lib = _lib.load()
     _need_gpu(codebooks)
     codebooks = _f32c(codebooks)
@@ -198,7 +200,14 @@ def rvq_pack(codebooks: Tensor) -> Tensor:
     if n < 0:
         _lib.check(int(n), "agx_rvq_packed_floats")
     packed = torch.empty(int(n), dtype=torch.float32, device=codebooks.device)
-    _lib.check(lib.agx_rvq_pack(_ptr(codebooks), q, k, d, _ptr(packed), _stream()), "agx_rvq_pack")
+    if sizes is None:
+        _lib.check(lib.agx_rvq_pack(_ptr(codebooks), q, k, d, _ptr(packed), _stream()), "agx_rvq_pack")
+    else:
+        if len(sizes) != q:
+            raise AgxError(f"rvq_pack: {len(sizes)} sizes for {q} stages")
+        arr = (ctypes.c_int32 * q)(*[int(v) for v in sizes])
+        _lib.check(lib.agx_rvq_pack_sized(_ptr(codebooks), ctypes.cast(arr, ctypes.c_void_p), q, k, d, _ptr(packed),
+                                          _stream()), "agx_rvq_pack_sized")
     return packed
 
 

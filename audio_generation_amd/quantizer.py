@@ -59,29 +59,34 @@ class _Stage(nn.Module):
 
     @property
     def codebook(self) -> Tensor:
-        return self._parent.codebooks[self.i]
+        return self._parent.codebooks[self.i][:self._parent.codebook_sizes[self.i]]
 
     def dequantize(self, idx: Tensor) -> Tensor:
         """``(..,) int -> (.., D)`` gather (call site vae.py:333)."""
-        return ops.rvq_dequantize(self._parent.codebooks.detach()[self.i], idx)
+        return ops.rvq_dequantize(self.codebook.detach(), idx)
 
 
 class ResidualQuantizer(nn.Module):
     def __init__(self, num_quantizers=8, dim=512, quantizer_class="ema", codebook_sizes=1024,
                  vq_cutoff_freq=1, use_som=True, som_kernel_type="hard", ema_decay=0.99):
         super().__init__()
-        sizes = tuple_checker(codebook_sizes, num_quantizers)
-        if len(set(int(s) for s in sizes)) != 1:
-            raise NotImplementedError("the HIP search kernel needs one codebook size for all stages")
+        sizes = tuple(int(v) for v in tuple_checker(codebook_sizes, num_quantizers))
+        if min(sizes) < 1:
+            raise ValueError("codebook sizes must be positive")
         self.num_quantizers = int(num_quantizers)
         self.dim = int(dim)
-        self.codebook_size = int(sizes[0])
+        # One size per stage (vae.py:233).  Storage is (Q, K, D) with K = the largest stage; rows beyond a stage's
+        # own size are zero padding that the search kernel can never select (ops.rvq_pack(..., sizes)).
+        self.codebook_sizes = sizes
+        self.codebook_size = max(sizes)
         self.quantizer_class = quantizer_class
         self.vq_cutoff_freq = vq_cutoff_freq
         self.use_som = use_som
         self.som_kernel_type = som_kernel_type
         self.ema_decay = ema_decay
         init = torch.randn(self.num_quantizers, self.codebook_size, self.dim)
+        for q, kq in enumerate(sizes):
+            init[q, kq:] = 0.0
         if quantizer_class == "base":          # learnable codebook (config/training.yml: vq_type "base")
             self.codebooks = nn.Parameter(init)
         else:                                   # "ema": statistics-updated, not a parameter
@@ -97,7 +102,8 @@ class ResidualQuantizer(nn.Module):
         cb = self.codebooks
         key = (cb.data_ptr(), cb._version)
         if self._packed is None or self._packed_key != key:
-            self._packed = ops.rvq_pack(cb.detach())
+            uniform = min(self.codebook_sizes) == self.codebook_size
+            self._packed = ops.rvq_pack(cb.detach(), None if uniform else self.codebook_sizes)
             self._packed_key = key
         return self._packed
 
@@ -142,13 +148,14 @@ class ResidualQuantizer(nn.Module):
         cb = self.codebooks.data
         for q in range(index.shape[1]):
             idx = index[:, q]
-            counts = torch.bincount(idx, minlength=self.codebook_size).to(cb.dtype)
+            counts = torch.bincount(idx, minlength=self.codebook_size).to(cb.dtype)     # (padding rows are never hit)
             sums = torch.zeros_like(cb[q]).index_add_(0, idx, residual)
             self.cluster_frequency[q].mul_(self.ema_decay).add_(counts, alpha=1 - self.ema_decay)
             if self.quantizer_class != "base":
                 self.ema_sum[q].mul_(self.ema_decay).add_(sums, alpha=1 - self.ema_decay)
                 denom = self.cluster_frequency[q].clamp_min(1e-5).unsqueeze(1)
                 cb[q].copy_(self.ema_sum[q] / denom)
+                cb[q, self.codebook_sizes[q]:] = 0.0
             residual = residual - cb[q][idx]
         self.codebooks._version  # noqa: B018  (in-place copy_ above bumps the version -> repack)
 
@@ -167,6 +174,8 @@ class ResidualQuantizer(nn.Module):
         cb[0].copy_(frames[pick] + 0.1 * sigma * noise[0])
         for q in range(1, self.num_quantizers):
             cb[q].copy_(noise[q] * (sigma * decay ** q))
+        for q, kq in enumerate(self.codebook_sizes):
+            cb[q, kq:] = 0.0
         # keep the EMA statistics consistent with the new codewords (codebook = ema_sum / frequency)
         self.cluster_frequency.fill_(1.0)
         self.ema_sum.copy_(cb)
@@ -174,7 +183,8 @@ class ResidualQuantizer(nn.Module):
 
     def get_stale_clusters(self) -> List[int]:
         """Number of codewords per stage whose EMA usage fell below the cutoff."""
-        return [int((self.cluster_frequency[q] < self.vq_cutoff_freq).sum()) for q in range(self.num_quantizers)]
+        return [int((self.cluster_frequency[q][:self.codebook_sizes[q]] < self.vq_cutoff_freq).sum())
+                for q in range(self.num_quantizers)]
 
     def update_cutoff(self, new_cutoff=None, ratio=None):
         if new_cutoff is not None:

@@ -529,13 +529,13 @@ class CausalVQAE(nn.Module):
         """Waveform -> (uint8 bitstream, (B, T, Q)).  ceil(log2(K)) bits per code, dense."""
         with torch.no_grad():
             _, _, index = self.encode(x, codebook_n=codebook_n)
-        bits = max(1, (int(self.codebook_size[0]) - 1).bit_length())
+        bits = max(1, (max(int(k) for k in self.codebook_size) - 1).bit_length())   # every stage at the widest stage's width
         return ops.codes_pack(index, bits), tuple(index.shape)
 
     def decompress(self, stream, shape):
         """Inverse of ``compress``: bitstream -> codes -> sum of codewords -> decoder."""
         b, t, q = shape
-        bits = max(1, (int(self.codebook_size[0]) - 1).bit_length())
+        bits = max(1, (max(int(k) for k in self.codebook_size) - 1).bit_length())   # every stage at the widest stage's width
         index = ops.codes_unpack(stream, b * t * q, bits).reshape(b, t, q)
         with torch.no_grad():
             zq = None

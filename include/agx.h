@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AGX_VERSION 111 /* 0.1.1: agx_conv_desc gained groups / padding (zero = old behaviour); 111: resample, conv2d column split */
+#define AGX_VERSION 112 /* 0.1.1: agx_conv_desc gained groups / padding (zero = old behaviour); 111: resample, conv2d column split */
 
 #define AGX_OK 0
 #define AGX_ERR_BAD_SHAPE (-1)
@@ -183,6 +183,11 @@ int agx_resblock_forward(const agx_conv_desc *d, const float *x, const float *pa
 int64_t agx_rvq_packed_floats(int32_t n_q, int32_t k, int32_t dim);
 int agx_rvq_pack(const float *codebooks /* (Q,K,D) */, int32_t n_q, int32_t k, int32_t dim,
                  float *packed, void *stream);
+/* The same for stages with different codebook sizes (the reference takes one size per quantizer, vae.py:233):
+ * codebooks is (Q, K, D) with K = the largest stage, sizes[q] <= K (HOST array, NULL = all K) the number of real
+ * codewords of stage q; rows beyond it are padding that agx_rvq_forward can never select.  Q <= 64. */
+int agx_rvq_pack_sized(const float *codebooks, const int32_t *sizes, int32_t n_q, int32_t k, int32_t dim, float *packed,
+                       void *stream);
 
 /* Nearest-codeword search over q_used residual stages.
  *   x, xq   : frames, element (b,t,d) at  b*stride_b + t*stride_t + d*stride_d

@@ -104,7 +104,7 @@ def fast_search(frames: np.ndarray, codebook: np.ndarray, score_dtype=torch.floa
 
 
 def residual_quantize(x: Tensor, codebooks: Tensor, codebook_n: Optional[int] = None,
-                      method: str = "fast", score_dtype=torch.float64
+                      method: str = "fast", score_dtype=torch.float64, sizes=None
                       ) -> Tuple[Tensor, Tensor, Tensor]:
     """RVQ forward in eval mode.
 
@@ -113,6 +113,8 @@ def residual_quantize(x: Tensor, codebooks: Tensor, codebook_n: Optional[int] = 
       index (B,T,Q_used) int64,
       commit loss (scalar f32) = sum over stages of mean((r_in - c_sel)^2),
         accumulated in float64 (the GPU side is compared with a tolerance).
+    ``sizes[q]`` (optional): stage q searches only its first sizes[q] codewords -- one codebook size per
+    quantizer (the reference's ``codebook_size`` tuple, vae.py:233) stored in a (Q, max K, D) tensor.
     """
     q_total, k, d = codebooks.shape
     q_used = q_total if codebook_n is None else max(0, min(int(codebook_n), q_total))
@@ -123,7 +125,7 @@ def residual_quantize(x: Tensor, codebooks: Tensor, codebook_n: Optional[int] = 
     commit = 0.0
     cbs = codebooks.detach().to(torch.float32).contiguous().numpy()
     for q in range(q_used):
-        cb = np.ascontiguousarray(cbs[q])
+        cb = np.ascontiguousarray(cbs[q] if sizes is None else cbs[q][:int(sizes[q])])
         if method == "exact":
             idx = exact_search(frames, cb)
         else:

@@ -212,6 +212,37 @@ def test_rvq_large_codebook_and_wide_frames():
     _rvq_case(1, 33, 544, 96, 2, seed=22)
 
 
+def test_rvq_one_codebook_size_per_stage():
+    """The reference's per-quantizer ``codebook_size`` tuple (vae.py:233): stages of 1024 / 300 / 37 / 512 codewords in
+    one (Q, 1024, D) tensor whose padding rows are poisoned -- they must never be selected, and the result must be the
+    oracle's search over the real codewords only (bit-exact indices), also with duplicate codewords (ties -> the full
+    defining search, which must stop at the stage's own size)."""
+    torch.manual_seed(31)
+    sizes = (1024, 300, 37, 512)
+    q, k, d = len(sizes), 1024, 64
+    cbs = torch.randn(q, k, d)
+    for i, kq in enumerate(sizes):
+        cbs[i] *= 0.7 ** i
+        cbs[i, kq:] = 0.0            # what the module stores there; exactly the mean-ish region a careless search would pick
+    cbs[2, :37] = cbs[2, :1].clone() + 1e-3 * torch.randn(37, d)      # a crowded stage: many candidates per frame
+    cbs[2, 5] = cbs[2, 3]                                              # and an exact duplicate
+    x = torch.randn(3, 70, d)
+    want_q, want_i, want_c = rvq.residual_quantize(x, cbs, sizes=sizes)
+    packed = ops.rvq_pack(cbs.to(DEV), sizes)
+    xq, idx, sq = ops.rvq_forward(x.to(DEV), cbs.to(DEV), packed, q)
+    assert torch.equal(idx.cpu(), want_i)
+    for i, kq in enumerate(sizes):
+        assert int(idx[..., i].max()) < kq
+    assert torch.equal(xq.cpu(), want_q)
+    from audio_generation_amd.quantizer import ResidualQuantizer
+    mod = ResidualQuantizer(num_quantizers=q, dim=d, codebook_sizes=sizes).to(DEV).eval()
+    assert mod.codebook_sizes == sizes and mod.codebooks.shape == (q, 1024, d)
+    assert [tuple(s.codebook.shape) for s in mod.quantizers] == [(kq, d) for kq in sizes]
+    mod.codebooks.data.copy_(cbs.to(DEV))
+    got_q, got_i, _ = mod(x.to(DEV))
+    assert torch.equal(got_i.cpu(), want_i) and torch.equal(got_q.cpu(), want_q)
+
+
 def test_rvq_ties_duplicates_and_truncation():
     _rvq_case(2, 40, 64, 128, 4, seed=8, dup=True)
     _rvq_case(2, 40, 64, 128, 4, seed=9, q_used=2)
