@@ -63,8 +63,11 @@ class _SNConv(nn.Module):
             self.weight_orig = conv.weight_orig
             self.register_buffer("weight_u", conv.weight_u.detach().clone())
             self.register_buffer("weight_v", conv.weight_v.detach().clone())
-        elif norm == "weight":
-            raise NotImplementedError("weight-normalised discriminators are not wired (the reference default is spectral)")
+        elif norm == "weight":      # add_util_norm(conv, "weight") = old-style torch.nn.utils.weight_norm (utils.py:34-42)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                conv = nn.utils.weight_norm(conv)
+            self.bias, self.weight_g, self.weight_v = conv.bias, conv.weight_g, conv.weight_v
         else:
             self.bias, self.weight = conv.bias, conv.weight
         self._key, self._packed, self._iter = None, None, 0
@@ -74,7 +77,30 @@ class _SNConv(nn.Module):
 
     @property
     def raw_weight(self) -> Tensor:
-        return self.weight_orig if self.norm == "spectral" else self.weight
+        """The tensor the kernels pack: weight_orig (spectral: 1 / sigma is folded in by the pack kernel), the plain
+        weight, or -- weight norm, a non-default option -- g v / |v| formed by a few ATen ops on the parameters."""
+        if self.norm == "spectral":
+            return self.weight_orig
+        if self.norm == "weight":
+            key = (self.weight_g._version, self.weight_v._version, self.weight_g.data_ptr(), self.weight_v.data_ptr())
+            if getattr(self, "_wn_key", None) != key:
+                with torch.no_grad():
+                    self._wn_w = torch._weight_norm(self.weight_v, self.weight_g, 0).contiguous()
+                self._wn_key = key
+            return self._wn_w
+        return self.weight
+
+    def _finish_grads(self, gl):
+        """[dbias?, dW] -> the gradients of grad_params(): the weight-norm chain rule on the (small) weight tensors,
+        dg = <dW, v> / |v|, dv = (g / |v|) (dW - v <dW, v> / |v|^2) per output channel."""
+        if self.norm != "weight":
+            return gl
+        dw = gl[-1]
+        v, g = self.weight_v.detach(), self.weight_g.detach()
+        dims = tuple(range(1, v.dim()))
+        nrm = v.norm(2, dim=dims, keepdim=True)
+        dot = (dw * v).sum(dim=dims, keepdim=True)
+        return list(gl[:-1]) + [dot / nrm, (g / nrm) * (dw - v * dot / (nrm * nrm))]
 
     def _sigma(self) -> Optional[Tensor]:
         if self.norm != "spectral":
@@ -88,7 +114,7 @@ class _SNConv(nn.Module):
         the power iteration moves sigma)."""
         w = self.raw_weight
         key = (w.data_ptr(), w._version, self.training, self._iter, self.impl,
-               None if self.norm != "spectral" else (self.weight_u._version, self.weight_v._version))
+               getattr(self, "_wn_key", None) if self.norm != "spectral" else (self.weight_u._version, self.weight_v._version))
         if self.training or key != self._key:
             sigma = self._sigma()
             # what this forward normalised with (the native backward needs exactly these)
@@ -96,11 +122,13 @@ class _SNConv(nn.Module):
             desc = make_desc()
             self._packed = pack_plain(desc, w.detach()) if sigma is None else pack_sigma(desc, w.detach(), sigma)
             self._key = (w.data_ptr(), w._version, self.training, self._iter, self.impl,
-                         None if self.norm != "spectral" else (self.weight_u._version, self.weight_v._version))
+                         getattr(self, "_wn_key", None) if self.norm != "spectral" else (self.weight_u._version, self.weight_v._version))
         return self._packed
 
     def aten_weight(self) -> Tensor:
         """Differentiable normalised weight from the CURRENT buffers (no power iteration): backward bridge."""
+        if self.norm == "weight":
+            return torch._weight_norm(self.weight_v, self.weight_g, 0)
         if self.norm != "spectral":
             return self.weight
         w = self.weight_orig
@@ -155,7 +183,7 @@ class _SNConv(nn.Module):
                 dx = ops.conv2d_bwd_data_fewchannels(desc, dy, w, sigma, add)
             else:
                 dx = ops.conv2d_bwd_data(desc, dy, ops.conv2d_pack_bwd(desc, w, sigma), mask, slope, add)
-        return dx, ([db, dw] if self.bias is not None else [dw])
+        return dx, self._finish_grads([db, dw] if self.bias is not None else [dw])
 
     def desc1d(self, x: Tensor, slope: Optional[float] = None):
         return ops.conv_desc(CONV_PADDED, x.shape[0], self.in_channels, self.out_channels, x.shape[2],
@@ -179,10 +207,11 @@ class _SNConv(nn.Module):
                 dx = ops.conv_bwd_data(desc, dz, pk, add, mask, slope)
         if sigma is not None:
             ops.spectral_grad_(dw, w, sigma, u, v)
-        return dx, ([db, dw] if self.bias is not None else [dw])
+        return dx, self._finish_grads([db, dw] if self.bias is not None else [dw])
 
     def grad_params(self):
-        return ([self.bias] if self.bias is not None else []) + [self.raw_weight]
+        weights = [self.weight_g, self.weight_v] if self.norm == "weight" else [self.raw_weight]
+        return ([self.bias] if self.bias is not None else []) + weights
 
 
 def set_arithmetic(module: nn.Module, mode: str = "fp32") -> nn.Module:

@@ -494,3 +494,75 @@ def test_conv2d_backward_data_few_input_channels(cin, cout, kh, kw, ph, pw, h, w
     d = ops.conv2d_desc(2, cin, cout, h, w, kh, kw, (1, 1), (ph, pw))
     got = ops.conv2d_bwd_data_fewchannels(d, dy.to(DEV), wt.to(DEV), sigma.to(DEV), extra.to(DEV))
     close(got, x.grad + extra, 2e-5)
+
+
+def test_weight_normalised_discriminators_match_torch():
+    """norm="weight" (add_util_norm's other branch, utils.py:34-42; the default is spectral): forward, loss and every
+    gradient (weight_g / weight_v / bias, and the input) against the same stacks built from torch modules with
+    torch.nn.utils.weight_norm on the CPU."""
+    import warnings
+    torch.manual_seed(3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        wave = ad.WaveFormDiscriminator(1, n_blocks=2, norm="weight").to(DEV).train()
+        stft = ad.STFTDiscriminator(first_channel_size=8, win_length=128, norm="weight").to(DEV).train()
+    assert sorted(k for k in wave.state_dict() if "layers.1" in k and k.startswith("layers.0."))[:3] == \
+        ["layers.0.layers.1.0.bias", "layers.0.layers.1.0.weight_g", "layers.0.layers.1.0.weight_v"]
+    x = (0.3 * torch.randn(2, 1, 32768)).to(DEV)
+    y = (x + 0.05 * torch.randn_like(x)).requires_grad_(True)
+    for disc in (wave, stft):
+        gl, dl = ad.discriminator_generator_loss(x, y, disc)
+        (gl + dl).backward()
+        got = {n: p.grad.detach().cpu().clone() for n, p in disc.named_parameters()}
+        gy = y.grad.detach().cpu().clone()
+        for p in disc.parameters():
+            p.grad = None
+        y.grad = None
+        # reference: the ATen restatement of the same module, differentiated by autograd on the CPU
+        sd = {k: v.detach().cpu() for k, v in disc.state_dict().items()}
+        params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.endswith(("weight_g", "weight_v", "bias"))}
+
+        def wn(prefix):
+            return torch._weight_norm(params[prefix + "weight_v"], params[prefix + "weight_g"], 0)
+
+        def ref_wave(inp):
+            outs, feats = [], []
+            for b in range(2):
+                h = F.avg_pool1d(inp, 2 * 2 ** b, stride=2 ** b, padding=2 ** b)
+                feats.append(h)
+                for i in range(7):
+                    last = i == 6
+                    pre = f"layers.{b}.layers.{i + 1}." + ("" if last else "0.")
+                    h = F.conv1d(h, wn(pre), params[pre + "bias"], stride=od.WAVE_STRIDES[i], groups=od.WAVE_GROUPS[i])
+                    if not last:
+                        h = F.leaky_relu(h, 0.2)
+                    feats.append(h)
+                outs.append(torch.sigmoid(h))
+            return outs, feats
+
+        def ref_stft(inp):
+            h = od.stft_two_sided(inp.squeeze(1), 128, 32, True)
+            h = F.conv2d(h, wn("first_conv."), params["first_conv.bias"], padding=3)
+            feats = [h]
+            for i, stride in enumerate(od.STFT_STRIDES):
+                pre = f"blocks.{i}.layers."
+                h = F.leaky_relu(F.conv2d(h, wn(pre + "0."), params[pre + "0.bias"], padding=1), 0.2)
+                k = (stride[0] + 2, stride[1] + 2)
+                h = F.conv2d(h, wn(pre + "2."), params[pre + "2.bias"], stride=stride, padding=((k[0] - 1) // 2, (k[1] - 1) // 2))
+                feats.append(h)
+            h = F.conv2d(h, wn("final_conv."), params["final_conv.bias"], padding=(0, (128 // 128 - 1) // 2))
+            return [torch.sigmoid(h)], feats
+
+        xc, yc = x.cpu(), y.detach().cpu().requires_grad_(True)
+        rgl, rdl = od.discriminator_generator_loss(xc, yc, ref_wave if disc is wave else ref_stft)
+        (rgl + rdl).backward()
+        assert abs(float(gl) - float(rgl)) <= 2e-4 * abs(float(rgl)) and abs(float(dl) - float(rdl)) <= 2e-4 * abs(float(rdl))
+        # (the L1 feature loss makes these gradients ill-conditioned -- sign flips of near-zero differences -- so: direction
+        # to 1e-4, element-wise to 5 % of the largest entry (as in the bf16x3 comparison above); the per-kernel tests above carry the tight tolerances)
+        def same(a, b):
+            a, b = a.double().flatten().cpu(), b.double().flatten()
+            assert float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-300)) > 0.9999
+            close(a.float(), b.float(), 5e-2)
+        same(gy, yc.grad)
+        for n, g in got.items():
+            same(g, params[n].grad)
