@@ -63,10 +63,17 @@ def test_backward_data_residual_and_activation_gradient():
     assert max_abs(dx.cpu(), want) < 3e-5 * max(1.0, float(want.abs().max()))
 
 
+# longer rows (the DMA path of the barrier-free kernel over many interior chunks of the phase-split copies), odd
+# strides with a dilation, lengths that are no multiple of the stride, a single-chunk row
+DW_EXTRA = [("conv", 32, 64, 5, 2, 1, 3, 5001), ("conv", 24, 40, 7, 3, 2, 2, 3001), ("conv", 64, 128, 9, 4, 1, 1, 4100),
+            ("upconv", 64, 32, 5, 2, 1, 2, 2100), ("convt", 32, 16, 9, 4, 1, 2, 1500), ("conv", 16, 16, 3, 5, 1, 2, 31),
+            ("conv", 160, 130, 3, 1, 2, 1, 2050), ("upconv", 40, 24, 7, 3, 1, 1, 999)]
+
+
 def test_backward_weight_bias_and_weight_norm_match_autograd():
     gen = torch.Generator().manual_seed(33)
     checked = 0
-    for (kind, cin, cout, k, s, d, b, length) in SHAPES:
+    for (kind, cin, cout, k, s, d, b, length) in SHAPES + DW_EXTRA:
         wshape = (cin, cout, k) if kind == "convt" else (cout, cin, k)
         v = (torch.randn(wshape, generator=gen) / (cin * k) ** 0.5).requires_grad_(True)
         g = (torch.rand((wshape[0], 1, 1), generator=gen) + 0.5).requires_grad_(True)
@@ -93,7 +100,7 @@ def test_backward_weight_bias_and_weight_norm_match_autograd():
         dw3, _, _ = ops.conv_bwd_weight(desc3, x.to(DEV), dy.to(DEV), w_plain.detach().to(DEV), None, want_bias=False)
         assert max_abs(dw3.cpu(), want_w) < 2e-4 * max(1.0, float(want_w.abs().max())), (kind, cin, cout, k, s, d)
         checked += 1
-    assert checked == len(SHAPES)
+    assert checked == len(SHAPES) + len(DW_EXTRA)
 
 
 @pytest.mark.parametrize("channelwise", [True, False])
