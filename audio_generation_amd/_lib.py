@@ -42,6 +42,8 @@ _P2 = POINTER(Conv2dDesc)
 SIGNATURES = {
     "agx_version": (c_int, []),
     "agx_last_error": (c_char_p, []),
+    "agx_sizeof_conv_desc": (c_int32, []),
+    "agx_sizeof_conv2d_desc": (c_int32, []),
     "agx_set_tuning": (c_int, [c_char_p, c_int32]),
     "agx_get_tuning": (c_int, [c_char_p]),
     "agx_conv_out_len": (c_int64, [_PD]),
@@ -164,6 +166,10 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError if the ABI and the header drifted apart
         fn.restype = res
         fn.argtypes = args
+    if (lib.agx_sizeof_conv_desc() != ctypes.sizeof(ConvDesc)
+            or lib.agx_sizeof_conv2d_desc() != ctypes.sizeof(Conv2dDesc)):
+        raise AgxError("libagx.so was built from a different include/agx.h than this binding (descriptor sizes differ): "
+                       "rebuild with `python -m audio_generation_amd.build`")
     for kv in filter(None, os.environ.get("AGX_TUNING", "").split(",")):     # measurement knobs, e.g. AGX_TUNING=dw_wgs=768
         name, _, value = kv.partition("=")
         if lib.agx_set_tuning(name.strip().encode(), int(value)) != 0:

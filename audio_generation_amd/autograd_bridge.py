@@ -1,4 +1,4 @@
-"""Fallback trainability: HIP forward, ATen backward.
+"""Fallback trainability: HIP forward, ATen backward -- FENCED: it raises unless ``AGX_ALLOW_ATEN_BRIDGE=1``.
 
 Every default path has hand-written backward kernels now (native_backward.py, transformers.py,
 discriminator.py); this bridge is what remains for the shapes they do not cover (attention head_dim > 64,
@@ -17,11 +17,22 @@ the drop-in modules; gradients are checked against the oracle's autograd in
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Sequence
 
 import torch
 
+from ._lib import AgxError
+
 Tensor = torch.Tensor
+
+
+def require_allowed(what: str) -> None:
+    """The bridge differentiates an ATen restatement (MIOpen / rocBLAS kernels, not this library's).  It must
+    never be reached silently: opt in with ``AGX_ALLOW_ATEN_BRIDGE=1``."""
+    if os.environ.get("AGX_ALLOW_ATEN_BRIDGE", "0") != "1":
+        raise AgxError(f"{what}: no native backward kernel covers this configuration; the ATen backward bridge is "
+                       "disabled by default (set AGX_ALLOW_ATEN_BRIDGE=1 to differentiate the ATen restatement instead)")
 
 
 class _HipForwardAtenBackward(torch.autograd.Function):
@@ -49,6 +60,7 @@ class _HipForwardAtenBackward(torch.autograd.Function):
 def hip_forward_aten_backward(hip_fn: Callable, aten_fn: Callable, x: Tensor, params: Sequence[Tensor]) -> Tensor:
     """``hip_fn(x)`` with a backward defined by differentiating ``aten_fn(x)``.
     ``params`` are the parameters ``aten_fn`` reads (so that their gradients flow)."""
+    require_allowed(getattr(hip_fn, "__qualname__", "hip_forward_aten_backward"))
     return _HipForwardAtenBackward.apply(hip_fn, aten_fn, x, *params)
 
 

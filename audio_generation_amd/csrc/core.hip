@@ -211,6 +211,8 @@ int lower_conv_bwd_data(const agx_conv_desc *d, ConvPlan *b) {
 extern "C" {
 
 int agx_version(void) { return AGX_VERSION; }
+int32_t agx_sizeof_conv_desc(void) { return (int32_t)sizeof(agx_conv_desc); }
+int32_t agx_sizeof_conv2d_desc(void) { return (int32_t)sizeof(agx_conv2d_desc); }
 
 const char *agx_last_error(void) { return agx::last_error(); }
 

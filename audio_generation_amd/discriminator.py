@@ -31,7 +31,7 @@ from torch import nn
 
 from . import ops
 from ._lib import CONV_PADDED, EPI_LEAKY_PRE, IMPL_AUTO, IMPL_MFMA_BF16X3
-from .autograd_bridge import needs_grad
+from .autograd_bridge import needs_grad, require_allowed
 from .quantizer import tuple_checker
 
 Tensor = torch.Tensor
@@ -265,6 +265,7 @@ class _MultiOutBridge(torch.autograd.Function):
 def _run_bridged(module: nn.Module, x: Tensor, hip_fn, aten_fn, n_out: int) -> Tuple[List[Tensor], List[Tensor]]:
     """``hip_fn(x) -> outs + feats`` (flat list); differentiable when a gradient is needed."""
     if needs_grad(x, module):
+        require_allowed(type(module).__name__ + " with an activation other than LeakyReLU")
         flat = _MultiOutBridge.apply(module, hip_fn, aten_fn, x, *list(module.parameters()))
     else:
         flat = hip_fn(x)

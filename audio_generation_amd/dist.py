@@ -3,9 +3,11 @@
 
 The codec forward shards over the batch with **no data-path collective**: every
 item is independent through encoder, RVQ search and decoder.  The
-only exchange step of the whole system is the gradient all-reduce of a training
-step, provided here as one flattened bucket (``allreduce_mean_``) so that the
-~200 small weight-norm tensors travel as a single RCCL call.
+exchange steps of the whole system belong to a training step: the gradient
+all-reduce, one flat bucket allocated once (``GradBucket``: the ~200 small
+weight-norm tensors travel as a single in-place RCCL call), and -- with
+``update_codebook=True`` -- one all-reduce of the RVQ's per-code counts and sums
+(``allreduce_sum_``, called from ``quantizer._ema_update``).
 """
 from __future__ import annotations
 
@@ -62,9 +64,34 @@ def sum_over_ranks(value: float, device="cpu") -> float:
     return float(t.item())
 
 
+def allreduce_sum_(t: torch.Tensor) -> None:
+    """In-place sum over ranks (no-op for one rank).  Used for the RVQ's per-code counts and sums."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        if t.is_cuda and dist.get_backend() == "gloo":
+            host = t.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            t.copy_(host)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
+def broadcast_(tensors: Iterable[torch.Tensor], src: int = 0) -> None:
+    """In-place broadcast of a list of tensors from ``src`` (no-op for one rank)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    for t in tensors:
+        if t.is_cuda and dist.get_backend() == "gloo":
+            host = t.cpu()
+            dist.broadcast(host, src=src)
+            t.copy_(host)
+        else:
+            dist.broadcast(t, src=src)
+
+
 def allreduce_mean_(tensors: Iterable[torch.Tensor]) -> None:
     """In-place mean over ranks of a list of same-dtype tensors through ONE
-    flattened bucket (one collective instead of one per tensor)."""
+    flattened bucket (one collective instead of one per tensor).  One-off form: it
+    concatenates and copies back; a training loop uses ``GradBucket`` instead."""
     tensors = [t for t in tensors if t is not None]
     if not tensors or not dist.is_initialized():
         return
@@ -76,6 +103,73 @@ def allreduce_mean_(tensors: Iterable[torch.Tensor]) -> None:
         n = t.numel()
         t.copy_(flat[off:off + n].view_as(t))
         off += n
+
+
+class GradBucket:
+    """The gradient exchange step of a data-parallel training step (SURVEY 5 / 8e;
+    ``training.py:380-390`` is the step it sits in): ONE flat fp32 buffer allocated at
+    init, every parameter's ``.grad`` a view into it, so the all-reduce is a single
+    in-place RCCL call on memory the backward kernels wrote directly -- no ``cat``,
+    no copy-back, nothing allocated per step.
+
+    ``allreduce_mean_()`` after the backward; ``zero_()`` instead of
+    ``optimizer.zero_grad()`` (which must not replace the views: call it with
+    ``set_to_none=False`` or not at all).  Several buckets (generator, each
+    discriminator) can be reduced on their own as soon as their backward is done.
+    """
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("GradBucket: no trainable parameter")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        offs, n = [], 0
+        for p in self.params:
+            if p.device != dev or p.dtype != dt:
+                raise ValueError("GradBucket: parameters must share device and dtype")
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4       # 16-byte aligned views (float4 stores of the dW kernels)
+        self.flat = torch.zeros(n, dtype=dt, device=dev)
+        for p, o in zip(self.params, offs):
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
+
+    def intact(self) -> bool:
+        """True while every ``.grad`` still aliases the bucket (an optimizer's ``zero_grad(set_to_none=True)``
+        or a ``p.grad = ...`` assignment breaks it)."""
+        lo = self.flat.data_ptr()
+        hi = lo + self.flat.numel() * self.flat.element_size()
+        return all(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in self.params)
+
+    def zero_(self) -> None:
+        self.flat.zero_()
+
+    def allreduce_mean_(self) -> None:
+        if not self.intact():
+            raise RuntimeError("GradBucket: a parameter's .grad no longer aliases the bucket "
+                               "(use bucket.zero_() or zero_grad(set_to_none=False))")
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            if self.flat.is_cuda and dist.get_backend() == "gloo":      # CPU rehearsal of the RCCL step
+                host = self.flat.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                self.flat.copy_(host)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(dist.get_world_size())
+
+
+def replica_checksums(module: torch.nn.Module) -> Tuple[float, float]:
+    """(min, max) over ranks of a checksum of ALL state -- parameters and buffers (the RVQ's EMA codebooks,
+    sums and frequencies are buffers).  Replicas are in sync iff min == max."""
+    chk = torch.zeros((), dtype=torch.float64)
+    for t in list(module.parameters()) + list(module.buffers()):
+        chk = chk + t.detach().double().abs().sum().cpu()
+    if not dist.is_initialized():
+        return float(chk), float(chk)
+    dev = next(module.parameters()).device if dist.get_backend() == "nccl" else "cpu"
+    lo, hi = chk.clone().to(dev).reshape(1), chk.clone().to(dev).reshape(1)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return float(lo.item()), float(hi.item())
 
 
 def gather_index_shards(index: torch.Tensor) -> List[torch.Tensor]:

@@ -141,23 +141,49 @@ class ResidualQuantizer(nn.Module):
         return self._quantize(x, "b l c", codebook_n, update_codebook)
 
     # --------------------------------------------------------- training bookkeeping
+    def _invalidate_packed(self) -> None:
+        """Drop the packed search image (centred transposed codewords, |c'|^2, cmax, mu).  Every writer of the
+        codebooks calls this: writes through ``.data`` do not move ``codebooks._version``."""
+        self._packed = None
+        self._packed_key = None
+
     @torch.no_grad()
     def _ema_update(self, frames: Tensor, index: Tensor) -> None:
-        """Plain EMA k-means update per stage (build-defined; see module docstring)."""
+        """Plain EMA k-means update per stage (build-defined; see module docstring).
+
+        Data parallel (the reference toggles ``update_codebook`` inside the step,
+        training.py:305-308, 326): the per-code assignment counts (K,) and residual sums (K,D) of all
+        stages travel in ONE all-reduce (sum over ranks), so every replica applies the same global-batch
+        statistics and the codebooks stay bit-identical across ranks."""
+        from . import dist as agx_dist
+        q_used = index.shape[1]
         residual = frames.clone()
-        cb = self.codebooks.data
-        for q in range(index.shape[1]):
+        cb = self.codebooks.detach()            # shares storage and version counter with the module's tensor
+        stats = torch.zeros(q_used, self.codebook_size, self.dim + 1, dtype=cb.dtype, device=cb.device)
+        for q in range(q_used):
             idx = index[:, q]
-            counts = torch.bincount(idx, minlength=self.codebook_size).to(cb.dtype)     # (padding rows are never hit)
-            sums = torch.zeros_like(cb[q]).index_add_(0, idx, residual)
+            stats[q, :, 0] = torch.bincount(idx, minlength=self.codebook_size).to(cb.dtype)  # padding rows: never hit
+            stats[q, :, 1:].index_add_(0, idx, residual)
+            # the forward that chose index[:, q+1] saw the residual against the PRE-update codeword
+            residual = residual - cb[q][idx]
+        agx_dist.allreduce_sum_(stats)
+        for q in range(q_used):
+            counts, sums = stats[q, :, 0], stats[q, :, 1:]
             self.cluster_frequency[q].mul_(self.ema_decay).add_(counts, alpha=1 - self.ema_decay)
             if self.quantizer_class != "base":
                 self.ema_sum[q].mul_(self.ema_decay).add_(sums, alpha=1 - self.ema_decay)
                 denom = self.cluster_frequency[q].clamp_min(1e-5).unsqueeze(1)
                 cb[q].copy_(self.ema_sum[q] / denom)
                 cb[q, self.codebook_sizes[q]:] = 0.0
-            residual = residual - cb[q][idx]
-        self.codebooks._version  # noqa: B018  (in-place copy_ above bumps the version -> repack)
+        self._invalidate_packed()
+
+    @torch.no_grad()
+    def sync_from_rank0(self) -> None:
+        """Broadcast codebooks and EMA statistics from rank 0 (after ``init_from_latents`` on per-rank shards,
+        or after loading a checkpoint on one rank)."""
+        from . import dist as agx_dist
+        agx_dist.broadcast_([self.codebooks.detach(), self.cluster_frequency, self.ema_sum])
+        self._invalidate_packed()
 
     @torch.no_grad()
     def init_from_latents(self, z: Tensor, seed: int = 7, decay: float = 0.6) -> float:
@@ -170,7 +196,7 @@ class ResidualQuantizer(nn.Module):
         sigma = float((frames - frames.mean(dim=0, keepdim=True)).std())
         pick = torch.randint(0, frames.shape[0], (self.codebook_size,), generator=gen).to(frames.device)
         noise = torch.randn(self.num_quantizers, self.codebook_size, self.dim, generator=gen).to(frames.device)
-        cb = self.codebooks.data
+        cb = self.codebooks.detach()
         cb[0].copy_(frames[pick] + 0.1 * sigma * noise[0])
         for q in range(1, self.num_quantizers):
             cb[q].copy_(noise[q] * (sigma * decay ** q))
@@ -179,7 +205,24 @@ class ResidualQuantizer(nn.Module):
         # keep the EMA statistics consistent with the new codewords (codebook = ema_sum / frequency)
         self.cluster_frequency.fill_(1.0)
         self.ema_sum.copy_(cb)
+        self._invalidate_packed()
         return sigma
+
+    @torch.no_grad()
+    def init_randn(self, sigma: float, seed: int = 7) -> None:
+        """SURVEY 8(d)'s synthetic codebooks: ``randn(Q,K,D) * sigma`` from seed 7."""
+        gen = torch.Generator().manual_seed(seed)
+        cb = self.codebooks.detach()
+        cb.copy_((torch.randn(self.num_quantizers, self.codebook_size, self.dim, generator=gen) * sigma).to(cb.device))
+        for q, kq in enumerate(self.codebook_sizes):
+            cb[q, kq:] = 0.0
+        self.cluster_frequency.fill_(1.0)
+        self.ema_sum.copy_(cb)
+        self._invalidate_packed()
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self._invalidate_packed()
 
     def get_stale_clusters(self) -> List[int]:
         """Number of codewords per stage whose EMA usage fell below the cutoff."""

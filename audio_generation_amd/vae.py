@@ -71,18 +71,21 @@ class _ConvParams(nn.Module):
         w = torch.empty(shape)
         nn.init.kaiming_uniform_(w, a=math.sqrt(5))
         fan_in = shape[1] * kernel
+        bias_p = None
+        if bias:
+            bound = 1.0 / math.sqrt(fan_in)
+            bias_p = nn.Parameter(torch.empty(c_out).uniform_(-bound, bound))
         if norm == "weight":
+            # registration order of torch's weight_norm(Conv1d): bias, weight_g, weight_v -- ``parameters()`` order is
+            # what an index-based optimizer state of the reference (trainer_state.pkl, training.py:225-242) refers to
+            self.register_parameter("bias", bias_p)
             self.weight_g = nn.Parameter(w.reshape(shape[0], -1).norm(dim=1).reshape(-1, 1, 1))
             self.weight_v = nn.Parameter(w)
         elif norm == "spectral":
             raise NotImplementedError("spectral norm is only used by the discriminators (out of scope)")
         else:
             self.weight = nn.Parameter(w)
-        if bias:
-            bound = 1.0 / math.sqrt(fan_in)
-            self.bias = nn.Parameter(torch.empty(c_out).uniform_(-bound, bound))
-        else:
-            self.register_parameter("bias", None)
+            self.register_parameter("bias", bias_p)
         self._packed: Optional[Tensor] = None
         self._packed_key = None
 

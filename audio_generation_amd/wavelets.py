@@ -23,6 +23,7 @@ from torch import nn
 
 from . import ops
 from ._lib import CONV_CAUSAL, CONV_SAME, EPI_GELU_PRE, EPI_LEAKY_PRE
+from .autograd_bridge import hip_forward_aten_backward, needs_grad
 
 Tensor = torch.Tensor
 
@@ -44,8 +45,24 @@ class CausalMultiresConv1d(nn.Module):
         self.w = nn.Parameter(torch.empty(channels, depth + 2).uniform_(-1., 1.) * sqrt(2.0 / (2 * depth + 4)))
         self.dropout_layer = nn.Dropout(dropout)
 
-    def forward(self, x: Tensor) -> Tensor:
+    def _hip(self, x: Tensor) -> Tensor:
         return ops.multires_forward(x, self.h0.detach(), self.h1.detach(), self.w.detach(), self.depth)
+
+    def _aten(self, x: Tensor) -> Tensor:
+        """ATen restatement of wavelets.py:79-96 for the fenced backward bridge only (autograd_bridge.py)."""
+        def dw(t, h, dil):
+            return F.conv1d(F.pad(t, (dil * (self.kernel_size - 1), 0)), h, dilation=dil, groups=self.channels)
+        low, y, dil = x, torch.zeros_like(x), 1
+        for i in range(self.depth, 0, -1):
+            y = y + self.w[:, i:i + 1] * dw(low, self.h1, dil)
+            low = dw(low, self.h0, dil)
+            dil *= 2
+        return F.gelu(y + self.w[:, :1] * low + self.w[:, -1:] * x)
+
+    def forward(self, x: Tensor) -> Tensor:
+        if needs_grad(x, self):     # no native backward for this layer (the reference never instantiates it, vae.py:7)
+            return hip_forward_aten_backward(self._hip, self._aten, x, [self.h0, self.h1, self.w])
+        return self._hip(x)
 
 
 class _PlainConv(nn.Module):
@@ -95,9 +112,18 @@ class MultiresScaleBlock(nn.Module):
         self.multires_conv = CausalMultiresConv1d(in_channels, kernel_size, multires_depth, dropout, activation)
         self.conv = _PlainConv(in_channels, out_channels, 1)
 
-    def forward(self, x: Tensor) -> Tensor:
-        y = self.conv.run(self.multires_conv(x), CONV_CAUSAL, EPI_GELU_PRE)
+    def _hip(self, x: Tensor) -> Tensor:
+        y = self.conv.run(self.multires_conv._hip(x), CONV_CAUSAL, EPI_GELU_PRE)
         return y.repeat_interleave(self.scale_factor, dim=-1)
+
+    def _aten(self, x: Tensor) -> Tensor:
+        y = self.multires_conv._aten(x).repeat_interleave(self.scale_factor, dim=-1)
+        return F.gelu(F.conv1d(y, self.conv.weight, self.conv.bias))
+
+    def forward(self, x: Tensor) -> Tensor:
+        if needs_grad(x, self):
+            return hip_forward_aten_backward(self._hip, self._aten, x, list(self.parameters()))
+        return self._hip(x)
 
 
 class WaveletLayer(nn.Module):

@@ -80,8 +80,9 @@ class LaunchTimer:
         if kind == "rvq":
             b, t, d, k, q = info
             name, work = "rvq_forward", (b * t * q * k * d, b * t * q * k * d, 4 * b * t * d * 2 + 8 * b * t * q)
-        elif kind == "other":
-            name, work = info[0], (0, 0, info[1])
+        elif kind == "other":           # (name, algorithmic bytes[, MACs])
+            macs = info[2] if len(info) > 2 else 0
+            name, work = info[0], (macs, macs, info[1])
         elif kind == "resblock":
             name = ops.resblock_kernel_name(info)
             e1_, r1_, _ = conv_work(info)
@@ -117,6 +118,30 @@ class LaunchTimer:
         return per
 
 
+def encoder_roofline(model, x, bsz, enc_bytes, reps=10):
+    """The conv encoder on its own (north_star: '>= 40 % HBM-bandwidth roofline on the conv encoder'): HIP events
+    around ``reps`` eager encoder passes (30 convs in 18 launches), against BOTH ceilings -- the fp32 matrix pipe
+    on the executed FLOPs (390.4 kFLOP/sample) and HBM on SURVEY 8(d)'s layer-boundary byte model (4 864 B/sample).
+    In fp32 the FLOP ceiling binds first: 157.3 TFLOP/s / 390.4 kFLOP = 403 Msamples/s = 24.5 % of HBM on that model."""
+    with torch.no_grad():
+        for _ in range(2):
+            model._run_encoders(x)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            model._run_encoders(x)
+        e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    rate = bsz * CLIP / (1e-3 * ms)
+    flop_per_sample = 2.0 * 195194          # SURVEY 2.1: 14 053.9 MMAC per 72 000-sample item
+    tflops = rate * flop_per_sample * 1e-12
+    return {"ms": ms, "samples_per_s": rate, "tflops": tflops, "frac_of_fp32_peak": tflops / PEAK_FP32_TFLOPS,
+            "layer_boundary_GBps": rate * enc_bytes * 1e-9, "frac_of_hbm_peak": rate * enc_bytes * 1e-9 / PEAK_HBM_GBPS,
+            "hbm_frac_ceiling_in_fp32": PEAK_FP32_TFLOPS * 1e12 / flop_per_sample * enc_bytes * 1e-9 / PEAK_HBM_GBPS,
+            "bytes_per_sample_model": enc_bytes, "launch": "eager"}
+
+
 # ----------------------------------------------------------------------------- main
 def make_inputs(batch, rank):
     gen = torch.Generator().manual_seed(1234 + rank)   # SURVEY 8d
@@ -130,11 +155,33 @@ def build_model(dev):
     return model.to(dev)
 
 
-def calibrate_codebooks(model, x_small):
-    """Codebooks at the scale and location of the encoder output so that the arg-min is
-    non-degenerate: stage 0 = latent frames + noise, later stages shrinking randn."""
+def calibrate_codebooks(model, x_small, recipe):
+    """Synthetic codebooks.  ``survey``: the letter of 8(d) -- ``randn(Q,K,D) * sigma``, seed 7, sigma =
+    std of the encoder output measured in the same run.  ``latents``: stage 0 = latent frames of the first clips +
+    noise, later stages shrinking randn (what a k-means-initialised quantiser looks like: the arg-min is spread
+    over hundreds of codes instead of the few nearest to the latents' common offset)."""
     with torch.no_grad():
-        return model.quantizer.init_from_latents(model._run_encoders(x_small), seed=7)
+        z = model._run_encoders(x_small)
+        if recipe == "survey":
+            sigma = float(z.std())
+            model.quantizer.init_randn(sigma, seed=7)
+            return sigma
+        return model.quantizer.init_from_latents(z, seed=7)
+
+
+def pmc_entry(pmc, dom_name):
+    """Entry of profiles/pmc_traffic.json for a kernel the observer names ``stem<a,b,c>[:bf16x3]``.  The PMC names
+    carry the full template list ``stem<a,b,c,...,IMPL>`` whose LAST argument is the arithmetic (0 = fp32 MFMA,
+    1 = bf16x3): match the stem AND that suffix, never the first prefix hit."""
+    bf = dom_name.endswith(":bf16x3")
+    stem = dom_name.replace("2x:", "").replace(":bf16x3", "").rstrip(">")
+    want = "1" if bf else "0"
+    for k in pmc:
+        if k == stem + ">":
+            return k
+        if k.startswith(stem + ",") and k.rstrip(">").rsplit(",", 1)[1] == want:
+            return k
+    return None
 
 
 def cpu_baseline_and_parity(model, x_cpu, y_gpu, idx_gpu, z_gpu, n_items):
@@ -193,6 +240,9 @@ def main():
     ap.add_argument("--arith", choices=("fp32", "mixed"), default="fp32",
                     help="arithmetic of the MEASURED configuration: fp32 = fp32-input MFMA everywhere (bitwise an fp32 FMA "
                          "chain); mixed = encoder + RVQ as fp32, decoder on the bf16x3 kernels (fp32-class accuracy)")
+    ap.add_argument("--codebooks", choices=("survey", "latents"), default="survey",
+                    help="synthetic codebook recipe of the measured run (see calibrate_codebooks); the other one is "
+                         "measured as well and reported under other_codebooks")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurement of the other arithmetic")
     args = ap.parse_args()
 
@@ -220,7 +270,7 @@ def main():
     model = build_model(dev)
     x_cpu = make_inputs(bsz, rank)
     x = x_cpu.to(dev)                       # inputs resident in HBM before the timed region
-    sigma = calibrate_codebooks(model, x[:8])
+    sigma = calibrate_codebooks(model, x[:8], args.codebooks)
     if args.arith == "mixed":
         model.set_conv_arithmetic(decoders="bf16x3")
 
@@ -248,6 +298,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = agx_dist.max_over_ranks(time.perf_counter() - t0, device=red_dev)
     y, commit, index = out
+    distinct0 = int(index[..., 0].unique().numel())
 
     ms_per_step = 1e3 * elapsed / args.steps
     total_samples = world * bsz * CLIP * args.steps
@@ -260,7 +311,9 @@ def main():
                    "batch_per_gpu": bsz, "global_batch": bsz * world, "clip_samples": CLIP,
                    "parallelism": f"batch-sharded x{world}, no data-path collective",
                    "launch": "eager" if args.no_graph else "hipGraph replay",
-                   "codebook_sigma": sigma,
+                   "codebooks": ("SURVEY 8(d): randn(Q,K,D) * sigma, seed 7" if args.codebooks == "survey" else
+                                 "stage 0 = latent frames + 0.1 sigma noise, stage q = randn * sigma * 0.6^q, seed 7"),
+                   "codebook_sigma": sigma, "distinct_stage0_codes": distinct0,
                    "arithmetic": ("fp32-input MFMA in every conv (bitwise an fp32 FMA chain), RVQ fp32 scores + exact fp64 re-check"
                                   if args.arith == "fp32" else
                                   "encoder + RVQ as in fp32 mode; decoder convs on the bf16x3 kernels (operands split into three "
@@ -294,10 +347,10 @@ def main():
         # HBM bytes per launch of that kernel from the committed PMC passes (tools/pmc_summary.py)
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
-            stem = dom_name.replace("2x:", "").rstrip(">")   # PMC names carry extra template arguments
-            key = next((k for k in pmc if k == stem + ">" or k.startswith(stem + ",")), None)
+            key = pmc_entry(pmc, dom_name)
             if key is not None:
                 roof["traffic"] = pmc[key]["bytes_per_launch"]
+                roof["traffic_kernel"] = key
                 roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, per launch)"
                 roof["algorithmic_bytes_per_launch"] = dom["bytes"] / dom["launches"]
         except (OSError, ValueError, KeyError):
@@ -309,7 +362,7 @@ def main():
                      "whole_forward_tflops_executed": 1e-9 * exec_flops / ms_per_step,
                      "whole_forward_tflops_reference_count": 1e-9 * ref_flops / ms_per_step,
                      "whole_forward_frac_of_fp32_peak": 1e-9 * exec_flops / ms_per_step / PEAK_FP32_TFLOPS,
-                     "layer_boundary_hbm_frac_encoder_model": (bsz * CLIP / (1e-3 * ms_per_step)) * enc_bytes / 1e9 / PEAK_HBM_GBPS,
+                     "encoder": encoder_roofline(model, x, bsz, enc_bytes),
                      "kernels": {k: {"ms_per_step": round(v["ms_per_step"], 4), "avg_us": round(v["avg_us"], 2),
                                      "launches_per_step": v["launches_per_step"], "tflops": round(v["tflops"], 2),
                                      "gbps": round(v["gbps"], 1)} for k, v in sorted(per.items())}})
@@ -351,6 +404,16 @@ def main():
                                       "it is NOT a supported configuration", **measure("bf16x3", "bf16x3")))
         model.set_conv_arithmetic(decoders="bf16x3" if args.arith == "mixed" else "fp32")
         result["other_arithmetic"] = others
+        # the other synthetic-codebook recipe, same arithmetic as the measured run (eager)
+        other = "latents" if args.codebooks == "survey" else "survey"
+        keep = {k: v.clone() for k, v in model.quantizer.state_dict().items()}
+        calibrate_codebooks(model, x[:8], other)
+        r = measure("bf16x3" if args.arith == "mixed" else "fp32", "fp32")
+        r.pop("index_agreement_with_measured_run"), r.pop("waveform_rms_vs_measured_run")
+        with torch.no_grad():
+            r["distinct_stage0_codes"] = int(model(x)[2][..., 0].unique().numel())
+        result["other_codebooks"] = dict(recipe=other, **r)
+        model.quantizer.load_state_dict(keep)
 
     if rank == 0:
         print(json.dumps(result), flush=True)

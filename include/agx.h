@@ -38,6 +38,12 @@ extern "C" {
 int agx_version(void);
 const char *agx_last_error(void);
 
+/* sizeof() of the two descriptor structs as THIS library was compiled: a binding (ctypes / cgo / JNI stub) asserts
+ * its own struct size against these once at load time, so that a descriptor that gained a field cannot be read
+ * past the end of a caller's shorter struct. */
+int32_t agx_sizeof_conv_desc(void);
+int32_t agx_sizeof_conv2d_desc(void);
+
 /* Diagnostic tuning knobs (A/B experiments from one process; defaults are the
  * shipped configuration).  Unknown names return AGX_ERR_BAD_SHAPE.
  *   "rb_cc"  16 | 32   channels per LDS chunk of the fused residual block

@@ -63,3 +63,86 @@ def test_shard_range_properties():
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
     assert agx_dist.max_over_ranks(3.5) == 3.5  # single process: identity
+
+
+def _ema_worker(rank, world, port, out):
+    """update_codebook=True under data parallelism (training.py:305-308, 326): every rank
+    quantises its OWN shard, the per-code counts / sums are all-reduced, codebooks must stay bit-identical."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    agx_dist.init("gloo")
+    from audio_generation_amd.quantizer import ResidualQuantizer
+    from oracle import rvq
+    torch.manual_seed(0)                                   # same initial codebooks on every rank
+    rq = ResidualQuantizer(num_quantizers=3, dim=8, codebook_sizes=(16, 16, 12), quantizer_class="ema").train()
+    if rank == 1:                                          # a rank that initialised differently ...
+        rq.codebooks.add_(1.0)
+    rq.sync_from_rank0()                                   # ... is brought back by the broadcast
+    gen = torch.Generator().manual_seed(100 + rank)        # every rank its own shard
+    for _ in range(3):
+        x = torch.randn(2, 20, 8, generator=gen)
+        _, index, _ = rvq.residual_quantize(x, rq.codebooks, sizes=rq.codebook_sizes)
+        rq._ema_update(x.reshape(-1, 8), index.reshape(-1, 3))
+    lo, hi = agx_dist.replica_checksums(rq)
+    # GradBucket: grads are views of one flat buffer, mean over ranks in place, views stay intact
+    lin = torch.nn.Linear(5, 3)
+    with torch.no_grad():
+        for p in lin.parameters():
+            p.fill_(0.5)
+    bucket = agx_dist.GradBucket(lin.parameters())
+    ptrs = [p.grad.data_ptr() for p in lin.parameters()]
+    lin(torch.full((2, 5), float(rank + 1))).sum().backward()
+    bucket.allreduce_mean_()
+    ok = bucket.intact() and ptrs == [p.grad.data_ptr() for p in lin.parameters()]
+    g = lin.weight.grad[0, 0].item()                       # d/dw = sum over the 2 rows of x = 2 (rank+1) -> mean 3
+    agx_dist.barrier()
+    out.put((rank, rq.codebooks.clone().numpy(), rq.ema_sum.clone().numpy(), rq.cluster_frequency.clone().numpy(),
+             lo, hi, ok, g, rq._packed is None))
+    dist.destroy_process_group()
+
+
+def test_two_rank_codebook_update_and_grad_bucket():
+    import numpy as np
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_ema_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((out.get(timeout=180) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a, b = res
+    for i in (1, 2, 3):                                     # codebooks, sums, frequencies: bit-identical
+        assert np.array_equal(a[i], b[i])
+    assert a[4] == a[5] == b[4] == b[5]                     # min == max of the state checksum, on both ranks
+    assert a[6] and b[6] and a[7] == b[7] == 3.0
+    assert a[8] and b[8]                                    # the packed search image was dropped by the update
+    # the padding rows of the 12-codeword stage stay zero, and the update moved the codebooks
+    assert np.all(a[1][2, 12:] == 0.0)
+
+
+def test_ema_update_uses_pre_update_codewords_and_invalidates_pack():
+    """the next stage's residual must be formed with the codeword the forward saw (pre-update),
+    and any codebook write must drop the packed image."""
+    from audio_generation_amd.quantizer import ResidualQuantizer
+    from oracle import rvq
+    torch.manual_seed(1)
+    rq = ResidualQuantizer(num_quantizers=2, dim=4, codebook_sizes=8, quantizer_class="ema", ema_decay=0.5).train()
+    cb0 = rq.codebooks.clone()
+    x = torch.randn(1, 30, 4)
+    _, index, _ = rvq.residual_quantize(x, cb0)
+    rq._packed, v0 = torch.zeros(1), rq.codebooks._version
+    rq._ema_update(x.reshape(-1, 4), index.reshape(-1, 2))
+    assert rq._packed is None and rq.codebooks._version > v0
+    frames = x.reshape(-1, 4)
+    idx0, idx1 = index.reshape(-1, 2).T
+    r1 = frames - cb0[0][idx0]                              # residual against the PRE-update stage-0 codewords
+    sums1 = torch.zeros(8, 4).index_add_(0, idx1, r1)
+    cnt1 = torch.bincount(idx1, minlength=8).float()
+    want = (0.5 * cb0[1] + 0.5 * sums1) / (0.5 + 0.5 * cnt1).clamp_min(1e-5).unsqueeze(1)
+    assert torch.allclose(rq.codebooks[1], want, atol=1e-6)
+    rq._packed = torch.zeros(1)
+    rq.init_randn(0.3)
+    assert rq._packed is None

@@ -238,7 +238,8 @@ def test_rvq_one_codebook_size_per_stage():
     mod = ResidualQuantizer(num_quantizers=q, dim=d, codebook_sizes=sizes).to(DEV).eval()
     assert mod.codebook_sizes == sizes and mod.codebooks.shape == (q, 1024, d)
     assert [tuple(s.codebook.shape) for s in mod.quantizers] == [(kq, d) for kq in sizes]
-    mod.codebooks.data.copy_(cbs.to(DEV))
+    with torch.no_grad():
+        mod.codebooks.copy_(cbs.to(DEV))          # through the tensor itself: bumps _version -> the search image is repacked
     got_q, got_i, _ = mod(x.to(DEV))
     assert torch.equal(got_i.cpu(), want_i) and torch.equal(got_q.cpu(), want_q)
 

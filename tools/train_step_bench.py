@@ -38,6 +38,8 @@ def main():
     x = (0.1 * torch.randn(batch, 1, 72000, generator=gen)).clamp(-1, 1).to(dev)
     with torch.no_grad():
         model.quantizer.init_from_latents(model._run_encoders(x[:4]))
+    model.quantizer.sync_from_rank0()         # every rank fed its own shard above: rank 0's codebooks win
+    update_cb = os.environ.get("AGX_UPDATE_CODEBOOK", "1") == "1"     # training.py:305-308, 326
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
     bf = os.environ.get("AGX_BF16X3", "0") == "1"     # decoder + discriminator Conv2d layers on the bf16x3 kernels
     if bf:
@@ -66,18 +68,19 @@ def main():
     def all_params():
         return list(model.parameters()) + [p for d in discs for p in d.parameters()]
 
+    # the exchange step: ONE flat gradient buffer, allocated here, every .grad a view into it
+    bucket = agx_dist.GradBucket(all_params())
+
     def step():
-        opt.zero_grad(set_to_none=True)
-        for o in opt_d:
-            o.zero_grad(set_to_none=True)
+        bucket.zero_()
         if signal:
             xin = sg.lowpass_biquad(x, 24000, 5000.0)
-            y, commit, _ = model(xin)
+            y, commit, _ = model(xin, update_codebook=update_cb)
             loss = ((sg.preemphasis(y, 0.97) - sg.preemphasis(xin, 0.97)) ** 2).mean() + commit
             loss = loss + sg.multispectral_reconstruction_loss(xin, y, specs, windows, spec_loss_weight=0.01)
         else:
             xin = x
-            y, commit, _ = model(xin)
+            y, commit, _ = model(xin, update_codebook=update_cb)
             loss = ((y - xin) ** 2).mean() + commit
         if gan:                                 # training.py:363-376
             d_loss = 0
@@ -87,15 +90,7 @@ def main():
                 d_loss = d_loss + d_loss_i
             d_loss.backward(retain_graph=True)
         loss.backward()
-        if world > 1:                          # one flattened bucket, mean over ranks
-            grads = [p.grad for p in all_params() if p.grad is not None]
-            if backend == "gloo":
-                cpu = [g.cpu() for g in grads]
-                agx_dist.allreduce_mean_(cpu)
-                for g, c in zip(grads, cpu):
-                    g.copy_(c)
-            else:
-                agx_dist.allreduce_mean_(grads)
+        bucket.allreduce_mean_()               # in place on the flat buffer (RCCL; staged through the host on gloo)
         opt.step()
         for o in opt_d:
             o.step()
@@ -110,15 +105,15 @@ def main():
     ms = 1e3 * (time.perf_counter() - t0) / steps
     fwd_flop = 2 * (195194 + 13107 + 208713) * 72000 * batch          # executed (polyphase) MACs of the forward
     ms = agx_dist.max_over_ranks(ms, device=dev if backend == "nccl" else "cpu")
-    # replicas must stay identical: compare a parameter checksum across ranks
-    chk = float(sum(p.detach().double().sum() for p in all_params()))
-    same = abs(agx_dist.max_over_ranks(chk, device=dev if backend == "nccl" else "cpu") - chk) < 1e-9 * max(1.0, abs(chk))
+    # replicas must stay identical: min and max over ranks of a checksum of parameters AND buffers (EMA codebooks)
+    lo, hi = zip(*[agx_dist.replica_checksums(m) for m in [model] + discs])
+    same = all(a == b for a, b in zip(lo, hi))
     if rank == 0:
         print(json.dumps({"what": "train step (fwd + native bwd + grad all-reduce + Adam), config S" +
                           (f" + {len(discs)} discriminators (native forward + backward)" if gan else "") +
                           (" + low-pass, pre-emphasis, 7-window mel loss" if signal else "") +
                           (" [bf16x3: decoder forward, discriminator Conv2d forward + backward-data]" if bf else ""),
-                          "n_gpus": world, "batch_per_gpu": batch, "ms_per_step": ms, "replicas_in_sync": same,
+                          "n_gpus": world, "batch_per_gpu": batch, "ms_per_step": ms, "replicas_in_sync": same, "update_codebook": update_cb,
                           "samples_per_s": world * batch * 72000 / ms * 1e3, "losses": losses,
                           "approx_tflops_at_3x_forward": world * 3 * fwd_flop / ms * 1e-9,
                           "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}))
