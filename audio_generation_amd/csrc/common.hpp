@@ -34,6 +34,8 @@ struct Tuning {
     int conv_shape = 0; // diagnostic: 1 = 128x128 conv tiles as 4 row-waves x (1x4) fragments
     int conv_short = 1; // 1: 128x64 conv tiles when the 128x128 grid is under two workgroups per CU
     int rb_occ = 2;    // 3: build of the fused residual block capped at 168 VGPRs (3 waves/SIMD)
+    int rb_stagger = 0; // diagnostic: odd-slot workgroups of the fused residual block start rb_stagger x ~1k cycles late
+    int rb_impl = 1;    // fused residual block: 1 = persistent ring kernel (resblock_p.hip) where it applies, 0 = resblock_mfma.hip
     int rb_sched = -1; // phase scheduling of the fused residual block (mfma_tile.hpp: 0 / 1 / 2; -1 = per-shape table)
 };
 Tuning &tuning();
@@ -97,6 +99,23 @@ __host__ __device__ inline int64_t packed_weight_floats_bf(int Cin, int J, int M
 }
 __host__ __device__ inline size_t packed_weight_index(int ci, int j, int m, int J, int M) {
     return (size_t(ci / kWG) * J + j) * M * kWG + size_t(m) * kWG + (ci % kWG);
+}
+
+// "Tile image" (resblock_p.hip): a second copy of a dense layer's folded fp32 weights, laid out so that a chunk of
+// channels is ONE contiguous block that LDS-DMA drops into LDS as it stands and the MFMA A fragments come out of
+// with conflict-free 16-byte reads:   Wt[((ci / 4) * J + j) * M + m][ci % 4]
+// It follows the standard image and the dim0 scale scratch inside the same packed buffer
+// (agx_conv_packed_floats accounts for it), for the layers tile_image_eligible() names.
+__host__ __device__ inline int64_t tile_image_floats(int Cin, int J, int M) {
+    return int64_t((Cin + 3) / 4) * J * M * 4;
+}
+__host__ __device__ inline size_t tile_image_index(int ci, int j, int m, int J, int M) {
+    return ((size_t(ci / 4) * J + j) * M + m) * 4 + (ci % 4);
+}
+// stride-1 causal layers of the fused residual block: the dilated k = 7 conv and the k = 1 conv, C in {32,64,128,256}
+inline bool tile_image_eligible(const ConvPlan &p, int kind) {
+    return kind == AGX_CONV_CAUSAL && p.prec == 0 && p.G == 1 && p.s == 1 && p.q == 1 && p.Cin == p.Cout &&
+           (p.Cin == 32 || p.Cin == 64 || p.Cin == 128 || p.Cin == 256) && (p.J == 7 || p.J == 1);
 }
 
 // Lower a descriptor; returns AGX_OK or an error (message set).

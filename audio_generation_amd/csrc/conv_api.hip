@@ -13,6 +13,10 @@ int launch_resblock_fused(const ConvPlan &p, const float *x, const float *w1, co
                           const float *w2, const float *b2, float *y, int post_act, hipStream_t st);
 bool resblock_fused_supported(const ConvPlan &p);
 const char *resblock_variant(const ConvPlan &p);
+int launch_resblock_p(const ConvPlan &p, const float *x, const float *w1, const float *b1, const float *w2,
+                      const float *b2, float *y, int post_act, hipStream_t st);
+bool resblock_p_supported(const ConvPlan &p);
+const char *resblock_p_variant(const ConvPlan &p);
 
 // dx *= gelu'(pre)  (exact erf GELU)
 __global__ __launch_bounds__(256) void gelu_grad_mul_kernel(float *__restrict__ dx, const float *__restrict__ pre, int64_t n) {
@@ -102,7 +106,9 @@ int agx_resblock_kernel_name(const agx_conv_desc *d, char *buf, size_t buf_len) 
     ConvPlan p;
     int rc = lower_conv(&d1, &p);
     if (rc != AGX_OK) return rc;
-    if (d->impl != AGX_IMPL_DIRECT && resblock_fused_supported(p)) {
+    if (d->impl != AGX_IMPL_DIRECT && tuning().rb_impl == 1 && resblock_p_supported(p)) {
+        snprintf(buf, buf_len, "%s", resblock_p_variant(p));
+    } else if (d->impl != AGX_IMPL_DIRECT && resblock_fused_supported(p)) {
         snprintf(buf, buf_len, "%s%s", resblock_variant(p), p.prec ? ":bf16x3" : "");
     } else {
         int impl = d->impl;
@@ -127,6 +133,8 @@ int agx_resblock_forward(const agx_conv_desc *d, const float *x, const float *pa
     ConvPlan p1;
     int rc = lower_conv(&d1, &p1);
     if (rc != AGX_OK) return rc;
+    if (d->impl != AGX_IMPL_DIRECT && tuning().rb_impl == 1 && resblock_p_supported(p1))
+        return launch_resblock_p(p1, x, packed1, bias1, packed2, bias2, y, post_act, st);
     if (d->impl != AGX_IMPL_DIRECT && resblock_fused_supported(p1))
         return launch_resblock_fused(p1, x, packed1, bias1, packed2, bias2, y, post_act, st);
     // two launches: h = leaky(conv1(x)+b1) -> workspace;  y = [leaky](x + conv2(h) + b2)

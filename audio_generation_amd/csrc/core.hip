@@ -222,6 +222,8 @@ int agx_set_tuning(const char *name, int32_t value) {
     else if (!strcmp(name, "rb_wgs")) agx::tuning().rb_wgs = value;
     else if (!strcmp(name, "rb_sched")) agx::tuning().rb_sched = value;
     else if (!strcmp(name, "rb_occ")) agx::tuning().rb_occ = value;
+    else if (!strcmp(name, "rb_stagger")) agx::tuning().rb_stagger = value;
+    else if (!strcmp(name, "rb_impl")) agx::tuning().rb_impl = value;
     else if (!strcmp(name, "bf_sched")) agx::tuning().bf_sched = value;
     else if (!strcmp(name, "patch_tie")) agx::tuning().patch_tie = value;
     else if (!strcmp(name, "dw2_direct")) agx::tuning().dw2_direct = value;
@@ -241,6 +243,8 @@ int agx_get_tuning(const char *name) {
     if (!strcmp(name, "rb_wgs")) return agx::tuning().rb_wgs;
     if (!strcmp(name, "rb_sched")) return agx::tuning().rb_sched;
     if (!strcmp(name, "rb_occ")) return agx::tuning().rb_occ;
+    if (!strcmp(name, "rb_stagger")) return agx::tuning().rb_stagger;
+    if (!strcmp(name, "rb_impl")) return agx::tuning().rb_impl;
     if (!strcmp(name, "bf_sched")) return agx::tuning().bf_sched;
     if (!strcmp(name, "patch_tie")) return agx::tuning().patch_tie;
     if (!strcmp(name, "dw2_direct")) return agx::tuning().dw2_direct;
@@ -266,7 +270,8 @@ int64_t agx_conv_packed_floats(const agx_conv_desc *d) {
     // + dim0 floats of scratch at the tail for the weight-norm scales
     const int dim0 = (d->kind == AGX_CONV_TRANSPOSED) ? d->c_in : d->c_out;
     if (p.prec) return agx::packed_weight_floats_bf(p.Cin, p.J, p.M) + dim0;
-    return agx::packed_weight_floats(p.Cin / p.G, p.J, p.M) + dim0;
+    const int64_t tile = agx::tile_image_eligible(p, d->kind) ? agx::tile_image_floats(p.Cin, p.J, p.M) : 0;
+    return agx::packed_weight_floats(p.Cin / p.G, p.J, p.M) + dim0 + tile;
 }
 
 }  // extern "C"

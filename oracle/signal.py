@@ -36,9 +36,10 @@ def lowpass_biquad(x: Tensor, sample_rate: int, cutoff_freq: float, q: float = 0
     b0, b1, b2 = (1 - math.cos(w0)) / 2, 1 - math.cos(w0), (1 - math.cos(w0)) / 2
     a0, a1, a2 = 1 + alpha, -2 * math.cos(w0), 1 - alpha
     b0, b1, b2, a1, a2 = b0 / a0, b1 / a0, b2 / a0, a1 / a0, a2 / a0
-    xs = x.reshape(-1, x.shape[-1]).to(torch.float32)
+    xs = x.reshape(-1, x.shape[-1])
+    xs = xs if xs.dtype == torch.float64 else xs.to(torch.float32)   # fp64 only for error-analysis runs of the tests
     y = torch.zeros_like(xs)
-    x1 = x2 = y1 = y2 = torch.zeros(xs.shape[0])
+    x1 = x2 = y1 = y2 = torch.zeros(xs.shape[0], dtype=xs.dtype)
     for n in range(xs.shape[1]):                      # direct form I, fp32, sequential (the definition)
         xn = xs[:, n]
         yn = b0 * xn + b1 * x1 + b2 * x2 - a1 * y1 - a2 * y2
@@ -77,7 +78,7 @@ def mel_spectrogram(x: Tensor, sample_rate: int, window: int, n_mels: int = 64) 
     spec = torch.fft.rfft(frames, dim=-1)                                  # (B, T, F)
     spec = spec / float(win.pow(2).sum().sqrt())                           # normalized=True -> "window"
     power = spec.real ** 2 + spec.imag ** 2
-    return torch.matmul(power, mel_fbanks(n_fft // 2 + 1, sample_rate, n_mels)).transpose(1, 2)
+    return torch.matmul(power, mel_fbanks(n_fft // 2 + 1, sample_rate, n_mels).to(power.dtype)).transpose(1, 2)
 
 
 def multispectral_reconstruction_loss(original: Tensor, reconstruction: Tensor, sample_rate: int,

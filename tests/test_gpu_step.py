@@ -139,17 +139,27 @@ def test_whole_config5_step_against_oracle_autograd():
         model.quantizer.init_from_latents(z0.transpose(1, 2))
     discs = [ad.WaveFormDiscriminator(1), ad.STFTDiscriminator(win_length=256)]
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    cbs = sd["quantizer.codebooks"]
-    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if not k.startswith("quantizer.")}
-    d_sd = [{k: (v.detach().clone().requires_grad_(True) if k.endswith(("weight_orig", "bias")) else v.detach().clone())
-             for k, v in d.state_dict().items()} for d in discs]
-    d_fns = [lambda t, s=d_sd[0]: od.waveform_discriminator(t, s, train=True),
-             lambda t, s=d_sd[1]: od.stft_discriminator(t, s, 256, train=True)]
-    want_loss, want_d, want_idx = _oracle_step(x, leaves, spec, cbs, d_fns, windows)
-    want_d.backward(retain_graph=True)                       # training.py:374
-    want_dgrads = [{k: v.grad.clone() for k, v in s.items() if v.requires_grad and v.grad is not None} for s in d_sd]
-    want_loss.backward()                                     # training.py:380
-    want_g = {k: v.grad for k, v in leaves.items()}
+
+    def oracle(dt):
+        cbs = sd["quantizer.codebooks"].to(dt)
+        leaves = {k: v.clone().to(dt).requires_grad_(True) for k, v in sd.items() if not k.startswith("quantizer.")}
+        d_sd = [{k: (v.detach().clone().to(dt).requires_grad_(True) if k.endswith(("weight_orig", "bias"))
+                     else v.detach().clone().to(dt)) for k, v in d.state_dict().items()} for d in discs]
+        d_fns = [lambda t, s=d_sd[0]: od.waveform_discriminator(t, s, train=True),
+                 lambda t, s=d_sd[1]: od.stft_discriminator(t, s, 256, train=True)]
+        loss, d_loss, _ = _oracle_step(x.to(dt), leaves, spec, cbs, d_fns, windows)
+        d_loss.backward(retain_graph=True)                       # training.py:374
+        dgrads = [{k: v.grad.clone().double() for k, v in s.items() if v.requires_grad and v.grad is not None}
+                  for s in d_sd]
+        loss.backward()                                          # training.py:380
+        return float(loss), float(d_loss), {k: v.grad.double() for k, v in leaves.items()}, dgrads
+
+    # The oracle in fp32 is the comparator; the same restatement in fp64 measures how far fp32 arithmetic itself
+    # sits from the exact gradient (the encoder's gradients here are ~1e-6 sums of cancelling GAN / feature terms:
+    # the fp32 oracle is off by up to 9 % on them).  A gradient passes if it is within 5e-3 of the fp32 oracle, or no
+    # further from the fp64 result than 3x the fp32 oracle's own distance from it.
+    want_loss, want_d, want_g, want_dgrads = oracle(torch.float32)
+    _, _, true_g, true_dgrads = oracle(torch.float64)
 
     model = model.to(DEV).train()
     discs = [d.to(DEV).train() for d in discs]
@@ -165,24 +175,27 @@ def test_whole_config5_step_against_oracle_autograd():
     got_dgrads = [{k: p.grad.clone() for k, p in d.named_parameters() if p.grad is not None} for d in discs]
     loss.backward()
 
-    def close(a, b, tol, name):
-        scale = float(b.abs().max()) + 1e-12
-        err = float((a.cpu() - b).abs().max())
-        assert err <= tol * scale + 1e-8, (name, err / scale)
+    def close(got, want, true, tol, name):
+        got = got.detach().cpu().double()
+        scale = float(true.abs().max()) + 1e-12
+        err32 = float((got - want).abs().max())
+        err64, noise = float((got - true).abs().max()), float((want - true).abs().max())
+        assert err32 <= tol * scale + 1e-8 or err64 <= 3.0 * noise + tol * scale, (name, err32 / scale, err64 / scale,
+                                                                                 noise / scale)
 
     checked = 0
     for name, p in model.named_parameters():
         if name.startswith("quantizer."):
             continue
         assert p.grad is not None, name
-        close(p.grad, want_g[name], 5e-3, name)
+        close(p.grad, want_g[name], true_g[name], 5e-3, name)
         checked += 1
     assert checked >= 180
-    for got, want in zip(got_dgrads, want_dgrads):          # after the first backward only: the D loss's own gradients
+    for got, want, true in zip(got_dgrads, want_dgrads, true_dgrads):   # the D loss's own gradients (first backward)
         n = 0
         for k, w in want.items():
             if float(w.abs().max()) == 0.0:
                 continue
-            close(got[k], w, 5e-3, k)
+            close(got[k], w, true[k], 5e-3, k)
             n += 1
         assert n >= 14

@@ -6,6 +6,11 @@
 #include "../audio_generation_amd/csrc/core.hip"
 #include "../audio_generation_amd/csrc/pack.hip"
 #include "../audio_generation_amd/csrc/resblock_mfma.hip"
+// the 2-D lowering lives in conv2d.hip (not linked into the probe): pack.hip only needs the symbols to exist
+namespace agx {
+int lower_conv2d(const agx_conv2d_desc *, ConvPlan *) { return AGX_ERR_UNSUPPORTED; }
+int lower_conv2d_bwd_data(const agx_conv2d_desc *, ConvPlan *) { return AGX_ERR_UNSUPPORTED; }
+}  // namespace agx
 
 #include <cstdio>
 #include <vector>
