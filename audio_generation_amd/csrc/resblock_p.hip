@@ -54,7 +54,8 @@ struct RbpGeom {
     static constexpr int RA = (NPA + 3) / 4;           // ... per wave
     static constexpr int NCB = CCH * NCELL;            // 16-byte cells of the input chunk
     static constexpr int RB = (NCB + 255) / 256;       // ... DMA rounds (256 cells each)
-    static constexpr size_t LDS_BYTES = size_t(NSLOT) * SLOT * sizeof(float);
+    static constexpr int BIAS0 = NSLOT * SLOT;         // [2][C] floats behind the ring: b1, b2 (zeros when absent)
+    static constexpr size_t LDS_BYTES = size_t(NSLOT * SLOT + 2 * C) * sizeof(float);
     static_assert(AFL % 256 == 0, "weight chunk must be whole 1 KiB pieces");
     static_assert(KS == 2 || KS == 4 || KS == 8, "chunk of 4, 8 or 16 channels");
 };
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void resblock_p_kernel(ConvPlan p, int tile
                                                             const float *__restrict__ x,
                                                             const float *__restrict__ wt1, const float *__restrict__ b1,
                                                             const float *__restrict__ wt2, const float *__restrict__ b2,
-                                                            const float *__restrict__ w1_any, float *__restrict__ y) {
+                                                            float *__restrict__ y) {
     using G = RbpGeom<MW, NW, CCH, D>;
     constexpr int C = G::C, BN = G::BN, KS = G::KS, NCH = G::NCH, SLOT = G::SLOT, AFL = G::AFL;
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [3][AFL + BFL]
@@ -197,13 +198,12 @@ __global__ __launch_bounds__(256, 2) void resblock_p_kernel(ConvPlan p, int tile
     };
 
     if (nq == 0) return;
+    for (int i = tid; i < 2 * C; i += 256)   // biases: read once per kernel, served from LDS afterwards
+        lds[G::BIAS0 + i] = i < C ? (b1 ? b1[i] : 0.f) : (b2 ? b2[i - C] : 0.f);
     issue();
     issue();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-
-    const bool has_b1 = b1 != nullptr, has_b2 = b2 != nullptr;
-    const float *b1p = has_b1 ? b1 : w1_any, *b2p = has_b2 ? b2 : w1_any;
 
     Frag<MW, NW, KS> f0, f1;
     load_frag<MW, NW, CCH, D>(f0, lds + aLane, lds + bLane, 0);
@@ -224,121 +224,114 @@ __global__ __launch_bounds__(256, 2) void resblock_p_kernel(ConvPlan p, int tile
                 for (int r = 0; r < 16; ++r) acc[i][kk][r] = 0.f;
 
         // ---- GEMM1 over the tile's chunks, two per iteration (the operand sets swap roles every 7 phases) -------
-        for (int c = 0; c < NCH; c += 2) {
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                issue();
-                const float *As = lds + (q % G::NSLOT) * SLOT + aLane, *Bs = lds + (q % G::NSLOT) * SLOT + bLane;
-                const float *An = lds + ((q + 1) % G::NSLOT) * SLOT + aLane, *Bn = lds + ((q + 1) % G::NSLOT) * SLOT + bLane;
-                if (half == 0) {
-                    phase<MW, NW, CCH, D>(acc, f0, f1, As, Bs, 1);
-                    phase<MW, NW, CCH, D>(acc, f1, f0, As, Bs, 2);
-                    phase<MW, NW, CCH, D>(acc, f0, f1, As, Bs, 3);
-                    phase<MW, NW, CCH, D>(acc, f1, f0, As, Bs, 4);
-                    phase<MW, NW, CCH, D>(acc, f0, f1, As, Bs, 5);
-                    phase<MW, NW, CCH, D>(acc, f1, f0, As, Bs, 6);
-                    phase<MW, NW, CCH, D>(acc, f0, f1, An, Bn, 0);   // next chunk's first phase: complete since the previous barrier
-                } else {
-                    phase<MW, NW, CCH, D>(acc, f1, f0, As, Bs, 1);
-                    phase<MW, NW, CCH, D>(acc, f0, f1, As, Bs, 2);
-                    phase<MW, NW, CCH, D>(acc, f1, f0, As, Bs, 3);
-                    phase<MW, NW, CCH, D>(acc, f0, f1, As, Bs, 4);
-                    phase<MW, NW, CCH, D>(acc, f1, f0, As, Bs, 5);
-                    phase<MW, NW, CCH, D>(acc, f0, f1, As, Bs, 6);
-                    phase<MW, NW, CCH, D>(acc, f1, f0, An, Bn, 0);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of chunk q+2 has landed
-                __syncthreads();                                   // everyone's has; slot q is free
-                ++q;
-            }
-        }
-
-        // ---- hidden activation, in registers ----------------------------------------------------------------------
-#pragma unroll
-        for (int i = 0; i < MW; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float bl = b1p[i * 32 + acc_row(r, lh)];
-                const float bv = has_b1 ? bl : 0.f;
-#pragma unroll
-                for (int kk = 0; kk < NW; ++kk) {
-                    const float v = acc[i][kk][r] + bv;
-                    acc[i][kk][r] = v > 0.f ? v : v * p.slope;
-                }
-            }
-
-        // ---- GEMM2: out = W2 . h, B operand = the accumulator registers (resblock_mfma.hip) -------------------------
-        f32x16 out[MW][NW];
-#pragma unroll
-        for (int i = 0; i < MW; ++i)
-#pragma unroll
-            for (int kk = 0; kk < NW; ++kk)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) out[i][kk][r] = 0.f;
-        unsigned w2off = unsigned(lh * C + li) * 16u;   // opaque per-tile copy: the 4*MW*MW fragment addresses are formed here,
-        asm volatile("" : "+v"(w2off));                  // not hoisted above the main loop (they would cost 2 VGPRs each there)
-        const char *w2b = reinterpret_cast<const char *>(wt2);
-#pragma unroll
-        for (int i = 0; i < MW; ++i) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {   // register group g: hidden channels i*32 + 8g + 4lh + (0..3) = block 8i + 2g + lh of the tile image
-                f32x4 a[MW];
-#pragma unroll
-                for (int io = 0; io < MW; ++io)
-                    a[io] = *reinterpret_cast<const f32x4 *>(w2b + (w2off + unsigned(((8 * i + 2 * g) * C + io * 32) * 16)));
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                    for (int io = 0; io < MW; ++io)
-#pragma unroll
-                        for (int kk = 0; kk < NW; ++kk)
-                            out[io][kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[io][s4], acc[i][kk][4 * g + s4], out[io][kk], 0, 0, 0);
-            }
-        }
-
-        // ---- epilogue: + b2 + x, trailing activation -----------------------------------------------------------------
+        // One interval: request chunk q+2, run the 7 tap phases of chunk q (the last one already reads the first
+        // operands of chunk q+1), wait for this wave's DMA, barrier.
+#define AGX_RBP_CHUNK(FA, FB, PRE)                                                                                   \
+    {                                                                                                                \
+        issue();                                                                                                     \
+        PRE;                                                                                                         \
+        const float *As = lds + (q % G::NSLOT) * SLOT + aLane, *Bs = lds + (q % G::NSLOT) * SLOT + bLane;            \
+        const float *An = lds + ((q + 1) % G::NSLOT) * SLOT + aLane, *Bn = lds + ((q + 1) % G::NSLOT) * SLOT + bLane; \
+        phase<MW, NW, CCH, D>(acc, FA, FB, As, Bs, 1);                                                               \
+        phase<MW, NW, CCH, D>(acc, FB, FA, As, Bs, 2);                                                               \
+        phase<MW, NW, CCH, D>(acc, FA, FB, As, Bs, 3);                                                               \
+        phase<MW, NW, CCH, D>(acc, FB, FA, As, Bs, 4);                                                               \
+        phase<MW, NW, CCH, D>(acc, FA, FB, As, Bs, 5);                                                               \
+        phase<MW, NW, CCH, D>(acc, FB, FA, As, Bs, 6);                                                               \
+        phase<MW, NW, CCH, D>(acc, FA, FB, An, Bn, 0); /* next chunk's first phase: complete since the last barrier */ \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's part of chunk q+2 has landed */               \
+        __syncthreads();                                 /* everyone's has; slot q is free */                         \
+        ++q;                                                                                                         \
+    }
         const char *xb = reinterpret_cast<const char *>(x + size_t(b) * C * Lin);
         char *yb = reinterpret_cast<char *>(y + size_t(b) * C * Lin);
-        int linv = Lin;                       // opaque per-tile copy: keeps the 16*MW row offsets from being hoisted out
-        asm volatile("" : "+v"(linv));        // of the tile loop (they would be live across the whole main loop)
-        constexpr int EG = MW <= 2 ? MW : 2;
+        int linv = Lin;                       // opaque per-tile copies: keep the row offsets / fragment addresses from being
+        asm volatile("" : "+v"(linv));        // hoisted out of the tile loop (they would be live across the whole main loop)
+        // GEMM2's accumulator starts from the residual: out = x (+ b2 below) + W2 . h.  Its 16*MW*NW loads go out at
+        // the top of the tile's LAST interval and have the whole interval to arrive.
+        f32x16 out[MW][NW];
+        auto load_residual = [&]() {
 #pragma unroll
-        for (int g0 = 0; g0 < MW; g0 += EG) {
-            float xv[EG][NW][16];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ig = 0; ig < EG; ++ig)
+            for (int io = 0; io < MW; ++io)
 #pragma unroll
                 for (int kk = 0; kk < NW; ++kk) {
                     const int tc = min(t0 + n0 + kk * 32 + li, Lin - 1);
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        xv[ig][kk][r] = *reinterpret_cast<const float *>(
-                            xb + unsigned(((g0 + ig) * 32 + acc_row(r, lh)) * linv + tc) * 4u);
+                        out[io][kk][r] = *reinterpret_cast<const float *>(xb + unsigned((io * 32 + acc_row(r, lh)) * linv + tc) * 4u);
                 }
-            __builtin_amdgcn_sched_barrier(0);
+        };
+        for (int c = 0; c < NCH - 2; c += 2) {
+            AGX_RBP_CHUNK(f0, f1, (void)0)
+            AGX_RBP_CHUNK(f1, f0, (void)0)
+        }
+        AGX_RBP_CHUNK(f0, f1, (void)0)
+        AGX_RBP_CHUNK(f1, f0, load_residual())
+#undef AGX_RBP_CHUNK
+
+        // ---- tail: the first GEMM2 weight block travels while the activation runs -------------------------------------
+        unsigned w2off = unsigned(lh * C + li) * 16u;
+        asm volatile("" : "+v"(w2off));
+        const char *w2b = reinterpret_cast<const char *>(wt2);
+        // GEMM2 weight block (i, g): hidden channels i*32 + 8g + 4lh + (0..3) = block 8i + 2g + lh of the tile image
+        auto load_w2 = [&](f32x4 (&a)[MW], int blk) {
 #pragma unroll
-            for (int ig = 0; ig < EG; ++ig) {
-                const int io = g0 + ig;
-                float bv[16];
+            for (int io = 0; io < MW; ++io)
+                a[io] = *reinterpret_cast<const f32x4 *>(w2b + (w2off + unsigned((2 * blk * C + io * 32) * 16)));
+        };
+        f32x4 wa[2][MW];
+        load_w2(wa[0], 0);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- hidden activation, in registers (bias from LDS) ---------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bq = *reinterpret_cast<const f32x4 *>(lds + G::BIAS0 + i * 32 + 8 * g + 4 * lh);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int kk = 0; kk < NW; ++kk) {
+                        const float v = acc[i][kk][4 * g + s4] + bq[s4];
+                        acc[i][kk][4 * g + s4] = v > 0.f ? v : v * p.slope;
+                    }
+                const f32x4 b2q = *reinterpret_cast<const f32x4 *>(lds + G::BIAS0 + C + i * 32 + 8 * g + 4 * lh);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int kk = 0; kk < NW; ++kk) out[i][kk][4 * g + s4] += b2q[s4];
+            }
+
+        // ---- GEMM2: out += W2 . h, B operand = the accumulator registers (resblock_mfma.hip); weights one block ahead --
+#pragma unroll
+        for (int blk = 0; blk < 4 * MW; ++blk) {
+            const int i = blk >> 2, g = blk & 3;
+            if (blk + 1 < 4 * MW) load_w2(wa[(blk + 1) & 1], blk + 1);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int io = 0; io < MW; ++io)
+#pragma unroll
+                    for (int kk = 0; kk < NW; ++kk)
+                        out[io][kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[blk & 1][io][s4], acc[i][kk][4 * g + s4],
+                                                                          out[io][kk], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- epilogue: trailing activation, store -----------------------------------------------------------------------
+#pragma unroll
+        for (int io = 0; io < MW; ++io)
+#pragma unroll
+            for (int kk = 0; kk < NW; ++kk) {
+                const int t = t0 + n0 + kk * 32 + li;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float bl = b2p[io * 32 + acc_row(r, lh)];
-                    bv[r] = has_b2 ? bl : 0.f;
-                }
-#pragma unroll
-                for (int kk = 0; kk < NW; ++kk) {
-                    const int t = t0 + n0 + kk * 32 + li;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float v = out[io][kk][r] + bv[r] + xv[ig][kk][r];
-                        if (post_act) v = leaky(v, p.slope);
-                        if (t < Lin)
-                            *reinterpret_cast<float *>(yb + unsigned((io * 32 + acc_row(r, lh)) * linv + t) * 4u) = v;
-                    }
+                    float v = out[io][kk][r];
+                    if (post_act) v = leaky(v, p.slope);
+                    if (t < Lin) *reinterpret_cast<float *>(yb + unsigned((io * 32 + acc_row(r, lh)) * linv + t) * 4u) = v;
                 }
             }
-        }
     }
 }
 
@@ -371,7 +364,7 @@ static int launch_rbp(const ConvPlan &p, const float *x, const float *w1, const 
     const float *wt1 = w1 + packed_weight_floats(G::C, G::J, G::C) + G::C;
     const float *wt2 = w2 + packed_weight_floats(G::C, 1, G::C) + G::C;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G::LDS_BYTES, st, p, tiles_per_clip, ntiles, grid / tiles_per_clip,
-                       grid % tiles_per_clip, post_act, tuning().rb_stagger, x, wt1, b1, wt2, b2, w1, y);
+                       grid % tiles_per_clip, post_act, tuning().rb_stagger, x, wt1, b1, wt2, b2, y);
     return check_launch("resblock_p");
 }
 
