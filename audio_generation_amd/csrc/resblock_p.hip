@@ -36,7 +36,7 @@ __device__ __forceinline__ void glds_b128(const float *gsrc_lane, float *lds_wav
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int MW, int NW, int CCH, int D>
+template <int MW, int NW, int CCH, int D, int NS = 3>
 struct RbpGeom {
     static constexpr int C = 32 * MW, BN = 128 * NW, J = 7;
     static constexpr int P = (J - 1) * D;              // causal left pad of the stride-1 conv (vae.py:32)
@@ -49,7 +49,9 @@ struct RbpGeom {
     static constexpr int AFL = CCH * J * C;            // floats of weights per chunk
     static constexpr int BFL = CCH * SPANP;            // floats of input per chunk
     static constexpr int SLOT = AFL + BFL;
-    static constexpr int NSLOT = 3;
+    static constexpr int NSLOT = NS;                   // ring slots: 3 = the next chunk is complete one interval early (its first
+                                                       // operands are read before the barrier), 2 = it completes AT the barrier
+    static constexpr int HS = MW > 4 ? MW / 2 : MW;    // output row blocks per GEMM2 pass (register budget: 16 * HS * NW accumulators)
     static constexpr int NPA = AFL / 256;              // 1 KiB DMA pieces of the weight chunk
     static constexpr int RA = (NPA + 3) / 4;           // ... per wave
     static constexpr int NCB = CCH * NCELL;            // 16-byte cells of the input chunk
@@ -125,15 +127,17 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[MW][NW], const Frag<MW, NW, 
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int MW, int NW, int CCH, int D>
+template <int MW, int NW, int CCH, int D, int NS>
 __global__ __launch_bounds__(256, 2) void resblock_p_kernel(ConvPlan p, int tiles_per_clip, int ntiles, int step_b,
                                                             int step_t, int post_act, int stagger,
                                                             const float *__restrict__ x,
                                                             const float *__restrict__ wt1, const float *__restrict__ b1,
                                                             const float *__restrict__ wt2, const float *__restrict__ b2,
                                                             float *__restrict__ y) {
-    using G = RbpGeom<MW, NW, CCH, D>;
-    constexpr int C = G::C, BN = G::BN, KS = G::KS, NCH = G::NCH, SLOT = G::SLOT, AFL = G::AFL;
+    using G = RbpGeom<MW, NW, CCH, D, NS>;
+    constexpr int C = G::C, BN = G::BN, KS = G::KS, NCH = G::NCH, SLOT = G::SLOT, AFL = G::AFL, HS = G::HS;
+    constexpr bool PRE3 = G::NSLOT == 3;
+    constexpr bool EARLY_RES = MW <= 4;   // residual requested during the tile's last interval (C = 256: no registers to park it in)
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [3][AFL + BFL]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: LDS-DMA destinations stay in SGPRs
@@ -201,12 +205,12 @@ __global__ __launch_bounds__(256, 2) void resblock_p_kernel(ConvPlan p, int tile
     for (int i = tid; i < 2 * C; i += 256)   // biases: read once per kernel, served from LDS afterwards
         lds[G::BIAS0 + i] = i < C ? (b1 ? b1[i] : 0.f) : (b2 ? b2[i - C] : 0.f);
     issue();
-    issue();
+    if (PRE3) issue();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     Frag<MW, NW, KS> f0, f1;
-    load_frag<MW, NW, CCH, D>(f0, lds + aLane, lds + bLane, 0);
+    if (PRE3) load_frag<MW, NW, CCH, D>(f0, lds + aLane, lds + bLane, 0);
 
     int q = 0, cb = first_b, ct = first_t;
     for (int k = 0; k < my_tiles; ++k) {
@@ -222,11 +226,13 @@ __global__ __launch_bounds__(256, 2) void resblock_p_kernel(ConvPlan p, int tile
             for (int kk = 0; kk < NW; ++kk)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][kk][r] = 0.f;
+        if (!PRE3)   // 2-slot ring: the tile's first operands are read here (its first chunk landed at the last barrier)
+            load_frag<MW, NW, CCH, D>(f0, lds + (q % G::NSLOT) * SLOT + aLane, lds + (q % G::NSLOT) * SLOT + bLane, 0);
 
         // ---- GEMM1 over the tile's chunks, two per iteration (the operand sets swap roles every 7 phases) -------
         // One interval: request chunk q+2, run the 7 tap phases of chunk q (the last one already reads the first
         // operands of chunk q+1), wait for this wave's DMA, barrier.
-#define AGX_RBP_CHUNK(FA, FB, PRE)                                                                                   \
+#define AGX_RBP_CHUNK(FA, FB, PRE, TAILC)                                                                            \
     {                                                                                                                \
         issue();                                                                                                     \
         PRE;                                                                                                         \
@@ -238,9 +244,15 @@ __global__ __launch_bounds__(256, 2) void resblock_p_kernel(ConvPlan p, int tile
         phase<MW, NW, CCH, D>(acc, FB, FA, As, Bs, 4);                                                               \
         phase<MW, NW, CCH, D>(acc, FA, FB, As, Bs, 5);                                                               \
         phase<MW, NW, CCH, D>(acc, FB, FA, As, Bs, 6);                                                               \
-        phase<MW, NW, CCH, D>(acc, FA, FB, An, Bn, 0); /* next chunk's first phase: complete since the last barrier */ \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's part of chunk q+2 has landed */               \
+        if (PRE3) {                                                                                                  \
+            phase<MW, NW, CCH, D>(acc, FA, FB, An, Bn, 0); /* next chunk's first phase: complete since the last barrier */ \
+        } else {                                                                                                     \
+            mfma_frag<MW, NW, KS>(acc, FA);                                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+        }                                                                                                            \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's part of the requested chunk has landed */     \
         __syncthreads();                                 /* everyone's has; slot q is free */                         \
+        if (!PRE3 && !(TAILC)) load_frag<MW, NW, CCH, D>(FB, An, Bn, 0);                                              \
         ++q;                                                                                                         \
     }
         const char *xb = reinterpret_cast<const char *>(x + size_t(b) * C * Lin);
@@ -249,38 +261,40 @@ __global__ __launch_bounds__(256, 2) void resblock_p_kernel(ConvPlan p, int tile
         asm volatile("" : "+v"(linv));        // hoisted out of the tile loop (they would be live across the whole main loop)
         // GEMM2's accumulator starts from the residual: out = x (+ b2 below) + W2 . h.  Its 16*MW*NW loads go out at
         // the top of the tile's LAST interval and have the whole interval to arrive.
-        f32x16 out[MW][NW];
-        auto load_residual = [&]() {
+        f32x16 out[HS][NW];
+        auto load_residual = [&](int pass) {
 #pragma unroll
-            for (int io = 0; io < MW; ++io)
+            for (int io = 0; io < HS; ++io)
 #pragma unroll
                 for (int kk = 0; kk < NW; ++kk) {
                     const int tc = min(t0 + n0 + kk * 32 + li, Lin - 1);
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        out[io][kk][r] = *reinterpret_cast<const float *>(xb + unsigned((io * 32 + acc_row(r, lh)) * linv + tc) * 4u);
+                        out[io][kk][r] = *reinterpret_cast<const float *>(
+                            xb + unsigned(((pass * HS + io) * 32 + acc_row(r, lh)) * linv + tc) * 4u);
                 }
         };
         for (int c = 0; c < NCH - 2; c += 2) {
-            AGX_RBP_CHUNK(f0, f1, (void)0)
-            AGX_RBP_CHUNK(f1, f0, (void)0)
+            AGX_RBP_CHUNK(f0, f1, (void)0, false)
+            AGX_RBP_CHUNK(f1, f0, (void)0, false)
         }
-        AGX_RBP_CHUNK(f0, f1, (void)0)
-        AGX_RBP_CHUNK(f1, f0, load_residual())
+        AGX_RBP_CHUNK(f0, f1, (void)0, false)
+        AGX_RBP_CHUNK(f1, f0, if (EARLY_RES) load_residual(0), true)
 #undef AGX_RBP_CHUNK
 
         // ---- tail: the first GEMM2 weight block travels while the activation runs -------------------------------------
         unsigned w2off = unsigned(lh * C + li) * 16u;
         asm volatile("" : "+v"(w2off));
         const char *w2b = reinterpret_cast<const char *>(wt2);
-        // GEMM2 weight block (i, g): hidden channels i*32 + 8g + 4lh + (0..3) = block 8i + 2g + lh of the tile image
-        auto load_w2 = [&](f32x4 (&a)[MW], int blk) {
+        // GEMM2 weight block (i, g) for output row blocks pass*HS ..: hidden channels i*32 + 8g + 4lh + (0..3) = block
+        // 8i + 2g + lh of the tile image
+        auto load_w2 = [&](f32x4 (&a)[HS], int blk, int pass) {
 #pragma unroll
-            for (int io = 0; io < MW; ++io)
-                a[io] = *reinterpret_cast<const f32x4 *>(w2b + (w2off + unsigned((2 * blk * C + io * 32) * 16)));
+            for (int io = 0; io < HS; ++io)
+                a[io] = *reinterpret_cast<const f32x4 *>(w2b + (w2off + unsigned((2 * blk * C + (pass * HS + io) * 32) * 16)));
         };
-        f32x4 wa[2][MW];
-        load_w2(wa[0], 0);
+        f32x4 wa[2][HS];
+        load_w2(wa[0], 0, 0);
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- hidden activation, in registers (bias from LDS) ---------------------------------------------------------
@@ -296,50 +310,62 @@ __global__ __launch_bounds__(256, 2) void resblock_p_kernel(ConvPlan p, int tile
                         const float v = acc[i][kk][4 * g + s4] + bq[s4];
                         acc[i][kk][4 * g + s4] = v > 0.f ? v : v * p.slope;
                     }
-                const f32x4 b2q = *reinterpret_cast<const f32x4 *>(lds + G::BIAS0 + C + i * 32 + 8 * g + 4 * lh);
+            }
+
+#pragma unroll
+        for (int pass = 0; pass < MW / HS; ++pass) {
+            if (pass > 0 || !EARLY_RES) {   // (C = 256 only) this latency is exposed, twice per 8192-MFMA tile
+                if (pass > 0) load_w2(wa[0], 0, pass);
+                load_residual(pass);
+            }
+#pragma unroll
+            for (int io = 0; io < HS; ++io)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 b2q = *reinterpret_cast<const f32x4 *>(lds + G::BIAS0 + C + (pass * HS + io) * 32 + 8 * g + 4 * lh);
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                        for (int kk = 0; kk < NW; ++kk) out[io][kk][4 * g + s4] += b2q[s4];
+                }
+            // ---- GEMM2: out += W2 . h, B operand = the accumulator registers (resblock_mfma.hip); weights one block ahead
+#pragma unroll
+            for (int blk = 0; blk < 4 * MW; ++blk) {
+                const int i = blk >> 2, g = blk & 3;
+                if (blk + 1 < 4 * MW) load_w2(wa[(blk + 1) & 1], blk + 1, pass);
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-                    for (int kk = 0; kk < NW; ++kk) out[i][kk][4 * g + s4] += b2q[s4];
+                    for (int io = 0; io < HS; ++io)
+#pragma unroll
+                        for (int kk = 0; kk < NW; ++kk)
+                            out[io][kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[blk & 1][io][s4], acc[i][kk][4 * g + s4],
+                                                                              out[io][kk], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-
-        // ---- GEMM2: out += W2 . h, B operand = the accumulator registers (resblock_mfma.hip); weights one block ahead --
+            // ---- epilogue: trailing activation, store -------------------------------------------------------------------
 #pragma unroll
-        for (int blk = 0; blk < 4 * MW; ++blk) {
-            const int i = blk >> 2, g = blk & 3;
-            if (blk + 1 < 4 * MW) load_w2(wa[(blk + 1) & 1], blk + 1);
+            for (int io = 0; io < HS; ++io)
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4)
+                for (int kk = 0; kk < NW; ++kk) {
+                    const int t = t0 + n0 + kk * 32 + li;
 #pragma unroll
-                for (int io = 0; io < MW; ++io)
-#pragma unroll
-                    for (int kk = 0; kk < NW; ++kk)
-                        out[io][kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[blk & 1][io][s4], acc[i][kk][4 * g + s4],
-                                                                          out[io][kk], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-
-        // ---- epilogue: trailing activation, store -----------------------------------------------------------------------
-#pragma unroll
-        for (int io = 0; io < MW; ++io)
-#pragma unroll
-            for (int kk = 0; kk < NW; ++kk) {
-                const int t = t0 + n0 + kk * 32 + li;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = out[io][kk][r];
-                    if (post_act) v = leaky(v, p.slope);
-                    if (t < Lin) *reinterpret_cast<float *>(yb + unsigned((io * 32 + acc_row(r, lh)) * linv + t) * 4u) = v;
+                    for (int r = 0; r < 16; ++r) {
+                        float v = out[io][kk][r];
+                        if (post_act) v = leaky(v, p.slope);
+                        if (t < Lin)
+                            *reinterpret_cast<float *>(yb + unsigned(((pass * HS + io) * 32 + acc_row(r, lh)) * linv + t) * 4u) = v;
+                    }
                 }
-            }
+        }
     }
 }
 
-template <int MW, int NW, int CCH, int D>
+template <int MW, int NW, int CCH, int D, int NS>
 static int launch_rbp(const ConvPlan &p, const float *x, const float *w1, const float *b1, const float *w2,
                       const float *b2, float *y, int post_act, hipStream_t st) {
-    using G = RbpGeom<MW, NW, CCH, D>;
-    auto kern = resblock_p_kernel<MW, NW, CCH, D>;
+    using G = RbpGeom<MW, NW, CCH, D, NS>;
+    auto kern = resblock_p_kernel<MW, NW, CCH, D, NS>;
     static bool attr_set = false;
     static int n_cu = 0;
     if (!attr_set) {
@@ -368,11 +394,11 @@ static int launch_rbp(const ConvPlan &p, const float *x, const float *w1, const 
     return check_launch("resblock_p");
 }
 
-// shapes the persistent kernel is instantiated for: C in {32, 64, 128}, k = 7, dilation in {1, 3, 9}, L % 4 == 0
+// shapes the persistent kernel is instantiated for: C in {32, 64, 128, 256}, k = 7, dilation in {1, 3, 9}, L % 4 == 0
 bool resblock_p_supported(const ConvPlan &p) {
     if (p.prec != 0 || p.Cin != p.Cout || p.s != 1 || p.q != 1 || p.J != 7 || p.G != 1) return false;
     if (p.Lvalid != p.Lin || p.Lt != p.Lin || p.Lin % 4 != 0 || p.Lin < 4) return false;
-    if (p.Cin != 32 && p.Cin != 64 && p.Cin != 128) return false;
+    if (p.Cin != 32 && p.Cin != 64 && p.Cin != 128 && p.Cin != 256) return false;
     return p.d == 1 || p.d == 3 || p.d == 9;
 }
 
@@ -380,21 +406,23 @@ const char *resblock_p_variant(const ConvPlan &p) {
     switch (p.Cin) {
         case 32: return "resblock_p<1,4,8>";
         case 64: return "resblock_p<2,2,8>";
-        default: return "resblock_p<4,1,4>";
+        case 128: return "resblock_p<4,1,4>";
+        default: return "resblock_p<8,1,4>";
     }
 }
 
 int launch_resblock_p(const ConvPlan &p, const float *x, const float *w1, const float *b1, const float *w2,
                       const float *b2, float *y, int post_act, hipStream_t st) {
     if (!resblock_p_supported(p)) return fail(AGX_ERR_UNSUPPORTED, "resblock_p: unsupported shape");
-#define AGX_RBP(MW, NW, CCH)                                                                     \
-    (p.d == 1 ? launch_rbp<MW, NW, CCH, 1>(p, x, w1, b1, w2, b2, y, post_act, st)                \
-     : p.d == 3 ? launch_rbp<MW, NW, CCH, 3>(p, x, w1, b1, w2, b2, y, post_act, st)              \
-                : launch_rbp<MW, NW, CCH, 9>(p, x, w1, b1, w2, b2, y, post_act, st))
+#define AGX_RBP(MW, NW, CCH, NS)                                                                 \
+    (p.d == 1 ? launch_rbp<MW, NW, CCH, 1, NS>(p, x, w1, b1, w2, b2, y, post_act, st)            \
+     : p.d == 3 ? launch_rbp<MW, NW, CCH, 3, NS>(p, x, w1, b1, w2, b2, y, post_act, st)          \
+                : launch_rbp<MW, NW, CCH, 9, NS>(p, x, w1, b1, w2, b2, y, post_act, st))
     switch (p.Cin) {
-        case 32: return AGX_RBP(1, 4, 8);
-        case 64: return AGX_RBP(2, 2, 8);
-        default: return AGX_RBP(4, 1, 4);
+        case 32: return AGX_RBP(1, 4, 8, 3);
+        case 64: return AGX_RBP(2, 2, 8, 3);
+        case 128: return AGX_RBP(4, 1, 4, 3);
+        default: return AGX_RBP(8, 1, 4, 2);   // 28.7 KB of weights per 4-channel chunk: two slots keep two workgroups per CU
     }
 #undef AGX_RBP
 }

@@ -37,11 +37,11 @@ def _kernel_name(m, x):
     return ops.resblock_kernel_name(d)
 
 
-@pytest.mark.parametrize("c", [32, 64, 128])
+@pytest.mark.parametrize("c", [32, 64, 128, 256])
 @pytest.mark.parametrize("d", [1, 3, 9])
 def test_small_and_ragged_clips(c, d):
     m, sd, gen = _block(c, d, 100 + c + d)
-    for b, length in ((1, 4), (2, 60), (3, 128 * (c == 128) + 256 * (c == 64) + 512 * (c == 32)), (2, 1000), (1, 2052)):
+    for b, length in ((1, 4), (2, 60), (3, {32: 512, 64: 256, 128: 128, 256: 128}[c]), (2, 1000), (1, 2052)):
         x = torch.randn(b, c, length, generator=gen)
         want = codec.residual_block(x, sd, "", d)
         try:
@@ -62,12 +62,13 @@ def test_small_and_ragged_clips(c, d):
         assert max_abs(y_act, y_old) < tol
 
 
-@pytest.mark.parametrize("c,d,b,length", [(32, 9, 8, 36000), (64, 3, 6, 24000), (128, 1, 4, 17000), (64, 9, 2, 72000)])
+@pytest.mark.parametrize("c,d,b,length", [(32, 9, 8, 36000), (64, 3, 6, 24000), (128, 1, 4, 17000), (64, 9, 2, 72000),
+                                          (256, 3, 20, 3400)])
 def test_more_tiles_than_workgroups(c, d, b, length):
     """> 512 tiles: every workgroup walks over several tiles (different clips and time blocks)."""
     m, sd, gen = _block(c, d, 7 + c)
     x = torch.randn(b, c, length, generator=gen)
-    bn = {32: 512, 64: 256, 128: 128}[c]
+    bn = {32: 512, 64: 256, 128: 128, 256: 128}[c]
     assert b * -(-length // bn) > 512
     want = codec.leaky(codec.residual_block(x, sd, "", d))
     with torch.no_grad():
