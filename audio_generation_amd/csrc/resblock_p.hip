@@ -28,6 +28,18 @@
 
 namespace agx {
 
+// probe build (tools/rbp_probe.hip): s_memtime at the phase boundaries of ONE interval (the workgroup's stamp_q-th) per wave
+#ifdef AGX_STAMPS
+#define AGX_RSTAMP(slot)                                                                           \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (q == AGX_STAMP_Q && lane == 0) g_stamps[(blockIdx.x * 4 + wave) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
+#else
+#define AGX_RSTAMP(slot) ((void)0)
+#endif
+
 // 16 bytes per lane global -> LDS (1 KiB per wave instruction); LDS destination = wave-uniform base + lane * 16
 __device__ __forceinline__ void glds_b128(const float *gsrc_lane, float *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc_lane,
@@ -35,6 +47,10 @@ __device__ __forceinline__ void glds_b128(const float *gsrc_lane, float *lds_wav
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// 1 KiB of zeros in the code object: the DMA source of input cells outside [0, L) (causal left pad, ragged last tile) and
+// of the instruction slots a wave has no piece for -- every DMA instruction is issued unconditionally, branch-free.
+__device__ __attribute__((aligned(1024))) float g_rbp_zero_page[256] = {0.f};
 
 template <int MW, int NW, int CCH, int D, int NS = 3>
 struct RbpGeom {
@@ -48,16 +64,20 @@ struct RbpGeom {
     static constexpr int NCH = C / CCH;                // chunks per tile
     static constexpr int AFL = CCH * J * C;            // floats of weights per chunk
     static constexpr int BFL = CCH * SPANP;            // floats of input per chunk
-    static constexpr int SLOT = AFL + BFL;
+    static constexpr int NCB = CCH * NCELL;            // 16-byte cells of the input chunk
+    static constexpr int NIB = (NCB + 63) / 64;        // ... = DMA instructions (64 consecutive cells each); the last one may
+    static constexpr int BFLP = NIB * 256;             //     overrun the rows by < 1 KiB: the slot's input region is padded to it
+    static constexpr int SLOT = AFL + BFLP;
     static constexpr int NSLOT = NS;                   // ring slots: 3 = the next chunk is complete one interval early (its first
                                                        // operands are read before the barrier), 2 = it completes AT the barrier
     static constexpr int HS = MW > 4 ? MW / 2 : MW;    // output row blocks per GEMM2 pass (register budget: 16 * HS * NW accumulators)
-    static constexpr int NPA = AFL / 256;              // 1 KiB DMA pieces of the weight chunk
-    static constexpr int RA = (NPA + 3) / 4;           // ... per wave
-    static constexpr int NCB = CCH * NCELL;            // 16-byte cells of the input chunk
-    static constexpr int RB = (NCB + 255) / 256;       // ... DMA rounds (256 cells each)
+    static constexpr int NPA = AFL / 256;              // 1 KiB DMA pieces (= instructions) of the weight chunk
+    static constexpr int RA = (NPA + 3) / 4;           // ... per wave (instruction n belongs to wave n % 4)
+    static constexpr int RB = (NIB + 3) / 4;
+    static constexpr int NOPS = RA + RB;               // DMA instructions per wave and interval, spread over the 7 phases
     static constexpr int BIAS0 = NSLOT * SLOT;         // [2][C] floats behind the ring: b1, b2 (zeros when absent)
-    static constexpr size_t LDS_BYTES = size_t(NSLOT * SLOT + 2 * C) * sizeof(float);
+    static constexpr int DUMMY0 = BIAS0 + 2 * C;       // 1 KiB nobody reads: destination of the DMA slots a wave has no piece for
+    static constexpr size_t LDS_BYTES = size_t(NSLOT * SLOT + 2 * C + 256) * sizeof(float);
     static_assert(AFL % 256 == 0, "weight chunk must be whole 1 KiB pieces");
     static_assert(KS == 2 || KS == 4 || KS == 8, "chunk of 4, 8 or 16 channels");
 };
@@ -110,12 +130,13 @@ __device__ __forceinline__ void mfma_frag(f32x16 (&acc)[MW][NW], const Frag<MW, 
 
 // One phase: request the operands of the NEXT phase, run this phase's MFMAs, with the LDS reads threaded
 // between the MFMAs (an MFMA holds the issue port for a fraction of its 64 cycles).
-template <int MW, int NW, int CCH, int D>
+template <int MW, int NW, int CCH, int D, class Extra>
 __device__ __forceinline__ void phase(f32x16 (&acc)[MW][NW], const Frag<MW, NW, CCH / 2> &cur,
                                       Frag<MW, NW, CCH / 2> &nxt, const float *__restrict__ As,
-                                      const float *__restrict__ Bs, int jn) {
+                                      const float *__restrict__ Bs, int jn, Extra &&extra) {
     constexpr int KS = CCH / 2;
     load_frag<MW, NW, CCH, D>(nxt, As, Bs, jn);
+    extra();   // this phase's share of the interval's DMA instructions (address selects + 1-2 global_load_lds)
     mfma_frag<MW, NW, KS>(acc, cur);
     constexpr int NDS = MW * (KS == 8 ? 2 : 1) + KS * NW, NMF = KS * MW * NW;
     constexpr int PER = NMF / NDS > 0 ? NMF / NDS : 1;
@@ -129,7 +150,7 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[MW][NW], const Frag<MW, NW, 
 
 template <int MW, int NW, int CCH, int D, int NS>
 __global__ __launch_bounds__(256, 2) void resblock_p_kernel(ConvPlan p, int tiles_per_clip, int ntiles, int step_b,
-                                                            int step_t, int post_act, int stagger,
+                                                            int step_t, int post_act,
                                                             const float *__restrict__ x,
                                                             const float *__restrict__ wt1, const float *__restrict__ b1,
                                                             const float *__restrict__ wt2, const float *__restrict__ b2,
@@ -145,21 +166,18 @@ __global__ __launch_bounds__(256, 2) void resblock_p_kernel(ConvPlan p, int tile
     const int n0 = wave * (32 * NW);
     const int Lin = p.Lin;
 
-    if (stagger > 0) {   // knob rb_stagger: every other workgroup of the grid starts late (de-synchronises the two workgroups of a CU)
-        if ((blockIdx.x / (gridDim.x / 2 > 0 ? gridDim.x / 2 : 1)) & 1)
-            for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(16);
-    }
-
     // ---- per-lane constants of the DMA (the same for every chunk and tile) ------------------------------------
-    unsigned boffB[G::RB];   // byte offset of this lane's 16-byte cell inside the chunk's rows
-    int colB[G::RB];         // its first column relative to the LDS row start; < 0: no cell in that round
+    // input instruction n = wave + 4 r covers cells 64 n .. 64 n + 63 of the chunk (cell e = row e / NCELL, columns 4 (e % NCELL) ..)
+    unsigned boffB[G::RB];   // byte offset of this lane's cell inside the chunk's rows
+    int colB[G::RB];         // its first column relative to the LDS row start; hugely negative: beyond the chunk
 #pragma unroll
     for (int r = 0; r < G::RB; ++r) {
-        const int e = wave * 64 + lane + 256 * r;
+        const int e = (wave + 4 * r) * 64 + lane;
         const int row = e / G::NCELL, col = e - row * G::NCELL;
         colB[r] = e < G::NCB ? 4 * col : -(1 << 28);
         boffB[r] = unsigned(row * Lin + 4 * col) * 4u;
     }
+    const char *zpage = reinterpret_cast<const char *>(g_rbp_zero_page) + lane * 16;
     // consumer-side lane offsets (floats, relative to a slot)
     const int aLane = (KS == 4 ? lh * G::J * C * 4 : (KS == 8 ? 2 * lh * G::J * C * 4 : lh * 2)) + li * 4;
     const int bLane = AFL + lh * KS * G::SPANP + n0 + li + G::SHIFT;
@@ -169,36 +187,55 @@ __global__ __launch_bounds__(256, 2) void resblock_p_kernel(ConvPlan p, int tile
     const int nq = my_tiles * NCH;  // chunks this workgroup consumes
     const int first_b = int(blockIdx.x) / tiles_per_clip, first_t = int(blockIdx.x) - first_b * tiles_per_clip;
 
-    // DMA cursor: the next chunk to request (runs two chunks ahead of the MFMAs, across tile boundaries)
-    int iq = 0, ic = 0, ib = first_b, it = first_t;
-    auto issue = [&]() {
-        if (iq >= nq) return;
-        float *slot = lds + (iq % G::NSLOT) * SLOT;
-        // weights: one contiguous block of the tile image, 1 KiB pieces dealt round-robin to the waves
-        const char *wsrc = reinterpret_cast<const char *>(wt1 + size_t(ic) * AFL);
-#pragma unroll
-        for (int r = 0; r < G::RA; ++r) {
-            const int pi = wave + 4 * r;
-            if (pi < G::NPA) glds_b128(reinterpret_cast<const float *>(wsrc + unsigned(pi * 1024 + lane * 16)), slot + pi * 256);
-        }
-        // input rows: 16-byte cells; cells outside [0, Lvalid) are written as zeros by the lane that owns them
-        const int in0a = it * BN - G::PA;
-        const char *xsrc = reinterpret_cast<const char *>(x + (size_t(ib) * C + size_t(ic) * CCH) * Lin + in0a);
-#pragma unroll
-        for (int r = 0; r < G::RB; ++r) {
-            float *dst = slot + AFL + (wave * 64 + 256 * r) * 4;
-            const int pos = in0a + colB[r];
-            const bool mine = colB[r] >= 0, ok = mine && pos >= 0 && pos < p.Lvalid;
-            if (ok) glds_b128(reinterpret_cast<const float *>(xsrc + boffB[r]), dst);
-            if (mine && !ok) *reinterpret_cast<f32x4 *>(dst + lane * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+    // DMA cursor: the next chunk to request (runs ahead of the MFMAs, across tile boundaries).  begin_chunk() fixes the
+    // interval's uniform bases; dma_op(k), k < NOPS, issues ONE instruction -- never a branch: a wave without a piece
+    // in that slot, a cell outside the signal and a request past the workgroup's last chunk all read the zero page.
+    // (all of it incremental: no multiplication or division per interval)
+    int iq = 0, ic = 0, ib = first_b, it = first_t, isl = 0;   // chunk index in the stream / in the tile, tile coordinates, ring slot
+    const char *w_next = reinterpret_cast<const char *>(wt1);
+    const char *x_next = reinterpret_cast<const char *>(x + size_t(ib) * C * Lin + (it * BN - G::PA));
+    float *d_slot = lds;
+    const char *d_w = nullptr, *d_x = nullptr;
+    int d_in0a = 0;
+    bool d_live = false;
+    auto begin_chunk = [&]() {
+        d_live = iq < nq;
+        d_slot = lds + isl * SLOT;
+        d_w = w_next;
+        d_x = x_next;
+        d_in0a = it * BN - G::PA;
         ++iq;
-        if (++ic == NCH) {
+        isl = isl + 1 == G::NSLOT ? 0 : isl + 1;
+        w_next += AFL * sizeof(float);
+        x_next += size_t(CCH) * Lin * sizeof(float);
+        if (++ic == NCH) {   // next tile
             ic = 0;
             ib += step_b;
             it += step_t;
             if (it >= tiles_per_clip) it -= tiles_per_clip, ++ib;
+            w_next = reinterpret_cast<const char *>(wt1);
+            x_next = reinterpret_cast<const char *>(x + size_t(ib) * C * Lin + (it * BN - G::PA));
         }
+    };
+    auto dma_op = [&](int k) {
+        if (k < G::RA) {              // weights: 1 KiB pieces of one contiguous block of the tile image
+            const int n = wave + 4 * k;
+            const bool has = d_live && n < G::NPA;
+            const char *src = has ? d_w + n * 1024 + lane * 16 : zpage;
+            glds_b128(reinterpret_cast<const float *>(src), has ? d_slot + n * 256 : lds + G::DUMMY0);
+        } else if (k < G::NOPS) {     // input rows, 64 cells per instruction
+            const int r = k - G::RA, n = wave + 4 * r;
+            const int pos = d_in0a + colB[r];
+            const bool has = d_live && n < G::NIB;
+            const bool ok = has && pos >= 0 && pos < p.Lvalid;
+            const char *src = ok ? d_x + boffB[r] : zpage;
+            glds_b128(reinterpret_cast<const float *>(src), has ? d_slot + AFL + n * 256 : lds + G::DUMMY0);
+        }
+    };
+    auto issue = [&]() {
+        begin_chunk();
+#pragma unroll
+        for (int k = 0; k < G::NOPS; ++k) dma_op(k);
     };
 
     if (nq == 0) return;
@@ -212,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void resblock_p_kernel(ConvPlan p, int tile
     Frag<MW, NW, KS> f0, f1;
     if (PRE3) load_frag<MW, NW, CCH, D>(f0, lds + aLane, lds + bLane, 0);
 
-    int q = 0, cb = first_b, ct = first_t;
+    int q = 0, qs = 0, cb = first_b, ct = first_t;   // consumed chunks, their ring slot, tile coordinates
     for (int k = 0; k < my_tiles; ++k) {
         const int b = cb, t0 = ct * BN;
         cb += step_b;
@@ -227,33 +264,48 @@ __global__ __launch_bounds__(256, 2) void resblock_p_kernel(ConvPlan p, int tile
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][kk][r] = 0.f;
         if (!PRE3)   // 2-slot ring: the tile's first operands are read here (its first chunk landed at the last barrier)
-            load_frag<MW, NW, CCH, D>(f0, lds + (q % G::NSLOT) * SLOT + aLane, lds + (q % G::NSLOT) * SLOT + bLane, 0);
+            load_frag<MW, NW, CCH, D>(f0, lds + qs * SLOT + aLane, lds + qs * SLOT + bLane, 0);
 
         // ---- GEMM1 over the tile's chunks, two per iteration (the operand sets swap roles every 7 phases) -------
         // One interval: request chunk q+2, run the 7 tap phases of chunk q (the last one already reads the first
         // operands of chunk q+1), wait for this wave's DMA, barrier.
+#define AGX_RBP_OPS(j) [&]() { dma_op(j); if (G::NOPS > 7) dma_op(j + 7); }
 #define AGX_RBP_CHUNK(FA, FB, PRE, TAILC)                                                                            \
     {                                                                                                                \
-        issue();                                                                                                     \
+        AGX_RSTAMP(0);                                                                                               \
+        begin_chunk();                                                                                               \
         PRE;                                                                                                         \
-        const float *As = lds + (q % G::NSLOT) * SLOT + aLane, *Bs = lds + (q % G::NSLOT) * SLOT + bLane;            \
-        const float *An = lds + ((q + 1) % G::NSLOT) * SLOT + aLane, *Bn = lds + ((q + 1) % G::NSLOT) * SLOT + bLane; \
-        phase<MW, NW, CCH, D>(acc, FA, FB, As, Bs, 1);                                                               \
-        phase<MW, NW, CCH, D>(acc, FB, FA, As, Bs, 2);                                                               \
-        phase<MW, NW, CCH, D>(acc, FA, FB, As, Bs, 3);                                                               \
-        phase<MW, NW, CCH, D>(acc, FB, FA, As, Bs, 4);                                                               \
-        phase<MW, NW, CCH, D>(acc, FA, FB, As, Bs, 5);                                                               \
-        phase<MW, NW, CCH, D>(acc, FB, FA, As, Bs, 6);                                                               \
+        AGX_RSTAMP(1);                                                                                               \
+        const int qsn = qs + 1 == G::NSLOT ? 0 : qs + 1;                                                             \
+        const float *As = lds + qs * SLOT + aLane, *Bs = lds + qs * SLOT + bLane;                                    \
+        const float *An = lds + qsn * SLOT + aLane, *Bn = lds + qsn * SLOT + bLane;                                  \
+        phase<MW, NW, CCH, D>(acc, FA, FB, As, Bs, 1, AGX_RBP_OPS(0));                                               \
+        AGX_RSTAMP(2);                                                                                               \
+        phase<MW, NW, CCH, D>(acc, FB, FA, As, Bs, 2, AGX_RBP_OPS(1));                                               \
+        AGX_RSTAMP(3);                                                                                               \
+        phase<MW, NW, CCH, D>(acc, FA, FB, As, Bs, 3, AGX_RBP_OPS(2));                                               \
+        AGX_RSTAMP(4);                                                                                               \
+        phase<MW, NW, CCH, D>(acc, FB, FA, As, Bs, 4, AGX_RBP_OPS(3));                                               \
+        AGX_RSTAMP(5);                                                                                               \
+        phase<MW, NW, CCH, D>(acc, FA, FB, As, Bs, 5, AGX_RBP_OPS(4));                                               \
+        AGX_RSTAMP(6);                                                                                               \
+        phase<MW, NW, CCH, D>(acc, FB, FA, As, Bs, 6, AGX_RBP_OPS(5));                                               \
+        AGX_RSTAMP(7);                                                                                               \
         if (PRE3) {                                                                                                  \
-            phase<MW, NW, CCH, D>(acc, FA, FB, An, Bn, 0); /* next chunk's first phase: complete since the last barrier */ \
+            phase<MW, NW, CCH, D>(acc, FA, FB, An, Bn, 0, AGX_RBP_OPS(6)); /* next chunk's first phase: complete since the last barrier */ \
         } else {                                                                                                     \
+            AGX_RBP_OPS(6)();                                                                                        \
             mfma_frag<MW, NW, KS>(acc, FA);                                                                          \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
         }                                                                                                            \
+        AGX_RSTAMP(8);                                                                                               \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's part of the requested chunk has landed */     \
+        AGX_RSTAMP(9);                                                                                               \
         __syncthreads();                                 /* everyone's has; slot q is free */                         \
+        AGX_RSTAMP(10);                                                                                              \
         if (!PRE3 && !(TAILC)) load_frag<MW, NW, CCH, D>(FB, An, Bn, 0);                                              \
         ++q;                                                                                                         \
+        qs = qsn;                                                                                                    \
     }
         const char *xb = reinterpret_cast<const char *>(x + size_t(b) * C * Lin);
         char *yb = reinterpret_cast<char *>(y + size_t(b) * C * Lin);
@@ -281,6 +333,7 @@ __global__ __launch_bounds__(256, 2) void resblock_p_kernel(ConvPlan p, int tile
         AGX_RBP_CHUNK(f0, f1, (void)0, false)
         AGX_RBP_CHUNK(f1, f0, if (EARLY_RES) load_residual(0), true)
 #undef AGX_RBP_CHUNK
+#undef AGX_RBP_OPS
 
         // ---- tail: the first GEMM2 weight block travels while the activation runs -------------------------------------
         unsigned w2off = unsigned(lh * C + li) * 16u;
@@ -383,14 +436,16 @@ static int launch_rbp(const ConvPlan &p, const float *x, const float *w1, const 
     const int64_t ntiles64 = int64_t(tiles_per_clip) * p.B;
     if (ntiles64 > (1 << 30)) return fail(AGX_ERR_BAD_SHAPE, "resblock_p: too many tiles");
     const int ntiles = int(ntiles64);
-    const int wg_per_cu = int((160 * 1024) / G::LDS_BYTES) >= 2 ? 2 : 1;
+    int wg_per_cu = int((160 * 1024) / G::LDS_BYTES) >= 2 ? 2 : 1;
+    size_t lds_bytes = G::LDS_BYTES;
+    if (tuning().rb_wgs == 1) wg_per_cu = 1, lds_bytes = 100 * 1024;   // diagnostic: one workgroup per CU
     int grid = n_cu * wg_per_cu;
     if (grid > ntiles) grid = ntiles;
     // the tile images follow the standard image and the dim0 scale scratch in the packed buffers (common.hpp)
     const float *wt1 = w1 + packed_weight_floats(G::C, G::J, G::C) + G::C;
     const float *wt2 = w2 + packed_weight_floats(G::C, 1, G::C) + G::C;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G::LDS_BYTES, st, p, tiles_per_clip, ntiles, grid / tiles_per_clip,
-                       grid % tiles_per_clip, post_act, tuning().rb_stagger, x, wt1, b1, wt2, b2, y);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, st, p, tiles_per_clip, ntiles, grid / tiles_per_clip,
+                       grid % tiles_per_clip, post_act, x, wt1, b1, wt2, b2, y);
     return check_launch("resblock_p");
 }
 
