@@ -36,6 +36,8 @@ struct Tuning {
     int rb_occ = 2;    // 3: build of the fused residual block capped at 168 VGPRs (3 waves/SIMD)
     int rb_stagger = 0; // diagnostic: odd-slot workgroups of the fused residual block start rb_stagger x ~1k cycles late
     int rb_dbg = 0;     // diagnostic bit mask of resblock_p.hip (timing-only builds: 1 no steady-state DMA, 2 no residual loads, 4 1/16 of the stores)
+    int rb_lw = 0;      // diagnostic (d = 1 only): resblock_p with a fifth, DMA-only wave per workgroup, one workgroup per CU
+    int conv_impl = 1;  // resampling / stride-1 1-D layers: 1 = persistent ring kernel (conv_p.hip) where it applies, 0 = conv_mfma.hip
     int rb_impl = 1;    // fused residual block: 1 = persistent ring kernel (resblock_p.hip) where it applies, 0 = resblock_mfma.hip
     int rb_sched = -1; // phase scheduling of the fused residual block (mfma_tile.hpp: 0 / 1 / 2; -1 = per-shape table)
 };
@@ -83,6 +85,7 @@ struct ConvPlan {
     // patch mode, backward-data of strided layers: qh output-row phases per base row (rows m = (co*qh + a)*q + c),
     // output row = qh * base row + a - oshift_h; Tt base rows (forward: qh = 1, oshift_h = 0, Tt = Tout)
     int qh, oshift_h, Tt;
+    int64_t tile_off;   // floats from the packed image to the layer's tile image (below), -1: the layer has none
     int prec;   // 0: fp32 MFMA (exact fp32 FMA chain); 1: bf16x3 on the bf16 MFMA (mfma_tile.hpp), 1-D MFMA kernels only
 };
 
@@ -113,10 +116,16 @@ __host__ __device__ inline int64_t tile_image_floats(int Cin, int J, int M) {
 __host__ __device__ inline size_t tile_image_index(int ci, int j, int m, int J, int M) {
     return ((size_t(ci / 4) * J + j) * M + m) * 4 + (ci % 4);
 }
-// stride-1 causal layers of the fused residual block: the dilated k = 7 conv and the k = 1 conv, C in {32,64,128,256}
+// Geometry class of a layer the persistent conv kernel is instantiated for (conv_p.hip), 0 = none.
+int conv_p_geometry(const ConvPlan &p);
+// Layers that get a tile image: the stride-1 causal layers of the fused residual block (the dilated k = 7 conv and the
+// k = 1 conv, C in {32,64,128,256}) and the resampling / stride-1 layers of conv_p.hip.
 inline bool tile_image_eligible(const ConvPlan &p, int kind) {
-    return kind == AGX_CONV_CAUSAL && p.prec == 0 && p.G == 1 && p.s == 1 && p.q == 1 && p.Cin == p.Cout &&
-           (p.Cin == 32 || p.Cin == 64 || p.Cin == 128 || p.Cin == 256) && (p.J == 7 || p.J == 1);
+    if (p.prec != 0 || p.G != 1) return false;
+    if (kind == AGX_CONV_CAUSAL && p.s == 1 && p.q == 1 && p.Cin == p.Cout &&
+        (p.Cin == 32 || p.Cin == 64 || p.Cin == 128 || p.Cin == 256) && (p.J == 7 || p.J == 1))
+        return true;
+    return conv_p_geometry(p) != 0;
 }
 
 // Lower a descriptor; returns AGX_OK or an error (message set).

@@ -1,0 +1,482 @@
+// Persistent "ring" form of the dense 1-D polyphase convolution for gfx950 -- the resampling layers of the codec:
+//
+//   y[b, co, Q*t + ph] = act( bias[co] + sum_{ci, j < J} Wp[ci, j][co*Q + ph] * x[b, ci, t*S + j - P] )
+//
+//   strided down-convs      CausalConv1d(K = 2s+1, stride s)          networks/vae.py:136-139   Q = 1, J = K, S = s
+//   polyphase up-convs      CausalUpsampleConv1d(K = 2s+1, x s)        networks/vae.py:176-179   Q = s, J = 3, S = 1
+//   stride-1 (transposed)   CausalConv1d k3 / CausalConvT1d k7 s1      networks/vae.py:266, 269  Q = 1, S = 1
+//
+// Same operand path as resblock_p.hip (measured there: +15-20 % over the register-fed first kernel): a persistent
+// workgroup walks over (clip, time block, row block) tiles; a ring of LDS slots holds, per chunk of CCH input channels,
+// the weights of the tile's BM rows (contiguous pieces of the layer's tile image, shared by the four waves) and the
+// input rows (16-byte cells, zero page outside the signal), both by dwordx4 LDS-DMA issued branch-free, spread over
+// the MFMA phases; operand registers ping-pong over the unrolled taps; every LDS offset is an immediate (the kernel
+// is instantiated per layer geometry).  Strided layers read the input tile with a lane stride of S dwords (an S-way
+// bank conflict for S = 2, 4, 8): with NW fragments per MW x NW MFMAs the LDS has the cycles to spare.
+#include <utility>
+
+#include "mfma_tile.hpp"
+
+namespace agx {
+
+// 1 KiB of zeros in the code object: DMA source of input cells outside the signal and of unused instruction slots
+__device__ __attribute__((aligned(1024))) float g_cp_zero_page[256] = {0.f};
+
+__device__ __forceinline__ void cp_glds_b128(const float *gsrc_lane, float *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc_lane,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+template <class F, int... I>
+__device__ __forceinline__ void cp_static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void cp_static_for(F &&f) {
+    cp_static_for_impl(static_cast<F &&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// MW x NW fragments of 32 x 32 per wave, WM x WN waves, CCH channels per chunk, J taps, input step S, Q output phases,
+// PL = left offset P, NS ring slots (3: the next chunk is complete one interval early and its first operands are read
+// before the barrier; 2: it completes AT the barrier)
+template <int MW_, int NW_, int WM_, int WN_, int CCH_, int J_, int S_, int Q_, int PL_, int NS_>
+struct CpGeom {
+    static constexpr int MW = MW_, NW = NW_, WM = WM_, WN = WN_, CCH = CCH_, J = J_, S = S_, Q = Q_, PL = PL_, NSLOT = NS_;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static constexpr int BM = 32 * MW * WM, BN = 32 * NW * WN;
+    static constexpr int PA = (PL + 3) / 4 * 4, SHIFT = PA - PL;
+    static constexpr int SPANP = (SHIFT + (BN - 1) * S + J + 3) / 4 * 4;   // floats per LDS input row
+    static constexpr int NCELL = SPANP / 4;
+    static constexpr int KS = CCH / 2;                  // MFMA k-steps per (chunk, tap) phase
+    static constexpr int NG4 = CCH / 4;                 // 4-channel blocks of the tile image per chunk
+    static constexpr int AFL = NG4 * J * BM * 4;        // floats of weights per chunk: [g4][j][BM][4]
+    static constexpr int NPA = AFL / 256;               // 1 KiB DMA instructions of the weight chunk
+    static constexpr int PPB = BM / 64;                 // ... per (g4, j) piece
+    static constexpr int NCB = CCH * NCELL, NIB = (NCB + 63) / 64, BFLP = NIB * 256;
+    static constexpr int SLOT = AFL + BFLP;
+    static constexpr int RA = (NPA + 3) / 4, RB = (NIB + 3) / 4, NOPS = RA + RB;
+    static constexpr int OPP = (NOPS + J - 1) / J;      // DMA instructions per phase
+    static constexpr int BIAS0 = NSLOT * SLOT;          // bias[Cout] staged once per kernel (Cout <= 1024)
+    static constexpr int NBIAS = 1024;
+    static constexpr int DUMMY0 = BIAS0 + NBIAS;        // 1 KiB nobody reads: destination of the DMA slots a wave has no piece for
+    static constexpr size_t LDS_BYTES = size_t(DUMMY0 + 256) * sizeof(float);
+    static constexpr int NDS = MW * (KS == 8 ? 2 : 1) + KS * NW, NMF = KS * MW * NW;   // LDS reads / MFMAs per phase
+    static_assert(KS == 2 || KS == 4 || KS == 8, "chunk of 4, 8 or 16 channels");
+    static_assert(BM % 64 == 0, "weight pieces are whole 1 KiB instructions");
+};
+
+template <int MW, int NW, int KS>
+struct CpFrag {
+    float a[KS][MW];
+    float b[KS][NW];
+};
+
+template <class G>
+__device__ __forceinline__ void cp_load_frag(CpFrag<G::MW, G::NW, G::KS> &f, const float *__restrict__ As,
+                                             const float *__restrict__ Bs, int j) {
+    constexpr int KS = G::KS;
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int i = 0; i < G::MW; ++i) {
+        if (KS == 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(As + (j * G::BM + i * 32) * 4);
+            f.a[0][i] = v[0], f.a[1][i] = v[1], f.a[2][i] = v[2], f.a[3][i] = v[3];
+        } else if (KS == 2) {
+            const f32x2_t v = *reinterpret_cast<const f32x2_t *>(As + (j * G::BM + i * 32) * 4);
+            f.a[0][i] = v[0], f.a[1][i] = v[1];
+        } else {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(As + ((h2 * G::J + j) * G::BM + i * 32) * 4);
+                f.a[4 * h2 + 0][i] = v[0], f.a[4 * h2 + 1][i] = v[1], f.a[4 * h2 + 2][i] = v[2], f.a[4 * h2 + 3][i] = v[3];
+            }
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int k = 0; k < G::NW; ++k) f.b[ks][k] = Bs[ks * G::SPANP + k * 32 * G::S + j];
+}
+
+template <class G>
+__device__ __forceinline__ void cp_mfma_frag(f32x16 (&acc)[G::MW][G::NW], const CpFrag<G::MW, G::NW, G::KS> &f) {
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks)
+#pragma unroll
+        for (int i = 0; i < G::MW; ++i)
+#pragma unroll
+            for (int k = 0; k < G::NW; ++k)
+                acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[ks][i], f.b[ks][k], acc[i][k], 0, 0, 0);
+}
+
+// thread the phase's LDS reads between its MFMAs
+template <class G>
+__device__ __forceinline__ void cp_interleave() {
+    constexpr int PER = G::NMF / G::NDS > 0 ? G::NMF / G::NDS : 1;
+#pragma unroll
+    for (int g = 0; g < G::NDS; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // DS read
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// (clip, time block, row block) of a tile, advanced by the grid size with carries -- no division in the kernel
+struct CpTileCur {
+    int mb, nb, b;
+    __device__ __forceinline__ void advance(int sm, int sn, int sb, int mblocks, int nblocks) {
+        mb += sm;
+        nb += sn;
+        b += sb;
+        if (mb >= mblocks) mb -= mblocks, ++nb;
+        if (nb >= nblocks) nb -= nblocks, ++b;
+    }
+};
+
+template <class G>
+__global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks, int nblocks, int ntiles, int step_m,
+                                                        int step_n, int step_b, const float *__restrict__ x,
+                                                        const float *__restrict__ timg, const float *__restrict__ bias,
+                                                        float *__restrict__ y) {
+    constexpr int MW = G::MW, NW = G::NW, KS = G::KS, J = G::J, S = G::S, Q = G::Q, BM = G::BM, BN = G::BN;
+    constexpr int SLOT = G::SLOT, AFL = G::AFL, CCH = G::CCH;
+    constexpr bool PRE3 = G::NSLOT == 3;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / G::WN, wn = wave % G::WN;
+    const int Lin = p.Lin, M = p.M;
+    const int nch = p.Cin / CCH;   // chunks per tile
+
+    // ---- per-lane / per-wave constants of the DMA ---------------------------------------------------------------
+    unsigned boffB[G::RB];
+    int colB[G::RB];
+#pragma unroll
+    for (int r = 0; r < G::RB; ++r) {
+        const int e = (wave + 4 * r) * 64 + lane;
+        const int row = e / G::NCELL, col = e - row * G::NCELL;
+        colB[r] = e < G::NCB ? 4 * col : -(1 << 28);
+        boffB[r] = unsigned(row * Lin + 4 * col) * 4u;
+    }
+    unsigned aoff[G::RA];   // weight instruction n = wave + 4 r: piece (g4, j) = n / PPB of the chunk, 1 KiB part n % PPB
+#pragma unroll
+    for (int r = 0; r < G::RA; ++r) {
+        const int n = wave + 4 * r;
+        aoff[r] = unsigned(n / G::PPB) * unsigned(M) * 16u + unsigned(n % G::PPB) * 1024u;
+    }
+    const char *zpage = reinterpret_cast<const char *>(g_cp_zero_page) + lane * 16;
+    // consumer-side lane offsets (floats, relative to a slot)
+    const int aLane = (KS == 4 ? lh * J * BM * 4 : (KS == 8 ? 2 * lh * J * BM * 4 : lh * 2)) + (wm * 32 * MW + li) * 4;
+    const int bLane = AFL + lh * KS * G::SPANP + (wn * 32 * NW + li) * S + G::SHIFT;
+
+    const int my_tiles = int(blockIdx.x) < ntiles ? (ntiles - 1 - int(blockIdx.x)) / int(gridDim.x) + 1 : 0;
+    const int nq = my_tiles * nch;
+    if (nq == 0) return;
+    CpTileCur first;
+    {
+        const int t = int(blockIdx.x);
+        first.mb = t % mblocks;
+        const int rest = t / mblocks;
+        first.nb = rest % nblocks;
+        first.b = rest / nblocks;
+    }
+    const size_t wchunk = size_t(G::NG4) * J * M * 16;   // bytes of the tile image per chunk (all rows)
+
+    // DMA cursor (runs ahead of the MFMAs, across tile boundaries)
+    CpTileCur ic = first;
+    int iq = 0, icc = 0, isl = 0;
+    const char *w_next = reinterpret_cast<const char *>(timg) + size_t(ic.mb) * BM * 16;
+    const char *x_next = reinterpret_cast<const char *>(x + size_t(ic.b) * p.Cin * Lin + (ic.nb * BN * S - G::PA));
+    float *d_slot = lds;
+    const char *d_w = nullptr, *d_x = nullptr;
+    int d_in0a = 0;
+    bool d_live = false;
+    auto begin_chunk = [&]() {
+        d_live = iq < nq;
+        d_slot = lds + isl * SLOT;
+        d_w = w_next;
+        d_x = x_next;
+        d_in0a = ic.nb * BN * S - G::PA;
+        ++iq;
+        isl = isl + 1 == G::NSLOT ? 0 : isl + 1;
+        w_next += wchunk;
+        x_next += size_t(CCH) * Lin * sizeof(float);
+        if (++icc == nch) {
+            icc = 0;
+            ic.advance(step_m, step_n, step_b, mblocks, nblocks);
+            w_next = reinterpret_cast<const char *>(timg) + size_t(ic.mb) * BM * 16;
+            x_next = reinterpret_cast<const char *>(x + size_t(ic.b) * p.Cin * Lin + (ic.nb * BN * S - G::PA));
+        }
+    };
+    auto dma_op = [&](int k) {
+        if (k < G::RA) {
+            const int n = wave + 4 * k;
+            const bool has = d_live && n < G::NPA;
+            const char *src = has ? d_w + aoff[k] + lane * 16 : zpage;
+            cp_glds_b128(reinterpret_cast<const float *>(src), has ? d_slot + n * 256 : lds + G::DUMMY0);
+        } else if (k < G::NOPS) {
+            const int r = k - G::RA, n = wave + 4 * r;
+            const int pos = d_in0a + colB[r];
+            const bool has = d_live && n < G::NIB;
+            const bool ok = has && pos >= 0 && pos < p.Lvalid;
+            const char *src = ok ? d_x + boffB[r] : zpage;
+            cp_glds_b128(reinterpret_cast<const float *>(src), has ? d_slot + AFL + n * 256 : lds + G::DUMMY0);
+        }
+    };
+    auto issue_all = [&]() {
+        begin_chunk();
+#pragma unroll
+        for (int k = 0; k < G::NOPS; ++k) dma_op(k);
+    };
+
+    for (int i = tid; i < G::NBIAS; i += 256) lds[G::BIAS0 + i] = (bias && i < p.Cout) ? bias[i] : 0.f;
+    issue_all();
+    if (PRE3) issue_all();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    CpFrag<MW, NW, KS> f[2];
+    if (PRE3) cp_load_frag<G>(f[0], lds + aLane, lds + bLane, 0);
+
+    const bool pre_act = (p.epilogue & AGX_EPI_LEAKY_PRE) != 0;
+    CpTileCur cc = first;
+    int qs = 0;   // ring slot of the chunk being consumed
+    f32x16 acc[MW][NW];
+
+    // One interval = the J tap phases of one chunk; PAR = which operand set holds tap 0.
+    auto chunk = [&](auto par_c, bool tail_chunk) {
+        constexpr int PAR = decltype(par_c)::value;
+        begin_chunk();
+        const int qsn = qs + 1 == G::NSLOT ? 0 : qs + 1;
+        const float *As = lds + qs * SLOT + aLane, *Bs = lds + qs * SLOT + bLane;
+        const float *An = lds + qsn * SLOT + aLane, *Bn = lds + qsn * SLOT + bLane;
+        cp_static_for<J>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            CpFrag<MW, NW, KS> &cur = f[(PAR + j) & 1], &nxt = f[(PAR + j + 1) & 1];
+            if (j + 1 < J) cp_load_frag<G>(nxt, As, Bs, j + 1);
+            else if (PRE3) cp_load_frag<G>(nxt, An, Bn, 0);   // next chunk's first phase: complete since the last barrier
+#pragma unroll
+            for (int o = 0; o < G::OPP; ++o) dma_op(j * G::OPP + o);
+            cp_mfma_frag<G>(acc, cur);
+            if (j + 1 < J || PRE3) cp_interleave<G>();
+            else __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the requested chunk has landed
+        __syncthreads();                                   // everyone's has; the consumed slot is free
+        if (!PRE3 && !tail_chunk) cp_load_frag<G>(f[(PAR + J) & 1], An, Bn, 0);
+        qs = qsn;
+    };
+
+    for (int k = 0; k < my_tiles; ++k) {
+        const int mb = cc.mb, nb = cc.nb, b = cc.b;
+        cc.advance(step_m, step_n, step_b, mblocks, nblocks);
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int kk = 0; kk < NW; ++kk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][kk][r] = 0.f;
+        if (!PRE3) cp_load_frag<G>(f[0], lds + qs * SLOT + aLane, lds + qs * SLOT + bLane, 0);
+
+        if (J % 2 == 0) {
+            for (int c = 0; c < nch - 1; ++c) chunk(std::integral_constant<int, 0>{}, false);
+            chunk(std::integral_constant<int, 0>{}, true);
+        } else {   // odd tap count: the operand sets swap roles every chunk (nch is even for these layers)
+            for (int c = 0; c < nch - 2; c += 2) {
+                chunk(std::integral_constant<int, 0>{}, false);
+                chunk(std::integral_constant<int, 1>{}, false);
+            }
+            chunk(std::integral_constant<int, 0>{}, false);
+            chunk(std::integral_constant<int, 1>{}, true);
+        }
+
+        // ---- epilogue: bias (LDS), activation, store ------------------------------------------------------------------
+        int loutv = p.Lout;                    // opaque per-tile copy: the row offsets are formed here, not hoisted above the main loop
+        asm volatile("" : "+v"(loutv));
+        const int mrow0 = mb * BM + wm * 32 * MW;
+        char *yb = reinterpret_cast<char *>(y + size_t(b) * p.Cout * p.Lout);
+#pragma unroll
+        for (int i = 0; i < MW; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int m4 = mrow0 + i * 32 + 8 * g + 4 * lh;   // first of this lane's 4 consecutive rows
+                if (Q == 1) {
+                    const f32x4 bq = *reinterpret_cast<const f32x4 *>(lds + G::BIAS0 + m4);
+#pragma unroll
+                    for (int kk = 0; kk < NW; ++kk) {
+                        const int t = nb * BN + wn * 32 * NW + kk * 32 + li;
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) {
+                            float v = acc[i][kk][4 * g + s4] + bq[s4];
+                            if (pre_act) v = leaky(v, p.slope);
+                            if (t < p.Lt) *reinterpret_cast<float *>(yb + unsigned((m4 + s4) * loutv + t) * 4u) = v;
+                        }
+                    }
+                } else if (Q % 4 == 0) {   // the 4 rows are 4 consecutive output phases of one channel: one 16-byte store
+                    const int co = m4 / Q, ph = m4 % Q;
+                    const float bv = lds[G::BIAS0 + co];
+#pragma unroll
+                    for (int kk = 0; kk < NW; ++kk) {
+                        const int t = nb * BN + wn * 32 * NW + kk * 32 + li;
+                        f32x4 v4;
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) {
+                            float v = acc[i][kk][4 * g + s4] + bv;
+                            if (pre_act) v = leaky(v, p.slope);
+                            v4[s4] = v;
+                        }
+                        if (t < p.Lt) *reinterpret_cast<f32x4 *>(yb + unsigned(co * loutv + Q * t + ph) * 4u) = v4;
+                    }
+                } else if (Q == 2) {       // rows (0,1) and (2,3): two channels x two phases -> two 8-byte stores
+                    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                    const int co = m4 / 2;
+                    const f32x2_t b2 = *reinterpret_cast<const f32x2_t *>(lds + G::BIAS0 + co);
+#pragma unroll
+                    for (int kk = 0; kk < NW; ++kk) {
+                        const int t = nb * BN + wn * 32 * NW + kk * 32 + li;
+#pragma unroll
+                        for (int hp = 0; hp < 2; ++hp) {
+                            f32x2_t v2;
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                float v = acc[i][kk][4 * g + 2 * hp + e] + b2[hp];
+                                if (pre_act) v = leaky(v, p.slope);
+                                v2[e] = v;
+                            }
+                            if (t < p.Lt) *reinterpret_cast<f32x2_t *>(yb + unsigned((co + hp) * loutv + 2 * t) * 4u) = v2;
+                        }
+                    }
+                } else {                   // any Q: one dword per element
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const int m = m4 + s4, co = m / Q, ph = m - co * Q;
+                        const float bv = lds[G::BIAS0 + co];
+#pragma unroll
+                        for (int kk = 0; kk < NW; ++kk) {
+                            const int t = nb * BN + wn * 32 * NW + kk * 32 + li;
+                            float v = acc[i][kk][4 * g + s4] + bv;
+                            if (pre_act) v = leaky(v, p.slope);
+                            if (t < p.Lt) *reinterpret_cast<float *>(yb + unsigned(co * loutv + Q * t + ph) * 4u) = v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <class G>
+static int launch_cp(const ConvPlan &p, const float *x, const float *wp, const float *bias, float *y, hipStream_t st) {
+    auto kern = conv_p_kernel<G>;
+    static bool attr_set = false;
+    static int n_cu = 0;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return fail(AGX_ERR_LAUNCH, "conv_p: cannot query the device");
+        n_cu = prop.multiProcessorCount;
+        attr_set = true;
+    }
+    static_assert(G::LDS_BYTES <= 160 * 1024, "ring does not fit LDS");
+    const int mblocks = p.M / G::BM, nblocks = ceil_div(p.Lt, G::BN);
+    const int64_t ntiles64 = int64_t(mblocks) * nblocks * p.B;
+    if (ntiles64 > (1 << 30)) return fail(AGX_ERR_BAD_SHAPE, "conv_p: too many tiles");
+    const int ntiles = int(ntiles64);
+    const int wg_per_cu = int((160 * 1024) / G::LDS_BYTES) >= 2 ? 2 : 1;
+    int grid = n_cu * wg_per_cu;
+    if (grid > ntiles) grid = ntiles;
+    // grid = sb * (mblocks * nblocks) + sn * mblocks + sm
+    const int per_clip = mblocks * nblocks;
+    const int sb = grid / per_clip, rem = grid % per_clip;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G::LDS_BYTES, st, p, mblocks, nblocks, ntiles, rem % mblocks,
+                       rem / mblocks, sb, x, wp + p.tile_off, bias, y);
+    return check_launch("conv_p");
+}
+
+// ---- layer geometries the kernel is instantiated for -------------------------------------------------------------------
+//                      MW NW WM WN CCH  J  S  Q  P NS
+typedef CpGeom<2, 2, 1, 4, 8, 5, 2, 1, 3, 2> CpDown2;     // Conv1d k5 s2, M = 64:      64 x 256 tiles
+typedef CpGeom<2, 2, 2, 2, 4, 9, 4, 1, 5, 2> CpDown4;     // Conv1d k9 s4:             128 x 128
+typedef CpGeom<2, 2, 2, 2, 4, 11, 5, 1, 6, 2> CpDown5;    // Conv1d k11 s5:            128 x 128
+typedef CpGeom<2, 1, 2, 2, 4, 17, 8, 1, 9, 3> CpDown8;    // Conv1d k17 s8:            128 x 64 (one workgroup per CU)
+typedef CpGeom<2, 1, 2, 2, 16, 3, 1, 1, 2, 2> CpK3;       // Conv1d k3 s1:             128 x 64
+typedef CpGeom<2, 1, 2, 2, 8, 7, 1, 1, 6, 2> CpK7;        // Conv1d k7 s1 / ConvT k7 s1 (flipped kernel): 128 x 64
+typedef CpGeom<2, 1, 2, 2, 16, 3, 1, 8, 1, 2> CpUp8;      // upsample x8 (J = 3):      128 x 64
+typedef CpGeom<2, 2, 2, 2, 16, 3, 1, 5, 1, 2> CpUp5;      // upsample x5:              128 x 128
+typedef CpGeom<2, 2, 2, 2, 16, 3, 1, 4, 1, 2> CpUp4;      // upsample x4:              128 x 128
+typedef CpGeom<2, 2, 1, 4, 16, 3, 1, 2, 1, 2> CpUp2;      // upsample x2, M = 64:       64 x 256
+
+enum { CP_NONE = 0, CP_DOWN2, CP_DOWN4, CP_DOWN5, CP_DOWN8, CP_K3, CP_K7, CP_UP8, CP_UP5, CP_UP4, CP_UP2 };
+
+template <class G>
+static bool cp_fits(const ConvPlan &p) {
+    return p.M % G::BM == 0 && p.Cin % G::CCH == 0 && (G::J % 2 == 0 || (p.Cin / G::CCH) % 2 == 0) && p.Cin / G::CCH >= 2 &&
+           p.Cout <= G::NBIAS;
+}
+
+// shape-only test (also decides whether agx_conv_pack appends a tile image: common.hpp)
+int conv_p_geometry(const ConvPlan &p) {
+    if (p.prec != 0 || p.G != 1 || p.d != 1 || p.kh != 1 || p.Tout != 1 || p.pm_R != 0) return CP_NONE;
+    const int J = p.J, S = p.s, Q = p.q, P = p.P;
+    if (Q == 1 && J == 5 && S == 2 && P == 3 && p.M == 64 && cp_fits<CpDown2>(p)) return CP_DOWN2;
+    if (Q == 1 && J == 9 && S == 4 && P == 5 && cp_fits<CpDown4>(p)) return CP_DOWN4;
+    if (Q == 1 && J == 11 && S == 5 && P == 6 && cp_fits<CpDown5>(p)) return CP_DOWN5;
+    if (Q == 1 && J == 17 && S == 8 && P == 9 && cp_fits<CpDown8>(p)) return CP_DOWN8;
+    if (Q == 1 && J == 3 && S == 1 && P == 2 && cp_fits<CpK3>(p)) return CP_K3;
+    if (Q == 1 && J == 7 && S == 1 && P == 6 && cp_fits<CpK7>(p)) return CP_K7;
+    if (Q == 8 && J == 3 && S == 1 && P == 1 && cp_fits<CpUp8>(p)) return CP_UP8;
+    if (Q == 5 && J == 3 && S == 1 && P == 1 && cp_fits<CpUp5>(p)) return CP_UP5;
+    if (Q == 4 && J == 3 && S == 1 && P == 1 && cp_fits<CpUp4>(p)) return CP_UP4;
+    if (Q == 2 && J == 3 && S == 1 && P == 1 && p.M == 64 && cp_fits<CpUp2>(p)) return CP_UP2;
+    return CP_NONE;
+}
+
+// can THIS call run on the ring kernel? (epilogue: bias + optional LeakyReLU only; 16-byte cells need L % 4 == 0)
+bool conv_p_supported(const ConvPlan &p) {
+    if (p.tile_off < 0 || conv_p_geometry(p) == CP_NONE) return false;
+    if ((p.epilogue & ~AGX_EPI_LEAKY_PRE) != 0 || p.oshift != 0 || p.mask != nullptr) return false;
+    if (p.Lvalid != p.Lin || p.Lin % 4 != 0 || p.Lout != p.q * p.Lt) return false;
+    if (p.q > 1 && p.q % 4 == 0 && (p.Lout % 4 != 0)) return false;
+    return true;
+}
+
+const char *conv_p_variant(const ConvPlan &p) {
+    switch (conv_p_geometry(p)) {
+        case CP_DOWN2: return "conv_p<down2,64x256>";
+        case CP_DOWN4: return "conv_p<down4,128x128>";
+        case CP_DOWN5: return "conv_p<down5,128x128>";
+        case CP_DOWN8: return "conv_p<down8,128x64>";
+        case CP_K3: return "conv_p<k3,128x64>";
+        case CP_K7: return "conv_p<k7,128x64>";
+        case CP_UP8: return "conv_p<up8,128x64>";
+        case CP_UP5: return "conv_p<up5,128x128>";
+        case CP_UP4: return "conv_p<up4,128x128>";
+        case CP_UP2: return "conv_p<up2,64x256>";
+        default: return "conv_p<unsupported>";
+    }
+}
+
+int launch_conv_p(const ConvPlan &p, const float *x, const float *wp, const float *bias, float *y, hipStream_t st) {
+    if (!conv_p_supported(p)) return fail(AGX_ERR_UNSUPPORTED, "conv_p: unsupported layer");
+    switch (conv_p_geometry(p)) {
+        case CP_DOWN2: return launch_cp<CpDown2>(p, x, wp, bias, y, st);
+        case CP_DOWN4: return launch_cp<CpDown4>(p, x, wp, bias, y, st);
+        case CP_DOWN5: return launch_cp<CpDown5>(p, x, wp, bias, y, st);
+        case CP_DOWN8: return launch_cp<CpDown8>(p, x, wp, bias, y, st);
+        case CP_K3: return launch_cp<CpK3>(p, x, wp, bias, y, st);
+        case CP_K7: return launch_cp<CpK7>(p, x, wp, bias, y, st);
+        case CP_UP8: return launch_cp<CpUp8>(p, x, wp, bias, y, st);
+        case CP_UP5: return launch_cp<CpUp5>(p, x, wp, bias, y, st);
+        case CP_UP4: return launch_cp<CpUp4>(p, x, wp, bias, y, st);
+        case CP_UP2: return launch_cp<CpUp2>(p, x, wp, bias, y, st);
+        default: return fail(AGX_ERR_UNSUPPORTED, "conv_p: unsupported layer");
+    }
+}
+
+}  // namespace agx

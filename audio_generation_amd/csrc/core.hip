@@ -144,6 +144,10 @@ int lower_conv(const agx_conv_desc *d, ConvPlan *p) {
     p->prec = d->impl == AGX_IMPL_MFMA_BF16X3 ? 1 : 0;
     p->x_cstride = p->Lin;
     p->y_cstride = p->Lout;
+    // forward packed image = [standard image][dim0 scale scratch][tile image, for the layers that have one]
+    p->tile_off = -1;
+    if (tile_image_eligible(*p, d->kind))
+        p->tile_off = packed_weight_floats(p->Cin / p->G, p->J, p->M) + (d->kind == AGX_CONV_TRANSPOSED ? d->c_in : d->c_out);
     return AGX_OK;
 }
 
@@ -161,6 +165,7 @@ int lower_conv_bwd_data(const agx_conv_desc *d, ConvPlan *b) {
     if (f.Lvalid != f.Lin) return fail(AGX_ERR_UNSUPPORTED, "bwd_data: cropped inputs (negative right pad) not supported");
     if (f.G != 1) return fail(AGX_ERR_UNSUPPORTED, "bwd_data: grouped convs have no backward kernel");
     *b = f;
+    b->tile_off = -1;   // backward images (agx_conv_pack_bwd) carry no tile image
     b->Cin = f.Cout;
     b->Cout = f.Cin;
     b->Lin = f.Lout;   // the op reads dy
@@ -224,7 +229,9 @@ int agx_set_tuning(const char *name, int32_t value) {
     else if (!strcmp(name, "rb_occ")) agx::tuning().rb_occ = value;
     else if (!strcmp(name, "rb_stagger")) agx::tuning().rb_stagger = value;
     else if (!strcmp(name, "rb_impl")) agx::tuning().rb_impl = value;
+    else if (!strcmp(name, "conv_impl")) agx::tuning().conv_impl = value;
     else if (!strcmp(name, "rb_dbg")) agx::tuning().rb_dbg = value;
+    else if (!strcmp(name, "rb_lw")) agx::tuning().rb_lw = value;
     else if (!strcmp(name, "bf_sched")) agx::tuning().bf_sched = value;
     else if (!strcmp(name, "patch_tie")) agx::tuning().patch_tie = value;
     else if (!strcmp(name, "dw2_direct")) agx::tuning().dw2_direct = value;
@@ -246,7 +253,9 @@ int agx_get_tuning(const char *name) {
     if (!strcmp(name, "rb_occ")) return agx::tuning().rb_occ;
     if (!strcmp(name, "rb_stagger")) return agx::tuning().rb_stagger;
     if (!strcmp(name, "rb_impl")) return agx::tuning().rb_impl;
+    if (!strcmp(name, "conv_impl")) return agx::tuning().conv_impl;
     if (!strcmp(name, "rb_dbg")) return agx::tuning().rb_dbg;
+    if (!strcmp(name, "rb_lw")) return agx::tuning().rb_lw;
     if (!strcmp(name, "bf_sched")) return agx::tuning().bf_sched;
     if (!strcmp(name, "patch_tie")) return agx::tuning().patch_tie;
     if (!strcmp(name, "dw2_direct")) return agx::tuning().dw2_direct;
@@ -272,7 +281,7 @@ int64_t agx_conv_packed_floats(const agx_conv_desc *d) {
     // + dim0 floats of scratch at the tail for the weight-norm scales
     const int dim0 = (d->kind == AGX_CONV_TRANSPOSED) ? d->c_in : d->c_out;
     if (p.prec) return agx::packed_weight_floats_bf(p.Cin, p.J, p.M) + dim0;
-    const int64_t tile = agx::tile_image_eligible(p, d->kind) ? agx::tile_image_floats(p.Cin, p.J, p.M) : 0;
+    const int64_t tile = p.tile_off >= 0 ? agx::tile_image_floats(p.Cin, p.J, p.M) : 0;
     return agx::packed_weight_floats(p.Cin / p.G, p.J, p.M) + dim0 + tile;
 }
 

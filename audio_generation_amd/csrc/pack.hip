@@ -78,11 +78,11 @@ __global__ __launch_bounds__(256) void pack_kernel(const float *__restrict__ v,
     packed[e] = fwd_weight(v, scale, kind, Cin, Cout, K, J, P, up, ci, j, m / q, m % q);
 }
 
-// tile image (common.hpp: tile_image_index): Wt[((ci/4)*J + j) * M + m][ci%4], dense stride-1 layers (q = 1)
+// tile image (common.hpp: tile_image_index): Wt[((ci/4)*J + j) * M + m][ci%4], rows m = co*q + ph as in the standard image
 __global__ __launch_bounds__(256) void pack_tile_kernel(const float *__restrict__ v, const float *__restrict__ scale,
                                                         float *__restrict__ timg, int kind, int Cin, int Cout, int K,
-                                                        int J, int P) {
-    const int M = Cout;
+                                                        int q, int J, int P, int up) {
+    const int M = q * Cout;
     const int64_t total = tile_image_floats(Cin, J, M);
     const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (e >= total) return;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void pack_tile_kernel(const float *__restrict_
     const int m = int((e / 4) % M);
     const int gj = int(e / (int64_t(4) * M));
     const int j = gj % J, ci = (gj / J) * 4 + c4;
-    timg[e] = ci < Cin ? fwd_weight(v, scale, kind, Cin, Cout, K, J, P, 1, ci, j, m, 0) : 0.f;
+    timg[e] = ci < Cin ? fwd_weight(v, scale, kind, Cin, Cout, K, J, P, up, ci, j, m / q, m % q) : 0.f;
 }
 
 // bf16x3 image: [((g * J + j) * M + m) * 48 + plane * 16 + c16] bf16, w = h + m + l split with round-to-nearest
@@ -231,10 +231,10 @@ static int pack_forward(const agx_conv_desc *d, const float *v, const float *g, 
     }
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)ceil_div64(n_w, 256)), dim3(256), 0, st, v, scale,
                        packed, d->kind, cpg, p.Cout, d->kernel, p.q, p.J, p.P, d->stride);
-    if (tile_image_eligible(p, d->kind)) {   // second copy in the LDS-DMA layout of resblock_p.hip, behind the scale scratch
+    if (p.tile_off >= 0) {   // second copy in the LDS-DMA layout of resblock_p.hip / conv_p.hip, behind the scale scratch
         const int64_t n_t = tile_image_floats(p.Cin, p.J, p.M);
         hipLaunchKernelGGL(pack_tile_kernel, dim3((unsigned)ceil_div64(n_t, 256)), dim3(256), 0, st, v, scale,
-                           packed + n_w + dim0, d->kind, p.Cin, p.Cout, d->kernel, p.J, p.P);
+                           packed + p.tile_off, d->kind, p.Cin, p.Cout, d->kernel, p.q, p.J, p.P, d->stride);
     }
     return check_launch(who);
 }

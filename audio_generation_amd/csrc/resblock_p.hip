@@ -148,8 +148,8 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[MW][NW], const Frag<MW, NW, 
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int MW, int NW, int CCH, int D, int NS>
-__global__ __launch_bounds__(256, 2) void resblock_p_kernel(ConvPlan p, int tiles_per_clip, int ntiles, int step_b,
+template <int MW, int NW, int CCH, int D, int NS, int LW>   // LW 1: a fifth wave issues every DMA instruction
+__global__ __launch_bounds__(256 + 64 * LW, 2) void resblock_p_kernel(ConvPlan p, int tiles_per_clip, int ntiles, int step_b,
                                                             int step_t, int post_act,
                                                             const float *__restrict__ x,
                                                             const float *__restrict__ wt1, const float *__restrict__ b1,
@@ -234,13 +234,40 @@ __global__ __launch_bounds__(256, 2) void resblock_p_kernel(ConvPlan p, int tile
     };
     auto issue = [&]() {
         begin_chunk();
+        if (LW) return;
 #pragma unroll
         for (int k = 0; k < G::NOPS; ++k) dma_op(k);
     };
+    // LW: the loader wave requests a whole chunk (every piece and every cell instruction)
+    auto load_chunk = [&]() {
+        begin_chunk();
+        if (!d_live) return;
+        for (int n = 0; n < G::NPA; ++n) glds_b128(reinterpret_cast<const float *>(d_w + n * 1024 + lane * 16), d_slot + n * 256);
+        for (int n = 0; n < G::NIB; ++n) {
+            const int e = n * 64 + lane;
+            const int row = e / G::NCELL, col = e - row * G::NCELL;
+            const int pos = d_in0a + 4 * col;
+            const bool ok = e < G::NCB && pos >= 0 && pos < p.Lvalid;
+            const char *src = ok ? d_x + unsigned(row * Lin + 4 * col) * 4u : zpage;
+            glds_b128(reinterpret_cast<const float *>(src), d_slot + AFL + n * 256);
+        }
+    };
 
     if (nq == 0) return;
-    for (int i = tid; i < 2 * C; i += 256)   // biases: read once per kernel, served from LDS afterwards
+    for (int i = tid; i < 2 * C; i += 256 + 64 * LW)   // biases: read once per kernel, served from LDS afterwards
         lds[G::BIAS0 + i] = i < C ? (b1 ? b1[i] : 0.f) : (b2 ? b2[i - C] : 0.f);
+    if (LW && wave == 4) {   // ---- loader wave: one chunk per interval, NSLOT - 1 chunks ahead of the MFMA waves ----------
+        load_chunk();
+        if (PRE3) load_chunk();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int qq = 0; qq < nq; ++qq) {
+            load_chunk();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        return;
+    }
     issue();
     if (PRE3) issue();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -269,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void resblock_p_kernel(ConvPlan p, int tile
         // ---- GEMM1 over the tile's chunks, two per iteration (the operand sets swap roles every 7 phases) -------
         // One interval: request chunk q+2, run the 7 tap phases of chunk q (the last one already reads the first
         // operands of chunk q+1), wait for this wave's DMA, barrier.
-#define AGX_RBP_OPS(j) [&]() { dma_op(j); if (G::NOPS > 7) dma_op(j + 7); }
+#define AGX_RBP_OPS(j) [&]() { if (!LW) { dma_op(j); if (G::NOPS > 7) dma_op(j + 7); } }
 #define AGX_RBP_CHUNK(FA, FB, PRE, TAILC)                                                                            \
     {                                                                                                                \
         AGX_RSTAMP(0);                                                                                               \
@@ -414,11 +441,11 @@ __global__ __launch_bounds__(256, 2) void resblock_p_kernel(ConvPlan p, int tile
     }
 }
 
-template <int MW, int NW, int CCH, int D, int NS>
+template <int MW, int NW, int CCH, int D, int NS, int LW = 0>
 static int launch_rbp(const ConvPlan &p, const float *x, const float *w1, const float *b1, const float *w2,
                       const float *b2, float *y, int post_act, hipStream_t st) {
     using G = RbpGeom<MW, NW, CCH, D, NS>;
-    auto kern = resblock_p_kernel<MW, NW, CCH, D, NS>;
+    auto kern = resblock_p_kernel<MW, NW, CCH, D, NS, LW>;
     static bool attr_set = false;
     static int n_cu = 0;
     if (!attr_set) {
@@ -438,13 +465,13 @@ static int launch_rbp(const ConvPlan &p, const float *x, const float *w1, const 
     const int ntiles = int(ntiles64);
     int wg_per_cu = int((160 * 1024) / G::LDS_BYTES) >= 2 ? 2 : 1;
     size_t lds_bytes = G::LDS_BYTES;
-    if (tuning().rb_wgs == 1) wg_per_cu = 1, lds_bytes = 100 * 1024;   // diagnostic: one workgroup per CU
+    if (tuning().rb_wgs == 1 || LW) wg_per_cu = 1, lds_bytes = 100 * 1024;   // (diagnostic) one workgroup per CU
     int grid = n_cu * wg_per_cu;
     if (grid > ntiles) grid = ntiles;
     // the tile images follow the standard image and the dim0 scale scratch in the packed buffers (common.hpp)
     const float *wt1 = w1 + packed_weight_floats(G::C, G::J, G::C) + G::C;
     const float *wt2 = w2 + packed_weight_floats(G::C, 1, G::C) + G::C;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, st, p, tiles_per_clip, ntiles, grid / tiles_per_clip,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256 + 64 * LW), lds_bytes, st, p, tiles_per_clip, ntiles, grid / tiles_per_clip,
                        grid % tiles_per_clip, post_act, x, wt1, b1, wt2, b2, y);
     return check_launch("resblock_p");
 }
@@ -470,7 +497,8 @@ int launch_resblock_p(const ConvPlan &p, const float *x, const float *w1, const 
                       const float *b2, float *y, int post_act, hipStream_t st) {
     if (!resblock_p_supported(p)) return fail(AGX_ERR_UNSUPPORTED, "resblock_p: unsupported shape");
 #define AGX_RBP(MW, NW, CCH, NS)                                                                 \
-    (p.d == 1 ? launch_rbp<MW, NW, CCH, 1, NS>(p, x, w1, b1, w2, b2, y, post_act, st)            \
+    (tuning().rb_lw == 1 && p.d == 1 ? launch_rbp<MW, NW, CCH, 1, NS, 1>(p, x, w1, b1, w2, b2, y, post_act, st) \
+     : p.d == 1 ? launch_rbp<MW, NW, CCH, 1, NS>(p, x, w1, b1, w2, b2, y, post_act, st)          \
      : p.d == 3 ? launch_rbp<MW, NW, CCH, 3, NS>(p, x, w1, b1, w2, b2, y, post_act, st)          \
                 : launch_rbp<MW, NW, CCH, 9, NS>(p, x, w1, b1, w2, b2, y, post_act, st))
     switch (p.Cin) {

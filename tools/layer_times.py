@@ -10,7 +10,7 @@ def main():
     dev = torch.device("cuda")
     model = bench.build_model(dev)
     x = bench.make_inputs(32, 0).to(dev)
-    bench.calibrate_codebooks(model, x[:8])
+    bench.calibrate_codebooks(model, x[:8], "latents")
     with torch.no_grad():
         for _ in range(2): model(x)
     agg = {}
