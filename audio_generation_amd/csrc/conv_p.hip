@@ -221,8 +221,33 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
             const int pos = d_in0a + colB[r];
             const bool has = d_live && n < G::NIB;
             const bool ok = has && pos >= 0 && pos < p.Lvalid;
-            const char *src = ok ? d_x + boffB[r] : zpage;
+            // a cell that straddles the end of the row (L % 4 != 0) is fetched from the row's LAST four elements
+            // (in bounds) and put right by fix_ragged() once it has landed
+            const int over = max(pos + 4 - p.Lvalid, 0);
+            const char *src = ok ? d_x + boffB[r] - over * 4 : zpage;
             cp_glds_b128(reinterpret_cast<const float *>(src), has ? d_slot + AFL + n * 256 : lds + G::DUMMY0);
+        }
+    };
+    // after this wave's DMA has landed: cells that straddle the end of a ragged row hold x[L-4 .. L-1]; shift them to
+    // x[pos .. L-1] followed by zeros.  Only the last time block of a clip, and only when L % 4 != 0.
+    const bool ragged = (p.Lvalid & 3) != 0;
+    auto fix_ragged = [&]() {
+        if (!ragged || !d_live || d_in0a + G::SPANP <= p.Lvalid) return;
+#pragma unroll
+        for (int r = 0; r < G::RB; ++r) {
+            const int n = wave + 4 * r;
+            const int pos = d_in0a + colB[r];
+            const int over = pos + 4 - p.Lvalid;
+            if (n < G::NIB && pos >= 0 && pos < p.Lvalid && over > 0) {
+                f32x4 *cell = reinterpret_cast<f32x4 *>(d_slot + AFL + n * 256 + lane * 4);
+                const f32x4 v = *cell;
+                f32x4 o;
+                o[0] = over == 1 ? v[1] : (over == 2 ? v[2] : v[3]);
+                o[1] = over == 1 ? v[2] : (over == 2 ? v[3] : 0.f);
+                o[2] = over == 1 ? v[3] : 0.f;
+                o[3] = 0.f;
+                *cell = o;
+            }
         }
     };
     auto issue_all = [&]() {
@@ -233,8 +258,13 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
 
     for (int i = tid; i < G::NBIAS; i += 256) lds[G::BIAS0 + i] = (bias && i < p.Cout) ? bias[i] : 0.f;
     issue_all();
-    if (PRE3) issue_all();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    fix_ragged();
+    if (PRE3) {
+        issue_all();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        fix_ragged();
+    }
     __syncthreads();
 
     CpFrag<MW, NW, KS> f[2];
@@ -264,6 +294,7 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
             else __builtin_amdgcn_sched_barrier(0);
         });
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the requested chunk has landed
+        fix_ragged();
         __syncthreads();                                   // everyone's has; the consumed slot is free
         if (!PRE3 && !tail_chunk) cp_load_frag<G>(f[(PAR + J) & 1], An, Bn, 0);
         qs = qsn;
@@ -437,11 +468,11 @@ int conv_p_geometry(const ConvPlan &p) {
     return CP_NONE;
 }
 
-// can THIS call run on the ring kernel? (epilogue: bias + optional LeakyReLU only; 16-byte cells need L % 4 == 0)
+// can THIS call run on the ring kernel? (epilogue: bias + optional LeakyReLU only)
 bool conv_p_supported(const ConvPlan &p) {
     if (p.tile_off < 0 || conv_p_geometry(p) == CP_NONE) return false;
     if ((p.epilogue & ~AGX_EPI_LEAKY_PRE) != 0 || p.oshift != 0 || p.mask != nullptr) return false;
-    if (p.Lvalid != p.Lin || p.Lin % 4 != 0 || p.Lout != p.q * p.Lt) return false;
+    if (p.Lvalid != p.Lin || p.Lin < 4 || p.Lout != p.q * p.Lt) return false;   // (ragged L: fix_ragged)
     if (p.q > 1 && p.q % 4 == 0 && (p.Lout % 4 != 0)) return false;
     return true;
 }

@@ -48,7 +48,9 @@ def _case(kind, cin, cout, k, s, b, length, gen, act=True):
 @pytest.mark.parametrize("variant,kind,cin,cout,k,s", LAYERS)
 def test_every_geometry_against_oracle_and_first_kernel(variant, kind, cin, cout, k, s):
     gen = torch.Generator().manual_seed(sum(map(ord, variant)) + cin)
-    for b, length, act in ((1, 4, True), (2, 60, False), (1, 132, True), (3, 520, True), (2, 1028, False)):
+    # lengths: multiples of 4 and ragged ones (16-byte cells straddling the row end are shifted into place in LDS)
+    for b, length, act in ((1, 4, True), (2, 60, False), (1, 132, True), (3, 520, True), (2, 1028, False), (2, 225, True),
+                           (3, 45, False), (1, 77, True), (2, 131, True), (1, 1026, True)):
         desc, packed, bias, x, want = _case(kind, cin, cout, k, s, b, length, gen, act)
         try:
             _set("conv_impl", 1)
@@ -75,8 +77,9 @@ def test_every_geometry_against_oracle_and_first_kernel(variant, kind, cin, cout
     ("up5", "upconv", 256, 128, 11, 5, 9, 1800),      # 5 x 15 x 9 = 675
     ("up4", "upconv", 128, 64, 9, 4, 4, 9000),        # 2 x 71 x 4 = 568
     ("up2", "upconv", 64, 32, 5, 2, 4, 36000),        # 141 x 4 = 564
-    ("k3", "conv", 512, 512, 3, 1, 36, 228),          # 4 x 4 x 36 = 576
-    ("k7", "convt", 512, 512, 7, 1, 36, 228),
+    ("k3", "conv", 512, 512, 3, 1, 36, 225),          # 4 x 4 x 36 = 576; config S's bottleneck length (225 = 4 x 56 + 1)
+    ("k7", "convt", 512, 512, 7, 1, 36, 225),
+    ("up8", "upconv", 512, 256, 17, 8, 9, 225),
 ])
 def test_more_tiles_than_workgroups(variant, kind, cin, cout, k, s, b, length):
     gen = torch.Generator().manual_seed(3)
@@ -88,7 +91,7 @@ def test_more_tiles_than_workgroups(variant, kind, cin, cout, k, s, b, length):
 
 def test_calls_the_ring_kernel_does_not_cover_fall_back():
     gen = torch.Generator().manual_seed(4)
-    desc, packed, bias, x, want = _case("conv", 64, 128, 9, 4, 2, 402, gen)       # length % 4 != 0
+    desc, packed, bias, x, want = _case("conv", 64, 128, 9, 4, 2, 3, gen)         # shorter than one 16-byte cell
     assert ops.conv_kernel_name(desc).startswith("conv_mfma")
     assert max_abs(ops.conv_forward(desc, x, packed, bias).cpu(), want) < 2e-5 * max(1.0, float(want.abs().max()))
     # residual epilogue (used by the two-launch residual block and the transformer): first kernel
