@@ -75,6 +75,8 @@ SIGNATURES = {
                                  c_void_p]),
     "agx_attention_alibi": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float,
                                     c_void_p]),
+    "agx_attention_alibi_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float,
+                                       c_int32, c_int32, c_void_p]),
     "agx_layernorm_ct_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p]),
     "agx_attention_alibi_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,

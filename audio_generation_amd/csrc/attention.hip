@@ -19,6 +19,9 @@
 
 namespace agx {
 
+int launch_attention_flash(const float *qkv, const float *slopes, float *out, int B, int H, int Dh, int T, float scale_div,
+                           int precision, hipStream_t st);   // attention_flash.hip
+
 // ---------------------------------------------------------------------- LayerNorm
 // Block = 64 time steps x all channels; wave w takes channels w, w+4, ...
 __global__ __launch_bounds__(256) void layernorm_ct_kernel(const float *__restrict__ x,
@@ -444,14 +447,22 @@ int agx_layernorm_ct(const float *x, const float *weight, const float *bias, flo
 
 int agx_attention_alibi(const float *qkv, const float *slopes, float *out, int32_t batch, int32_t heads,
                         int32_t head_dim, int32_t t, float scale_div, void *stream) {
+    return agx_attention_alibi_ex(qkv, slopes, out, batch, heads, head_dim, t, scale_div, AGX_ATTN_FP32, 0, stream);
+}
+
+int agx_attention_alibi_ex(const float *qkv, const float *slopes, float *out, int32_t batch, int32_t heads,
+                           int32_t head_dim, int32_t t, float scale_div, int32_t precision, int32_t flash, void *stream) {
     using namespace agx;
     if (batch <= 0 || heads <= 0 || head_dim <= 0 || t <= 0)
         return fail(AGX_ERR_BAD_SHAPE, "attention_alibi: bad shape B=%d H=%d Dh=%d T=%d", batch, heads, head_dim, t);
     if (!qkv || !slopes || !out) return fail(AGX_ERR_NULL_POINTER, "attention_alibi: NULL pointer");
-    if (t > 256) return fail(AGX_ERR_UNSUPPORTED, "attention_alibi: T=%d > 256 (single-pass kernel)", t);
+    if (precision != AGX_ATTN_FP32 && precision != AGX_ATTN_BF16)
+        return fail(AGX_ERR_BAD_SHAPE, "attention_alibi: unknown precision %d", precision);
     if (head_dim > 128) return fail(AGX_ERR_UNSUPPORTED, "attention_alibi: head_dim=%d > 128", head_dim);
     if (heads > 65535 || batch > 65535) return fail(AGX_ERR_BAD_SHAPE, "attention_alibi: grid too large");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (t > 256 || precision == AGX_ATTN_BF16 || flash)   // online softmax over key blocks (attention_flash.hip)
+        return launch_attention_flash(qkv, slopes, out, batch, heads, head_dim, t, scale_div, precision, st);
     const int nj = t <= 64 ? 2 : (t <= 128 ? 4 : 8);
     const int dvt = head_dim <= 32 ? 1 : (head_dim <= 64 ? 2 : 4);
 #define AGX_ATTN(NJ, DVT) return launch_attn<NJ, DVT>(qkv, slopes, out, batch, heads, head_dim, t, scale_div, st)

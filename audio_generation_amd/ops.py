@@ -286,8 +286,14 @@ def layernorm_ct(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], ep
     return y
 
 
-def attention_alibi(qkv: Tensor, slopes: Tensor, heads: int, head_dim: int, scale_div: float) -> Tensor:
-    """softmax(QK^T/scale_div + ALiBi) V on a (B, 3*H*Dh, T) tensor -> (B, H*Dh, T)."""
+ATTN_FP32, ATTN_BF16 = 0, 1
+
+
+def attention_alibi(qkv: Tensor, slopes: Tensor, heads: int, head_dim: int, scale_div: float,
+                    precision: int = ATTN_FP32, flash: bool = False) -> Tensor:
+    """softmax(QK^T/scale_div + ALiBi) V on a (B, 3*H*Dh, T) tensor -> (B, H*Dh, T), any T.
+    ``precision``: ATTN_FP32 (exact fp32 MFMA) or ATTN_BF16 (bf16 MFMA, fp32 accumulate and softmax: BASELINE
+    config 3); ``flash`` forces the online-softmax form for fp32 at T <= 256 as well."""
     lib = _lib.load()
     _need_gpu(qkv, slopes)
     qkv = _f32c(qkv)
@@ -295,9 +301,13 @@ def attention_alibi(qkv: Tensor, slopes: Tensor, heads: int, head_dim: int, scal
     if c3 != 3 * heads * head_dim:
         raise AgxError(f"attention_alibi: qkv has {c3} channels, expected {3 * heads * head_dim}")
     out = torch.empty((b, heads * head_dim, t), dtype=torch.float32, device=qkv.device)
-    tok = _observer.begin("other", ("attention_alibi", 4 * (qkv.numel() + out.numel()))) if _observer is not None else None
-    _lib.check(lib.agx_attention_alibi(_ptr(qkv), _ptr(_f32c(slopes)), _ptr(out), b, heads, head_dim, t,
-                                       float(scale_div), _stream()), "agx_attention_alibi")
+    name = "attention_alibi" + (":bf16" if precision == ATTN_BF16 else "") + (":flash" if (flash or t > 256 or precision) else "")
+    # algorithmic work: QK^T and PV, 2 * B * H * T * T * Dh MACs; bytes: qkv read once + out written once
+    tok = (_observer.begin("other", (name, 4 * (qkv.numel() + out.numel()), 2 * b * heads * t * t * head_dim))
+           if _observer is not None else None)
+    _lib.check(lib.agx_attention_alibi_ex(_ptr(qkv), _ptr(_f32c(slopes)), _ptr(out), b, heads, head_dim, t,
+                                          float(scale_div), int(precision), int(bool(flash)), _stream()),
+               "agx_attention_alibi_ex")
     if tok is not None:
         _observer.end(tok)
     return out

@@ -119,6 +119,9 @@ class Attention(nn.Module):
         self.context = context_x
         self.alibi_obj = Alibi(context_x, None, n_heads=n_heads)
         self._qkv, self._o = _PackedLinear(), _PackedLinear()
+        # arithmetic of the QK^T / PV contractions: "fp32" (exact, the reference's) or "bf16" (bf16 MFMA, fp32 accumulate
+        # and softmax -- BASELINE config 3); inference only: the backward kernels assume the fp32 forward
+        self.attention_dtype = "fp32"
 
     def run_bct(self, x: Tensor, residual: Optional[Tensor] = None) -> Tensor:
         """(B, dim, T) -> W_o(attn(LN(x))) [+ residual], channel-major."""
@@ -129,7 +132,8 @@ class Attention(nn.Module):
         wqkv, bqkv = self._qkv.get([self.W_q, self.W_k, self.W_v])
         qkv = _linear_ct(xn, wqkv, bqkv, 3 * self.inner_dim)
         o = ops.attention_alibi(qkv, self.alibi_obj.head_scalars, self.n_heads, self.dim_head,
-                                self.dim_head ** 0.5)
+                                self.dim_head ** 0.5,
+                                ops.ATTN_BF16 if self.attention_dtype == "bf16" else ops.ATTN_FP32)
         wo, bo = self._o.get([self.W_o])
         return _linear_ct(o, wo, bo, self.dim, EPI_RESIDUAL if residual is not None else 0, residual)
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AGX_VERSION 112 /* 0.1.1: agx_conv_desc gained groups / padding (zero = old behaviour); 111: resample, conv2d column split */
+#define AGX_VERSION 113 /* 113: tile images (resblock_p / conv_p), agx_attention_alibi_ex, agx_sizeof_*; 0.1.1: agx_conv_desc gained groups / padding (zero = old behaviour); 111: resample, conv2d column split */
 
 #define AGX_OK 0
 #define AGX_ERR_BAD_SHAPE (-1)
@@ -60,7 +60,12 @@ int32_t agx_sizeof_conv2d_desc(void);
  *                      column-strided layers (x through its column-phase planes), 0 the staged kernel everywhere
  *   "dw1_wgs" N        workgroups the 1-D barrier-free weight-gradient kernel aims for (default 768)
  *   "dw_wgs" n         workgroups the conv2d weight-gradient kernel aims for (default 1536)
- *   "conv_shape" 0|1   1: 128x128 conv tiles as four row-waves of 1x4 fragments                    */
+ *   "conv_shape" 0|1   1: 128x128 conv tiles as four row-waves of 1x4 fragments
+ *   "rb_impl" 0|1      fused residual block: 1 (default) the persistent ring kernel (csrc/resblock_p.hip) where it applies,
+ *                      0 the first kernel (csrc/resblock_mfma.hip) everywhere
+ *   "conv_impl" 0|1    resampling / stride-1 1-D layers: 1 (default) the persistent ring kernel (csrc/conv_p.hip), 0 conv_mfma.hip
+ *   "rb_lw" 0|1        diagnostic: resblock_p with a fifth, DMA-only wave (one workgroup per CU; d = 1 instantiations only)
+ *   "rb_stagger", "rb_dbg"  retired diagnostics (accepted, no effect)                                      */
 int agx_set_tuning(const char *name, int32_t value);
 int agx_get_tuning(const char *name);
 
@@ -235,9 +240,17 @@ int agx_layernorm_ct(const float *x, const float *weight, const float *bias, flo
  * M[h,i,j] = -slopes[h] * |i - j| computed in the kernel (transformers.py:175-188;
  * Alibi :38-39, 62-75).  qkv is (B, 3*H*Dh, T): q rows [0,H*Dh), k rows
  * [H*Dh, 2*H*Dh), v rows [2*H*Dh, 3*H*Dh), head-major inside each.  out is
- * (B, H*Dh, T).  fp32-input MFMA for both contractions.  T <= 256, Dh <= 128. */
+ * (B, H*Dh, T).  fp32-input MFMA for both contractions (exact fp32), any T: a single-pass kernel for T <= 256, the
+ * online-softmax (flash) form over key blocks beyond.  Dh <= 128. */
 int agx_attention_alibi(const float *qkv, const float *slopes, float *out, int32_t batch,
                         int32_t heads, int32_t head_dim, int32_t t, float scale_div, void *stream);
+/* The same with a choice of arithmetic: AGX_ATTN_FP32 (as above) or AGX_ATTN_BF16 -- operands rounded to bf16, both
+ * contractions on the bf16 MFMA with fp32 accumulation, fp32 softmax (BASELINE config 3; flash form at every T).
+ * `flash` != 0 forces the flash form for fp32 at T <= 256 too (tests). */
+#define AGX_ATTN_FP32 0
+#define AGX_ATTN_BF16 1
+int agx_attention_alibi_ex(const float *qkv, const float *slopes, float *out, int32_t batch, int32_t heads,
+                           int32_t head_dim, int32_t t, float scale_div, int32_t precision, int32_t flash, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Wavelet / multiresolution layers (networks/wavelets.py)                     *
