@@ -36,8 +36,15 @@ namespace agx {
         if (q == AGX_STAMP_Q && lane == 0) g_stamps[(blockIdx.x * 4 + wave) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
         __builtin_amdgcn_sched_barrier(0);                                                         \
     } while (0)
+#define AGX_TSTAMP(slot)                                                                           \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (k == 2 && lane == 0) g_stamps[(blockIdx.x * 4 + wave) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
 #else
 #define AGX_RSTAMP(slot) ((void)0)
+#define AGX_TSTAMP(slot) ((void)0)
 #endif
 
 // 16 bytes per lane global -> LDS (1 KiB per wave instruction); LDS destination = wave-uniform base + lane * 16
@@ -76,8 +83,11 @@ struct RbpGeom {
     static constexpr int RB = (NIB + 3) / 4;
     static constexpr int NOPS = RA + RB;               // DMA instructions per wave and interval, spread over the 7 phases
     static constexpr int BIAS0 = NSLOT * SLOT;         // [2][C] floats behind the ring: b1, b2 (zeros when absent)
-    static constexpr int DUMMY0 = BIAS0 + 2 * C;       // 1 KiB nobody reads: destination of the DMA slots a wave has no piece for
-    static constexpr size_t LDS_BYTES = size_t(NSLOT * SLOT + 2 * C + 256) * sizeof(float);
+    static constexpr int SCR0 = BIAS0 + 2 * C;         // 1 KiB per wave: transposition scratch of the tile tail (8 rows x 32 columns)
+    static constexpr int DUMMY0 = SCR0;                // ... and, during the main loop, the destination of the DMA slots the wave has no
+                                                       // piece for (its own scratch: every DMA of a wave has landed before its tail
+                                                       // starts -- vmcnt(0) at the end of each interval)
+    static constexpr size_t LDS_BYTES = size_t(NSLOT * SLOT + 2 * C + 4 * 256) * sizeof(float);
     static_assert(AFL % 256 == 0, "weight chunk must be whole 1 KiB pieces");
     static_assert(KS == 2 || KS == 4 || KS == 8, "chunk of 4, 8 or 16 channels");
 };
@@ -150,7 +160,7 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[MW][NW], const Frag<MW, NW, 
 
 template <int MW, int NW, int CCH, int D, int NS, int LW>   // LW 1: a fifth wave issues every DMA instruction
 __global__ __launch_bounds__(256 + 64 * LW, 2) void resblock_p_kernel(ConvPlan p, int tiles_per_clip, int ntiles, int step_b,
-                                                            int step_t, int post_act,
+                                                            int step_t, int post_act, int stagger,
                                                             const float *__restrict__ x,
                                                             const float *__restrict__ wt1, const float *__restrict__ b1,
                                                             const float *__restrict__ wt2, const float *__restrict__ b2,
@@ -222,14 +232,14 @@ __global__ __launch_bounds__(256 + 64 * LW, 2) void resblock_p_kernel(ConvPlan p
             const int n = wave + 4 * k;
             const bool has = d_live && n < G::NPA;
             const char *src = has ? d_w + n * 1024 + lane * 16 : zpage;
-            glds_b128(reinterpret_cast<const float *>(src), has ? d_slot + n * 256 : lds + G::DUMMY0);
+            glds_b128(reinterpret_cast<const float *>(src), has ? d_slot + n * 256 : lds + G::DUMMY0 + wave * 256);
         } else if (k < G::NOPS) {     // input rows, 64 cells per instruction
             const int r = k - G::RA, n = wave + 4 * r;
             const int pos = d_in0a + colB[r];
             const bool has = d_live && n < G::NIB;
             const bool ok = has && pos >= 0 && pos < p.Lvalid;
             const char *src = ok ? d_x + boffB[r] : zpage;
-            glds_b128(reinterpret_cast<const float *>(src), has ? d_slot + AFL + n * 256 : lds + G::DUMMY0);
+            glds_b128(reinterpret_cast<const float *>(src), has ? d_slot + AFL + n * 256 : lds + G::DUMMY0 + wave * 256);
         }
     };
     auto issue = [&]() {
@@ -254,6 +264,12 @@ __global__ __launch_bounds__(256 + 64 * LW, 2) void resblock_p_kernel(ConvPlan p
     };
 
     if (nq == 0) return;
+    if (stagger > 0) {
+        // knob rb_stagger (diagnostic): workgroups start (blockIdx.x % 8) x stagger x ~1k cycles late, once, so that the
+        // epilogue store bursts of the whole chip do not hit HBM at the same time
+        const int n = int(blockIdx.x % 8) * stagger;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
+    }
     for (int i = tid; i < 2 * C; i += 256 + 64 * LW)   // biases: read once per kernel, served from LDS afterwards
         lds[G::BIAS0 + i] = i < C ? (b1 ? b1[i] : 0.f) : (b2 ? b2[i - C] : 0.f);
     if (LW && wave == 4) {   // ---- loader wave: one chunk per interval, NSLOT - 1 chunks ahead of the MFMA waves ----------
@@ -296,10 +312,11 @@ __global__ __launch_bounds__(256 + 64 * LW, 2) void resblock_p_kernel(ConvPlan p
         // ---- GEMM1 over the tile's chunks, two per iteration (the operand sets swap roles every 7 phases) -------
         // One interval: request chunk q+2, run the 7 tap phases of chunk q (the last one already reads the first
         // operands of chunk q+1), wait for this wave's DMA, barrier.
-#define AGX_RBP_OPS(j) [&]() { if (!LW) { dma_op(j); if (G::NOPS > 7) dma_op(j + 7); } }
+#define AGX_RBP_OPS(j) [&]() { if (!LW) { dma_op(j); if (G::NOPS > 7) dma_op(j + 7); } if (TAILC_ && EARLY_RES) load_residual(0, j, 7); }
 #define AGX_RBP_CHUNK(FA, FB, PRE, TAILC)                                                                            \
     {                                                                                                                \
         AGX_RSTAMP(0);                                                                                               \
+        constexpr bool TAILC_ = TAILC;                                                                               \
         begin_chunk();                                                                                               \
         PRE;                                                                                                         \
         AGX_RSTAMP(1);                                                                                               \
@@ -338,31 +355,49 @@ __global__ __launch_bounds__(256 + 64 * LW, 2) void resblock_p_kernel(ConvPlan p
         char *yb = reinterpret_cast<char *>(y + size_t(b) * C * Lin);
         int linv = Lin;                       // opaque per-tile copies: keep the row offsets / fragment addresses from being
         asm volatile("" : "+v"(linv));        // hoisted out of the tile loop (they would be live across the whole main loop)
-        // GEMM2's accumulator starts from the residual: out = x (+ b2 below) + W2 . h.  Its 16*MW*NW loads go out at
-        // the top of the tile's LAST interval and have the whole interval to arrive.
+        // GEMM2's accumulator starts from the residual: out = x (+ b2 below) + W2 . h.  The residual tile is fetched in
+        // 16-byte pieces (one instruction = 8 rows x 128 B, lane -> row l / 8, columns 4 (l % 8) ..), spread over the phases of
+        // the tile's LAST interval, parked in the `out` registers as it comes and brought into the accumulator layout through
+        // a 1 KiB per-wave LDS scratch in the tail.  Piece (io, g, kk) = rows 8g .. 8g+7 of row block io, column block kk.
         f32x16 out[HS][NW];
-        auto load_residual = [&](int pass) {
+        float *scr = lds + G::SCR0 + wave * 256;
+        const int prow = lane >> 3, pcol = (lane & 7) * 4;
+        constexpr int NPIECE = HS * 4 * NW;
+        auto load_residual = [&](int pass, int first, int step) {
+#pragma unroll
+            for (int pc = first; pc < NPIECE; pc += step) {
+                const int io = pc / (4 * NW), g = (pc / NW) % 4, kk = pc % NW;
+                const int tq = min(t0 + n0 + kk * 32 + pcol, Lin - 4);   // columns beyond the clip are never stored
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(
+                    xb + unsigned(((pass * HS + io) * 32 + 8 * g + prow) * linv + tq) * 4u);
+                out[io][kk][4 * g + 0] = v[0], out[io][kk][4 * g + 1] = v[1], out[io][kk][4 * g + 2] = v[2], out[io][kk][4 * g + 3] = v[3];
+            }
+        };
+        // piece-major rows -> accumulator layout (lane (li, lh), register 4g + s4 = row 8g + 4lh + s4, column li)
+        auto residual_to_acc_layout = [&]() {
 #pragma unroll
             for (int io = 0; io < HS; ++io)
 #pragma unroll
-                for (int kk = 0; kk < NW; ++kk) {
-                    const int tc = min(t0 + n0 + kk * 32 + li, Lin - 1);
+                for (int kk = 0; kk < NW; ++kk)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        out[io][kk][r] = *reinterpret_cast<const float *>(
-                            xb + unsigned(((pass * HS + io) * 32 + acc_row(r, lh)) * linv + tc) * 4u);
-                }
+                    for (int g = 0; g < 4; ++g) {
+                        *reinterpret_cast<f32x4 *>(scr + lane * 4) =
+                            f32x4{out[io][kk][4 * g + 0], out[io][kk][4 * g + 1], out[io][kk][4 * g + 2], out[io][kk][4 * g + 3]};
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) out[io][kk][4 * g + s4] = scr[(4 * lh + s4) * 32 + li];
+                    }
         };
         for (int c = 0; c < NCH - 2; c += 2) {
             AGX_RBP_CHUNK(f0, f1, (void)0, false)
             AGX_RBP_CHUNK(f1, f0, (void)0, false)
         }
         AGX_RBP_CHUNK(f0, f1, (void)0, false)
-        AGX_RBP_CHUNK(f1, f0, if (EARLY_RES) load_residual(0), true)
+        AGX_RBP_CHUNK(f1, f0, (void)0, true)
 #undef AGX_RBP_CHUNK
 #undef AGX_RBP_OPS
 
         // ---- tail: the first GEMM2 weight block travels while the activation runs -------------------------------------
+        AGX_TSTAMP(11);
         unsigned w2off = unsigned(lh * C + li) * 16u;
         asm volatile("" : "+v"(w2off));
         const char *w2b = reinterpret_cast<const char *>(wt2);
@@ -392,12 +427,14 @@ __global__ __launch_bounds__(256 + 64 * LW, 2) void resblock_p_kernel(ConvPlan p
                     }
             }
 
+        AGX_TSTAMP(12);
 #pragma unroll
         for (int pass = 0; pass < MW / HS; ++pass) {
             if (pass > 0 || !EARLY_RES) {   // (C = 256 only) this latency is exposed, twice per 8192-MFMA tile
                 if (pass > 0) load_w2(wa[0], 0, pass);
-                load_residual(pass);
+                load_residual(pass, 0, 1);
             }
+            residual_to_acc_layout();
 #pragma unroll
             for (int io = 0; io < HS; ++io)
 #pragma unroll
@@ -423,20 +460,26 @@ __global__ __launch_bounds__(256 + 64 * LW, 2) void resblock_p_kernel(ConvPlan p
                                                                               out[io][kk], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // ---- epilogue: trailing activation, store -------------------------------------------------------------------
+            if (pass == 0) AGX_TSTAMP(13);
+            // ---- epilogue: trailing activation; accumulator layout -> 8-row x 128-byte pieces through the scratch; 16-byte stores
 #pragma unroll
             for (int io = 0; io < HS; ++io)
 #pragma unroll
-                for (int kk = 0; kk < NW; ++kk) {
-                    const int t = t0 + n0 + kk * 32 + li;
+                for (int kk = 0; kk < NW; ++kk)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float v = out[io][kk][r];
-                        if (post_act) v = leaky(v, p.slope);
-                        if (t < Lin)
-                            *reinterpret_cast<float *>(yb + unsigned(((pass * HS + io) * 32 + acc_row(r, lh)) * linv + t) * 4u) = v;
+                    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) {
+                            float v = out[io][kk][4 * g + s4];
+                            if (post_act) v = leaky(v, p.slope);
+                            scr[(4 * lh + s4) * 32 + li] = v;
+                        }
+                        const f32x4 v4 = *reinterpret_cast<const f32x4 *>(scr + lane * 4);
+                        const int tq = t0 + n0 + kk * 32 + pcol;
+                        if (tq < Lin)   // L % 4 == 0: a piece is inside the clip or outside it
+                            *reinterpret_cast<f32x4 *>(yb + unsigned(((pass * HS + io) * 32 + 8 * g + prow) * linv + tq) * 4u) = v4;
                     }
-                }
+            if (pass == 0) AGX_TSTAMP(14);
         }
     }
 }
@@ -472,7 +515,7 @@ static int launch_rbp(const ConvPlan &p, const float *x, const float *w1, const 
     const float *wt1 = w1 + packed_weight_floats(G::C, G::J, G::C) + G::C;
     const float *wt2 = w2 + packed_weight_floats(G::C, 1, G::C) + G::C;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256 + 64 * LW), lds_bytes, st, p, tiles_per_clip, ntiles, grid / tiles_per_clip,
-                       grid % tiles_per_clip, post_act, x, wt1, b1, wt2, b2, y);
+                       grid % tiles_per_clip, post_act, tuning().rb_stagger, x, wt1, b1, wt2, b2, y);
     return check_launch("resblock_p");
 }
 

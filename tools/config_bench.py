@@ -28,12 +28,18 @@ DEV = "cuda"
 
 def run(name):
     torch.manual_seed(0)
+    bf16 = name == "C3bf16"      # config 3 as BASELINE states it: attention contractions on the bf16 MFMA (fp32 accumulate / softmax)
+    if bf16:
+        name = "C3"
     if name == "C3":
         kw = dict(in_channels=1, n_blocks=4, strides=(2, 4, 5, 8), num_quantizers=8, codebook_size=1024,
                   codebook_dim=512, input_format="n c l", wavelet_decoders=False)
         b, c, length = 32, 1, 72000
         model = CausalVQAE(**kw)
-        model.replace_quantizer(TransformerBottleneck(Transformer(512, depth=1, heads=8, head_dim=64, context_x=225)))
+        tf = Transformer(512, depth=1, heads=8, head_dim=64, context_x=225)
+        for att, _ in tf.layers:
+            att.attention_dtype = "bf16" if bf16 else "fp32"
+        model.replace_quantizer(TransformerBottleneck(tf))
         spec = codec.CodecSpec(in_channels=1, n_blocks=4, strides=(2, 4, 5, 8), codebook_dim=512,
                                wavelet_decoders=False, input_format="n c l")
     else:
@@ -86,8 +92,18 @@ def run(name):
         from oracle import rvq
         want = codec.decode_latents(rvq.residual_quantize(z, sd["quantizer.codebooks"])[0], sd, spec)
     rms = float((y1.double() - want.double()).pow(2).mean().sqrt())
+    att = {k: v for k, v in per.items() if k.startswith("attention_alibi")}
+    extra = {}
+    if att:
+        k, v = next(iter(att.items()))
+        peak = 2500.0 if bf16 else 157.3     # dense bf16 MFMA / fp32 MFMA peak (MI355X_MICROARCH.md), TFLOP/s
+        extra["attention"] = {"kernel": k, "avg_us": round(v["avg_us"], 1), "tflops": round(v["tflops"], 2),
+                              "frac_of_mfma_peak": v["tflops"] / peak, "peak_tflops": peak,
+                              "flops_counted": "QK^T + PV: 4 B H T^2 Dh", "bound_note":
+                              "32 x 8 = 256 (batch, head) pairs x 2 query tiles of 225 frames: 0.83 GFLOP in all -- launch / latency bound"}
     print(json.dumps({
-        "config": name, "batch": b, "channels": c, "clip_samples": length, "ms_per_step": ms,
+        "config": name + ("bf16" if bf16 else ""), "arithmetic": ("attention contractions bf16 MFMA, fp32 accumulate + softmax; convs fp32"
+                                                              if bf16 else "fp32 everywhere"), **extra, "batch": b, "channels": c, "clip_samples": length, "ms_per_step": ms,
         "samples_per_s": b * length / ms * 1e3, "launch": "hipGraph replay", "dtype": "f32",
         "waveform_rms_vs_oracle_clip0": rms,
         "kernels": {k: {"ms_per_step": round(v["ms_per_step"], 4), "avg_us": round(v["avg_us"], 1),
@@ -97,5 +113,5 @@ def run(name):
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
-    for n in (("C3", "C4") if which == "all" else (which,)):
+    for n in (("C3", "C3bf16", "C4") if which == "all" else (which,)):
         run(n)

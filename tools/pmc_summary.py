@@ -57,6 +57,10 @@ def main():
                 f"{n[3:]} {100 * c[n] / w:.1f}%" for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
                                                          "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_LDS",
                                                          "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_MISC") if n in c))
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c and c["GRBM_GUI_ACTIVE"]:
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS): cycles = /8; 256 CUs x 4 SIMDs share them
+            simd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
+            print(f"   -- MFMA utilisation (MFMA busy cycles / SIMD cycles of the dispatch): {100 * c['SQ_VALU_MFMA_BUSY_CYCLES'] / simd_cycles:.1f} %")
         if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c:
             print(f"   -- MFMA busy / SQ busy cycles: {c['SQ_VALU_MFMA_BUSY_CYCLES'] / c['SQ_BUSY_CYCLES']:.3f}")
         if "FETCH_SIZE" in c or "WRITE_SIZE" in c:

@@ -10,6 +10,7 @@
 namespace agx {
 int lower_conv2d(const agx_conv2d_desc *, ConvPlan *) { return AGX_ERR_UNSUPPORTED; }
 int lower_conv2d_bwd_data(const agx_conv2d_desc *, ConvPlan *) { return AGX_ERR_UNSUPPORTED; }
+int conv_p_geometry(const ConvPlan &) { return 0; }   // conv_p.hip is not linked into the probe
 }  // namespace agx
 
 #include <cstdio>

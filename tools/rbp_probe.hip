@@ -11,6 +11,7 @@
 namespace agx {
 int lower_conv2d(const agx_conv2d_desc *, ConvPlan *) { return AGX_ERR_UNSUPPORTED; }
 int lower_conv2d_bwd_data(const agx_conv2d_desc *, ConvPlan *) { return AGX_ERR_UNSUPPORTED; }
+int conv_p_geometry(const ConvPlan &) { return 0; }   // conv_p.hip is not linked into the probe
 }  // namespace agx
 
 #include <algorithm>
@@ -68,5 +69,19 @@ int main(int argc, char **argv) {
         tot += v[v.size() / 2];
     }
     printf("  sum of medians %.0f cycles\n", tot);
+    // tile tail of every workgroup's third tile: stamps 11 (after the last barrier) .. 14 (stores issued)
+    const char *tname[3] = {"tail: W2 request + hidden activation", "tail: GEMM2 (first row pass)", "tail: activation + stores (first row pass)"};
+    std::vector<double> ts[3];
+    for (int w = 0; w < 2048; ++w) {
+        unsigned long long *t = &z[w * 16];
+        if (!t[14] || !t[11]) continue;
+        for (int i = 0; i < 3; ++i) ts[i].push_back(double(t[12 + i] - t[11 + i]));
+    }
+    for (int i = 0; i < 3; ++i) {
+        auto &v = ts[i];
+        if (v.empty()) continue;
+        std::sort(v.begin(), v.end());
+        printf("  %-45s %8.0f [%8.0f .. %8.0f]\n", tname[i], v[v.size() / 2], v[v.size() / 10], v[v.size() * 9 / 10]);
+    }
     return 0;
 }
