@@ -84,9 +84,6 @@ struct RbpGeom {
     static constexpr int NOPS = RA + RB;               // DMA instructions per wave and interval, spread over the 7 phases
     static constexpr int BIAS0 = NSLOT * SLOT;         // [2][C] floats behind the ring: b1, b2 (zeros when absent)
     static constexpr int SCR0 = BIAS0 + 2 * C;         // 1 KiB per wave: transposition scratch of the tile tail (8 rows x 32 columns)
-    static constexpr int DUMMY0 = SCR0;                // ... and, during the main loop, the destination of the DMA slots the wave has no
-                                                       // piece for (its own scratch: every DMA of a wave has landed before its tail
-                                                       // starts -- vmcnt(0) at the end of each interval)
     static constexpr size_t LDS_BYTES = size_t(NSLOT * SLOT + 2 * C + 4 * 256) * sizeof(float);
     static_assert(AFL % 256 == 0, "weight chunk must be whole 1 KiB pieces");
     static_assert(KS == 2 || KS == 4 || KS == 8, "chunk of 4, 8 or 16 channels");
@@ -158,9 +155,9 @@ __device__ __forceinline__ void phase(f32x16 (&acc)[MW][NW], const Frag<MW, NW, 
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int MW, int NW, int CCH, int D, int NS, int LW>   // LW 1: a fifth wave issues every DMA instruction
-__global__ __launch_bounds__(256 + 64 * LW, 2) void resblock_p_kernel(ConvPlan p, int tiles_per_clip, int ntiles, int step_b,
-                                                            int step_t, int post_act, int stagger,
+template <int MW, int NW, int CCH, int D, int NS>
+__global__ __launch_bounds__(256, 2) void resblock_p_kernel(ConvPlan p, int tiles_per_clip, int ntiles, int step_b,
+                                                            int step_t, int post_act,
                                                             const float *__restrict__ x,
                                                             const float *__restrict__ wt1, const float *__restrict__ b1,
                                                             const float *__restrict__ wt2, const float *__restrict__ b2,
@@ -168,7 +165,6 @@ __global__ __launch_bounds__(256 + 64 * LW, 2) void resblock_p_kernel(ConvPlan p
     using G = RbpGeom<MW, NW, CCH, D, NS>;
     constexpr int C = G::C, BN = G::BN, KS = G::KS, NCH = G::NCH, SLOT = G::SLOT, AFL = G::AFL, HS = G::HS;
     constexpr bool PRE3 = G::NSLOT == 3;
-    constexpr bool EARLY_RES = MW <= 4;   // residual requested during the tile's last interval (C = 256: no registers to park it in)
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [3][AFL + BFL]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: LDS-DMA destinations stay in SGPRs
@@ -177,12 +173,16 @@ __global__ __launch_bounds__(256 + 64 * LW, 2) void resblock_p_kernel(ConvPlan p
     const int Lin = p.Lin;
 
     // ---- per-lane constants of the DMA (the same for every chunk and tile) ------------------------------------
-    // input instruction n = wave + 4 r covers cells 64 n .. 64 n + 63 of the chunk (cell e = row e / NCELL, columns 4 (e % NCELL) ..)
+    // Instruction slot (k, wave) of an interval moves piece n = wave + 4 k; a slot beyond the chunk's last piece repeats
+    // piece n % count (same bytes to the same place: harmless), so that every slot issues unconditionally, branch-free.
+    // input instruction n covers cells 64 n .. 64 n + 63 of the chunk (cell e = row e / NCELL, columns 4 (e % NCELL) ..)
     unsigned boffB[G::RB];   // byte offset of this lane's cell inside the chunk's rows
     int colB[G::RB];         // its first column relative to the LDS row start; hugely negative: beyond the chunk
+    int nB[G::RB];
 #pragma unroll
     for (int r = 0; r < G::RB; ++r) {
-        const int e = (wave + 4 * r) * 64 + lane;
+        nB[r] = (wave + 4 * r) % G::NIB;
+        const int e = nB[r] * 64 + lane;
         const int row = e / G::NCELL, col = e - row * G::NCELL;
         colB[r] = e < G::NCB ? 4 * col : -(1 << 28);
         boffB[r] = unsigned(row * Lin + 4 * col) * 4u;
@@ -198,9 +198,9 @@ __global__ __launch_bounds__(256 + 64 * LW, 2) void resblock_p_kernel(ConvPlan p
     const int first_b = int(blockIdx.x) / tiles_per_clip, first_t = int(blockIdx.x) - first_b * tiles_per_clip;
 
     // DMA cursor: the next chunk to request (runs ahead of the MFMAs, across tile boundaries).  begin_chunk() fixes the
-    // interval's uniform bases; dma_op(k), k < NOPS, issues ONE instruction -- never a branch: a wave without a piece
-    // in that slot, a cell outside the signal and a request past the workgroup's last chunk all read the zero page.
-    // (all of it incremental: no multiplication or division per interval)
+    // interval's uniform bases (all of it incremental: no multiplication or division per interval); dma_op(k), k < NOPS,
+    // issues ONE instruction.  A cell outside the signal reads the zero page; so does every request past the workgroup's
+    // last chunk (into a ring slot nobody reads any more).
     int iq = 0, ic = 0, ib = first_b, it = first_t, isl = 0;   // chunk index in the stream / in the tile, tile coordinates, ring slot
     const char *w_next = reinterpret_cast<const char *>(wt1);
     const char *x_next = reinterpret_cast<const char *>(x + size_t(ib) * C * Lin + (it * BN - G::PA));
@@ -229,61 +229,26 @@ __global__ __launch_bounds__(256 + 64 * LW, 2) void resblock_p_kernel(ConvPlan p
     };
     auto dma_op = [&](int k) {
         if (k < G::RA) {              // weights: 1 KiB pieces of one contiguous block of the tile image
-            const int n = wave + 4 * k;
-            const bool has = d_live && n < G::NPA;
-            const char *src = has ? d_w + n * 1024 + lane * 16 : zpage;
-            glds_b128(reinterpret_cast<const float *>(src), has ? d_slot + n * 256 : lds + G::DUMMY0 + wave * 256);
+            const int n = (wave + 4 * k) % G::NPA;
+            const char *src = d_live ? d_w + n * 1024 + lane * 16 : zpage;
+            glds_b128(reinterpret_cast<const float *>(src), d_slot + n * 256);
         } else if (k < G::NOPS) {     // input rows, 64 cells per instruction
-            const int r = k - G::RA, n = wave + 4 * r;
+            const int r = k - G::RA;
             const int pos = d_in0a + colB[r];
-            const bool has = d_live && n < G::NIB;
-            const bool ok = has && pos >= 0 && pos < p.Lvalid;
+            const bool ok = d_live && pos >= 0 && pos < p.Lvalid;
             const char *src = ok ? d_x + boffB[r] : zpage;
-            glds_b128(reinterpret_cast<const float *>(src), has ? d_slot + AFL + n * 256 : lds + G::DUMMY0 + wave * 256);
+            glds_b128(reinterpret_cast<const float *>(src), d_slot + AFL + nB[r] * 256);
         }
     };
     auto issue = [&]() {
         begin_chunk();
-        if (LW) return;
 #pragma unroll
         for (int k = 0; k < G::NOPS; ++k) dma_op(k);
     };
-    // LW: the loader wave requests a whole chunk (every piece and every cell instruction)
-    auto load_chunk = [&]() {
-        begin_chunk();
-        if (!d_live) return;
-        for (int n = 0; n < G::NPA; ++n) glds_b128(reinterpret_cast<const float *>(d_w + n * 1024 + lane * 16), d_slot + n * 256);
-        for (int n = 0; n < G::NIB; ++n) {
-            const int e = n * 64 + lane;
-            const int row = e / G::NCELL, col = e - row * G::NCELL;
-            const int pos = d_in0a + 4 * col;
-            const bool ok = e < G::NCB && pos >= 0 && pos < p.Lvalid;
-            const char *src = ok ? d_x + unsigned(row * Lin + 4 * col) * 4u : zpage;
-            glds_b128(reinterpret_cast<const float *>(src), d_slot + AFL + n * 256);
-        }
-    };
 
     if (nq == 0) return;
-    if (stagger > 0) {
-        // knob rb_stagger (diagnostic): workgroups start (blockIdx.x % 8) x stagger x ~1k cycles late, once, so that the
-        // epilogue store bursts of the whole chip do not hit HBM at the same time
-        const int n = int(blockIdx.x % 8) * stagger;
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
-    }
-    for (int i = tid; i < 2 * C; i += 256 + 64 * LW)   // biases: read once per kernel, served from LDS afterwards
+    for (int i = tid; i < 2 * C; i += 256)   // biases: read once per kernel, served from LDS afterwards
         lds[G::BIAS0 + i] = i < C ? (b1 ? b1[i] : 0.f) : (b2 ? b2[i - C] : 0.f);
-    if (LW && wave == 4) {   // ---- loader wave: one chunk per interval, NSLOT - 1 chunks ahead of the MFMA waves ----------
-        load_chunk();
-        if (PRE3) load_chunk();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int qq = 0; qq < nq; ++qq) {
-            load_chunk();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-        return;
-    }
     issue();
     if (PRE3) issue();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -291,6 +256,42 @@ __global__ __launch_bounds__(256 + 64 * LW, 2) void resblock_p_kernel(ConvPlan p
 
     Frag<MW, NW, KS> f0, f1;
     if (PRE3) load_frag<MW, NW, CCH, D>(f0, lds + aLane, lds + bLane, 0);
+
+    // ---- tile tail <-> memory: 16-byte pieces through a per-wave LDS scratch ----------------------------------------------
+    // A piece = rows 8g .. 8g+7 of row block io x the 32 columns of column block kk: one instruction moves 8 rows x 128 B
+    // (lane -> row l / 8, columns 4 (l % 8) ..).  In the accumulator layout lane (li, lh) holds rows 8g + 4lh + (0..3) of
+    // column li in registers 4g .. 4g+3; the 1 KiB scratch (8 rows x 32 columns) converts between the two.
+    // The residual tile is requested in pieces spread over the phases of the tile's LAST interval, parked in the `out`
+    // registers, brought into the accumulator layout in the tail (GEMM2's accumulator starts from x + b2), and the finished
+    // tile is stored right after GEMM2.  (Measured and dropped: deferring the stores into the next tile's first phases --
+    // 127 vs 131 TFLOP/s at C = 64; a fifth, DMA-only wave; start-time staggers within a CU and across the chip.)
+    constexpr bool EARLY = MW <= 4;              // residual requested during the tile's last interval (C = 256: no registers to park it in)
+    constexpr int NPIECE = HS * 4 * NW;
+    f32x16 out[HS][NW];
+    float *scr = lds + G::SCR0 + wave * 256;
+    const int prow = lane >> 3, pcol = (lane & 7) * 4;
+    auto store_piece = [&](int pc, int pass, char *ybase, int tcol0, int linv) {
+        const int io = pc / (4 * NW), g = (pc / NW) % 4, kk = pc % NW;
+        // (all scratch accesses are float-typed and fenced for the compiler: a vector-typed store next to scalar loads of the
+        //  same bytes was reordered under type-based alias analysis)
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) scr[(4 * lh + s4) * 32 + li] = out[io][kk][4 * g + s4];
+        asm volatile("" ::: "memory");
+        f32x4 v4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v4[e] = scr[lane * 4 + e];
+        asm volatile("" ::: "memory");
+        const int tq = tcol0 + n0 + kk * 32 + pcol;
+        if (tq < Lin)   // L % 4 == 0: a piece is inside the clip or outside it
+            *reinterpret_cast<f32x4 *>(ybase + unsigned(((pass * HS + io) * 32 + 8 * g + prow) * linv + tq) * 4u) = v4;
+    };
+    auto load_piece = [&](int pc, int pass, const char *xbase, int tcol0, int linv) {
+        const int io = pc / (4 * NW), g = (pc / NW) % 4, kk = pc % NW;
+        const int tq = min(tcol0 + n0 + kk * 32 + pcol, Lin - 4);   // columns beyond the clip are never stored
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(xbase + unsigned(((pass * HS + io) * 32 + 8 * g + prow) * linv + tq) * 4u);
+        out[io][kk][4 * g + 0] = v[0], out[io][kk][4 * g + 1] = v[1], out[io][kk][4 * g + 2] = v[2], out[io][kk][4 * g + 3] = v[3];
+    };
 
     int q = 0, qs = 0, cb = first_b, ct = first_t;   // consumed chunks, their ring slot, tile coordinates
     for (int k = 0; k < my_tiles; ++k) {
@@ -309,16 +310,28 @@ __global__ __launch_bounds__(256 + 64 * LW, 2) void resblock_p_kernel(ConvPlan p
         if (!PRE3)   // 2-slot ring: the tile's first operands are read here (its first chunk landed at the last barrier)
             load_frag<MW, NW, CCH, D>(f0, lds + qs * SLOT + aLane, lds + qs * SLOT + bLane, 0);
 
-        // ---- GEMM1 over the tile's chunks, two per iteration (the operand sets swap roles every 7 phases) -------
-        // One interval: request chunk q+2, run the 7 tap phases of chunk q (the last one already reads the first
-        // operands of chunk q+1), wait for this wave's DMA, barrier.
-#define AGX_RBP_OPS(j) [&]() { if (!LW) { dma_op(j); if (G::NOPS > 7) dma_op(j + 7); } if (TAILC_ && EARLY_RES) load_residual(0, j, 7); }
-#define AGX_RBP_CHUNK(FA, FB, PRE, TAILC)                                                                            \
+        const char *xb = reinterpret_cast<const char *>(x + size_t(b) * C * Lin);
+        char *yb = reinterpret_cast<char *>(y + size_t(b) * C * Lin);
+        int linv = Lin;                       // opaque per-tile copies: keep the row offsets / fragment addresses from being
+        asm volatile("" : "+v"(linv));        // hoisted out of the tile loop (they would be live across the whole main loop)
+
+        // ---- GEMM1 over the tile's chunks (the operand sets swap roles every 7 phases) -----------------------------------
+        // One interval: request the chunk NSLOT-1 ahead, run the 7 tap phases of chunk q (the last one already reads the
+        // first operands of chunk q+1), wait for this wave's DMA, barrier.  Each phase also carries its share of the DMA
+        // instructions and, in the tile's LAST chunk, of the residual loads.
+#define AGX_RBP_OPS(j)                                                                                                \
+    [&]() {                                                                                                           \
+        dma_op(j);                                                                                                    \
+        if (G::NOPS > 7) dma_op(j + 7);                                                                               \
+        if (EARLY && LAST_) {                                                                                         \
+            _Pragma("unroll") for (int pc = (j); pc < NPIECE; pc += 7) load_piece(pc, 0, xb, t0, linv);               \
+        }                                                                                                             \
+    }
+#define AGX_RBP_CHUNK(FA, FB, LAST)                                                                                  \
     {                                                                                                                \
         AGX_RSTAMP(0);                                                                                               \
-        constexpr bool TAILC_ = TAILC;                                                                               \
+        constexpr bool LAST_ = LAST;                                                                                 \
         begin_chunk();                                                                                               \
-        PRE;                                                                                                         \
         AGX_RSTAMP(1);                                                                                               \
         const int qsn = qs + 1 == G::NSLOT ? 0 : qs + 1;                                                             \
         const float *As = lds + qs * SLOT + aLane, *Bs = lds + qs * SLOT + bLane;                                    \
@@ -347,52 +360,16 @@ __global__ __launch_bounds__(256 + 64 * LW, 2) void resblock_p_kernel(ConvPlan p
         AGX_RSTAMP(9);                                                                                               \
         __syncthreads();                                 /* everyone's has; slot q is free */                         \
         AGX_RSTAMP(10);                                                                                              \
-        if (!PRE3 && !(TAILC)) load_frag<MW, NW, CCH, D>(FB, An, Bn, 0);                                              \
-        ++q;                                                                                                         \
+        if (!PRE3 && !(LAST)) load_frag<MW, NW, CCH, D>(FB, An, Bn, 0);                                               \
+        ++q; (void)q;                                                                                                \
         qs = qsn;                                                                                                    \
     }
-        const char *xb = reinterpret_cast<const char *>(x + size_t(b) * C * Lin);
-        char *yb = reinterpret_cast<char *>(y + size_t(b) * C * Lin);
-        int linv = Lin;                       // opaque per-tile copies: keep the row offsets / fragment addresses from being
-        asm volatile("" : "+v"(linv));        // hoisted out of the tile loop (they would be live across the whole main loop)
-        // GEMM2's accumulator starts from the residual: out = x (+ b2 below) + W2 . h.  The residual tile is fetched in
-        // 16-byte pieces (one instruction = 8 rows x 128 B, lane -> row l / 8, columns 4 (l % 8) ..), spread over the phases of
-        // the tile's LAST interval, parked in the `out` registers as it comes and brought into the accumulator layout through
-        // a 1 KiB per-wave LDS scratch in the tail.  Piece (io, g, kk) = rows 8g .. 8g+7 of row block io, column block kk.
-        f32x16 out[HS][NW];
-        float *scr = lds + G::SCR0 + wave * 256;
-        const int prow = lane >> 3, pcol = (lane & 7) * 4;
-        constexpr int NPIECE = HS * 4 * NW;
-        auto load_residual = [&](int pass, int first, int step) {
-#pragma unroll
-            for (int pc = first; pc < NPIECE; pc += step) {
-                const int io = pc / (4 * NW), g = (pc / NW) % 4, kk = pc % NW;
-                const int tq = min(t0 + n0 + kk * 32 + pcol, Lin - 4);   // columns beyond the clip are never stored
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(
-                    xb + unsigned(((pass * HS + io) * 32 + 8 * g + prow) * linv + tq) * 4u);
-                out[io][kk][4 * g + 0] = v[0], out[io][kk][4 * g + 1] = v[1], out[io][kk][4 * g + 2] = v[2], out[io][kk][4 * g + 3] = v[3];
-            }
-        };
-        // piece-major rows -> accumulator layout (lane (li, lh), register 4g + s4 = row 8g + 4lh + s4, column li)
-        auto residual_to_acc_layout = [&]() {
-#pragma unroll
-            for (int io = 0; io < HS; ++io)
-#pragma unroll
-                for (int kk = 0; kk < NW; ++kk)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        *reinterpret_cast<f32x4 *>(scr + lane * 4) =
-                            f32x4{out[io][kk][4 * g + 0], out[io][kk][4 * g + 1], out[io][kk][4 * g + 2], out[io][kk][4 * g + 3]};
-#pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) out[io][kk][4 * g + s4] = scr[(4 * lh + s4) * 32 + li];
-                    }
-        };
         for (int c = 0; c < NCH - 2; c += 2) {
-            AGX_RBP_CHUNK(f0, f1, (void)0, false)
-            AGX_RBP_CHUNK(f1, f0, (void)0, false)
+            AGX_RBP_CHUNK(f0, f1, false)
+            AGX_RBP_CHUNK(f1, f0, false)
         }
-        AGX_RBP_CHUNK(f0, f1, (void)0, false)
-        AGX_RBP_CHUNK(f1, f0, (void)0, true)
+        AGX_RBP_CHUNK(f0, f1, false)
+        AGX_RBP_CHUNK(f1, f0, true)
 #undef AGX_RBP_CHUNK
 #undef AGX_RBP_OPS
 
@@ -430,21 +407,27 @@ __global__ __launch_bounds__(256 + 64 * LW, 2) void resblock_p_kernel(ConvPlan p
         AGX_TSTAMP(12);
 #pragma unroll
         for (int pass = 0; pass < MW / HS; ++pass) {
-            if (pass > 0 || !EARLY_RES) {   // (C = 256 only) this latency is exposed, twice per 8192-MFMA tile
+            if (pass > 0 || !EARLY) {   // (C = 256 only) the residual is requested here: exposed latency, twice per 8192-MFMA tile
                 if (pass > 0) load_w2(wa[0], 0, pass);
-                load_residual(pass, 0, 1);
+#pragma unroll
+                for (int pc = 0; pc < NPIECE; ++pc) load_piece(pc, pass, xb, t0, linv);
             }
-            residual_to_acc_layout();
+            // residual pieces -> accumulator layout, + b2: GEMM2's accumulator starts from x + b2
 #pragma unroll
             for (int io = 0; io < HS; ++io)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 b2q = *reinterpret_cast<const f32x4 *>(lds + G::BIAS0 + C + (pass * HS + io) * 32 + 8 * g + 4 * lh);
+                for (int kk = 0; kk < NW; ++kk)
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4)
+                    for (int g = 0; g < 4; ++g) {
+                        asm volatile("" ::: "memory");
 #pragma unroll
-                        for (int kk = 0; kk < NW; ++kk) out[io][kk][4 * g + s4] += b2q[s4];
-                }
+                        for (int e = 0; e < 4; ++e) scr[lane * 4 + e] = out[io][kk][4 * g + e];
+                        asm volatile("" ::: "memory");
+                        const f32x4 b2q = *reinterpret_cast<const f32x4 *>(lds + G::BIAS0 + C + (pass * HS + io) * 32 + 8 * g + 4 * lh);
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) out[io][kk][4 * g + s4] = scr[(4 * lh + s4) * 32 + li] + b2q[s4];
+                        asm volatile("" ::: "memory");
+                    }
             // ---- GEMM2: out += W2 . h, B operand = the accumulator registers (resblock_mfma.hip); weights one block ahead
 #pragma unroll
             for (int blk = 0; blk < 4 * MW; ++blk) {
@@ -461,34 +444,27 @@ __global__ __launch_bounds__(256 + 64 * LW, 2) void resblock_p_kernel(ConvPlan p
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (pass == 0) AGX_TSTAMP(13);
-            // ---- epilogue: trailing activation; accumulator layout -> 8-row x 128-byte pieces through the scratch; 16-byte stores
+            // ---- trailing activation, store (16-byte pieces through the scratch)
+            if (post_act) {
 #pragma unroll
-            for (int io = 0; io < HS; ++io)
+                for (int io = 0; io < HS; ++io)
 #pragma unroll
-                for (int kk = 0; kk < NW; ++kk)
+                    for (int kk = 0; kk < NW; ++kk)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
+                        for (int r = 0; r < 16; ++r) out[io][kk][r] = leaky(out[io][kk][r], p.slope);
+            }
 #pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) {
-                            float v = out[io][kk][4 * g + s4];
-                            if (post_act) v = leaky(v, p.slope);
-                            scr[(4 * lh + s4) * 32 + li] = v;
-                        }
-                        const f32x4 v4 = *reinterpret_cast<const f32x4 *>(scr + lane * 4);
-                        const int tq = t0 + n0 + kk * 32 + pcol;
-                        if (tq < Lin)   // L % 4 == 0: a piece is inside the clip or outside it
-                            *reinterpret_cast<f32x4 *>(yb + unsigned(((pass * HS + io) * 32 + 8 * g + prow) * linv + tq) * 4u) = v4;
-                    }
+            for (int pc = 0; pc < NPIECE; ++pc) store_piece(pc, pass, yb, t0, linv);
             if (pass == 0) AGX_TSTAMP(14);
         }
     }
 }
 
-template <int MW, int NW, int CCH, int D, int NS, int LW = 0>
+template <int MW, int NW, int CCH, int D, int NS>
 static int launch_rbp(const ConvPlan &p, const float *x, const float *w1, const float *b1, const float *w2,
                       const float *b2, float *y, int post_act, hipStream_t st) {
     using G = RbpGeom<MW, NW, CCH, D, NS>;
-    auto kern = resblock_p_kernel<MW, NW, CCH, D, NS, LW>;
+    auto kern = resblock_p_kernel<MW, NW, CCH, D, NS>;
     static bool attr_set = false;
     static int n_cu = 0;
     if (!attr_set) {
@@ -508,14 +484,14 @@ static int launch_rbp(const ConvPlan &p, const float *x, const float *w1, const 
     const int ntiles = int(ntiles64);
     int wg_per_cu = int((160 * 1024) / G::LDS_BYTES) >= 2 ? 2 : 1;
     size_t lds_bytes = G::LDS_BYTES;
-    if (tuning().rb_wgs == 1 || LW) wg_per_cu = 1, lds_bytes = 100 * 1024;   // (diagnostic) one workgroup per CU
+    if (tuning().rb_wgs == 1) wg_per_cu = 1, lds_bytes = 100 * 1024;   // diagnostic: one workgroup per CU
     int grid = n_cu * wg_per_cu;
     if (grid > ntiles) grid = ntiles;
     // the tile images follow the standard image and the dim0 scale scratch in the packed buffers (common.hpp)
     const float *wt1 = w1 + packed_weight_floats(G::C, G::J, G::C) + G::C;
     const float *wt2 = w2 + packed_weight_floats(G::C, 1, G::C) + G::C;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256 + 64 * LW), lds_bytes, st, p, tiles_per_clip, ntiles, grid / tiles_per_clip,
-                       grid % tiles_per_clip, post_act, tuning().rb_stagger, x, wt1, b1, wt2, b2, y);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, st, p, tiles_per_clip, ntiles, grid / tiles_per_clip,
+                       grid % tiles_per_clip, post_act, x, wt1, b1, wt2, b2, y);
     return check_launch("resblock_p");
 }
 
@@ -540,8 +516,7 @@ int launch_resblock_p(const ConvPlan &p, const float *x, const float *w1, const 
                       const float *b2, float *y, int post_act, hipStream_t st) {
     if (!resblock_p_supported(p)) return fail(AGX_ERR_UNSUPPORTED, "resblock_p: unsupported shape");
 #define AGX_RBP(MW, NW, CCH, NS)                                                                 \
-    (tuning().rb_lw == 1 && p.d == 1 ? launch_rbp<MW, NW, CCH, 1, NS, 1>(p, x, w1, b1, w2, b2, y, post_act, st) \
-     : p.d == 1 ? launch_rbp<MW, NW, CCH, 1, NS>(p, x, w1, b1, w2, b2, y, post_act, st)          \
+    (p.d == 1 ? launch_rbp<MW, NW, CCH, 1, NS>(p, x, w1, b1, w2, b2, y, post_act, st)            \
      : p.d == 3 ? launch_rbp<MW, NW, CCH, 3, NS>(p, x, w1, b1, w2, b2, y, post_act, st)          \
                 : launch_rbp<MW, NW, CCH, 9, NS>(p, x, w1, b1, w2, b2, y, post_act, st))
     switch (p.Cin) {
