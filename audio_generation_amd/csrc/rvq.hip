@@ -158,7 +158,8 @@ struct RvqArgs {
     float *xq;
     int64_t q_sb, q_st, q_sd;
     int64_t *index;  // (B*T, Q)
-    double *sq_err;  // (Q)
+    double *sq_err;  // (Q) [unused by the kernel since the partials moved to `part`]
+    double *part;    // (workgroups, Q) squared error of each workgroup's 32 frames per stage
 };
 
 template <int MT, bool TAIL_LDS>   // TAIL_LDS: the stage's |c'|^2 and |c'| tables are copied to LDS (they fit beside R / O)
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
         if (wave == 0) {                  // the stage's squared error: 32 frames, pairwise in double
             double s = (lane < FT && n0 + lane < N) ? double(wmin[lane]) : 0.0;
             for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off);
-            if (lane == 0) atomicAdd(&a.sq_err[q], s);
+            if (lane == 0) a.part[size_t(blockIdx.x) * a.Q + q] = s;   // reduced in a fixed order by rvq_sqerr_kernel
         }
     }
     // ---- write x_q ----
@@ -578,6 +579,21 @@ __global__ __launch_bounds__(256) void rvq_dequant_kernel(const float *__restric
     }
 }
 
+// sq_err[q] = sum over workgroups of part[wg][q] (pairwise per lane, then a fixed shuffle tree); commit = sum_q sq_err[q] * inv
+__global__ __launch_bounds__(64) void rvq_sqerr_kernel(const double *__restrict__ part, int nwg, int Q, double *__restrict__ sq_err,
+                                                       float *__restrict__ commit, double inv_numel) {
+    const int lane = threadIdx.x;
+    double total = 0.0;
+    for (int q = 0; q < Q; ++q) {
+        double s = 0.0;
+        for (int w = lane; w < nwg; w += 64) s += part[size_t(w) * Q + q];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) sq_err[q] = s;
+        total += s;
+    }
+    if (lane == 0 && commit) *commit = float(total * inv_numel);
+}
+
 }  // namespace agx
 
 extern "C" {
@@ -610,15 +626,27 @@ int agx_rvq_pack(const float *codebooks, int32_t n_q, int32_t k, int32_t dim, fl
     return agx_rvq_pack_sized(codebooks, nullptr, n_q, k, dim, packed, stream);
 }
 
-size_t agx_rvq_workspace_bytes(int32_t, int32_t, int32_t, int32_t, int32_t) { return 0; }
+size_t agx_rvq_workspace_bytes(int32_t batch, int32_t t, int32_t, int32_t, int32_t q_used) {
+    if (batch <= 0 || t <= 0 || q_used <= 0) return 0;
+    return size_t(agx::ceil_div64(int64_t(batch) * t, agx::FT)) * q_used * sizeof(double);
+}
 
 int agx_rvq_forward(const float *x, int64_t x_sb, int64_t x_st, int64_t x_sd, const float *codebooks,
                     const float *packed, int32_t batch, int32_t t, int32_t dim, int32_t k, int32_t q_used,
                     float *xq, int64_t q_sb, int64_t q_st, int64_t q_sd, int64_t *index, double *sq_err,
                     void *workspace, size_t workspace_bytes, void *stream) {
+    return agx_rvq_forward_ex(x, x_sb, x_st, x_sd, codebooks, packed, batch, t, dim, k, q_used, xq, q_sb, q_st, q_sd, index,
+                              sq_err, nullptr, workspace, workspace_bytes, stream);
+}
+
+int agx_rvq_forward_ex(const float *x, int64_t x_sb, int64_t x_st, int64_t x_sd, const float *codebooks,
+                       const float *packed, int32_t batch, int32_t t, int32_t dim, int32_t k, int32_t q_used,
+                       float *xq, int64_t q_sb, int64_t q_st, int64_t q_sd, int64_t *index, double *sq_err,
+                       float *commit_loss, void *workspace, size_t workspace_bytes, void *stream) {
     using namespace agx;
-    (void)workspace;
-    (void)workspace_bytes;
+    if (q_used > 0 && (!workspace || workspace_bytes < agx_rvq_workspace_bytes(batch, t, dim, k, q_used)))
+        return fail(AGX_ERR_WORKSPACE, "rvq_forward: workspace too small (%zu < %zu)", workspace_bytes,
+                    agx_rvq_workspace_bytes(batch, t, dim, k, q_used));
     if (batch <= 0 || t <= 0 || dim <= 0 || k <= 0 || q_used < 0)
         return fail(AGX_ERR_BAD_SHAPE, "rvq_forward: bad shape B=%d T=%d D=%d K=%d Q=%d", batch, t, dim, k, q_used);
     if (!x || !codebooks || !packed || !xq || (q_used > 0 && (!index || !sq_err)))
@@ -626,7 +654,8 @@ int agx_rvq_forward(const float *x, int64_t x_sb, int64_t x_st, int64_t x_sd, co
     bool tail_lds = false;
     const size_t lds = rvq_lds_bytes(dim, k, &tail_lds);
     if (lds > 160 * 1024) return fail(AGX_ERR_UNSUPPORTED, "rvq_forward: D=%d needs %zu B of LDS", dim, lds);
-    RvqArgs a{x, x_sb, x_st, x_sd, codebooks, packed, batch, t, dim, k, q_used, xq, q_sb, q_st, q_sd, index, sq_err};
+    RvqArgs a{x, x_sb, x_st, x_sd, codebooks, packed, batch, t, dim, k, q_used, xq, q_sb, q_st, q_sd, index, sq_err,
+              static_cast<double *>(workspace)};
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t n = int64_t(batch) * t;
     dim3 grid((unsigned)ceil_div64(n, FT)), block(NT);
@@ -635,6 +664,9 @@ int agx_rvq_forward(const float *x, int64_t x_sb, int64_t x_st, int64_t x_sd, co
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(kern, grid, block, lds, st, a);
+        if (q_used > 0)   // per-stage sums and the commit loss, in a fixed order: deterministic, no atomics, no host arithmetic
+            hipLaunchKernelGGL(rvq_sqerr_kernel, dim3(1), dim3(64), 0, st, a.part, int(grid.x), q_used, sq_err, commit_loss,
+                               1.0 / (double(batch) * t * dim));
         return check_launch("rvq_forward");
     };
     // codewords per pass = 8 waves x MT x 32.  MT = 4 (one pass for K = 1024) spills at the 256-VGPR cap

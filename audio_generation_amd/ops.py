@@ -214,7 +214,8 @@ def rvq_pack(codebooks: Tensor, sizes: Optional[Sequence[int]] = None) -> Tensor
 def rvq_forward(x: Tensor, codebooks: Tensor, packed: Tensor, q_used: int,
                 layout: str = "b l c") -> Tuple[Tensor, Tensor, Tensor]:
     """x: (B,T,D) for layout "b l c" or (B,D,T) for "b c l" (any strides).
-    Returns (x_q in the same layout/shape, index (B,T,q_used) int64, sq_err (q_used) f64)."""
+    Returns (x_q in the same layout/shape, index (B,T,q_used) int64, sq_err (q_used) f64); the commit loss
+    sum(sq_err) / x.numel() computed by the same launch is left in ``rvq_forward.last_commit`` (0-d f32 tensor)."""
     lib = _lib.load()
     _need_gpu(x, codebooks, packed)
     if x.dtype != torch.float32:
@@ -239,16 +240,23 @@ def rvq_forward(x: Tensor, codebooks: Tensor, packed: Tensor, q_used: int,
     else:
         qb, qd, qt = xq.stride()
     index = torch.empty((b, t, q_used), dtype=torch.int64, device=x.device)
-    sq_err = torch.zeros(max(q_used, 1), dtype=torch.float64, device=x.device)
+    # one f64 buffer: [q_used per-stage sums | per-workgroup partials (the library's workspace)]; the commit loss is a
+    # separate f32 scalar -- all three written by the launch, nothing to zero, no reduction on the torch side
+    ws_bytes = int(lib.agx_rvq_workspace_bytes(b, t, d, k, q_used))
+    buf = torch.empty(max(q_used, 1) + ws_bytes // 8, dtype=torch.float64, device=x.device)
+    commit = torch.empty((), dtype=torch.float32, device=x.device)
     tok = _observer.begin("rvq", (b, t, d, k, q_used)) if _observer is not None else None
-    _lib.check(lib.agx_rvq_forward(_ptr(x), sb, st, sd, _ptr(codebooks), _ptr(packed), b, t, d, k, q_used,
-                                   _ptr(xq), qb, qt, qd, _ptr(index), _ptr(sq_err), None, 0, _stream()),
-               "agx_rvq_forward")
+    _lib.check(lib.agx_rvq_forward_ex(_ptr(x), sb, st, sd, _ptr(codebooks), _ptr(packed), b, t, d, k, q_used,
+                                      _ptr(xq), qb, qt, qd, _ptr(index), _ptr(buf), _ptr(commit),
+                                      ctypes.c_void_p(buf.data_ptr() + 8 * max(q_used, 1)), ws_bytes, _stream()),
+               "agx_rvq_forward_ex")
     if tok is not None:
         _observer.end(tok)
     if q_used == 0:
         xq.zero_()
-    return xq, index, sq_err[:q_used]
+        commit.zero_()
+    rvq_forward.last_commit = commit
+    return xq, index, buf[:q_used]
 
 
 def rvq_dequantize(codebook: Tensor, idx: Tensor, out: Optional[Tensor] = None,

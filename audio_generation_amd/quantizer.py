@@ -126,7 +126,7 @@ class ResidualQuantizer(nn.Module):
                 commit = commit + ((x - partial) ** 2).mean()
             xq = x + (xq - x).detach()
         else:
-            commit = (sq_err.sum() / float(x.numel())).to(torch.float32)
+            commit = ops.rvq_forward.last_commit          # sum(sq_err) / numel, written by the search launch itself
         if update_codebook and self.training:
             frames = x if layout == "b l c" else x.transpose(1, 2)
             self._ema_update(frames.reshape(-1, self.dim), index.reshape(-1, q_used))

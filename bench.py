@@ -170,18 +170,22 @@ def calibrate_codebooks(model, x_small, recipe):
 
 
 def pmc_entry(pmc, dom_name):
-    """Entry of profiles/pmc_traffic.json for a kernel the observer names ``stem<a,b,c>[:bf16x3]``.  The PMC names
-    carry the full template list ``stem<a,b,c,...,IMPL>`` whose LAST argument is the arithmetic (0 = fp32 MFMA,
-    1 = bf16x3): match the stem AND that suffix, never the first prefix hit."""
+    """Entries of profiles/pmc_traffic.json for a kernel the observer names ``stem<a,b,c>[:bf16x3]``.  The PMC names
+    carry the full template list.  First-round kernels (``resblock_mfma`` / ``conv_mfma``): ``stem<a,b,c,...,IMPL>`` whose
+    LAST argument is the arithmetic (0 = fp32 MFMA, 1 = bf16x3) -- match the stem AND that suffix, never the first prefix
+    hit.  Ring kernels (``resblock_p<MW,NW,CCH,D,NS>``: fp32 only): one entry per dilation, all of them are returned (the
+    observer aggregates the three dilations under one name, so their traffic is averaged)."""
     bf = dom_name.endswith(":bf16x3")
     stem = dom_name.replace("2x:", "").replace(":bf16x3", "").rstrip(">")
     want = "1" if bf else "0"
+    ring = stem.startswith(("resblock_p", "conv_p"))
+    hits = []
     for k in pmc:
         if k == stem + ">":
-            return k
-        if k.startswith(stem + ",") and k.rstrip(">").rsplit(",", 1)[1] == want:
-            return k
-    return None
+            return [k]
+        if k.startswith(stem + ",") and (ring or k.rstrip(">").rsplit(",", 1)[1] == want):
+            hits.append(k)
+    return hits if ring else hits[:1]
 
 
 def cpu_baseline_and_parity(model, x_cpu, y_gpu, idx_gpu, z_gpu, n_items):
@@ -347,10 +351,10 @@ def main():
         # HBM bytes per launch of that kernel from the committed PMC passes (tools/pmc_summary.py)
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
-            key = pmc_entry(pmc, dom_name)
-            if key is not None:
-                roof["traffic"] = pmc[key]["bytes_per_launch"]
-                roof["traffic_kernel"] = key
+            keys = pmc_entry(pmc, dom_name)
+            if keys:
+                roof["traffic"] = sum(pmc[k]["bytes_per_launch"] for k in keys) / len(keys)
+                roof["traffic_kernel"] = keys
                 roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, per launch)"
                 roof["algorithmic_bytes_per_launch"] = dom["bytes"] / dom["launches"]
         except (OSError, ValueError, KeyError):

@@ -204,10 +204,11 @@ int agx_rvq_pack_sized(const float *codebooks, const int32_t *sizes, int32_t n_q
  *   x, xq   : frames, element (b,t,d) at  b*stride_b + t*stride_t + d*stride_d
  *             (so both "b l c" and "b c l" tensors are accepted without a copy);
  *   index   : (B,T,q_used) int64, contiguous (utils.py:249);
- *   sq_err  : q_used doubles, += sum over all elements of the squared residual
- *             left after each stage (caller zeroes it; commit loss =
- *             sum(sq_err)/(B*T*D));
- *   workspace: agx_rvq_workspace_bytes() bytes.
+ *   sq_err  : q_used doubles, = sum over all elements of the squared residual
+ *             left after each stage (written, not accumulated; commit loss =
+ *             sum(sq_err)/(B*T*D)), reduced over the workgroups in a fixed order
+ *             by a second tiny kernel -- deterministic, no float atomics;
+ *   workspace: agx_rvq_workspace_bytes() bytes (the per-workgroup partial sums).
  * The arg-min is exact: binary32 MFMA scores select candidates, ties and near
  * ties are decided by the defining binary64 arithmetic (oracle/rvq_exact.c). */
 size_t agx_rvq_workspace_bytes(int32_t batch, int32_t t, int32_t dim, int32_t k, int32_t q_used);
@@ -216,6 +217,13 @@ int agx_rvq_forward(const float *x, int64_t x_sb, int64_t x_st, int64_t x_sd,
                     int32_t batch, int32_t t, int32_t dim, int32_t k, int32_t q_used,
                     float *xq, int64_t q_sb, int64_t q_st, int64_t q_sd,
                     int64_t *index, double *sq_err, void *workspace, size_t workspace_bytes,
+                    void *stream);
+/* The same; additionally writes the commit loss sum(sq_err) / (B*T*D) as one float to `commit_loss` (may be NULL). */
+int agx_rvq_forward_ex(const float *x, int64_t x_sb, int64_t x_st, int64_t x_sd,
+                    const float *codebooks /* (Q,K,D) */, const float *packed,
+                    int32_t batch, int32_t t, int32_t dim, int32_t k, int32_t q_used,
+                    float *xq, int64_t q_sb, int64_t q_st, int64_t q_sd,
+                    int64_t *index, double *sq_err, float *commit_loss, void *workspace, size_t workspace_bytes,
                     void *stream);
 
 /* quantizers[i].dequantize(idx) (vae.py:333): out[n,:] (+)= codebook[idx[n],:].
