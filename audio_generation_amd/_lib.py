@@ -85,6 +85,9 @@ SIGNATURES = {
                                           c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p]),
     "agx_attention_alibi_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                              c_int32, c_float, c_void_p]),
+    "agx_attention_backward_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "agx_attention_alibi_backward_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                                c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
     "agx_conv_bwd_data_gelu": (c_int, [_PD, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "agx_multires_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                      c_int32, c_int32, c_void_p]),

@@ -1,7 +1,7 @@
 """Fallback trainability: HIP forward, ATen backward -- FENCED: it raises unless ``AGX_ALLOW_ATEN_BRIDGE=1``.
 
 Every default path has hand-written backward kernels now (native_backward.py, transformers.py,
-discriminator.py); this bridge is what remains for the shapes they do not cover (attention head_dim > 64,
+discriminator.py); this bridge is what remains for the shapes they do not cover (attention head_dim > 128,
 discriminators with an activation other than LeakyReLU, encoder stacks with norm != Identity).  Such a module runs
 
 * **forward** through libagx exactly as in inference (no autograd graph), and

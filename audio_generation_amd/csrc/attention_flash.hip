@@ -210,7 +210,7 @@ static int launch_flash(const float *qkv, const float *slopes, float *out, int B
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);   // head_dim 128: 90 KB
         if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
@@ -232,3 +232,285 @@ int launch_attention_flash(const float *qkv, const float *slopes, float *out, in
 }
 
 }  // namespace agx
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward for any T (and head_dim <= 128): attention.hip's backward holds K and V of one (head, item) in LDS and the
+// dK / dV accumulators in registers -- T <= 256, head_dim <= 64.  Beyond that the work is split the flash way, in
+// three deterministic VALU kernels (no atomics; a bottleneck of 1125 frames is 10 GFLOP per batch of 32):
+//   stats   lse_i = log sum_j exp(s_ij)  (online over key blocks),  delta_i = sum_d dO[d,i] O[d,i]  (= sum_j P_ij dP_ij)
+//   dq      per 16-query block, loop over key blocks:  P = exp(s - lse), dP = dO^T V, dS = P (dP - delta),  dQ += dS K^T / scale
+//   dkv     per 64-key block, loop over query blocks:  dK += dS^T Q / scale,  dV += P^T dO   (accumulators in registers)
+// s_ij = q_i . k_j / scale - slope |i - j|  (transformers.py:177-183).
+namespace agx {
+
+constexpr int AB_QB = 16;    // queries per block
+constexpr int AB_KB = 64;    // keys per block
+
+// one workgroup per (query block, head, item): lse and delta of its 16 queries
+__global__ __launch_bounds__(256) void attn_bwd_stats_kernel(const float *__restrict__ qkv, const float *__restrict__ slopes,
+                                                             const float *__restrict__ out, const float *__restrict__ dout,
+                                                             float *__restrict__ lse, float *__restrict__ delta, int H, int Dh,
+                                                             int T, float scale_div) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *Qs = sm;                 // [Dh][QB]
+    float *Ks = Qs + Dh * AB_QB;    // [Dh][KB]
+    float *Ss = Ks + Dh * AB_KB;    // [QB][KB]
+    __shared__ float red[AB_QB][16];
+    const int tid = threadIdx.x, h = blockIdx.y, b = blockIdx.z, i0 = blockIdx.x * AB_QB;
+    const int HD = H * Dh;
+    const float *qg = qkv + (size_t(b) * 3 * HD + h * Dh) * T, *kg = qg + size_t(HD) * T;
+    const float *og = out + (size_t(b) * HD + h * Dh) * T, *dg = dout + (size_t(b) * HD + h * Dh) * T;
+    const float slope = slopes[h], inv = 1.f / scale_div;
+    for (int e = tid; e < Dh * AB_QB; e += 256) {
+        const int d = e / AB_QB, q = e - d * AB_QB;
+        Qs[e] = qg[size_t(d) * T + min(i0 + q, T - 1)];
+    }
+    const int rq = tid / 16, rl = tid % 16;   // 16 threads per query row
+    float m = -3.0e38f, l = 0.f;
+    for (int j0 = 0; j0 < T; j0 += AB_KB) {
+        __syncthreads();
+        for (int e = tid; e < Dh * AB_KB; e += 256) {
+            const int d = e / AB_KB, j = e - d * AB_KB;
+            Ks[e] = kg[size_t(d) * T + min(j0 + j, T - 1)];
+        }
+        __syncthreads();
+        for (int e = tid; e < AB_QB * AB_KB; e += 256) {
+            const int q = e / AB_KB, j = e - q * AB_KB;
+            float s = 0.f;
+            for (int d = 0; d < Dh; ++d) s = fmaf(Qs[d * AB_QB + q], Ks[d * AB_KB + j], s);
+            Ss[e] = (j0 + j < T) ? s * inv - fabsf(float(i0 + q - (j0 + j))) * slope : -3.0e38f;
+        }
+        __syncthreads();
+        float bm = -3.0e38f;
+        for (int j = rl; j < AB_KB; j += 16) bm = fmaxf(bm, Ss[rq * AB_KB + j]);
+        red[rq][rl] = bm;
+        __syncthreads();
+        bm = red[rq][0];
+        for (int k = 1; k < 16; ++k) bm = fmaxf(bm, red[rq][k]);
+        const float mn = fmaxf(m, bm);
+        float bs = 0.f;
+        for (int j = rl; j < AB_KB; j += 16) bs += expf(Ss[rq * AB_KB + j] - mn);
+        __syncthreads();
+        red[rq][rl] = bs;
+        __syncthreads();
+        bs = 0.f;
+        for (int k = 0; k < 16; ++k) bs += red[rq][k];
+        l = l * expf(m - mn) + bs;
+        m = mn;
+    }
+    // delta_i = sum_d dO[d,i] O[d,i]
+    float dl = 0.f;
+    const int iq = min(i0 + rq, T - 1);
+    for (int d = rl; d < Dh; d += 16) dl = fmaf(dg[size_t(d) * T + iq], og[size_t(d) * T + iq], dl);
+    __syncthreads();
+    red[rq][rl] = dl;
+    __syncthreads();
+    if (rl == 0 && i0 + rq < T) {
+        float s = 0.f;
+        for (int k = 0; k < 16; ++k) s += red[rq][k];
+        const size_t o = (size_t(b) * H + h) * T + i0 + rq;
+        lse[o] = m + logf(l);
+        delta[o] = s;
+    }
+}
+
+// one workgroup per (query block, head, item): dQ of its 16 queries, keys in blocks of 64
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float *__restrict__ qkv, const float *__restrict__ slopes,
+                                                          const float *__restrict__ dout, const float *__restrict__ lse,
+                                                          const float *__restrict__ delta, float *__restrict__ dqkv, int H,
+                                                          int Dh, int T, float scale_div) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *Qs = sm;                  // [Dh][QB]
+    float *Os = Qs + Dh * AB_QB;     // [Dh][QB]  dO
+    float *Ks = Os + Dh * AB_QB;     // [Dh][KB]
+    float *Vs = Ks + Dh * AB_KB;     // [Dh][KB]
+    float *Ss = Vs + Dh * AB_KB;     // [QB][KB]  dS / scale
+    const int tid = threadIdx.x, h = blockIdx.y, b = blockIdx.z, i0 = blockIdx.x * AB_QB;
+    const int HD = H * Dh;
+    const float *qg = qkv + (size_t(b) * 3 * HD + h * Dh) * T, *kg = qg + size_t(HD) * T, *vg = kg + size_t(HD) * T;
+    const float *dg = dout + (size_t(b) * HD + h * Dh) * T;
+    float *dqg = dqkv + (size_t(b) * 3 * HD + h * Dh) * T;
+    const float slope = slopes[h], inv = 1.f / scale_div;
+    const size_t so = (size_t(b) * H + h) * T;
+    for (int e = tid; e < Dh * AB_QB; e += 256) {
+        const int d = e / AB_QB, q = e - d * AB_QB, i = min(i0 + q, T - 1);
+        Qs[e] = qg[size_t(d) * T + i];
+        Os[e] = dg[size_t(d) * T + i];
+    }
+    constexpr int MAXA = 8;          // dQ elements per thread: Dh * 16 <= 128 * 16 = 8 * 256
+    float dq[MAXA];
+#pragma unroll
+    for (int u = 0; u < MAXA; ++u) dq[u] = 0.f;
+    for (int j0 = 0; j0 < T; j0 += AB_KB) {
+        __syncthreads();
+        for (int e = tid; e < Dh * AB_KB; e += 256) {
+            const int d = e / AB_KB, j = e - d * AB_KB, jc = min(j0 + j, T - 1);
+            Ks[e] = kg[size_t(d) * T + jc];
+            Vs[e] = vg[size_t(d) * T + jc];
+        }
+        __syncthreads();
+        for (int e = tid; e < AB_QB * AB_KB; e += 256) {
+            const int q = e / AB_KB, j = e - q * AB_KB, i = i0 + q;
+            float s = 0.f, dp = 0.f;
+            for (int d = 0; d < Dh; ++d) {
+                s = fmaf(Qs[d * AB_QB + q], Ks[d * AB_KB + j], s);
+                dp = fmaf(Os[d * AB_QB + q], Vs[d * AB_KB + j], dp);
+            }
+            float ds = 0.f;
+            if (i < T && j0 + j < T) {
+                const float pn = expf(s * inv - fabsf(float(i - (j0 + j))) * slope - lse[so + i]);
+                ds = pn * (dp - delta[so + i]) * inv;
+            }
+            Ss[e] = ds;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < MAXA; ++u) {
+            const int e = tid + u * 256;
+            if (e < Dh * AB_QB) {
+                const int d = e / AB_QB, q = e - d * AB_QB;
+                float a = dq[u];
+                for (int j = 0; j < AB_KB; ++j) a = fmaf(Ss[q * AB_KB + j], Ks[d * AB_KB + j], a);
+                dq[u] = a;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < MAXA; ++u) {
+        const int e = tid + u * 256;
+        if (e < Dh * AB_QB) {
+            const int d = e / AB_QB, q = e - d * AB_QB;
+            if (i0 + q < T) dqg[size_t(d) * T + i0 + q] = dq[u];
+        }
+    }
+}
+
+// one workgroup per (key block, head, item): dK and dV of its 64 keys, queries in blocks of 16
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float *__restrict__ qkv, const float *__restrict__ slopes,
+                                                           const float *__restrict__ dout, const float *__restrict__ lse,
+                                                           const float *__restrict__ delta, float *__restrict__ dqkv, int H,
+                                                           int Dh, int T, float scale_div) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *Ks = sm;                  // [Dh][KB]
+    float *Vs = Ks + Dh * AB_KB;     // [Dh][KB]
+    float *Qs = Vs + Dh * AB_KB;     // [Dh][QB]
+    float *Os = Qs + Dh * AB_QB;     // [Dh][QB]
+    float *Ps = Os + Dh * AB_QB;     // [QB][KB]
+    float *Ss = Ps + AB_QB * AB_KB;  // [QB][KB]
+    const int tid = threadIdx.x, h = blockIdx.y, b = blockIdx.z, j0 = blockIdx.x * AB_KB;
+    const int HD = H * Dh;
+    const float *qg = qkv + (size_t(b) * 3 * HD + h * Dh) * T, *kg = qg + size_t(HD) * T, *vg = kg + size_t(HD) * T;
+    const float *dg = dout + (size_t(b) * HD + h * Dh) * T;
+    float *dkg = dqkv + (size_t(b) * 3 * HD + size_t(HD) + h * Dh) * T, *dvg = dkg + size_t(HD) * T;
+    const float slope = slopes[h], inv = 1.f / scale_div;
+    const size_t so = (size_t(b) * H + h) * T;
+    for (int e = tid; e < Dh * AB_KB; e += 256) {
+        const int d = e / AB_KB, j = e - d * AB_KB, jc = min(j0 + j, T - 1);
+        Ks[e] = kg[size_t(d) * T + jc];
+        Vs[e] = vg[size_t(d) * T + jc];
+    }
+    constexpr int MAXE = 32;         // dK / dV elements per thread: Dh * 64 <= 128 * 64 = 32 * 256
+    float dk[MAXE], dv[MAXE];
+#pragma unroll
+    for (int u = 0; u < MAXE; ++u) dk[u] = dv[u] = 0.f;
+    for (int i0 = 0; i0 < T; i0 += AB_QB) {
+        __syncthreads();
+        for (int e = tid; e < Dh * AB_QB; e += 256) {
+            const int d = e / AB_QB, q = e - d * AB_QB, i = min(i0 + q, T - 1);
+            Qs[e] = qg[size_t(d) * T + i];
+            Os[e] = (i0 + q < T) ? dg[size_t(d) * T + i] : 0.f;
+        }
+        __syncthreads();
+        for (int e = tid; e < AB_QB * AB_KB; e += 256) {
+            const int q = e / AB_KB, j = e - q * AB_KB, i = i0 + q;
+            float s = 0.f, dp = 0.f;
+            for (int d = 0; d < Dh; ++d) {
+                s = fmaf(Qs[d * AB_QB + q], Ks[d * AB_KB + j], s);
+                dp = fmaf(Os[d * AB_QB + q], Vs[d * AB_KB + j], dp);
+            }
+            float pn = 0.f, ds = 0.f;
+            if (i < T && j0 + j < T) {
+                pn = expf(s * inv - fabsf(float(i - (j0 + j))) * slope - lse[so + i]);
+                ds = pn * (dp - delta[so + i]) * inv;
+            }
+            Ps[e] = pn;
+            Ss[e] = ds;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < MAXE; ++u) {
+            const int e = tid + u * 256;
+            if (e < Dh * AB_KB) {
+                const int d = e / AB_KB, j = e - d * AB_KB;
+                float ak = dk[u], av = dv[u];
+#pragma unroll
+                for (int q = 0; q < AB_QB; ++q) {
+                    ak = fmaf(Ss[q * AB_KB + j], Qs[d * AB_QB + q], ak);
+                    av = fmaf(Ps[q * AB_KB + j], Os[d * AB_QB + q], av);
+                }
+                dk[u] = ak;
+                dv[u] = av;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < MAXE; ++u) {
+        const int e = tid + u * 256;
+        if (e < Dh * AB_KB) {
+            const int d = e / AB_KB, j = e - d * AB_KB;
+            if (j0 + j < T) {
+                dkg[size_t(d) * T + j0 + j] = dk[u];
+                dvg[size_t(d) * T + j0 + j] = dv[u];
+            }
+        }
+    }
+}
+
+int launch_attention_flash_backward(const float *qkv, const float *slopes, const float *out, const float *dout, float *dqkv,
+                                    float *workspace, int B, int H, int Dh, int T, float scale_div, hipStream_t st) {
+    float *lse = workspace, *delta = workspace + size_t(B) * H * T;
+    const dim3 gq(ceil_div(T, AB_QB), H, B), gk(ceil_div(T, AB_KB), H, B);
+    const size_t l_stats = size_t(Dh * AB_QB + Dh * AB_KB + AB_QB * AB_KB) * sizeof(float);
+    const size_t l_dq = size_t(2 * Dh * AB_QB + 2 * Dh * AB_KB + AB_QB * AB_KB) * sizeof(float);
+    const size_t l_dkv = size_t(2 * Dh * AB_KB + 2 * Dh * AB_QB + 2 * AB_QB * AB_KB) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        for (const void *k : {reinterpret_cast<const void *>(attn_bwd_stats_kernel), reinterpret_cast<const void *>(attn_bwd_dq_kernel),
+                              reinterpret_cast<const void *>(attn_bwd_dkv_kernel)}) {
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);   // head_dim 128: 90 KB
+            if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_stats_kernel, gq, dim3(256), l_stats, st, qkv, slopes, out, dout, lse, delta, H, Dh, T, scale_div);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, gq, dim3(256), l_dq, st, qkv, slopes, dout, lse, delta, dqkv, H, Dh, T, scale_div);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, gk, dim3(256), l_dkv, st, qkv, slopes, dout, lse, delta, dqkv, H, Dh, T, scale_div);
+    return check_launch("attention_flash_backward");
+}
+
+}  // namespace agx
+
+extern "C" {
+
+size_t agx_attention_backward_workspace_bytes(int32_t batch, int32_t heads, int32_t t) {
+    if (batch <= 0 || heads <= 0 || t <= 0) return 0;
+    return size_t(2) * batch * heads * t * sizeof(float);
+}
+
+int agx_attention_alibi_backward_ex(const float *qkv, const float *slopes, const float *out, const float *dout, float *dqkv,
+                                    float *workspace, size_t workspace_bytes, int32_t batch, int32_t heads, int32_t head_dim,
+                                    int32_t t, float scale_div, void *stream) {
+    using namespace agx;
+    if (batch <= 0 || heads <= 0 || head_dim <= 0 || t <= 0)
+        return fail(AGX_ERR_BAD_SHAPE, "attention_alibi_backward_ex: bad shape");
+    if (!qkv || !slopes || !out || !dout || !dqkv || !workspace)
+        return fail(AGX_ERR_NULL_POINTER, "attention_alibi_backward_ex: NULL pointer");
+    if (head_dim > 128) return fail(AGX_ERR_UNSUPPORTED, "attention_alibi_backward_ex: head_dim=%d > 128", head_dim);
+    if (heads > 65535 || batch > 65535) return fail(AGX_ERR_BAD_SHAPE, "attention_alibi_backward_ex: grid too large");
+    if (workspace_bytes < agx_attention_backward_workspace_bytes(batch, heads, t))
+        return fail(AGX_ERR_WORKSPACE, "attention_alibi_backward_ex: workspace too small");
+    return launch_attention_flash_backward(qkv, slopes, out, dout, dqkv, workspace, batch, heads, head_dim, t, scale_div,
+                                           static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

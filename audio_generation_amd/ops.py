@@ -340,15 +340,26 @@ def layernorm_ct_backward(x: Tensor, weight: Optional[Tensor], dy: Tensor, eps: 
 
 
 def attention_alibi_backward(qkv: Tensor, slopes: Tensor, dout: Tensor, heads: int, head_dim: int,
-                             scale_div: float) -> Tensor:
+                             scale_div: float, out: Optional[Tensor] = None) -> Tensor:
+    """dqkv of ``attention_alibi``.  T <= 256 and head_dim <= 64: the single-launch kernel; otherwise the flash-style
+    split (``agx_attention_alibi_backward_ex``), which needs ``out`` = the forward's output."""
     lib = _lib.load()
-    _need_gpu(qkv, slopes, dout)
+    _need_gpu(qkv, slopes, dout, out)
     qkv, dout = _f32c(qkv), _f32c(dout)
     b, _, t = qkv.shape
     dqkv = torch.empty_like(qkv)
-    _lib.check(lib.agx_attention_alibi_backward(_ptr(qkv), _ptr(_f32c(slopes)), _ptr(dout), _ptr(dqkv), b, heads,
-                                                head_dim, t, float(scale_div), _stream()),
-               "agx_attention_alibi_backward")
+    if t <= 256 and head_dim <= 64:
+        _lib.check(lib.agx_attention_alibi_backward(_ptr(qkv), _ptr(_f32c(slopes)), _ptr(dout), _ptr(dqkv), b, heads,
+                                                    head_dim, t, float(scale_div), _stream()),
+                   "agx_attention_alibi_backward")
+        return dqkv
+    if out is None:
+        raise AgxError("attention_alibi_backward: T > 256 or head_dim > 64 needs the forward output (out=)")
+    nbytes = lib.agx_attention_backward_workspace_bytes(b, heads, t)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=qkv.device)
+    _lib.check(lib.agx_attention_alibi_backward_ex(_ptr(qkv), _ptr(_f32c(slopes)), _ptr(_f32c(out)), _ptr(dout), _ptr(dqkv),
+                                                   _ptr(ws), nbytes, b, heads, head_dim, t, float(scale_div), _stream()),
+               "agx_attention_alibi_backward_ex")
     return dqkv
 
 

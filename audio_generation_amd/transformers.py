@@ -238,7 +238,7 @@ class _TransformerNative(torch.autograd.Function):
             ln1, inner = attention.norm, attention.inner_dim
             do, dwo, dbo = _lin_bwd(attention._o, o, dx1, attention.dim)
             dqkv = ops.attention_alibi_backward(qkv, attention.alibi_obj.head_scalars, do, attention.n_heads,
-                                                attention.dim_head, attention.dim_head ** 0.5)
+                                                attention.dim_head, attention.dim_head ** 0.5, out=o)
             need_dx = li > 0 or ctx.needs_input_grad[1]
             dxn1, dwqkv, dbqkv = _lin_bwd(attention._qkv, xn1, dqkv, 3 * inner)
             dx, dg1, dbt1 = ops.layernorm_ct_backward(h, ln1.weight.detach(), dxn1, ln1.eps, add=dx1)
@@ -292,13 +292,13 @@ class Transformer(nn.Module):
     def run_bct(self, x: Tensor) -> Tensor:
         """Channel-major (B, dim, T) in and out: 7 launches per layer, both residual adds fused into
         the W_o / FFN-out conv epilogues.  With autograd on, the backward runs on the HIP kernels too
-        (_TransformerNative; head_dim > 64 falls back to the ATen bridge)."""
+        (_TransformerNative; head_dim > 128 has no kernel and needs the fenced ATen bridge)."""
         for attention, _ in self.layers:
             if x.shape[-1] > attention.context:
                 raise AgxError(f"sequence length {x.shape[-1]} exceeds the ALiBi context {attention.context} "
                                "(the reference fails here too, transformers.py:88-93)")
         if needs_grad(x, self):
-            if all(a.dim_head <= 64 for a, _ in self.layers):
+            if all(a.dim_head <= 128 for a, _ in self.layers):
                 return _TransformerNative.apply(self, x, *list(self.parameters()))
             return hip_forward_aten_backward(self._hip_bct, self._aten_bct, x, list(self.parameters()))
         return self._hip_bct(x)

@@ -9,9 +9,11 @@ called: every layer runs as a hand-written HIP kernel behind the C ABI of
 ``forward`` walks it and issues fused launches (residual block = one call,
 activation / padding / crop / upsample folded into the conv kernels).
 
-Differentiation: the forward always runs on libagx; when autograd needs a
-gradient the backward is bridged through an ATen restatement of the same stack
-(``autograd_bridge.py`` -- interim until the backward kernels of SURVEY 8(f1)).
+Differentiation: forward AND backward run on libagx (``native_backward.py``: conv
+backward-data / weight-gradient kernels, the RVQ straight-through pass).  Only
+configurations those kernels do not cover (depthwise variant, ``norm != Identity``)
+go through the fenced ATen bridge of ``autograd_bridge.py``, which raises unless
+``AGX_ALLOW_ATEN_BRIDGE=1``.
 """
 from __future__ import annotations
 

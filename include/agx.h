@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AGX_VERSION 113 /* 113: tile images (resblock_p / conv_p), agx_attention_alibi_ex, agx_sizeof_*; 0.1.1: agx_conv_desc gained groups / padding (zero = old behaviour); 111: resample, conv2d column split */
+#define AGX_VERSION 114 /* 114: agx_attention_alibi_backward_ex (any T), agx_rvq_forward_ex; 113: tile images (resblock_p / conv_p), agx_attention_alibi_ex, agx_sizeof_*; 0.1.1: agx_conv_desc gained groups / padding (zero = old behaviour); 111: resample, conv2d column split */
 
 #define AGX_OK 0
 #define AGX_ERR_BAD_SHAPE (-1)
@@ -294,6 +294,13 @@ int agx_layernorm_ct_backward(const float *x, const float *weight, const float *
 /* Backward of agx_attention_alibi: dqkv (B, 3*H*Dh, T) from qkv and dout (B, H*Dh, T).  head_dim <= 64, T <= 256. */
 int agx_attention_alibi_backward(const float *qkv, const float *slopes, const float *dout, float *dqkv, int32_t batch,
                                  int32_t heads, int32_t head_dim, int32_t t, float scale_div, void *stream);
+/* The same for ANY t and head_dim <= 128 (flash-style split into three deterministic kernels: row statistics, dQ per query block,
+ * dK / dV per key block; csrc/attention_flash.hip).  `out` = the forward's output (B, H*Dh, T); workspace:
+ * agx_attention_backward_workspace_bytes() bytes. */
+size_t agx_attention_backward_workspace_bytes(int32_t batch, int32_t heads, int32_t t);
+int agx_attention_alibi_backward_ex(const float *qkv, const float *slopes, const float *out, const float *dout, float *dqkv,
+                                    float *workspace, size_t workspace_bytes, int32_t batch, int32_t heads, int32_t head_dim,
+                                    int32_t t, float scale_div, void *stream);
 /* agx_conv_bwd_data followed by the exact-GELU gradient: dx = (W^T dy [+ add]) * gelu'(pre)  (two launches). */
 int agx_conv_bwd_data_gelu(const agx_conv_desc *d, const float *dy, const float *packed_bwd, const float *add,
                            const float *pre, float *dx, void *stream);

@@ -91,3 +91,70 @@ def test_sample_data_length_through_the_bottleneck():
     # decoder of the oracle on those outputs: whole waveform
     want = codec.decode_latents(want_b, sd, spec)
     assert rms(y.cpu(), want) < 1e-4
+
+
+@pytest.mark.parametrize("b,heads,dh,t", [(2, 8, 64, 1125), (1, 4, 16, 257), (2, 3, 20, 300), (1, 2, 128, 200),
+                                          (1, 2, 100, 513), (2, 2, 64, 256), (1, 1, 8, 1), (1, 5, 33, 64)])
+def test_backward_any_length_against_autograd(b, heads, dh, t):
+    """agx_attention_alibi_backward_ex (statistics / dQ / dK,dV kernels) against fp64 autograd of the definition."""
+    g = torch.Generator().manual_seed(t * 7 + dh)
+    qkv = (0.5 * torch.randn(b, 3 * heads * dh, t, generator=g)).double().requires_grad_(True)
+    slopes = oattn.alibi_slopes(heads)
+    q, k, v = (z.reshape(b, heads, dh, t) for z in qkv.chunk(3, dim=1))
+    s = torch.einsum("bhdi,bhdj->bhij", q, k) / dh ** 0.5 + oattn.alibi_bias(heads, t, t).double()
+    o = torch.einsum("bhij,bhdj->bhdi", s.softmax(-1), v).reshape(b, heads * dh, t)
+    do = torch.randn(o.shape, generator=g)
+    o.backward(do.double())
+    q32 = qkv.detach().float().to(DEV)
+    out = ops.attention_alibi(q32, slopes.to(DEV), heads, dh, dh ** 0.5)
+    lib = ops._lib.load()
+    nbytes = lib.agx_attention_backward_workspace_bytes(b, heads, t)
+    assert nbytes == 2 * b * heads * t * 4
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=DEV)
+    got = torch.empty_like(q32)
+    ops._lib.check(lib.agx_attention_alibi_backward_ex(q32.data_ptr(), slopes.to(DEV).data_ptr(), out.data_ptr(),
+                                                       do.to(DEV).data_ptr(), got.data_ptr(), ws.data_ptr(), nbytes, b, heads,
+                                                       dh, t, dh ** 0.5, torch.cuda.current_stream().cuda_stream), "bwd_ex")
+    want = qkv.grad.float()
+    assert max_abs(got.cpu(), want) < 5e-5 * max(1.0, float(want.abs().max()))
+    assert rms(got.cpu(), want) < 1e-5 * max(1.0, rms(want, torch.zeros_like(want)))
+    if t <= 256 and dh <= 64:   # the single-launch kernel computes the same thing
+        one = ops.attention_alibi_backward(q32, slopes.to(DEV), do.to(DEV), heads, dh, dh ** 0.5)
+        assert max_abs(one.cpu(), got.cpu()) < 5e-5 * max(1.0, float(want.abs().max()))
+    else:                       # ops routes long sequences / wide heads to the split path
+        via = ops.attention_alibi_backward(q32, slopes.to(DEV), do.to(DEV), heads, dh, dh ** 0.5, out=out)
+        assert torch.equal(via, got)   # deterministic: no atomics
+
+
+def test_backward_ex_rejects_bad_arguments():
+    lib = ops._lib.load()
+    x = torch.zeros(3 * 8 * 300, device=DEV)
+    args = lambda ws, dh: (x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), ws, 1, 1, dh,
+                           300, 1.0, None)
+    assert lib.agx_attention_alibi_backward_ex(*args(16, 8)) == -3   # AGX_ERR_WORKSPACE
+    assert lib.agx_attention_alibi_backward_ex(*args(1 << 20, 129)) == -5   # AGX_ERR_UNSUPPORTED
+    with pytest.raises(ops.AgxError):
+        ops.attention_alibi_backward(torch.zeros(1, 24, 300, device=DEV), torch.ones(1, device=DEV),
+                                     torch.zeros(1, 8, 300, device=DEV), 1, 8, 1.0)
+
+
+def test_transformer_bottleneck_trains_at_1125_frames():
+    """Native backward through the whole transformer block at the inference caller's length (training.py:488-496):
+    gradients against autograd on the oracle's formulas, and the ATen bridge is never asked for."""
+    torch.manual_seed(11)
+    tf = Transformer(64, depth=1, heads=4, head_dim=32, context_x=1200).to(DEV)
+    x = (0.5 * torch.randn(1, 64, 1125)).to(DEV).requires_grad_(True)
+    y = tf.run_bct(x)
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+    got = {n: p.grad.detach().cpu().clone() for n, p in tf.named_parameters()}
+    gx = x.grad.detach().cpu().clone()
+    tf.zero_grad()
+    x2 = x.detach().clone().requires_grad_(True)
+    y2 = tf._aten_bct(x2)
+    assert max_abs(y2.detach().cpu(), y.detach().cpu()) < 1e-4
+    (y2 * w).sum().backward()
+    assert max_abs(gx, x2.grad.cpu()) < 2e-4 * max(1.0, float(x2.grad.abs().max()))
+    for n, p in tf.named_parameters():
+        ref = p.grad.detach().cpu()
+        assert max_abs(got[n], ref) < 5e-4 * max(1.0, float(ref.abs().max())), n

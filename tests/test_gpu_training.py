@@ -1,4 +1,4 @@
-"""Trainability of the drop-in (interim: HIP forward, ATen backward -- autograd_bridge.py).
+"""Trainability of the drop-in (HIP forward and HIP backward kernels; the ATen bridge is fenced off).
 Gradients are checked against the CPU oracle's autograd; a few Adam steps must reduce the loss
 (the reference's own smoke script does exactly that, vae.py:384-392)."""
 import pytest
