@@ -596,6 +596,69 @@ __global__ __launch_bounds__(64) void rvq_sqerr_kernel(const double *__restrict_
 
 }  // namespace agx
 
+namespace agx {
+
+// Assignment statistics of the EMA codebook update (quantizer.py:_ema_update): for stage q and code k
+//     stats[q][k][0] = #{n : index[n][q] = k},   stats[q][k][1 + d] = sum over those n, IN FRAME ORDER, of r_q[n][d]
+// with r_q[n] = frames[n] - c_0[index[n][0]] - ... - c_{q-1}[index[n][q-1]] (fp32, subtracted in stage order: the residual
+// the search saw).  One workgroup per (code, stage): an ordered compaction of the matching frames (ballot + prefix),
+// then every thread owns dim / 256 columns and adds the rows one after another -- no atomics, so the update is
+// reproducible run to run (torch's index_add_ on the device is not).
+constexpr int EMA_LIST = 1024;
+
+__global__ __launch_bounds__(256) void rvq_ema_stats_kernel(const float *__restrict__ frames, const float *__restrict__ cb,
+                                                            const int64_t *__restrict__ index, float *__restrict__ stats,
+                                                            int n, int dim, int K, int Q) {
+    __shared__ int list[EMA_LIST];
+    __shared__ int wave_cnt[4];
+    const int k = blockIdx.x, q = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int held = 0, total = 0;
+    auto drain = [&]() {
+        for (int e = 0; e < held; ++e) {
+            const int f = list[e];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int d = tid + 256 * u;
+                if (d < dim) {
+                    float r = frames[size_t(f) * dim + d];
+                    for (int p = 0; p < q; ++p) r -= cb[(size_t(p) * K + index[size_t(f) * Q + p]) * dim + d];
+                    acc[u] += r;
+                }
+            }
+        }
+    };
+    for (int base = 0; base < n; base += 256) {
+        const int f = base + tid;
+        const bool hit = f < n && index[size_t(f) * Q + q] == k;
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = held;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = f;
+        const int add = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        held += add;
+        total += add;
+        __syncthreads();
+        if (held > EMA_LIST - 256) {   // uniform: the next block of 256 might not fit
+            drain();
+            held = 0;
+            __syncthreads();
+        }
+    }
+    drain();
+    float *o = stats + (size_t(q) * K + k) * (dim + 1);
+    if (tid == 0) o[0] = float(total);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int d = tid + 256 * u;
+        if (d < dim) o[1 + d] = acc[u];
+    }
+}
+
+}  // namespace agx
+
 extern "C" {
 
 int64_t agx_rvq_packed_floats(int32_t n_q, int32_t k, int32_t dim) {
@@ -684,6 +747,18 @@ int agx_rvq_dequantize(const float *codebook, const int64_t *idx, int64_t n, int
     hipLaunchKernelGGL(rvq_dequant_kernel, dim3((unsigned)ceil_div64(n, 4)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), codebook, idx, n, k, dim, out, o_sn, o_sd, accumulate);
     return check_launch("rvq_dequantize");
+}
+
+int agx_rvq_ema_stats(const float *frames, const float *codebooks, const int64_t *index, float *stats, int64_t n_frames,
+                      int32_t dim, int32_t k, int32_t q_used, void *stream) {
+    using namespace agx;
+    if (n_frames <= 0 || n_frames > INT32_MAX || dim <= 0 || k <= 0 || q_used <= 0 || q_used > 65535)
+        return fail(AGX_ERR_BAD_SHAPE, "rvq_ema_stats: bad shape N=%lld D=%d K=%d Q=%d", (long long)n_frames, dim, k, q_used);
+    if (dim > 1024) return fail(AGX_ERR_UNSUPPORTED, "rvq_ema_stats: D=%d > 1024", dim);
+    if (!frames || !codebooks || !index || !stats) return fail(AGX_ERR_NULL_POINTER, "rvq_ema_stats: NULL pointer");
+    hipLaunchKernelGGL(rvq_ema_stats_kernel, dim3(k, q_used), dim3(256), 0, static_cast<hipStream_t>(stream), frames, codebooks,
+                       index, stats, int(n_frames), dim, k, q_used);
+    return check_launch("rvq_ema_stats");
 }
 
 }  // extern "C"

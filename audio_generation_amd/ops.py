@@ -259,6 +259,22 @@ def rvq_forward(x: Tensor, codebooks: Tensor, packed: Tensor, q_used: int,
     return xq, index, buf[:q_used]
 
 
+def rvq_ema_stats(frames: Tensor, codebooks: Tensor, index: Tensor) -> Tensor:
+    """Per-stage, per-code assignment counts and residual sums of the EMA codebook update: frames (N, D),
+    codebooks (Q, K, D), index (N, q_used) -> stats (q_used, K, D + 1); sums in frame order (deterministic)."""
+    lib = _lib.load()
+    _need_gpu(frames, codebooks, index)
+    frames, codebooks = _f32c(frames), _f32c(codebooks)
+    index = index.contiguous().to(torch.int64)
+    n, d = frames.shape
+    q_used = index.shape[1]
+    k = codebooks.shape[1]
+    stats = torch.empty(q_used, k, d + 1, dtype=torch.float32, device=frames.device)
+    _lib.check(lib.agx_rvq_ema_stats(_ptr(frames), _ptr(codebooks), _ptr(index), _ptr(stats), n, d, k, q_used, _stream()),
+               "agx_rvq_ema_stats")
+    return stats
+
+
 def rvq_dequantize(codebook: Tensor, idx: Tensor, out: Optional[Tensor] = None,
                    accumulate: bool = False) -> Tensor:
     """``codebook[idx]``: idx (...,) int64 -> (..., D)."""

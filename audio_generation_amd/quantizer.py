@@ -157,15 +157,10 @@ class ResidualQuantizer(nn.Module):
         statistics and the codebooks stay bit-identical across ranks."""
         from . import dist as agx_dist
         q_used = index.shape[1]
-        residual = frames.clone()
         cb = self.codebooks.detach()            # shares storage and version counter with the module's tensor
-        stats = torch.zeros(q_used, self.codebook_size, self.dim + 1, dtype=cb.dtype, device=cb.device)
-        for q in range(q_used):
-            idx = index[:, q]
-            stats[q, :, 0] = torch.bincount(idx, minlength=self.codebook_size).to(cb.dtype)  # padding rows: never hit
-            stats[q, :, 1:].index_add_(0, idx, residual)
-            # the forward that chose index[:, q+1] saw the residual against the PRE-update codeword
-            residual = residual - cb[q][idx]
+        # counts and sums of the residual each stage's search saw (against the PRE-update codewords), one launch,
+        # added in frame order: the update is reproducible run to run (index_add_ on the device is not)
+        stats = ops.rvq_ema_stats(frames, cb, index)
         agx_dist.allreduce_sum_(stats)
         for q in range(q_used):
             counts, sums = stats[q, :, 0], stats[q, :, 1:]

@@ -201,19 +201,29 @@ def cpu_baseline_and_parity(model, x_cpu, y_gpu, idx_gpu, z_gpu, n_items):
     cbs = sd["quantizer.codebooks"]
     xs = x_cpu[:n_items]
 
-    def run():
+    def run(xin):
+        """One CPU forward; returns the results and the (encoder, RVQ, decoder) seconds."""
         with torch.no_grad():
-            z = codec.encode_latents(xs, sd, spec)
+            t0 = time.perf_counter()
+            z = codec.encode_latents(xin, sd, spec)
+            t1 = time.perf_counter()
             zq, idx, _ = rvq.residual_quantize(z, cbs, score_dtype=torch.float32)
-            return z, zq, idx, codec.decode_latents(zq, sd, spec)
+            t2 = time.perf_counter()
+            y = codec.decode_latents(zq, sd, spec)
+            t3 = time.perf_counter()
+        return (z, zq, idx, y), (t1 - t0, t2 - t1, t3 - t2)
 
-    run()  # warm-up (thread pools, page faults)
-    times = []
-    for _ in range(2):
-        t0 = time.perf_counter()
-        z, zq, idx, y = run()
-        times.append(time.perf_counter() - t0)
-    sec = sorted(times)[0]
+    # BASELINE.md section 3: 1 warm-up + 3 timed forwards, median; all host cores of this process's share
+    run(xs)  # warm-up (thread pools, page faults)
+    runs = [run(xs) for _ in range(3)]
+    order = sorted(range(3), key=lambda i: sum(runs[i][1]))
+    (z, zq, idx, y), stage = runs[order[1]]
+    sec = sum(stage)
+    # ... and the per-core figure: the same forward on ONE clip with one thread (1 warm-up + 1 timed)
+    torch.set_num_threads(1)
+    run(xs[:1])
+    _, stage1 = run(xs[:1])
+    torch.set_num_threads(cores)
     # parity: (a) oracle RVQ on the GPU's latents must give the GPU's indices exactly;
     #         (b) waveform RMS vs the oracle decode of those codes; (c) independent path agreement
     with torch.no_grad():
@@ -226,9 +236,12 @@ def cpu_baseline_and_parity(model, x_cpu, y_gpu, idx_gpu, z_gpu, n_items):
         "independent_path_waveform_rms": float((y_gpu[:n_items].cpu().double() - y.double()).pow(2).mean().sqrt()),
         "latent_rms_vs_oracle": float((z_gpu[:n_items].cpu().transpose(1, 2).double() - z.double()).pow(2).mean().sqrt()),
     }
-    base = {"value": n_items * CLIP / sec, "unit": "samples/s", "cores": cores, "kind": "port",
+    nsmp = n_items * CLIP
+    base = {"value": nsmp / sec, "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"{n_items} clips x {CLIP} samples (same inputs/weights as the GPU run), "
-                      f"oracle conv stacks (torch fp32 CPU, {cores} threads) + exact RVQ, best of 2 after 1 warm-up"}
+                      f"oracle conv stacks (torch fp32 CPU, {cores} threads) + exact RVQ, median of 3 after 1 warm-up",
+            "stages": {"encoder": nsmp / stage[0], "rvq": nsmp / stage[1], "decoder": nsmp / stage[2]},
+            "one_thread": {"value": CLIP / sum(stage1), "sample": f"1 clip x {CLIP} samples, 1 thread, 1 timed after 1 warm-up"}}
     return base, parity
 
 
@@ -238,7 +251,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-per-gpu", type=int, default=BATCH_PER_GPU)
-    ap.add_argument("--cpu-items", type=int, default=4, help="clips in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-items", type=int, default=8, help="clips in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="issue the launches eagerly instead of replaying a hipGraph")
     ap.add_argument("--arith", choices=("fp32", "mixed"), default="fp32",

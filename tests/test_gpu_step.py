@@ -199,3 +199,78 @@ def test_whole_config5_step_against_oracle_autograd():
             close(got[k], w, true[k], 5e-3, k)
             n += 1
         assert n >= 14
+
+
+def test_training_backward_leaves_the_gradients_of_the_two_backward_calls():
+    """step.training_backward (one traversal per discriminator, graphs freed one by one) against the reference's
+    order -- discriminator_loss.backward(retain_graph=True), loss.backward() (training.py:374, 380) -- from the
+    same state: same losses, same .grad on every generator and discriminator parameter (summation order only)."""
+    import copy
+    from audio_generation_amd.step import training_backward
+    torch.manual_seed(5)
+    model = CausalVQAE(in_channels=1, n_blocks=4, strides=(2, 4, 5, 8), first_block_channels=8, num_quantizers=3,
+                       codebook_size=64, codebook_dim=64, input_format="n c l", wavelet_decoders=False).to(DEV).train()
+    x = (0.2 * torch.randn(2, 1, 24000)).clamp(-1, 1).to(DEV)
+    with torch.no_grad():
+        model.quantizer.init_from_latents(model._run_encoders(x))
+    discs = [ad.WaveFormDiscriminator(1).to(DEV).train(), ad.STFTDiscriminator(win_length=256).to(DEV).train(),
+             ad.STFTDiscriminator(win_length=128).to(DEV).train()]
+    windows = [32, 128, 512]
+    specs = [sg.MelSpectrogram(24000, max(w, 512), w, w // 4, 64, True).to(DEV) for w in windows]
+    kw = dict(sample_rate=24000, frequency_filter=5000.0, pre_emphasis=0.97, spectrograms=specs, spec_windows=windows,
+              spec_loss_weight=0.01, generator_loss_weight=0.7, update_codebook=True)
+    state = [copy.deepcopy(m.state_dict()) for m in [model] + discs]   # u / v of the power iteration, EMA codebooks
+
+    def grads():
+        out = {}
+        for i, m in enumerate([model] + discs):
+            for n, p in m.named_parameters():
+                if p.grad is not None:
+                    out[(i, n)] = p.grad.detach().clone()
+                    p.grad = None
+        return out
+
+    loss, d_loss, parts = training_losses(model, x, discs, **kw)
+    d_loss.backward(retain_graph=True)
+    loss.backward()
+    want, want_vals = grads(), (float(loss), float(d_loss))
+    after = [copy.deepcopy(m.state_dict()) for m in [model] + discs]
+    for m, s in zip([model] + discs, state):
+        m.load_state_dict(s)
+    loss2, d_loss2, parts2 = training_backward(model, x, discs, **kw)
+    got = grads()
+    assert not loss2.requires_grad and not d_loss2.requires_grad
+    assert abs(float(loss2) - want_vals[0]) <= 1e-5 * abs(want_vals[0])
+    assert abs(float(d_loss2) - want_vals[1]) <= 1e-6 * abs(want_vals[1])
+    assert set(parts2) == set(parts)
+    assert set(got) == set(want) and len(got) > 200
+    for k, w in want.items():
+        scale = float(w.abs().max())
+        assert float((got[k] - w).abs().max()) <= 2e-4 * scale + 1e-9, k   # fp32 sums in another order (measured 2.4e-5)
+    for m, s in zip([model] + discs, after):                           # buffers advanced identically
+        for n, v in m.state_dict().items():
+            assert torch.equal(v, s[n]), n
+
+
+def test_ema_statistics_kernel_counts_sums_and_is_reproducible():
+    """agx_rvq_ema_stats: per-stage per-code counts (exact) and residual sums (frame order, fp32) against a float64
+    restatement; two launches are bit-identical; a code holding > 1024 frames exercises the list drain."""
+    g = torch.Generator().manual_seed(3)
+    n, d, k, q = 5000, 96, 37, 3
+    frames = torch.randn(n, d, generator=g)
+    cbs = torch.randn(4, k, d, generator=g)            # one stage more than used
+    index = torch.randint(0, k, (n, q), generator=g)
+    index[:2600, 0] = 5                                 # a crowded code
+    index[::7, 1] = 36
+    got = ops.rvq_ema_stats(frames.to(DEV), cbs.to(DEV), index.to(DEV))
+    again = ops.rvq_ema_stats(frames.to(DEV), cbs.to(DEV), index.to(DEV))
+    assert torch.equal(got, again)
+    assert got.shape == (q, k, d + 1)
+    r = frames.clone()
+    for s in range(q):
+        counts = torch.bincount(index[:, s], minlength=k)
+        assert torch.equal(got[s, :, 0].cpu(), counts.float())
+        want = torch.zeros(k, d, dtype=torch.float64).index_add_(0, index[:, s], r.double())
+        err = (got[s, :, 1:].cpu().double() - want).abs().max()
+        assert float(err) < 1e-6 * float(counts.max()) * 4, (s, float(err))
+        r = r - cbs[s][index[:, s]]                     # fp32, stage order: what the kernel subtracts

@@ -71,25 +71,33 @@ def main():
     # the exchange step: ONE flat gradient buffer, allocated here, every .grad a view into it
     bucket = agx_dist.GradBucket(all_params())
 
+    two_calls = os.environ.get("AGX_TWO_CALLS", "0") == "1"   # A/B: the reference's literal backward order
+
     def step():
         bucket.zero_()
-        if signal:
-            xin = sg.lowpass_biquad(x, 24000, 5000.0)
-            y, commit, _ = model(xin, update_codebook=update_cb)
-            loss = ((sg.preemphasis(y, 0.97) - sg.preemphasis(xin, 0.97)) ** 2).mean() + commit
-            loss = loss + sg.multispectral_reconstruction_loss(xin, y, specs, windows, spec_loss_weight=0.01)
+        if signal and not two_calls:          # step.training_backward: one traversal per discriminator, graphs freed one by one
+            from audio_generation_amd.step import training_backward
+            loss, _, _ = training_backward(model, x, discs, sample_rate=24000, frequency_filter=5000.0, pre_emphasis=0.97,
+                                           spectrograms=specs, spec_windows=windows, spec_loss_weight=0.01,
+                                           update_codebook=update_cb)
         else:
-            xin = x
-            y, commit, _ = model(xin, update_codebook=update_cb)
-            loss = ((y - xin) ** 2).mean() + commit
-        if gan:                                 # training.py:363-376
-            d_loss = 0
-            for d in discs:
-                g_loss, d_loss_i = discriminator_generator_loss(xin, y, d)
-                loss = loss + g_loss
-                d_loss = d_loss + d_loss_i
-            d_loss.backward(retain_graph=True)
-        loss.backward()
+            if signal:
+                xin = sg.lowpass_biquad(x, 24000, 5000.0)
+                y, commit, _ = model(xin, update_codebook=update_cb)
+                loss = ((sg.preemphasis(y, 0.97) - sg.preemphasis(xin, 0.97)) ** 2).mean() + commit
+                loss = loss + sg.multispectral_reconstruction_loss(xin, y, specs, windows, spec_loss_weight=0.01)
+            else:
+                xin = x
+                y, commit, _ = model(xin, update_codebook=update_cb)
+                loss = ((y - xin) ** 2).mean() + commit
+            if gan:                                 # training.py:363-376
+                d_loss = 0
+                for d in discs:
+                    g_loss, d_loss_i = discriminator_generator_loss(xin, y, d)
+                    loss = loss + g_loss
+                    d_loss = d_loss + d_loss_i
+                d_loss.backward(retain_graph=True)
+            loss.backward()
         bucket.allreduce_mean_()               # in place on the flat buffer (RCCL; staged through the host on gloo)
         opt.step()
         for o in opt_d:
@@ -113,6 +121,7 @@ def main():
                           (f" + {len(discs)} discriminators (native forward + backward)" if gan else "") +
                           (" + low-pass, pre-emphasis, 7-window mel loss" if signal else "") +
                           (" [bf16x3: decoder forward, discriminator Conv2d forward + backward-data]" if bf else ""),
+                          "backward_order": ("two calls (training.py:374, 380)" if (two_calls or not signal) else "step.training_backward"),
                           "n_gpus": world, "batch_per_gpu": batch, "ms_per_step": ms, "replicas_in_sync": same, "update_codebook": update_cb,
                           "samples_per_s": world * batch * 72000 / ms * 1e3, "losses": losses,
                           "approx_tflops_at_3x_forward": world * 3 * fwd_flop / ms * 1e-9,
