@@ -148,19 +148,23 @@ class ResidualQuantizer(nn.Module):
         self._packed_key = None
 
     @torch.no_grad()
-    def _ema_update(self, frames: Tensor, index: Tensor) -> None:
+    def _ema_update(self, frames: Tensor, index: Tensor, stats: Optional[Tensor] = None) -> None:
         """Plain EMA k-means update per stage (build-defined; see module docstring).
 
         Data parallel (the reference toggles ``update_codebook`` inside the step,
         training.py:305-308, 326): the per-code assignment counts (K,) and residual sums (K,D) of all
         stages travel in ONE all-reduce (sum over ranks), so every replica applies the same global-batch
-        statistics and the codebooks stay bit-identical across ranks."""
+        statistics and the codebooks stay bit-identical across ranks.  ``stats`` (q_used, K, D+1): this rank's
+        statistics if the caller already holds them (host-logic tests); otherwise one ``agx_rvq_ema_stats`` launch."""
         from . import dist as agx_dist
         q_used = index.shape[1]
         cb = self.codebooks.detach()            # shares storage and version counter with the module's tensor
         # counts and sums of the residual each stage's search saw (against the PRE-update codewords), one launch,
         # added in frame order: the update is reproducible run to run (index_add_ on the device is not)
-        stats = ops.rvq_ema_stats(frames, cb, index)
+        if stats is None:
+            stats = ops.rvq_ema_stats(frames, cb, index)
+        else:
+            stats = stats.clone()
         agx_dist.allreduce_sum_(stats)
         for q in range(q_used):
             counts, sums = stats[q, :, 0], stats[q, :, 1:]

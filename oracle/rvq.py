@@ -163,3 +163,20 @@ def init_codebooks(q: int, k: int, d: int, sigma: float = 1.0, seed: int = 7) ->
     """``randn(Q,K,D) * sigma`` from seed 7."""
     gen = torch.Generator().manual_seed(seed)
     return torch.randn(q, k, d, generator=gen) * sigma
+
+
+def ema_assignment_stats(frames: torch.Tensor, codebooks: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+    """CPU statement of ``agx_rvq_ema_stats`` (build-defined EMA codebook update; the external quantiser's own rule is
+    unknown): frames (N, D), codebooks (Q, K, D) BEFORE the update, index (N, q_used) ->
+    stats (q_used, K, D + 1) with [q, k, 0] = assignment count and [q, k, 1:] = sum of the stage-q residuals of the
+    frames assigned to k -- the residual the search saw, i.e. against the pre-update codewords."""
+    n, d = frames.shape
+    q_used, k = index.shape[1], codebooks.shape[1]
+    stats = torch.zeros(q_used, k, d + 1, dtype=frames.dtype)
+    residual = frames.clone()
+    for q in range(q_used):
+        idx = index[:, q]
+        stats[q, :, 0] = torch.bincount(idx, minlength=k).to(frames.dtype)
+        stats[q, :, 1:].index_add_(0, idx, residual)
+        residual = residual - codebooks[q][idx]
+    return stats

@@ -82,7 +82,8 @@ def _ema_worker(rank, world, port, out):
     for _ in range(3):
         x = torch.randn(2, 20, 8, generator=gen)
         _, index, _ = rvq.residual_quantize(x, rq.codebooks, sizes=rq.codebook_sizes)
-        rq._ema_update(x.reshape(-1, 8), index.reshape(-1, 3))
+        fr, ix = x.reshape(-1, 8), index.reshape(-1, 3)
+        rq._ema_update(fr, ix, stats=rvq.ema_assignment_stats(fr, rq.codebooks, ix))   # the kernel's CPU statement
     lo, hi = agx_dist.replica_checksums(rq)
     # GradBucket: grads are views of one flat buffer, mean over ranks in place, views stay intact
     lin = torch.nn.Linear(5, 3)
@@ -134,7 +135,8 @@ def test_ema_update_uses_pre_update_codewords_and_invalidates_pack():
     x = torch.randn(1, 30, 4)
     _, index, _ = rvq.residual_quantize(x, cb0)
     rq._packed, v0 = torch.zeros(1), rq.codebooks._version
-    rq._ema_update(x.reshape(-1, 4), index.reshape(-1, 2))
+    rq._ema_update(x.reshape(-1, 4), index.reshape(-1, 2),
+                   stats=rvq.ema_assignment_stats(x.reshape(-1, 4), cb0, index.reshape(-1, 2)))
     assert rq._packed is None and rq.codebooks._version > v0
     frames = x.reshape(-1, 4)
     idx0, idx1 = index.reshape(-1, 2).T

@@ -266,6 +266,7 @@ def test_ema_statistics_kernel_counts_sums_and_is_reproducible():
     again = ops.rvq_ema_stats(frames.to(DEV), cbs.to(DEV), index.to(DEV))
     assert torch.equal(got, again)
     assert got.shape == (q, k, d + 1)
+    assert torch.allclose(got.cpu(), rvq.ema_assignment_stats(frames, cbs, index), rtol=1e-5, atol=1e-3)
     r = frames.clone()
     for s in range(q):
         counts = torch.bincount(index[:, s], minlength=k)
