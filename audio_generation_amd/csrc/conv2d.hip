@@ -121,8 +121,10 @@ int lower_conv2d_bwd_data(const agx_conv2d_desc *d, ConvPlan *b) {
         b->M = d->c_in * d->stride_h * d->stride_w;
         b->pm_R = 1;
         b->prec = d->impl == AGX_IMPL_MFMA_BF16X3 ? 1 : 0;
-    } else if (d->stride_h != 1 || d->stride_w != 1 || d->kh - 1 - d->pad_h < 0 || d->kw - 1 - d->pad_w < 0) {
-        // odd shapes (strided layers with few / unaligned channels: the tiny test models): gather kernel below
+    } else if (d->c_out <= 4 || d->stride_h != 1 || d->stride_w != 1 || d->kh - 1 - d->pad_h < 0 || d->kw - 1 - d->pad_w < 0) {
+        // few dy channels (the 1-channel final conv: kh * kw * Cout <= 32 MACs per dx element -- a bandwidth-bound
+        // gather, 0.25-0.9 ms on the GEMM kernels against 0.03) and odd shapes (strided layers with few / unaligned
+        // channels: the tiny test models): gather kernel below
         b->pm_R = -1;
         b->ncv = d->c_out;
         b->J = d->kh * d->kw;
@@ -262,6 +264,57 @@ __global__ __launch_bounds__(256) void pack_bwd2d_kernel(const float *__restrict
     dst[16] = mm;
     dst[32] = (__bf16)(r1 - (float)mm);
 }
+// Forward of a layer with very few OUTPUT channels (the 1-channel final conv of the STFT discriminators, 512 -> 1 with a
+// (1, k) kernel on a 35 x 16 ... 281 x 2 map): M = Cout rows would leave the MFMA tile empty (0.65-2.3 ms for 40 MMAC).
+// One wave per output position: the lanes split the Cin * kh virtual channels of the row-folded image
+// (packed[((c'/16) * J + j) * M + m][c' % 16], c' = ci * kh + dh), shuffle-reduce, lane 0 applies bias / LeakyReLU.
+template <int MM>
+__global__ __launch_bounds__(256) void conv2d_fewout_kernel(ConvPlan p, const float *__restrict__ x,
+                                                            const float *__restrict__ wp, const float *__restrict__ bias,
+                                                            float *__restrict__ y, int64_t npos) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pos = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (pos >= npos) return;   // whole waves leave together
+    const int j = int(pos % p.Lout), i = int((pos / p.Lout) % p.Tout), b = int(pos / (int64_t(p.Lout) * p.Tout));
+    const float *xb = x + size_t(b) * p.cin_real * p.x_cstride;
+    float acc[MM];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) acc[m] = 0.f;
+    for (int c = lane; c < p.ncv; c += 64) {
+        const int ci = c / p.kh, dh = c - ci * p.kh;
+        const int r = i * p.sh + dh - p.ph;
+        if (r < 0 || r >= p.Tin) continue;
+        const float *row = xb + size_t(ci) * p.x_cstride + size_t(r) * p.Lin;
+        const float *wc = wp + size_t(c / kWG) * p.J * p.M * kWG + (c % kWG);
+        for (int jj = 0; jj < p.J; ++jj) {
+            const int col = j * p.s + jj - p.P;
+            if (col < 0 || col >= p.Lin) continue;
+            const float xv = row[col];
+#pragma unroll
+            for (int m = 0; m < MM; ++m)
+                if (m < p.M) acc[m] = fmaf(wc[(size_t(jj) * p.M + m) * kWG], xv, acc[m]);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) acc[m] += __shfl_xor(acc[m], o);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int m = 0; m < MM; ++m)
+            if (m < p.M) {
+                float v = acc[m] + (bias ? bias[m] : 0.f);
+                if ((p.epilogue & AGX_EPI_LEAKY_PRE) && v < 0.f) v *= p.slope;
+                y[(size_t(b) * p.M + m) * p.y_cstride + size_t(i) * p.Lout + j] = v;
+            }
+    }
+}
+
+static bool conv2d_fewout(const agx_conv2d_desc *d, const ConvPlan &p) {
+    return d->impl == AGX_IMPL_AUTO && p.pm_R == 0 && p.prec == 0 && p.M <= 4 && p.q == 1 && p.d == 1;
+}
+
 }  // namespace agx
 
 extern "C" {
@@ -362,6 +415,12 @@ int agx_conv2d_forward(const agx_conv2d_desc *d, const float *x, const float *pa
     if (rc != AGX_OK) return rc;
     if (!x || !packed || !y) return fail(AGX_ERR_NULL_POINTER, "agx_conv2d_forward: NULL pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (conv2d_fewout(d, p)) {
+        const int64_t npos = int64_t(p.B) * p.Tout * p.Lout;
+        hipLaunchKernelGGL(conv2d_fewout_kernel<4>, dim3((unsigned)ceil_div64(npos, 4)), dim3(256), 0, st, p, x, packed, bias, y,
+                           npos);
+        return check_launch("agx_conv2d_forward");
+    }
     const int impl = conv2d_impl(d, p);
     if (p.pm_R && impl != AGX_IMPL_MFMA)
         return fail(AGX_ERR_UNSUPPORTED, "conv2d: no MFMA tile fits this layer (set impl = AGX_IMPL_DIRECT for pack and forward)");
@@ -376,7 +435,8 @@ int agx_conv2d_kernel_name(const agx_conv2d_desc *d, char *buf, size_t buf_len) 
     int rc = lower_conv2d(d, &p);
     if (rc != AGX_OK) return rc;
     if (!buf || buf_len == 0) return fail(AGX_ERR_NULL_POINTER, "agx_conv2d_kernel_name: NULL buffer");
-    snprintf(buf, buf_len, "%s", conv2d_impl(d, p) == AGX_IMPL_MFMA ? conv_mfma_variant(p) : conv_direct_variant(p));
+    snprintf(buf, buf_len, "%s", agx::conv2d_fewout(d, p) ? "conv2d_fewout<4>"
+                                 : (conv2d_impl(d, p) == AGX_IMPL_MFMA ? conv_mfma_variant(p) : conv_direct_variant(p)));
     return AGX_OK;
 }
 

@@ -599,31 +599,62 @@ __global__ __launch_bounds__(64) void rvq_sqerr_kernel(const double *__restrict_
 namespace agx {
 
 // Assignment statistics of the EMA codebook update (quantizer.py:_ema_update): for stage q and code k
-//     stats[q][k][0] = #{n : index[n][q] = k},   stats[q][k][1 + d] = sum over those n, IN FRAME ORDER, of r_q[n][d]
+//     stats[q][k][0] = #{n : index[n][q] = k},   stats[q][k][1 + d] = sum over those n of r_q[n][d]
 // with r_q[n] = frames[n] - c_0[index[n][0]] - ... - c_{q-1}[index[n][q-1]] (fp32, subtracted in stage order: the residual
-// the search saw).  One workgroup per (code, stage): an ordered compaction of the matching frames (ballot + prefix),
-// then every thread owns dim / 256 columns and adds the rows one after another -- no atomics, so the update is
-// reproducible run to run (torch's index_add_ on the device is not).
+// the search saw).  Two launches, no atomics, so the update is reproducible run to run (torch's index_add_ on the
+// device is not):
+//   rvq_residuals_kernel   R[q][n][:] for every stage (workspace, Q N D floats)
+//   rvq_ema_stats_kernel   one workgroup per (code, stage): ordered compaction of the matching frames (ballot + prefix),
+//                          wave w adds rows w, w+4, ... of the list in list order, the four partial sums are added in
+//                          wave order.
 constexpr int EMA_LIST = 1024;
 
-__global__ __launch_bounds__(256) void rvq_ema_stats_kernel(const float *__restrict__ frames, const float *__restrict__ cb,
-                                                            const int64_t *__restrict__ index, float *__restrict__ stats,
+__global__ __launch_bounds__(256) void rvq_residuals_kernel(const float *__restrict__ frames, const float *__restrict__ cb,
+                                                            const int64_t *__restrict__ index, float *__restrict__ R,
                                                             int n, int dim, int K, int Q) {
+    const int64_t total = int64_t(n) * dim;
+    for (int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x; e < total; e += int64_t(gridDim.x) * 256) {
+        const int f = int(e / dim), d = int(e - int64_t(f) * dim);
+        float r = frames[e];
+        for (int q = 0; q < Q; ++q) {
+            R[int64_t(q) * total + e] = r;
+            const int64_t c = index[int64_t(f) * Q + q];
+            if (c >= 0 && c < K) r -= cb[(int64_t(q) * K + c) * dim + d];
+        }
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void rvq_ema_stats_kernel(const float *__restrict__ R, const int64_t *__restrict__ index,
+                                                            float *__restrict__ stats, int n, int dim, int K, int Q) {
+    constexpr int NA = VEC ? 4 : 16;          // accumulators per lane: dim <= 1024
     __shared__ int list[EMA_LIST];
     __shared__ int wave_cnt[4];
+    __shared__ float part[4][1024];
     const int k = blockIdx.x, q = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float *Rq = R + int64_t(q) * n * dim;
+    f32x4 av[VEC ? NA : 1];
+    float as[VEC ? 1 : NA];
+#pragma unroll
+    for (int u = 0; u < (VEC ? NA : 1); ++u) av[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < (VEC ? 1 : NA); ++u) as[u] = 0.f;
     int held = 0, total = 0;
     auto drain = [&]() {
-        for (int e = 0; e < held; ++e) {
-            const int f = list[e];
+#pragma unroll 4
+        for (int e = wave; e < held; e += 4) {
+            const float *row = Rq + int64_t(list[e]) * dim;
+            if (VEC) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int d = tid + 256 * u;
-                if (d < dim) {
-                    float r = frames[size_t(f) * dim + d];
-                    for (int p = 0; p < q; ++p) r -= cb[(size_t(p) * K + index[size_t(f) * Q + p]) * dim + d];
-                    acc[u] += r;
+                for (int u = 0; u < NA; ++u) {
+                    const int c = 4 * (lane + 64 * u);
+                    if (c < dim) av[u] += *reinterpret_cast<const f32x4 *>(row + c);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < NA; ++u) {
+                    const int d = lane + 64 * u;
+                    if (d < dim) as[u] += row[d];
                 }
             }
         }
@@ -648,13 +679,25 @@ __global__ __launch_bounds__(256) void rvq_ema_stats_kernel(const float *__restr
         }
     }
     drain();
+    if (VEC) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int c = 4 * (lane + 64 * u);
+            if (c < dim)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) part[wave][c + i] = av[u][i];
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int d = lane + 64 * u;
+            if (d < dim) part[wave][d] = as[u];
+        }
+    }
+    __syncthreads();
     float *o = stats + (size_t(q) * K + k) * (dim + 1);
     if (tid == 0) o[0] = float(total);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int d = tid + 256 * u;
-        if (d < dim) o[1 + d] = acc[u];
-    }
+    for (int d = tid; d < dim; d += 256) o[1 + d] = ((part[0][d] + part[1][d]) + part[2][d]) + part[3][d];
 }
 
 }  // namespace agx
@@ -749,15 +792,31 @@ int agx_rvq_dequantize(const float *codebook, const int64_t *idx, int64_t n, int
     return check_launch("rvq_dequantize");
 }
 
+size_t agx_rvq_ema_workspace_bytes(int64_t n_frames, int32_t dim, int32_t q_used) {
+    if (n_frames <= 0 || dim <= 0 || q_used <= 0) return 0;
+    return size_t(n_frames) * dim * q_used * sizeof(float);
+}
+
 int agx_rvq_ema_stats(const float *frames, const float *codebooks, const int64_t *index, float *stats, int64_t n_frames,
-                      int32_t dim, int32_t k, int32_t q_used, void *stream) {
+                      int32_t dim, int32_t k, int32_t q_used, void *workspace, size_t workspace_bytes, void *stream) {
     using namespace agx;
     if (n_frames <= 0 || n_frames > INT32_MAX || dim <= 0 || k <= 0 || q_used <= 0 || q_used > 65535)
         return fail(AGX_ERR_BAD_SHAPE, "rvq_ema_stats: bad shape N=%lld D=%d K=%d Q=%d", (long long)n_frames, dim, k, q_used);
     if (dim > 1024) return fail(AGX_ERR_UNSUPPORTED, "rvq_ema_stats: D=%d > 1024", dim);
-    if (!frames || !codebooks || !index || !stats) return fail(AGX_ERR_NULL_POINTER, "rvq_ema_stats: NULL pointer");
-    hipLaunchKernelGGL(rvq_ema_stats_kernel, dim3(k, q_used), dim3(256), 0, static_cast<hipStream_t>(stream), frames, codebooks,
-                       index, stats, int(n_frames), dim, k, q_used);
+    if (!frames || !codebooks || !index || !stats || !workspace) return fail(AGX_ERR_NULL_POINTER, "rvq_ema_stats: NULL pointer");
+    if (workspace_bytes < agx_rvq_ema_workspace_bytes(n_frames, dim, q_used))
+        return fail(AGX_ERR_WORKSPACE, "rvq_ema_stats: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float *R = static_cast<float *>(workspace);
+    const int64_t total = n_frames * dim;
+    hipLaunchKernelGGL(rvq_residuals_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64(total, 256), 16384)), dim3(256), 0, st,
+                       frames, codebooks, index, R, int(n_frames), dim, k, q_used);
+    if (dim % 4 == 0)
+        hipLaunchKernelGGL(rvq_ema_stats_kernel<true>, dim3(k, q_used), dim3(256), 0, st, R, index, stats, int(n_frames), dim, k,
+                           q_used);
+    else
+        hipLaunchKernelGGL(rvq_ema_stats_kernel<false>, dim3(k, q_used), dim3(256), 0, st, R, index, stats, int(n_frames), dim,
+                           k, q_used);
     return check_launch("rvq_ema_stats");
 }
 

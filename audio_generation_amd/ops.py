@@ -270,8 +270,10 @@ def rvq_ema_stats(frames: Tensor, codebooks: Tensor, index: Tensor) -> Tensor:
     q_used = index.shape[1]
     k = codebooks.shape[1]
     stats = torch.empty(q_used, k, d + 1, dtype=torch.float32, device=frames.device)
-    _lib.check(lib.agx_rvq_ema_stats(_ptr(frames), _ptr(codebooks), _ptr(index), _ptr(stats), n, d, k, q_used, _stream()),
-               "agx_rvq_ema_stats")
+    nbytes = lib.agx_rvq_ema_workspace_bytes(n, d, q_used)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=frames.device)
+    _lib.check(lib.agx_rvq_ema_stats(_ptr(frames), _ptr(codebooks), _ptr(index), _ptr(stats), n, d, k, q_used, _ptr(ws), nbytes,
+                                     _stream()), "agx_rvq_ema_stats")
     return stats
 
 

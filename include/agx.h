@@ -228,10 +228,12 @@ int agx_rvq_forward_ex(const float *x, int64_t x_sb, int64_t x_st, int64_t x_sd,
 
 /* Assignment statistics of the EMA codebook update (`update_codebook=True`, vae.py:315-318; the update rule itself is
  * build-defined): stats (q_used, K, D+1): [q][k][0] = number of frames whose stage-q index is k, [q][k][1+d] = the
- * sum of their stage-q residuals, added in frame order (deterministic; no atomics).  frames (N, D) contiguous, index
- * (N, q_used) int64, codebooks (Q >= q_used, K, D) BEFORE the update.  D <= 1024. */
+ * sum of their stage-q residuals, added in a fixed order (deterministic; no atomics).  frames (N, D) contiguous, index
+ * (N, q_used) int64, codebooks (Q >= q_used, K, D) BEFORE the update.  D <= 1024.  workspace: the per-stage residuals,
+ * agx_rvq_ema_workspace_bytes() bytes. */
+size_t agx_rvq_ema_workspace_bytes(int64_t n_frames, int32_t dim, int32_t q_used);
 int agx_rvq_ema_stats(const float *frames, const float *codebooks, const int64_t *index, float *stats, int64_t n_frames,
-                      int32_t dim, int32_t k, int32_t q_used, void *stream);
+                      int32_t dim, int32_t k, int32_t q_used, void *workspace, size_t workspace_bytes, void *stream);
 
 /* quantizers[i].dequantize(idx) (vae.py:333): out[n,:] (+)= codebook[idx[n],:].
  * out element (n,d) at n*stride_n + d*stride_d. */
