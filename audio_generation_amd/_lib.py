@@ -113,6 +113,7 @@ SIGNATURES = {
     "agx_conv2d_pack": (c_int, [_P2, c_void_p, c_void_p, c_void_p, c_void_p]),
     "agx_conv2d_forward": (c_int, [_P2, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "agx_conv2d_kernel_name": (c_int, [_P2, c_char_p, c_size_t]),
+    "agx_conv2d_bwd_data_kernel_name": (c_int, [_P2, c_char_p, c_size_t]),
     "agx_conv2d_bwd_packed_floats": (c_int64, [_P2]),
     "agx_conv2d_pack_bwd": (c_int, [_P2, c_void_p, c_void_p, c_void_p, c_void_p]),
     "agx_conv2d_bwd_data": (c_int, [_P2, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),

@@ -119,6 +119,7 @@ __host__ __device__ inline size_t tile_image_index(int ci, int j, int m, int J, 
 }
 // Geometry class of a layer the persistent conv kernel is instantiated for (conv_p.hip), 0 = none.
 int conv_p_geometry(const ConvPlan &p);
+int conv_p2d_geometry(const ConvPlan &p);   // conv_p.hip: ring form of a patch-mode Conv2d plan (0 = none)
 // Layers that get a tile image: the stride-1 causal layers of the fused residual block (the dilated k = 7 conv and the
 // k = 1 conv, C in {32,64,128,256}) and the resampling / stride-1 layers of conv_p.hip.
 inline bool tile_image_eligible(const ConvPlan &p, int kind) {

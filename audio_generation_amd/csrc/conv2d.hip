@@ -16,6 +16,10 @@ int launch_conv_mfma(const ConvPlan &p, const float *x, const float *wp, const f
 bool conv_mfma_supported(const ConvPlan &p);
 const char *conv_mfma_variant(const ConvPlan &p);
 const char *conv_direct_variant(const ConvPlan &p);
+bool conv_p2d_supported(const ConvPlan &p);
+const char *conv_p2d_variant(const ConvPlan &p);
+int launch_conv_p2d(const ConvPlan &p, const float *x, const float *wp, const float *bias, const float *res, float *y,
+                    hipStream_t st);
 
 int lower_conv2d(const agx_conv2d_desc *d, ConvPlan *p) {
     if (!d) return fail(AGX_ERR_NULL_POINTER, "conv2d descriptor is NULL");
@@ -63,6 +67,9 @@ int lower_conv2d(const agx_conv2d_desc *d, ConvPlan *p) {
     p->Tt = p->Tout;
     p->prec = (patch && d->impl == AGX_IMPL_MFMA_BF16X3) ? 1 : 0;   // bf16x3: patch layers only
     if (int64_t(p->B) * p->Tout > (int64_t(1) << 30)) return fail(AGX_ERR_BAD_SHAPE, "conv2d: batch * output rows too large");
+    // layers the persistent ring kernel covers (conv_p.hip, D2 geometries) carry a tile image behind the scale scratch
+    p->tile_off = -1;
+    if (patch && d->impl == AGX_IMPL_AUTO && conv_p2d_geometry(*p) != 0) p->tile_off = packed_weight_floats(p->ncv, p->J, p->M) + p->Cout;
     return AGX_OK;
 }
 
@@ -147,7 +154,39 @@ int lower_conv2d_bwd_data(const agx_conv2d_desc *d, ConvPlan *b) {
         b->pm_R = 0;
     }
     b->pm_WF = 0;
+    b->tile_off = -1;
+    if (patch && d->impl == AGX_IMPL_AUTO && conv_p2d_geometry(*b) != 0) b->tile_off = packed_weight_floats(b->ncv, b->J, b->M);
     return AGX_OK;
+}
+
+// Tile image of a row-folded layer for conv_p.hip's D2 geometries: virtual channel v = a * C + c (kernel row a, input
+// channel c of THIS op), Wt[((v / 4) * kw + j) * M + m][v % 4] (common.hpp: tile_image_index with Cin -> kh * C).
+//   forward            C = Cin,  M = Cout:  w[m][c][a][j] * scale[m]
+//   backward-data (stride 1, flipped kernel)  C = Cout, M = Cin:  w[c][m][kh-1-a][kw-1-j] / sigma
+__global__ __launch_bounds__(256) void pack_tile2d_kernel(const float *__restrict__ w, const float *__restrict__ scale,
+                                                          const float *__restrict__ sigma, float *__restrict__ timg, int C,
+                                                          int M, int kh, int kw, int bwd) {
+    const int64_t total = tile_image_floats(kh * C, kw, M);
+    const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int c4 = int(e % 4);
+    const int m = int((e / 4) % M);
+    const int gj = int(e / (int64_t(4) * M));
+    const int j = gj % kw, v = (gj / kw) * 4 + c4;
+    float out = 0.f;
+    if (v < kh * C) {
+        const int a = v / C, c = v - a * C;
+        if (!bwd) out = w[((size_t(m) * C + c) * kh + a) * kw + j] * (scale ? scale[m] : 1.f);
+        else out = w[((size_t(c) * M + m) * kh + (kh - 1 - a)) * kw + (kw - 1 - j)] * (sigma ? 1.f / sigma[0] : 1.f);
+    }
+    timg[e] = out;
+}
+
+void launch_pack_tile2d(const float *w, const float *scale, const float *sigma, float *timg, int C, int M, int kh, int kw,
+                        int bwd, hipStream_t st) {
+    const int64_t nt = tile_image_floats(kh * C, kw, M);
+    hipLaunchKernelGGL(pack_tile2d_kernel, dim3((unsigned)ceil_div64(nt, 256)), dim3(256), 0, st, w, scale, sigma, timg, C, M, kh,
+                       kw, bwd);
 }
 
 // Catch-all backward-data: one thread per dx element, gather over (co, dh, dw).  wimg = the weight tensor
@@ -324,7 +363,8 @@ int64_t agx_conv2d_bwd_packed_floats(const agx_conv2d_desc *d) {
     int rc = agx::lower_conv2d_bwd_data(d, &b);
     if (rc != AGX_OK) return rc;
     if (b.pm_R < 0) return int64_t(d->c_out) * d->c_in * d->kh * d->kw;
-    return b.prec ? agx::packed_weight_floats_bf(b.ncv, b.J, b.M) : agx::packed_weight_floats(b.ncv, b.J, b.M);
+    const int64_t tile = b.tile_off >= 0 ? agx::tile_image_floats(b.kh * b.Cin, b.J / b.kh, b.M) : 0;
+    return (b.prec ? agx::packed_weight_floats_bf(b.ncv, b.J, b.M) : agx::packed_weight_floats(b.ncv, b.J, b.M)) + tile;
 }
 
 int agx_conv2d_pack_bwd(const agx_conv2d_desc *d, const float *w, const float *sigma, float *packed, void *stream) {
@@ -343,6 +383,8 @@ int agx_conv2d_pack_bwd(const agx_conv2d_desc *d, const float *w, const float *s
     hipLaunchKernelGGL(pack_bwd2d_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), w, sigma, packed, d->c_in, d->c_out, d->kh, d->kw, d->stride_h,
                        d->stride_w, b.pm_R ? 1 : 0, b.ncv, b.J, b.M, b.prec);
+    if (b.tile_off >= 0)
+        launch_pack_tile2d(w, nullptr, sigma, packed + b.tile_off, b.Cin, b.M, b.kh, b.J / b.kh, 1, static_cast<hipStream_t>(stream));
     return check_launch("agx_conv2d_pack_bwd");
 }
 
@@ -364,6 +406,7 @@ int agx_conv2d_bwd_data(const agx_conv2d_desc *d, const float *dy, const float *
                            d->kh, d->kw, d->stride_h, d->stride_w, d->pad_h, d->pad_w);
         return check_launch("agx_conv2d_bwd_data");
     }
+    if (tuning().conv_impl == 1 && conv_p2d_supported(b)) return launch_conv_p2d(b, dy, packed_bwd, nullptr, add, dx, st);
     if (b.pm_R || (d->impl != AGX_IMPL_DIRECT && conv_mfma_supported(b)))
         return launch_conv_mfma(b, dy, packed_bwd, nullptr, add, dx, st);
     return launch_conv_direct(b, dy, packed_bwd, nullptr, add, dx, st);
@@ -421,6 +464,7 @@ int agx_conv2d_forward(const agx_conv2d_desc *d, const float *x, const float *pa
                            npos);
         return check_launch("agx_conv2d_forward");
     }
+    if (tuning().conv_impl == 1 && conv_p2d_supported(p)) return launch_conv_p2d(p, x, packed, bias, nullptr, y, st);
     const int impl = conv2d_impl(d, p);
     if (p.pm_R && impl != AGX_IMPL_MFMA)
         return fail(AGX_ERR_UNSUPPORTED, "conv2d: no MFMA tile fits this layer (set impl = AGX_IMPL_DIRECT for pack and forward)");
@@ -435,8 +479,22 @@ int agx_conv2d_kernel_name(const agx_conv2d_desc *d, char *buf, size_t buf_len) 
     int rc = lower_conv2d(d, &p);
     if (rc != AGX_OK) return rc;
     if (!buf || buf_len == 0) return fail(AGX_ERR_NULL_POINTER, "agx_conv2d_kernel_name: NULL buffer");
-    snprintf(buf, buf_len, "%s", agx::conv2d_fewout(d, p) ? "conv2d_fewout<4>"
+    snprintf(buf, buf_len, "%s", (agx::tuning().conv_impl == 1 && agx::conv_p2d_supported(p)) ? agx::conv_p2d_variant(p)
+                                 : agx::conv2d_fewout(d, p) ? "conv2d_fewout<4>"
                                  : (conv2d_impl(d, p) == AGX_IMPL_MFMA ? conv_mfma_variant(p) : conv_direct_variant(p)));
+    return AGX_OK;
+}
+
+int agx_conv2d_bwd_data_kernel_name(const agx_conv2d_desc *d, char *buf, size_t buf_len) {
+    using namespace agx;
+    ConvPlan b;
+    int rc = lower_conv2d_bwd_data(d, &b);
+    if (rc != AGX_OK) return rc;
+    if (!buf || buf_len == 0) return fail(AGX_ERR_NULL_POINTER, "agx_conv2d_bwd_data_kernel_name: NULL buffer");
+    snprintf(buf, buf_len, "%s", b.pm_R < 0 ? "conv2d_bwd_data_gather"
+                                 : (tuning().conv_impl == 1 && conv_p2d_supported(b)) ? conv_p2d_variant(b)
+                                 : (b.pm_R || (d->impl != AGX_IMPL_DIRECT && conv_mfma_supported(b))) ? conv_mfma_variant(b)
+                                                                                                       : conv_direct_variant(b));
     return AGX_OK;
 }
 

@@ -40,9 +40,13 @@ __device__ __forceinline__ void cp_static_for(F &&f) {
 // MW x NW fragments of 32 x 32 per wave, WM x WN waves, CCH channels per chunk, J taps, input step S, Q output phases,
 // PL = left offset P, NS ring slots (3: the next chunk is complete one interval early and its first operands are read
 // before the barrier; 2: it completes AT the barrier)
-template <int MW_, int NW_, int WM_, int WN_, int CCH_, int J_, int S_, int Q_, int PL_, int NS_>
+// D2: Conv2d layers "row-folded" onto the same machinery (conv2d.hip): one tile = BN columns of ONE output row, the
+// chunk sequence runs over (kernel row dh, CCH real channels) -- virtual channel v = dh * Cin + ci -- and the input rows
+// of a chunk are row i * sh - ph + dh of CCH consecutive feature maps (the page of zeros when that row is padding).
+template <int MW_, int NW_, int WM_, int WN_, int CCH_, int J_, int S_, int Q_, int PL_, int NS_, bool D2_ = false>
 struct CpGeom {
     static constexpr int MW = MW_, NW = NW_, WM = WM_, WN = WN_, CCH = CCH_, J = J_, S = S_, Q = Q_, PL = PL_, NSLOT = NS_;
+    static constexpr bool D2 = D2_;
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static constexpr int BM = 32 * MW * WM, BN = 32 * NW * WN;
     static constexpr int PA = (PL + 3) / 4 * 4, SHIFT = PA - PL;
@@ -138,7 +142,8 @@ template <class G>
 __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks, int nblocks, int ntiles, int step_m,
                                                         int step_n, int step_b, const float *__restrict__ x,
                                                         const float *__restrict__ timg, const float *__restrict__ bias,
-                                                        float *__restrict__ y) {
+                                                        float *__restrict__ y, const float *__restrict__ add2,
+                                                        const float *__restrict__ mask2) {
     constexpr int MW = G::MW, NW = G::NW, KS = G::KS, J = G::J, S = G::S, Q = G::Q, BM = G::BM, BN = G::BN;
     constexpr int SLOT = G::SLOT, AFL = G::AFL, CCH = G::CCH;
     constexpr bool PRE3 = G::NSLOT == 3;
@@ -148,7 +153,10 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wave / G::WN, wn = wave % G::WN;
     const int Lin = p.Lin, M = p.M;
-    const int nch = p.Cin / CCH;   // chunks per tile
+    constexpr bool D2 = G::D2;
+    const int ncc = p.Cin / CCH;                   // channel chunks (per kernel row)
+    const int nch = D2 ? ncc * p.kh : ncc;         // chunks per tile
+    const int rstride = D2 ? int(p.x_cstride) : Lin;   // floats between the input rows of a chunk
 
     // ---- per-lane / per-wave constants of the DMA ---------------------------------------------------------------
     unsigned boffB[G::RB];
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
         const int e = (wave + 4 * r) * 64 + lane;
         const int row = e / G::NCELL, col = e - row * G::NCELL;
         colB[r] = e < G::NCB ? 4 * col : -(1 << 28);
-        boffB[r] = unsigned(row * Lin + 4 * col) * 4u;
+        boffB[r] = unsigned(row * rstride + 4 * col) * 4u;
     }
     unsigned aoff[G::RA];   // weight instruction n = wave + 4 r: piece (g4, j) = n / PPB of the chunk, 1 KiB part n % PPB
 #pragma unroll
@@ -187,14 +195,27 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
     // DMA cursor (runs ahead of the MFMAs, across tile boundaries)
     CpTileCur ic = first;
     int iq = 0, icc = 0, isl = 0;
+    int icr = 0, idh = 0, irow0 = 0;   // D2: channel chunk within the kernel row, kernel row, input row of dh = 0
     const char *w_next = reinterpret_cast<const char *>(timg) + size_t(ic.mb) * BM * 16;
-    const char *x_next = reinterpret_cast<const char *>(x + size_t(ic.b) * p.Cin * Lin + (ic.nb * BN * S - G::PA));
+    const char *x_tile = nullptr;      // D2: (clip, channel 0, row irow0, first column) of the tile
+    auto tile_x = [&]() -> const char * {
+        if (D2) {
+            const int bq = ic.b / p.Tout, i = ic.b - bq * p.Tout;
+            irow0 = i * p.sh - p.ph;
+            x_tile = reinterpret_cast<const char *>(x + size_t(bq) * p.cin_real * p.x_cstride + int64_t(irow0) * Lin +
+                                                    (ic.nb * BN * S - G::PA));
+            return x_tile;
+        }
+        return reinterpret_cast<const char *>(x + size_t(ic.b) * p.Cin * Lin + (ic.nb * BN * S - G::PA));
+    };
+    const char *x_next = tile_x();
     float *d_slot = lds;
     const char *d_w = nullptr, *d_x = nullptr;
     int d_in0a = 0;
-    bool d_live = false;
+    bool d_live = false, d_rowok = true;
     auto begin_chunk = [&]() {
         d_live = iq < nq;
+        if (D2) d_rowok = unsigned(irow0 + idh) < unsigned(p.Tin);   // a padding row: the chunk's input cells come from the zero page
         d_slot = lds + isl * SLOT;
         d_w = w_next;
         d_x = x_next;
@@ -202,12 +223,19 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
         ++iq;
         isl = isl + 1 == G::NSLOT ? 0 : isl + 1;
         w_next += wchunk;
-        x_next += size_t(CCH) * Lin * sizeof(float);
+        x_next += size_t(CCH) * rstride * sizeof(float);
+        if (D2 && ++icr == ncc) {
+            icr = 0;
+            ++idh;
+            x_next = x_tile + size_t(idh) * Lin * sizeof(float);
+        }
         if (++icc == nch) {
             icc = 0;
+            icr = 0;
+            idh = 0;
             ic.advance(step_m, step_n, step_b, mblocks, nblocks);
             w_next = reinterpret_cast<const char *>(timg) + size_t(ic.mb) * BM * 16;
-            x_next = reinterpret_cast<const char *>(x + size_t(ic.b) * p.Cin * Lin + (ic.nb * BN * S - G::PA));
+            x_next = tile_x();
         }
     };
     auto dma_op = [&](int k) {
@@ -220,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
             const int r = k - G::RA, n = wave + 4 * r;
             const int pos = d_in0a + colB[r];
             const bool has = d_live && n < G::NIB;
-            const bool ok = has && pos >= 0 && pos < p.Lvalid;
+            const bool ok = has && d_rowok && pos >= 0 && pos < p.Lvalid;
             // a cell that straddles the end of the row (L % 4 != 0) is fetched from the row's LAST four elements
             // (in bounds) and put right by fix_ragged() once it has landed
             const int over = max(pos + 4 - p.Lvalid, 0);
@@ -232,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
     // x[pos .. L-1] followed by zeros.  Only the last time block of a clip, and only when L % 4 != 0.
     const bool ragged = (p.Lvalid & 3) != 0;
     auto fix_ragged = [&]() {
-        if (!ragged || !d_live || d_in0a + G::SPANP <= p.Lvalid) return;
+        if (!ragged || !d_live || !d_rowok || d_in0a + G::SPANP <= p.Lvalid) return;
 #pragma unroll
         for (int r = 0; r < G::RB; ++r) {
             const int n = wave + 4 * r;
@@ -324,10 +352,16 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
         }
 
         // ---- epilogue: bias (LDS), activation, store ------------------------------------------------------------------
-        int loutv = p.Lout;                    // opaque per-tile copy: the row offsets are formed here, not hoisted above the main loop
+        int loutv = D2 ? int(p.y_cstride) : p.Lout;   // opaque per-tile copy: the row offsets are formed here, not hoisted above the main loop
         asm volatile("" : "+v"(loutv));
         const int mrow0 = mb * BM + wm * 32 * MW;
-        char *yb = reinterpret_cast<char *>(y + size_t(b) * p.Cout * p.Lout);
+        size_t ybase = size_t(b) * p.Cout * p.Lout;
+        if (D2) {
+            const int bq = b / p.Tout, i = b - bq * p.Tout;
+            ybase = size_t(bq) * p.Cout * p.y_cstride + size_t(i) * p.Lout;
+        }
+        char *yb = reinterpret_cast<char *>(y + ybase);
+        const char *ab = reinterpret_cast<const char *>(add2 + ybase), *kb = reinterpret_cast<const char *>(mask2 + ybase);
 #pragma unroll
         for (int i = 0; i < MW; ++i) {
 #pragma unroll
@@ -342,7 +376,12 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
                         for (int s4 = 0; s4 < 4; ++s4) {
                             float v = acc[i][kk][4 * g + s4] + bq[s4];
                             if (pre_act) v = leaky(v, p.slope);
-                            if (t < p.Lt) *reinterpret_cast<float *>(yb + unsigned((m4 + s4) * loutv + t) * 4u) = v;
+                            const unsigned o = unsigned((m4 + s4) * loutv + t) * 4u;
+                            if (D2 && t < p.Lt) {   // backward-data: gradient arriving at this map, LeakyReLU gradient of the layer below
+                                if (add2) v += *reinterpret_cast<const float *>(ab + o);
+                                if (mask2) v = *reinterpret_cast<const float *>(kb + o) > 0.f ? v : v * p.slope;
+                            }
+                            if (t < p.Lt) *reinterpret_cast<float *>(yb + o) = v;
                         }
                     }
                 } else if (Q % 4 == 0) {   // the 4 rows are 4 consecutive output phases of one channel: one 16-byte store
@@ -426,8 +465,42 @@ static int launch_cp(const ConvPlan &p, const float *x, const float *wp, const f
     const int per_clip = mblocks * nblocks;
     const int sb = grid / per_clip, rem = grid % per_clip;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G::LDS_BYTES, st, p, mblocks, nblocks, ntiles, rem % mblocks,
-                       rem / mblocks, sb, x, wp + p.tile_off, bias, y);
+                       rem / mblocks, sb, x, wp + p.tile_off, bias, y, static_cast<const float *>(nullptr),
+                       static_cast<const float *>(nullptr));
     return check_launch("conv_p");
+}
+
+// Conv2d layers (D2 geometries): tiles = row blocks x column blocks x (clip, output row)
+template <class G>
+static int launch_cp2d(const ConvPlan &p, const float *x, const float *wp, const float *bias, const float *add,
+                       float *y, hipStream_t st) {
+    auto kern = conv_p_kernel<G>;
+    static bool attr_set = false;
+    static int n_cu = 0;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return fail(AGX_ERR_LAUNCH, "conv_p: cannot query the device");
+        n_cu = prop.multiProcessorCount;
+        attr_set = true;
+    }
+    static_assert(G::LDS_BYTES <= 160 * 1024, "ring does not fit LDS");
+    const int mblocks = p.M / G::BM, nblocks = ceil_div(p.Lt, G::BN);
+    const int64_t ntiles64 = int64_t(mblocks) * nblocks * p.B * p.Tout;
+    if (ntiles64 > (1 << 30)) return fail(AGX_ERR_BAD_SHAPE, "conv_p: too many tiles");
+    const int ntiles = int(ntiles64);
+    const int wg_per_cu = int((160 * 1024) / G::LDS_BYTES) >= 2 ? 2 : 1;
+    int grid = n_cu * wg_per_cu;
+    if (grid > ntiles) grid = ntiles;
+    const int per_row = mblocks * nblocks;
+    const int sb = grid / per_row, rem = grid % per_row;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G::LDS_BYTES, st, p, mblocks, nblocks, ntiles, rem % mblocks,
+                       rem / mblocks, sb, x, wp + p.tile_off, bias, y, add, (p.epilogue & AGX_EPI_MASK) ? p.mask : nullptr);
+    return check_launch("conv_p2d");
 }
 
 // ---- layer geometries the kernel is instantiated for -------------------------------------------------------------------
@@ -442,6 +515,80 @@ typedef CpGeom<2, 1, 2, 2, 16, 3, 1, 8, 1, 2> CpUp8;      // upsample x8 (J = 3)
 typedef CpGeom<2, 2, 2, 2, 16, 3, 1, 5, 1, 2> CpUp5;      // upsample x5:              128 x 128
 typedef CpGeom<2, 2, 2, 2, 16, 3, 1, 4, 1, 2> CpUp4;      // upsample x4:              128 x 128
 typedef CpGeom<2, 2, 1, 4, 16, 3, 1, 2, 1, 2> CpUp2;      // upsample x2, M = 64:       64 x 256
+
+// Conv2d (row-folded; the kernel's row count / row stride / row padding are run-time):
+//                      MW NW WM WN CCH  J  S  Q  P NS  D2
+typedef CpGeom<2, 2, 2, 2, 16, 3, 1, 1, 1, 2, true> Cp2dK3;        // kh x 3 kernels, column stride 1, pad 1:  128 x 128
+typedef CpGeom<2, 2, 1, 4, 8, 3, 1, 1, 1, 2, true> Cp2dK3M64;      // ... 64 output rows:                         64 x 256
+typedef CpGeom<2, 2, 2, 2, 8, 4, 2, 1, 1, 2, true> Cp2dK4S2;       // kh x 4 kernels, column stride 2, pad 1:  128 x 128
+typedef CpGeom<2, 2, 1, 4, 8, 4, 2, 1, 1, 2, true> Cp2dK4S2M64;    // ... 64 output rows:                         64 x 256
+
+enum { CP2D_NONE = 0, CP2D_K3, CP2D_K3M64, CP2D_K4S2, CP2D_K4S2M64 };
+
+// weights-only part of the test: the packed image of a layer must not depend on the size of the feature map it is
+// later applied to (discriminator.py packs with a nominal size)
+template <class G>
+static bool cp2d_fits(const ConvPlan &p) {
+    const int ncc = p.Cin / G::CCH;
+    const int nch = ncc * p.kh;
+    return p.M % G::BM == 0 && p.Cin % G::CCH == 0 && p.Cin == p.cin_real && ncc >= 1 && nch >= 2 &&
+           (G::J % 2 == 0 || nch % 2 == 0) && p.Cout <= G::NBIAS;
+}
+
+// patch-mode plan of conv2d.hip (forward, or backward-data of a stride-1 layer) -> ring geometry; depends on the
+// layer (channels, kernel, strides, padding) only: decides whether the packed image carries a tile image
+int conv_p2d_geometry(const ConvPlan &p) {
+    if (p.pm_R == 0 || p.prec != 0 || p.G != 1 || p.d != 1 || p.q != 1 || p.qh != 1 || p.oshift != 0 || p.oshift_h != 0)
+        return CP2D_NONE;
+    if (p.kh <= 0 || p.J % p.kh != 0) return CP2D_NONE;
+    const int kw = p.J / p.kh;
+    if (kw == 3 && p.s == 1 && p.P == 1) {
+        if (p.M == 64 && cp2d_fits<Cp2dK3M64>(p)) return CP2D_K3M64;
+        if (cp2d_fits<Cp2dK3>(p)) return CP2D_K3;
+    }
+    if (kw == 4 && p.s == 2 && p.P == 1) {
+        if (p.M == 64 && cp2d_fits<Cp2dK4S2M64>(p)) return CP2D_K4S2M64;
+        if (cp2d_fits<Cp2dK4S2>(p)) return CP2D_K4S2;
+    }
+    return CP2D_NONE;
+}
+
+// can THIS call run on the ring kernel?  (feature-map size: column blocks at least 70 % full -- narrow maps stay on the
+// patch tiles --, 32-bit DMA / epilogue offsets; epilogue: bias, LeakyReLU, gradient add, LeakyReLU-gradient mask)
+bool conv_p2d_supported(const ConvPlan &p) {
+    const int g = conv_p2d_geometry(p);
+    if (p.tile_off < 0 || g == CP2D_NONE) return false;
+    if ((p.epilogue & ~(AGX_EPI_LEAKY_PRE | AGX_EPI_RESIDUAL | AGX_EPI_MASK)) != 0) return false;
+    if (p.Lvalid != p.Lin || p.Lin < 4 || p.Lt != p.Lout || p.Tt != p.Tout) return false;
+    if (int64_t(16) * p.x_cstride * 4 >= (int64_t(1) << 31)) return false;
+    if (int64_t(p.Cout) * p.y_cstride * 4 >= (int64_t(1) << 32)) return false;
+    const int bn = (g == CP2D_K3M64 || g == CP2D_K4S2M64) ? 256 : 128;
+    return 10 * int64_t(p.Lt) >= 7 * int64_t(ceil_div(p.Lt, bn)) * bn;
+}
+
+const char *conv_p2d_variant(const ConvPlan &p) {
+    switch (conv_p2d_geometry(p)) {
+        case CP2D_K3: return "conv_p2d<k3,128x128>";
+        case CP2D_K3M64: return "conv_p2d<k3,64x256>";
+        case CP2D_K4S2: return "conv_p2d<k4s2,128x128>";
+        case CP2D_K4S2M64: return "conv_p2d<k4s2,64x256>";
+        default: return "conv_p2d<unsupported>";
+    }
+}
+
+// res = the tensor added in the epilogue (AGX_EPI_RESIDUAL; backward-data: the gradient arriving at this feature map)
+int launch_conv_p2d(const ConvPlan &p, const float *x, const float *wp, const float *bias, const float *res, float *y,
+                    hipStream_t st) {
+    if (!conv_p2d_supported(p)) return fail(AGX_ERR_UNSUPPORTED, "conv_p2d: unsupported layer");
+    const float *add = (p.epilogue & AGX_EPI_RESIDUAL) ? res : nullptr;
+    switch (conv_p2d_geometry(p)) {
+        case CP2D_K3: return launch_cp2d<Cp2dK3>(p, x, wp, bias, add, y, st);
+        case CP2D_K3M64: return launch_cp2d<Cp2dK3M64>(p, x, wp, bias, add, y, st);
+        case CP2D_K4S2: return launch_cp2d<Cp2dK4S2>(p, x, wp, bias, add, y, st);
+        case CP2D_K4S2M64: return launch_cp2d<Cp2dK4S2M64>(p, x, wp, bias, add, y, st);
+        default: return fail(AGX_ERR_UNSUPPORTED, "conv_p2d: unsupported layer");
+    }
+}
 
 enum { CP_NONE = 0, CP_DOWN2, CP_DOWN4, CP_DOWN5, CP_DOWN8, CP_K3, CP_K7, CP_UP8, CP_UP5, CP_UP4, CP_UP2 };
 

@@ -252,11 +252,16 @@ extern "C" int agx_conv_pack_sigma(const agx_conv_desc *d, const float *w, const
 
 // 2-D layers: the (Cout, Cin, kh, kw) tensor read as (Cout, Cin * kh, kw) is already in virtual-channel
 // order c' = ci * kh + dh (common.hpp), so the 1-D pack kernel applies as is.
+namespace agx {
+void launch_pack_tile2d(const float *w, const float *scale, const float *sigma, float *timg, int C, int M, int kh, int kw,
+                        int bwd, hipStream_t st);   // conv2d.hip
+}
 extern "C" int64_t agx_conv2d_packed_floats(const agx_conv2d_desc *d) {
     agx::ConvPlan p;
     int rc = agx::lower_conv2d(d, &p);
     if (rc != AGX_OK) return rc;
-    return (p.prec ? agx::packed_weight_floats_bf(p.ncv, p.J, p.M) : agx::packed_weight_floats(p.ncv, p.J, p.M)) + p.Cout;
+    const int64_t tile = p.tile_off >= 0 ? agx::tile_image_floats(p.kh * p.Cin, p.J / p.kh, p.M) : 0;
+    return (p.prec ? agx::packed_weight_floats_bf(p.ncv, p.J, p.M) : agx::packed_weight_floats(p.ncv, p.J, p.M)) + p.Cout + tile;
 }
 
 extern "C" int agx_conv2d_pack(const agx_conv2d_desc *d, const float *w, const float *sigma, float *packed,
@@ -281,5 +286,7 @@ extern "C" int agx_conv2d_pack(const agx_conv2d_desc *d, const float *w, const f
     }
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)ceil_div64(n_w, 256)), dim3(256), 0, st, w, scale, packed,
                        AGX_CONV_PADDED, p.ncv, p.Cout, p.J, 1, p.J, p.P, 1);
+    if (p.tile_off >= 0)   // second copy for the ring kernel (conv_p.hip, D2 geometries)
+        launch_pack_tile2d(w, scale, nullptr, packed + p.tile_off, p.Cin, p.M, p.kh, p.J / p.kh, 0, st);
     return check_launch("agx_conv2d_pack");
 }

@@ -626,6 +626,12 @@ def conv2d_kernel_name(desc) -> str:
     return buf.value.decode()
 
 
+def conv2d_bwd_data_kernel_name(desc) -> str:
+    buf = ctypes.create_string_buffer(96)
+    _lib.check(_lib.load().agx_conv2d_bwd_data_kernel_name(ctypes.byref(desc), buf, 96), "agx_conv2d_bwd_data_kernel_name")
+    return buf.value.decode()
+
+
 _STFT_IMAGES = {}
 
 

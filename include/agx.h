@@ -364,6 +364,7 @@ int agx_conv2d_pack(const agx_conv2d_desc *d, const float *w, const float *sigma
 int agx_conv2d_forward(const agx_conv2d_desc *d, const float *x, const float *packed, const float *bias,
                        float *y, void *stream);
 int agx_conv2d_kernel_name(const agx_conv2d_desc *d, char *buf, size_t buf_len);
+int agx_conv2d_bwd_data_kernel_name(const agx_conv2d_desc *d, char *buf, size_t buf_len);   /* kernel agx_conv2d_bwd_data runs */
 /* Backward of the Conv2d layer `d` describes (forward descriptor): gradient w.r.t. its input from the
  * gradient w.r.t. its output, on the same kernels (strided layers as a 2-D polyphase conv over dy);
  * add: optional tensor added to dx (a gradient arriving from another consumer of the input, e.g. the
