@@ -162,10 +162,12 @@ int lower_conv2d_bwd_data(const agx_conv2d_desc *d, ConvPlan *b) {
 // Tile image of a row-folded layer for conv_p.hip's D2 geometries: virtual channel v = a * C + c (kernel row a, input
 // channel c of THIS op), Wt[((v / 4) * kw + j) * M + m][v % 4] (common.hpp: tile_image_index with Cin -> kh * C).
 //   forward            C = Cin,  M = Cout:  w[m][c][a][j] * scale[m]
-//   backward-data (stride 1, flipped kernel)  C = Cout, M = Cin:  w[c][m][kh-1-a][kw-1-j] / sigma
+//   backward-data      C = Cout, (kh, kw) = the phase GEMM's (Jh, Jw) = ceil(k / s), M = Cin * sh * sw with
+//                      m = (ci * sh + ra) * sw + rc:  w[c][ci][ra + sh (Jh-1-a)][rc + sw (Jw-1-j)] / sigma, 0 beyond the kernel
+//                      (stride 1: the flipped kernel)
 __global__ __launch_bounds__(256) void pack_tile2d_kernel(const float *__restrict__ w, const float *__restrict__ scale,
                                                           const float *__restrict__ sigma, float *__restrict__ timg, int C,
-                                                          int M, int kh, int kw, int bwd) {
+                                                          int M, int kh, int kw, int bwd, int sh, int sw, int kh_w, int kw_w) {
     const int64_t total = tile_image_floats(kh * C, kw, M);
     const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (e >= total) return;
@@ -176,17 +178,23 @@ __global__ __launch_bounds__(256) void pack_tile2d_kernel(const float *__restric
     float out = 0.f;
     if (v < kh * C) {
         const int a = v / C, c = v - a * C;
-        if (!bwd) out = w[((size_t(m) * C + c) * kh + a) * kw + j] * (scale ? scale[m] : 1.f);
-        else out = w[((size_t(c) * M + m) * kh + (kh - 1 - a)) * kw + (kw - 1 - j)] * (sigma ? 1.f / sigma[0] : 1.f);
+        if (!bwd) {
+            out = w[((size_t(m) * C + c) * kh + a) * kw + j] * (scale ? scale[m] : 1.f);
+        } else {
+            const int rc = m % sw, ra = (m / sw) % sh, ci = m / (sw * sh), Cin_w = M / (sh * sw);
+            const int dh = ra + sh * (kh - 1 - a), dw = rc + sw * (kw - 1 - j);
+            if (dh < kh_w && dw < kw_w)
+                out = w[((size_t(c) * Cin_w + ci) * kh_w + dh) * kw_w + dw] * (sigma ? 1.f / sigma[0] : 1.f);
+        }
     }
     timg[e] = out;
 }
 
 void launch_pack_tile2d(const float *w, const float *scale, const float *sigma, float *timg, int C, int M, int kh, int kw,
-                        int bwd, hipStream_t st) {
+                        int bwd, hipStream_t st, int sh = 1, int sw = 1, int kh_w = 0, int kw_w = 0) {
     const int64_t nt = tile_image_floats(kh * C, kw, M);
     hipLaunchKernelGGL(pack_tile2d_kernel, dim3((unsigned)ceil_div64(nt, 256)), dim3(256), 0, st, w, scale, sigma, timg, C, M, kh,
-                       kw, bwd);
+                       kw, bwd, sh, sw, kh_w ? kh_w : kh, kw_w ? kw_w : kw);
 }
 
 // Catch-all backward-data: one thread per dx element, gather over (co, dh, dw).  wimg = the weight tensor
@@ -384,7 +392,8 @@ int agx_conv2d_pack_bwd(const agx_conv2d_desc *d, const float *w, const float *s
                        static_cast<hipStream_t>(stream), w, sigma, packed, d->c_in, d->c_out, d->kh, d->kw, d->stride_h,
                        d->stride_w, b.pm_R ? 1 : 0, b.ncv, b.J, b.M, b.prec);
     if (b.tile_off >= 0)
-        launch_pack_tile2d(w, nullptr, sigma, packed + b.tile_off, b.Cin, b.M, b.kh, b.J / b.kh, 1, static_cast<hipStream_t>(stream));
+        launch_pack_tile2d(w, nullptr, sigma, packed + b.tile_off, b.Cin, b.M, b.kh, b.J / b.kh, 1, static_cast<hipStream_t>(stream),
+                           d->stride_h, d->stride_w, d->kh, d->kw);
     return check_launch("agx_conv2d_pack_bwd");
 }
 

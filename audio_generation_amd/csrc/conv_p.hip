@@ -43,10 +43,13 @@ __device__ __forceinline__ void cp_static_for(F &&f) {
 // D2: Conv2d layers "row-folded" onto the same machinery (conv2d.hip): one tile = BN columns of ONE output row, the
 // chunk sequence runs over (kernel row dh, CCH real channels) -- virtual channel v = dh * Cin + ci -- and the input rows
 // of a chunk are row i * sh - ph + dh of CCH consecutive feature maps (the page of zeros when that row is padding).
-template <int MW_, int NW_, int WM_, int WN_, int CCH_, int J_, int S_, int Q_, int PL_, int NS_, bool D2_ = false>
+// QH (D2 only): output-row phases -- backward-data of a strided Conv2d: rows m = (ci * QH + a) * Q + c of the GEMM are
+// the (row, column) phases of input channel ci, written to row QH * t' + a - oshift_h, column Q * f' + c - oshift.
+template <int MW_, int NW_, int WM_, int WN_, int CCH_, int J_, int S_, int Q_, int PL_, int NS_, bool D2_ = false, int QH_ = 1>
 struct CpGeom {
     static constexpr int MW = MW_, NW = NW_, WM = WM_, WN = WN_, CCH = CCH_, J = J_, S = S_, Q = Q_, PL = PL_, NSLOT = NS_;
     static constexpr bool D2 = D2_;
+    static constexpr int QH = QH_;
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static constexpr int BM = 32 * MW * WM, BN = 32 * NW * WN;
     static constexpr int PA = (PL + 3) / 4 * 4, SHIFT = PA - PL;
@@ -67,7 +70,9 @@ struct CpGeom {
     static constexpr size_t LDS_BYTES = size_t(DUMMY0 + 256) * sizeof(float);
     static constexpr int NDS = MW * (KS == 8 ? 2 : 1) + KS * NW, NMF = KS * MW * NW;   // LDS reads / MFMAs per phase
     static_assert(KS == 2 || KS == 4 || KS == 8, "chunk of 4, 8 or 16 channels");
-    static_assert(BM % 64 == 0, "weight pieces are whole 1 KiB instructions");
+    // weight pieces (g4, j) are whole 1 KiB instructions; a 32-row tile needs M == 32: its chunk of the tile image is one
+    // contiguous block and is copied flat
+    static_assert(BM % 64 == 0 || (BM == 32 && (NG4 * J) % 2 == 0), "weight pieces");
 };
 
 template <int MW, int NW, int KS>
@@ -172,7 +177,8 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
 #pragma unroll
     for (int r = 0; r < G::RA; ++r) {
         const int n = wave + 4 * r;
-        aoff[r] = unsigned(n / G::PPB) * unsigned(M) * 16u + unsigned(n % G::PPB) * 1024u;
+        if constexpr (G::PPB > 0) aoff[r] = unsigned(n / G::PPB) * unsigned(M) * 16u + unsigned(n % G::PPB) * 1024u;
+        else aoff[r] = unsigned(n) * 1024u;   // BM = M = 32
     }
     const char *zpage = reinterpret_cast<const char *>(g_cp_zero_page) + lane * 16;
     // consumer-side lane offsets (floats, relative to a slot)
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
     const char *x_tile = nullptr;      // D2: (clip, channel 0, row irow0, first column) of the tile
     auto tile_x = [&]() -> const char * {
         if (D2) {
-            const int bq = ic.b / p.Tout, i = ic.b - bq * p.Tout;
+            const int bq = ic.b / p.Tt, i = ic.b - bq * p.Tt;   // (clip, base row)
             irow0 = i * p.sh - p.ph;
             x_tile = reinterpret_cast<const char *>(x + size_t(bq) * p.cin_real * p.x_cstride + int64_t(irow0) * Lin +
                                                     (ic.nb * BN * S - G::PA));
@@ -356,9 +362,11 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
         asm volatile("" : "+v"(loutv));
         const int mrow0 = mb * BM + wm * 32 * MW;
         size_t ybase = size_t(b) * p.Cout * p.Lout;
+        int trow = 0;   // D2: base row of the tile
         if (D2) {
-            const int bq = b / p.Tout, i = b - bq * p.Tout;
-            ybase = size_t(bq) * p.Cout * p.y_cstride + size_t(i) * p.Lout;
+            const int bq = b / p.Tt;
+            trow = b - bq * p.Tt;
+            ybase = size_t(bq) * p.Cout * p.y_cstride + ((Q == 1 && G::QH == 1) ? size_t(trow) * p.Lout : size_t(0));
         }
         char *yb = reinterpret_cast<char *>(y + ybase);
         const char *ab = reinterpret_cast<const char *>(add2 + ybase), *kb = reinterpret_cast<const char *>(mask2 + ybase);
@@ -367,7 +375,28 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int m4 = mrow0 + i * 32 + 8 * g + 4 * lh;   // first of this lane's 4 consecutive rows
-                if (Q == 1) {
+                if constexpr (D2 && (Q > 1 || G::QH > 1)) {   // backward-data of a strided Conv2d: phases scatter to rows / columns
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const int m = m4 + s4;
+                        const int co = m / (Q * G::QH), a = (m / Q) % G::QH, c = m % Q;
+                        const int orow = G::QH * trow + a - p.oshift_h;
+                        const bool row_ok = orow >= 0 && orow < p.Tout;
+#pragma unroll
+                        for (int kk = 0; kk < NW; ++kk) {
+                            const int t = nb * BN + wn * 32 * NW + kk * 32 + li;
+                            const int ocol = Q * t + c - p.oshift;
+                            const bool ok = row_ok && t < p.Lt && ocol >= 0 && ocol < p.Lout;
+                            const unsigned o = unsigned(co * loutv + (row_ok ? orow : 0) * p.Lout + (ok ? ocol : 0)) * 4u;
+                            float v = acc[i][kk][4 * g + s4];
+                            if (ok) {
+                                if (add2) v += *reinterpret_cast<const float *>(ab + o);
+                                if (mask2) v = *reinterpret_cast<const float *>(kb + o) > 0.f ? v : v * p.slope;
+                                *reinterpret_cast<float *>(yb + o) = v;
+                            }
+                        }
+                    }
+                } else if (Q == 1) {
                     const f32x4 bq = *reinterpret_cast<const f32x4 *>(lds + G::BIAS0 + m4);
 #pragma unroll
                     for (int kk = 0; kk < NW; ++kk) {
@@ -470,7 +499,48 @@ static int launch_cp(const ConvPlan &p, const float *x, const float *wp, const f
     return check_launch("conv_p");
 }
 
-// Conv2d layers (D2 geometries): tiles = row blocks x column blocks x (clip, output row)
+// Backward-data of a column-strided Conv2d on the ring: the base grid f' in [0, Lt) of the phase GEMM has one position
+// more than fits whole blocks (Lt = W / sw + 1: 513, 257, ...), and its first position only produces the output columns
+// [0, Q - oshift).  The ring runs f' = 1 .. Lt - 1 (exactly W / sw positions: whole blocks) and this kernel the first
+// columns: dx[ci, QH t' + a - oshift_h, c - oshift] = sum_{co, jh} Wt[(jh, co)][Jw - 1][m] dy[co, t' - ph + jh, 0],
+// m = (ci QH + a) Q + c, c >= oshift.  One workgroup per (clip, base row); the dy column sits in LDS.
+__global__ __launch_bounds__(256) void conv2d_bwd_first_cols_kernel(ConvPlan p, const float *__restrict__ dy,
+                                                                    const float *__restrict__ timg,
+                                                                    const float *__restrict__ add,
+                                                                    const float *__restrict__ mask, float *__restrict__ dx) {
+    extern __shared__ float dcol[];   // [kh][Cin]
+    const int bq = blockIdx.x / p.Tt, trow = blockIdx.x - bq * p.Tt;
+    const int Jw = p.J / p.kh, nv = p.kh * p.Cin;
+    for (int v = threadIdx.x; v < nv; v += 256) {
+        const int jh = v / p.Cin, co = v - jh * p.Cin;
+        const int r = trow * p.sh - p.ph + jh;
+        dcol[v] = (r >= 0 && r < p.Tin) ? dy[(size_t(bq) * p.Cin + co) * p.x_cstride + size_t(r) * p.Lin] : 0.f;
+    }
+    __syncthreads();
+    const int ncol = p.q - p.oshift;   // output columns 0 .. ncol - 1
+    const int rows = (p.M / p.q) * ncol;
+    for (int e = threadIdx.x; e < rows; e += 256) {
+        const int mq = e / ncol, c = p.oshift + (e - mq * ncol);
+        const int m = mq * p.q + c;
+        const int ci = mq / p.qh, a = mq - ci * p.qh;
+        const int orow = p.qh * trow + a - p.oshift_h;
+        if (orow < 0 || orow >= p.Tout) continue;
+        float acc = 0.f;
+        for (int v4 = 0; v4 < nv / 4; ++v4) {
+            const f32x4 w = *reinterpret_cast<const f32x4 *>(timg + (size_t(v4) * Jw + (Jw - 1)) * p.M * 4 + size_t(m) * 4);
+            acc = fmaf(w[0], dcol[4 * v4], acc);
+            acc = fmaf(w[1], dcol[4 * v4 + 1], acc);
+            acc = fmaf(w[2], dcol[4 * v4 + 2], acc);
+            acc = fmaf(w[3], dcol[4 * v4 + 3], acc);
+        }
+        const size_t o = (size_t(bq) * p.Cout + ci) * p.y_cstride + size_t(orow) * p.Lout + (c - p.oshift);
+        if (add) acc += add[o];
+        if (mask) acc = mask[o] > 0.f ? acc : acc * p.slope;
+        dx[o] = acc;
+    }
+}
+
+// Conv2d layers (D2 geometries): tiles = row blocks x column blocks x (clip, base row)
 template <class G>
 static int launch_cp2d(const ConvPlan &p, const float *x, const float *wp, const float *bias, const float *add,
                        float *y, hipStream_t st) {
@@ -489,8 +559,17 @@ static int launch_cp2d(const ConvPlan &p, const float *x, const float *wp, const
         attr_set = true;
     }
     static_assert(G::LDS_BYTES <= 160 * 1024, "ring does not fit LDS");
-    const int mblocks = p.M / G::BM, nblocks = ceil_div(p.Lt, G::BN);
-    const int64_t ntiles64 = int64_t(mblocks) * nblocks * p.B * p.Tout;
+    const float *mask = (p.epilogue & AGX_EPI_MASK) ? p.mask : nullptr;
+    ConvPlan pp = p;
+    if (G::Q > 1) {   // column phases: the ring takes base positions 1 .. Lt - 1, conv2d_bwd_first_cols_kernel position 0
+        pp.Lt = p.Lt - 1;
+        pp.oshift = p.oshift - G::Q;
+        if (int64_t(p.B) * p.Tt > (int64_t(1) << 30)) return fail(AGX_ERR_BAD_SHAPE, "conv_p2d: grid too large");
+        hipLaunchKernelGGL(conv2d_bwd_first_cols_kernel, dim3(p.B * p.Tt), dim3(256), size_t(p.kh) * p.Cin * sizeof(float), st, p,
+                           x, wp + p.tile_off, add, mask, y);
+    }
+    const int mblocks = pp.M / G::BM, nblocks = ceil_div(pp.Lt, G::BN);
+    const int64_t ntiles64 = int64_t(mblocks) * nblocks * pp.B * pp.Tt;
     if (ntiles64 > (1 << 30)) return fail(AGX_ERR_BAD_SHAPE, "conv_p: too many tiles");
     const int ntiles = int(ntiles64);
     const int wg_per_cu = int((160 * 1024) / G::LDS_BYTES) >= 2 ? 2 : 1;
@@ -498,8 +577,8 @@ static int launch_cp2d(const ConvPlan &p, const float *x, const float *wp, const
     if (grid > ntiles) grid = ntiles;
     const int per_row = mblocks * nblocks;
     const int sb = grid / per_row, rem = grid % per_row;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G::LDS_BYTES, st, p, mblocks, nblocks, ntiles, rem % mblocks,
-                       rem / mblocks, sb, x, wp + p.tile_off, bias, y, add, (p.epilogue & AGX_EPI_MASK) ? p.mask : nullptr);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G::LDS_BYTES, st, pp, mblocks, nblocks, ntiles, rem % mblocks,
+                       rem / mblocks, sb, x, wp + p.tile_off, bias, y, add, mask);
     return check_launch("conv_p2d");
 }
 
@@ -520,10 +599,16 @@ typedef CpGeom<2, 2, 1, 4, 16, 3, 1, 2, 1, 2> CpUp2;      // upsample x2, M = 64
 //                      MW NW WM WN CCH  J  S  Q  P NS  D2
 typedef CpGeom<2, 2, 2, 2, 16, 3, 1, 1, 1, 2, true> Cp2dK3;        // kh x 3 kernels, column stride 1, pad 1:  128 x 128
 typedef CpGeom<2, 2, 1, 4, 8, 3, 1, 1, 1, 2, true> Cp2dK3M64;      // ... 64 output rows:                         64 x 256
+typedef CpGeom<1, 4, 1, 4, 8, 3, 1, 1, 1, 2, true> Cp2dK3M32;      // ... 32 output rows (= M):                   32 x 512
 typedef CpGeom<2, 2, 2, 2, 8, 4, 2, 1, 1, 2, true> Cp2dK4S2;       // kh x 4 kernels, column stride 2, pad 1:  128 x 128
 typedef CpGeom<2, 2, 1, 4, 8, 4, 2, 1, 1, 2, true> Cp2dK4S2M64;    // ... 64 output rows:                         64 x 256
 
-enum { CP2D_NONE = 0, CP2D_K3, CP2D_K3M64, CP2D_K4S2, CP2D_K4S2M64 };
+// backward-data of the column-stride-2 layers: 2 column taps over dy, Q = 2 column phases, QH row phases
+typedef CpGeom<2, 2, 2, 2, 16, 2, 1, 2, 0, 2, true, 1> Cp2dB2;      // (kh x 4, stride (1, 2)):   128 x 128
+typedef CpGeom<2, 2, 1, 4, 8, 2, 1, 2, 0, 2, true, 1> Cp2dB2M64;    // ... M = 64:                  64 x 256
+typedef CpGeom<2, 2, 2, 2, 16, 2, 1, 2, 0, 2, true, 2> Cp2dB2H2;    // (4 x 4, stride (2, 2)):    128 x 128
+
+enum { CP2D_NONE = 0, CP2D_K3, CP2D_K3M64, CP2D_K3M32, CP2D_K4S2, CP2D_K4S2M64, CP2D_B2, CP2D_B2M64, CP2D_B2H2 };
 
 // weights-only part of the test: the packed image of a layer must not depend on the size of the feature map it is
 // later applied to (discriminator.py packs with a nominal size)
@@ -538,11 +623,19 @@ static bool cp2d_fits(const ConvPlan &p) {
 // patch-mode plan of conv2d.hip (forward, or backward-data of a stride-1 layer) -> ring geometry; depends on the
 // layer (channels, kernel, strides, padding) only: decides whether the packed image carries a tile image
 int conv_p2d_geometry(const ConvPlan &p) {
-    if (p.pm_R == 0 || p.prec != 0 || p.G != 1 || p.d != 1 || p.q != 1 || p.qh != 1 || p.oshift != 0 || p.oshift_h != 0)
-        return CP2D_NONE;
-    if (p.kh <= 0 || p.J % p.kh != 0) return CP2D_NONE;
+    if (p.pm_R == 0 || p.prec != 0 || p.G != 1 || p.d != 1 || p.kh <= 0 || p.J % p.kh != 0) return CP2D_NONE;
     const int kw = p.J / p.kh;
+    if (p.q == 2 && kw == 2 && p.s == 1 && p.sh == 1 && p.P == 1 && p.oshift == 1) {   // backward-data, column stride 2, pad 1
+        if (p.qh == 1 && p.oshift_h == 0) {
+            if (p.M == 64 && cp2d_fits<Cp2dB2M64>(p)) return CP2D_B2M64;
+            if (cp2d_fits<Cp2dB2>(p)) return CP2D_B2;
+        }
+        if (p.qh == 2 && cp2d_fits<Cp2dB2H2>(p)) return CP2D_B2H2;
+        return CP2D_NONE;
+    }
+    if (p.q != 1 || p.qh != 1 || p.oshift != 0 || p.oshift_h != 0) return CP2D_NONE;
     if (kw == 3 && p.s == 1 && p.P == 1) {
+        if (p.M == 32 && cp2d_fits<Cp2dK3M32>(p)) return CP2D_K3M32;
         if (p.M == 64 && cp2d_fits<Cp2dK3M64>(p)) return CP2D_K3M64;
         if (cp2d_fits<Cp2dK3>(p)) return CP2D_K3;
     }
@@ -559,19 +652,25 @@ bool conv_p2d_supported(const ConvPlan &p) {
     const int g = conv_p2d_geometry(p);
     if (p.tile_off < 0 || g == CP2D_NONE) return false;
     if ((p.epilogue & ~(AGX_EPI_LEAKY_PRE | AGX_EPI_RESIDUAL | AGX_EPI_MASK)) != 0) return false;
-    if (p.Lvalid != p.Lin || p.Lin < 4 || p.Lt != p.Lout || p.Tt != p.Tout) return false;
+    if (p.Lvalid != p.Lin || p.Lin < 4) return false;
+    if (p.q == 1 && (p.Lt != p.Lout || p.Tt != p.Tout)) return false;
     if (int64_t(16) * p.x_cstride * 4 >= (int64_t(1) << 31)) return false;
     if (int64_t(p.Cout) * p.y_cstride * 4 >= (int64_t(1) << 32)) return false;
-    const int bn = (g == CP2D_K3M64 || g == CP2D_K4S2M64) ? 256 : 128;
-    return 10 * int64_t(p.Lt) >= 7 * int64_t(ceil_div(p.Lt, bn)) * bn;
+    const int bn = g == CP2D_K3M32 ? 512 : ((g == CP2D_K3M64 || g == CP2D_K4S2M64 || g == CP2D_B2M64) ? 256 : 128);
+    const int lt = p.q == 1 ? p.Lt : p.Lt - 1;   // column phases: the ring runs base positions 1 .. Lt - 1
+    return lt >= 1 && 10 * int64_t(lt) >= 7 * int64_t(ceil_div(lt, bn)) * bn;
 }
 
 const char *conv_p2d_variant(const ConvPlan &p) {
     switch (conv_p2d_geometry(p)) {
         case CP2D_K3: return "conv_p2d<k3,128x128>";
         case CP2D_K3M64: return "conv_p2d<k3,64x256>";
+        case CP2D_K3M32: return "conv_p2d<k3,32x512>";
         case CP2D_K4S2: return "conv_p2d<k4s2,128x128>";
         case CP2D_K4S2M64: return "conv_p2d<k4s2,64x256>";
+        case CP2D_B2: return "conv_p2d<bwd s(1,2),128x128>";
+        case CP2D_B2M64: return "conv_p2d<bwd s(1,2),64x256>";
+        case CP2D_B2H2: return "conv_p2d<bwd s(2,2),128x128>";
         default: return "conv_p2d<unsupported>";
     }
 }
@@ -584,8 +683,12 @@ int launch_conv_p2d(const ConvPlan &p, const float *x, const float *wp, const fl
     switch (conv_p2d_geometry(p)) {
         case CP2D_K3: return launch_cp2d<Cp2dK3>(p, x, wp, bias, add, y, st);
         case CP2D_K3M64: return launch_cp2d<Cp2dK3M64>(p, x, wp, bias, add, y, st);
+        case CP2D_K3M32: return launch_cp2d<Cp2dK3M32>(p, x, wp, bias, add, y, st);
         case CP2D_K4S2: return launch_cp2d<Cp2dK4S2>(p, x, wp, bias, add, y, st);
         case CP2D_K4S2M64: return launch_cp2d<Cp2dK4S2M64>(p, x, wp, bias, add, y, st);
+        case CP2D_B2: return launch_cp2d<Cp2dB2>(p, x, wp, bias, add, y, st);
+        case CP2D_B2M64: return launch_cp2d<Cp2dB2M64>(p, x, wp, bias, add, y, st);
+        case CP2D_B2H2: return launch_cp2d<Cp2dB2H2>(p, x, wp, bias, add, y, st);
         default: return fail(AGX_ERR_UNSUPPORTED, "conv_p2d: unsupported layer");
     }
 }

@@ -254,7 +254,7 @@ extern "C" int agx_conv_pack_sigma(const agx_conv_desc *d, const float *w, const
 // order c' = ci * kh + dh (common.hpp), so the 1-D pack kernel applies as is.
 namespace agx {
 void launch_pack_tile2d(const float *w, const float *scale, const float *sigma, float *timg, int C, int M, int kh, int kw,
-                        int bwd, hipStream_t st);   // conv2d.hip
+                        int bwd, hipStream_t st, int sh, int sw, int kh_w, int kw_w);   // conv2d.hip
 }
 extern "C" int64_t agx_conv2d_packed_floats(const agx_conv2d_desc *d) {
     agx::ConvPlan p;
@@ -287,6 +287,6 @@ extern "C" int agx_conv2d_pack(const agx_conv2d_desc *d, const float *w, const f
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)ceil_div64(n_w, 256)), dim3(256), 0, st, w, scale, packed,
                        AGX_CONV_PADDED, p.ncv, p.Cout, p.J, 1, p.J, p.P, 1);
     if (p.tile_off >= 0)   // second copy for the ring kernel (conv_p.hip, D2 geometries)
-        launch_pack_tile2d(w, scale, nullptr, packed + p.tile_off, p.Cin, p.M, p.kh, p.J / p.kh, 0, st);
+        launch_pack_tile2d(w, scale, nullptr, packed + p.tile_off, p.Cin, p.M, p.kh, p.J / p.kh, 0, st, 1, 1, 0, 0);
     return check_launch("agx_conv2d_pack");
 }

@@ -93,7 +93,7 @@ def test_backward_data_on_the_ring_kernel(cin, cout, kh, h, w, variant, knob):
 
 def test_narrow_maps_and_other_shapes_stay_on_the_patch_tiles():
     for (cin, cout, kh, kw, sh, sw, h, w) in [(128, 128, 3, 3, 1, 1, 9, 64), (64, 64, 3, 3, 1, 1, 9, 128),
-                                             (32, 32, 3, 3, 1, 1, 9, 1024), (64, 128, 4, 4, 2, 2, 18, 130),
+                                             (32, 32, 3, 3, 1, 1, 9, 300), (64, 128, 4, 4, 2, 2, 18, 130),
                                              (128, 128, 3, 3, 1, 1, 9, 1024 + 40)]:
         d = ops.conv2d_desc(2, cin, cout, h, w, kh, kw, (sh, sw), ((kh - 1) // 2, 1))
         name = ops.conv2d_kernel_name(d)
@@ -115,3 +115,53 @@ def test_packed_image_does_not_depend_on_the_feature_map_size():
         close(ops.conv2d_forward(real, x.to(DEV), pk_n, None), F.conv2d(x, wt.cpu(), None, stride=(sh, sw), padding=(1, 1)), 1e-5)
         if (sh, sw) == (1, 1):
             assert torch.equal(ops.conv2d_pack_bwd(nominal, wt), ops.conv2d_pack_bwd(real, wt))
+
+
+@pytest.mark.parametrize("cin,cout,kh,sh,h,w,variant", [
+    (32, 64, 3, 1, 6, 500, "conv_p2d<bwd s(1,2),64x256>"), (128, 128, 3, 1, 5, 480, "conv_p2d<bwd s(1,2),128x128>"),
+    (64, 128, 4, 2, 10, 256, "conv_p2d<bwd s(2,2),128x128>"), (64, 128, 4, 2, 11, 250, "conv_p2d<bwd s(2,2),128x128>"),
+    (256, 512, 4, 2, 6, 241, "conv_p2d<bwd s(2,2),128x128>"), (64, 32, 4, 2, 3, 256, "conv_p2d<bwd s(2,2),128x128>")])
+def test_strided_backward_data_on_the_ring_kernel(cin, cout, kh, sh, h, w, variant, knob):
+    """column stride 2 (kernels (3,4) stride (1,2) and (4,4) stride (2,2), padding 1): the phase GEMM on the ring for base
+    positions 1 .. W/2 plus conv2d_bwd_first_cols_kernel for output column 0."""
+    torch.manual_seed(cin + cout + h + w)
+    pre = torch.randn(2, cin, h, w)
+    xin = F.leaky_relu(pre, 0.2).detach().requires_grad_(True)
+    wt = torch.randn(cout, cin, kh, 4) / (cin * kh * 4) ** 0.5
+    y = F.conv2d(xin, wt / 1.3, None, stride=(sh, 2), padding=(1, 1))
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    extra = torch.randn(2, cin, h, w)
+    slope_mask = torch.where(xin.detach() > 0, 1.0, 0.2)
+    d = ops.conv2d_desc(2, cin, cout, h, w, kh, 4, (sh, 2), (1, 1))
+    assert ops.conv2d_bwd_data_kernel_name(d) == variant
+    sigma = torch.tensor([1.3]).to(DEV)
+    pk = ops.conv2d_pack_bwd(d, wt.to(DEV), sigma)
+    close(ops.conv2d_bwd_data(d, dy.to(DEV), pk), xin.grad, 2e-5)
+    got = ops.conv2d_bwd_data(d, dy.to(DEV), pk, xin.detach().to(DEV), 0.2, add=extra.to(DEV))
+    close(got, (xin.grad + extra) * slope_mask, 2e-5)
+    knob(0)
+    assert ops.conv2d_bwd_data_kernel_name(d).startswith("conv_mfma")
+    old = ops.conv2d_bwd_data(d, dy.to(DEV), ops.conv2d_pack_bwd(d, wt.to(DEV), sigma), xin.detach().to(DEV), 0.2,
+                              add=extra.to(DEV))
+    close(old, (xin.grad + extra) * slope_mask, 2e-5)
+
+
+def test_32_row_variant_forward_and_backward(knob):
+    """32 -> 32 3x3 (first block of the STFT discriminators): 32 x 512 tiles, the chunk of the tile image copied flat."""
+    torch.manual_seed(9)
+    for (h, w) in [(5, 1024), (4, 400), (1, 512)]:
+        pre = torch.randn(2, 32, h, w)
+        xin = F.leaky_relu(pre, 0.2).detach().requires_grad_(True)
+        wt = torch.randn(32, 32, 3, 3) / (32 * 9) ** 0.5
+        b = torch.randn(32)
+        y = F.conv2d(xin, wt, b, padding=(1, 1))
+        dy = torch.randn_like(y)
+        y.backward(dy)
+        d = ops.conv2d_desc(2, 32, 32, h, w, 3, 3, (1, 1), (1, 1), EPI_LEAKY_PRE, 0.2)
+        assert ops.conv2d_kernel_name(d) == "conv_p2d<k3,32x512>" and ops.conv2d_bwd_data_kernel_name(d) == "conv_p2d<k3,32x512>"
+        close(ops.conv2d_forward(d, xin.detach().to(DEV), ops.conv2d_pack(d, wt.to(DEV)), b.to(DEV)),
+              F.leaky_relu(y.detach(), 0.2), 1e-5)
+        d0 = ops.conv2d_desc(2, 32, 32, h, w, 3, 3, (1, 1), (1, 1))
+        got = ops.conv2d_bwd_data(d0, dy.to(DEV), ops.conv2d_pack_bwd(d0, wt.to(DEV)), xin.detach().to(DEV), 0.2)
+        close(got, xin.grad * torch.where(xin.detach() > 0, 1.0, 0.2), 2e-5)
