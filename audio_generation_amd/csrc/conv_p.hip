@@ -53,7 +53,12 @@ struct CpGeom {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static constexpr int BM = 32 * MW * WM, BN = 32 * NW * WN;
     static constexpr int PA = (PL + 3) / 4 * 4, SHIFT = PA - PL;
-    static constexpr int SPANP = (SHIFT + (BN - 1) * S + J + 3) / 4 * 4;   // floats per LDS input row
+    // D2 tiles may hold R = BN / WF output rows of WF columns each (narrow feature maps; WF a power of two >= MINWF,
+    // chosen by the launcher): the LDS row of a channel is then R segments of seg_floats(WF) floats
+    static constexpr int MINWF = 32;
+    static constexpr int seg_floats(int wf) { return (SHIFT + (wf - 1) * S + J + 3) / 4 * 4; }
+    static constexpr int SPAN1 = seg_floats(BN), SPANMR = (BN / MINWF) * seg_floats(MINWF);
+    static constexpr int SPANP = (D2 && SPANMR > SPAN1) ? SPANMR : SPAN1;   // floats per LDS input row
     static constexpr int NCELL = SPANP / 4;
     static constexpr int KS = CCH / 2;                  // MFMA k-steps per (chunk, tap) phase
     static constexpr int NG4 = CCH / 4;                 // 4-channel blocks of the tile image per chunk
@@ -83,7 +88,7 @@ struct CpFrag {
 
 template <class G>
 __device__ __forceinline__ void cp_load_frag(CpFrag<G::MW, G::NW, G::KS> &f, const float *__restrict__ As,
-                                             const float *__restrict__ Bs, int j) {
+                                             const float *__restrict__ Bs, int j, const int (&bk)[G::NW]) {
     constexpr int KS = G::KS;
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -105,7 +110,8 @@ __device__ __forceinline__ void cp_load_frag(CpFrag<G::MW, G::NW, G::KS> &f, con
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int k = 0; k < G::NW; ++k) f.b[ks][k] = Bs[ks * G::SPANP + k * 32 * G::S + j];
+        for (int k = 0; k < G::NW; ++k)
+            f.b[ks][k] = G::D2 ? Bs[bk[k] + ks * G::SPANP + j] : Bs[ks * G::SPANP + k * 32 * G::S + j];
 }
 
 template <class G>
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
                                                         int step_n, int step_b, const float *__restrict__ x,
                                                         const float *__restrict__ timg, const float *__restrict__ bias,
                                                         float *__restrict__ y, const float *__restrict__ add2,
-                                                        const float *__restrict__ mask2) {
+                                                        const float *__restrict__ mask2, int wfs) {
     constexpr int MW = G::MW, NW = G::NW, KS = G::KS, J = G::J, S = G::S, Q = G::Q, BM = G::BM, BN = G::BN;
     constexpr int SLOT = G::SLOT, AFL = G::AFL, CCH = G::CCH;
     constexpr bool PRE3 = G::NSLOT == 3;
@@ -162,16 +168,28 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
     const int ncc = p.Cin / CCH;                   // channel chunks (per kernel row)
     const int nch = D2 ? ncc * p.kh : ncc;         // chunks per tile
     const int rstride = D2 ? int(p.x_cstride) : Lin;   // floats between the input rows of a chunk
+    // D2: the tile is RT output rows x WF columns (WF = 1 << wfs); 1-D: one row of BN columns
+    const int WF = D2 ? (1 << wfs) : BN, RT = D2 ? (BN >> wfs) : 1;
+    const int segf = D2 ? (G::SHIFT + (WF - 1) * S + J + 3) / 4 * 4 : G::SPANP, segc = segf / 4;
+    const int rbs = D2 ? (p.Tt + RT - 1) / RT : 1;   // row blocks per clip
 
     // ---- per-lane / per-wave constants of the DMA ---------------------------------------------------------------
     unsigned boffB[G::RB];
     int colB[G::RB];
+    int rowB[D2 ? G::RB : 1];   // D2: input-row offset of the cell's segment
 #pragma unroll
     for (int r = 0; r < G::RB; ++r) {
         const int e = (wave + 4 * r) * 64 + lane;
         const int row = e / G::NCELL, col = e - row * G::NCELL;
-        colB[r] = e < G::NCB ? 4 * col : -(1 << 28);
-        boffB[r] = unsigned(row * rstride + 4 * col) * 4u;
+        if constexpr (D2) {
+            const int rr = col / segc, cc = col - rr * segc;   // segment (output row of the tile), cell within it
+            colB[r] = (e < G::NCB && rr < RT) ? 4 * cc : -(1 << 28);
+            rowB[r] = rr * p.sh;
+            boffB[r] = unsigned(row * rstride + rr * p.sh * Lin + 4 * cc) * 4u;
+        } else {
+            colB[r] = e < G::NCB ? 4 * col : -(1 << 28);
+            boffB[r] = unsigned(row * rstride + 4 * col) * 4u;
+        }
     }
     unsigned aoff[G::RA];   // weight instruction n = wave + 4 r: piece (g4, j) = n / PPB of the chunk, 1 KiB part n % PPB
 #pragma unroll
@@ -183,7 +201,13 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
     const char *zpage = reinterpret_cast<const char *>(g_cp_zero_page) + lane * 16;
     // consumer-side lane offsets (floats, relative to a slot)
     const int aLane = (KS == 4 ? lh * J * BM * 4 : (KS == 8 ? 2 * lh * J * BM * 4 : lh * 2)) + (wm * 32 * MW + li) * 4;
-    const int bLane = AFL + lh * KS * G::SPANP + (wn * 32 * NW + li) * S + G::SHIFT;
+    const int bLane = AFL + lh * KS * G::SPANP + (D2 ? 0 : (wn * 32 * NW + li) * S) + G::SHIFT;
+    int bk[NW];   // D2: LDS offset of this lane's column in fragment k (row segment + column)
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const int n = wn * 32 * NW + k * 32 + li;
+        bk[k] = (n >> wfs) * segf + (n & (WF - 1)) * S;
+    }
 
     const int my_tiles = int(blockIdx.x) < ntiles ? (ntiles - 1 - int(blockIdx.x)) / int(gridDim.x) + 1 : 0;
     const int nq = my_tiles * nch;
@@ -206,10 +230,10 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
     const char *x_tile = nullptr;      // D2: (clip, channel 0, row irow0, first column) of the tile
     auto tile_x = [&]() -> const char * {
         if (D2) {
-            const int bq = ic.b / p.Tt, i = ic.b - bq * p.Tt;   // (clip, base row)
+            const int bq = ic.b / rbs, i = (ic.b - bq * rbs) * RT;   // (clip, first base row of the tile)
             irow0 = i * p.sh - p.ph;
             x_tile = reinterpret_cast<const char *>(x + size_t(bq) * p.cin_real * p.x_cstride + int64_t(irow0) * Lin +
-                                                    (ic.nb * BN * S - G::PA));
+                                                    (ic.nb * WF * S - G::PA));
             return x_tile;
         }
         return reinterpret_cast<const char *>(x + size_t(ic.b) * p.Cin * Lin + (ic.nb * BN * S - G::PA));
@@ -218,14 +242,15 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
     float *d_slot = lds;
     const char *d_w = nullptr, *d_x = nullptr;
     int d_in0a = 0;
-    bool d_live = false, d_rowok = true;
+    bool d_live = false;
+    int d_irow = 0;   // D2: input row of the chunk's first segment (padding rows: cells from the zero page)
     auto begin_chunk = [&]() {
         d_live = iq < nq;
-        if (D2) d_rowok = unsigned(irow0 + idh) < unsigned(p.Tin);   // a padding row: the chunk's input cells come from the zero page
+        if (D2) d_irow = irow0 + idh;
         d_slot = lds + isl * SLOT;
         d_w = w_next;
         d_x = x_next;
-        d_in0a = ic.nb * BN * S - G::PA;
+        d_in0a = ic.nb * WF * S - G::PA;
         ++iq;
         isl = isl + 1 == G::NSLOT ? 0 : isl + 1;
         w_next += wchunk;
@@ -254,7 +279,8 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
             const int r = k - G::RA, n = wave + 4 * r;
             const int pos = d_in0a + colB[r];
             const bool has = d_live && n < G::NIB;
-            const bool ok = has && d_rowok && pos >= 0 && pos < p.Lvalid;
+            const bool rowok = !D2 || unsigned(d_irow + rowB[D2 ? r : 0]) < unsigned(p.Tin);
+            const bool ok = has && rowok && pos >= 0 && pos < p.Lvalid;
             // a cell that straddles the end of the row (L % 4 != 0) is fetched from the row's LAST four elements
             // (in bounds) and put right by fix_ragged() once it has landed
             const int over = max(pos + 4 - p.Lvalid, 0);
@@ -266,13 +292,14 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
     // x[pos .. L-1] followed by zeros.  Only the last time block of a clip, and only when L % 4 != 0.
     const bool ragged = (p.Lvalid & 3) != 0;
     auto fix_ragged = [&]() {
-        if (!ragged || !d_live || !d_rowok || d_in0a + G::SPANP <= p.Lvalid) return;
+        if (!ragged || !d_live || d_in0a + segf <= p.Lvalid) return;
 #pragma unroll
         for (int r = 0; r < G::RB; ++r) {
             const int n = wave + 4 * r;
             const int pos = d_in0a + colB[r];
             const int over = pos + 4 - p.Lvalid;
-            if (n < G::NIB && pos >= 0 && pos < p.Lvalid && over > 0) {
+            const bool rowok = !D2 || unsigned(d_irow + rowB[D2 ? r : 0]) < unsigned(p.Tin);
+            if (n < G::NIB && rowok && pos >= 0 && pos < p.Lvalid && over > 0) {
                 f32x4 *cell = reinterpret_cast<f32x4 *>(d_slot + AFL + n * 256 + lane * 4);
                 const f32x4 v = *cell;
                 f32x4 o;
@@ -302,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
     __syncthreads();
 
     CpFrag<MW, NW, KS> f[2];
-    if (PRE3) cp_load_frag<G>(f[0], lds + aLane, lds + bLane, 0);
+    if (PRE3) cp_load_frag<G>(f[0], lds + aLane, lds + bLane, 0, bk);
 
     const bool pre_act = (p.epilogue & AGX_EPI_LEAKY_PRE) != 0;
     CpTileCur cc = first;
@@ -319,8 +346,8 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
         cp_static_for<J>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             CpFrag<MW, NW, KS> &cur = f[(PAR + j) & 1], &nxt = f[(PAR + j + 1) & 1];
-            if (j + 1 < J) cp_load_frag<G>(nxt, As, Bs, j + 1);
-            else if (PRE3) cp_load_frag<G>(nxt, An, Bn, 0);   // next chunk's first phase: complete since the last barrier
+            if (j + 1 < J) cp_load_frag<G>(nxt, As, Bs, j + 1, bk);
+            else if (PRE3) cp_load_frag<G>(nxt, An, Bn, 0, bk);   // next chunk's first phase: complete since the last barrier
 #pragma unroll
             for (int o = 0; o < G::OPP; ++o) dma_op(j * G::OPP + o);
             cp_mfma_frag<G>(acc, cur);
@@ -330,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the requested chunk has landed
         fix_ragged();
         __syncthreads();                                   // everyone's has; the consumed slot is free
-        if (!PRE3 && !tail_chunk) cp_load_frag<G>(f[(PAR + J) & 1], An, Bn, 0);
+        if (!PRE3 && !tail_chunk) cp_load_frag<G>(f[(PAR + J) & 1], An, Bn, 0, bk);
         qs = qsn;
     };
 
@@ -343,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
             for (int kk = 0; kk < NW; ++kk)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][kk][r] = 0.f;
-        if (!PRE3) cp_load_frag<G>(f[0], lds + qs * SLOT + aLane, lds + qs * SLOT + bLane, 0);
+        if (!PRE3) cp_load_frag<G>(f[0], lds + qs * SLOT + aLane, lds + qs * SLOT + bLane, 0, bk);
 
         if (J % 2 == 0) {
             for (int c = 0; c < nch - 1; ++c) chunk(std::integral_constant<int, 0>{}, false);
@@ -364,9 +391,9 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
         size_t ybase = size_t(b) * p.Cout * p.Lout;
         int trow = 0;   // D2: base row of the tile
         if (D2) {
-            const int bq = b / p.Tt;
-            trow = b - bq * p.Tt;
-            ybase = size_t(bq) * p.Cout * p.y_cstride + ((Q == 1 && G::QH == 1) ? size_t(trow) * p.Lout : size_t(0));
+            const int bq = b / rbs;
+            trow = (b - bq * rbs) * RT;
+            ybase = size_t(bq) * p.Cout * p.y_cstride;
         }
         char *yb = reinterpret_cast<char *>(y + ybase);
         const char *ab = reinterpret_cast<const char *>(add2 + ybase), *kb = reinterpret_cast<const char *>(mask2 + ybase);
@@ -375,26 +402,49 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int m4 = mrow0 + i * 32 + 8 * g + 4 * lh;   // first of this lane's 4 consecutive rows
-                if constexpr (D2 && (Q > 1 || G::QH > 1)) {   // backward-data of a strided Conv2d: phases scatter to rows / columns
+                if constexpr (D2) {   // Conv2d: tile rows x columns; backward-data of a strided layer: phases scatter to rows / columns
+                    // the loads of a pair of rows (gradient add, mask) are issued on clamped offsets before any use
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        const int m = m4 + s4;
-                        const int co = m / (Q * G::QH), a = (m / Q) % G::QH, c = m % Q;
-                        const int orow = G::QH * trow + a - p.oshift_h;
-                        const bool row_ok = orow >= 0 && orow < p.Tout;
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        unsigned off[2][NW];
+                        bool okv[2][NW];
+                        float rv[2][NW], mv[2][NW], bv[2];
 #pragma unroll
-                        for (int kk = 0; kk < NW; ++kk) {
-                            const int t = nb * BN + wn * 32 * NW + kk * 32 + li;
-                            const int ocol = Q * t + c - p.oshift;
-                            const bool ok = row_ok && t < p.Lt && ocol >= 0 && ocol < p.Lout;
-                            const unsigned o = unsigned(co * loutv + (row_ok ? orow : 0) * p.Lout + (ok ? ocol : 0)) * 4u;
-                            float v = acc[i][kk][4 * g + s4];
-                            if (ok) {
-                                if (add2) v += *reinterpret_cast<const float *>(ab + o);
-                                if (mask2) v = *reinterpret_cast<const float *>(kb + o) > 0.f ? v : v * p.slope;
-                                *reinterpret_cast<float *>(yb + o) = v;
+                        for (int e = 0; e < 2; ++e) {
+                            const int m = m4 + 2 * h2 + e;
+                            const int co = m / (Q * G::QH), a = (m / Q) % G::QH, c = m % Q;
+                            bv[e] = lds[G::BIAS0 + co];
+#pragma unroll
+                            for (int kk = 0; kk < NW; ++kk) {
+                                const int n = wn * 32 * NW + kk * 32 + li;
+                                const int brow = trow + (n >> wfs), t = nb * WF + (n & (WF - 1));   // base row / column
+                                const int orow = G::QH * brow + a - p.oshift_h, ocol = Q * t + c - p.oshift;
+                                okv[e][kk] = brow < p.Tt && t < p.Lt && orow >= 0 && orow < p.Tout && ocol >= 0 && ocol < p.Lout;
+                                off[e][kk] = okv[e][kk] ? unsigned(co * loutv + orow * p.Lout + ocol) * 4u : 0u;
                             }
                         }
+                        if (add2) {
+#pragma unroll
+                            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                                for (int kk = 0; kk < NW; ++kk) rv[e][kk] = *reinterpret_cast<const float *>(ab + off[e][kk]);
+                        }
+                        if (mask2) {
+#pragma unroll
+                            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                                for (int kk = 0; kk < NW; ++kk) mv[e][kk] = *reinterpret_cast<const float *>(kb + off[e][kk]);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 2; ++e)
+#pragma unroll
+                            for (int kk = 0; kk < NW; ++kk) {
+                                float v = acc[i][kk][4 * g + 2 * h2 + e] + bv[e];
+                                if (pre_act) v = leaky(v, p.slope);
+                                if (add2) v += rv[e][kk];
+                                if (mask2) v = mv[e][kk] > 0.f ? v : v * p.slope;
+                                if (okv[e][kk]) *reinterpret_cast<float *>(yb + off[e][kk]) = v;
+                            }
                     }
                 } else if (Q == 1) {
                     const f32x4 bq = *reinterpret_cast<const f32x4 *>(lds + G::BIAS0 + m4);
@@ -405,12 +455,7 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
                         for (int s4 = 0; s4 < 4; ++s4) {
                             float v = acc[i][kk][4 * g + s4] + bq[s4];
                             if (pre_act) v = leaky(v, p.slope);
-                            const unsigned o = unsigned((m4 + s4) * loutv + t) * 4u;
-                            if (D2 && t < p.Lt) {   // backward-data: gradient arriving at this map, LeakyReLU gradient of the layer below
-                                if (add2) v += *reinterpret_cast<const float *>(ab + o);
-                                if (mask2) v = *reinterpret_cast<const float *>(kb + o) > 0.f ? v : v * p.slope;
-                            }
-                            if (t < p.Lt) *reinterpret_cast<float *>(yb + o) = v;
+                            if (t < p.Lt) *reinterpret_cast<float *>(yb + unsigned((m4 + s4) * loutv + t) * 4u) = v;
                         }
                     }
                 } else if (Q % 4 == 0) {   // the 4 rows are 4 consecutive output phases of one channel: one 16-byte store
@@ -495,8 +540,17 @@ static int launch_cp(const ConvPlan &p, const float *x, const float *wp, const f
     const int sb = grid / per_clip, rem = grid % per_clip;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G::LDS_BYTES, st, p, mblocks, nblocks, ntiles, rem % mblocks,
                        rem / mblocks, sb, x, wp + p.tile_off, bias, y, static_cast<const float *>(nullptr),
-                       static_cast<const float *>(nullptr));
+                       static_cast<const float *>(nullptr), 0);
     return check_launch("conv_p");
+}
+
+// columns per tile row: the smallest power of two >= min(lt, BN), at least 32 (the rest of the BN columns are further rows)
+static int cp2d_wf_shift(int lt, int bn) {
+    int wf = bn;
+    while (wf / 2 >= 32 && wf / 2 >= lt) wf /= 2;
+    int s = 0;
+    while ((1 << s) < wf) ++s;
+    return s;
 }
 
 // Backward-data of a column-strided Conv2d on the ring: the base grid f' in [0, Lt) of the phase GEMM has one position
@@ -568,8 +622,9 @@ static int launch_cp2d(const ConvPlan &p, const float *x, const float *wp, const
         hipLaunchKernelGGL(conv2d_bwd_first_cols_kernel, dim3(p.B * p.Tt), dim3(256), size_t(p.kh) * p.Cin * sizeof(float), st, p,
                            x, wp + p.tile_off, add, mask, y);
     }
-    const int mblocks = pp.M / G::BM, nblocks = ceil_div(pp.Lt, G::BN);
-    const int64_t ntiles64 = int64_t(mblocks) * nblocks * pp.B * pp.Tt;
+    const int wfs = cp2d_wf_shift(pp.Lt, G::BN);   // tile = (BN >> wfs) rows x (1 << wfs) columns
+    const int mblocks = pp.M / G::BM, nblocks = ceil_div(pp.Lt, 1 << wfs);
+    const int64_t ntiles64 = int64_t(mblocks) * nblocks * pp.B * ceil_div(pp.Tt, G::BN >> wfs);
     if (ntiles64 > (1 << 30)) return fail(AGX_ERR_BAD_SHAPE, "conv_p: too many tiles");
     const int ntiles = int(ntiles64);
     const int wg_per_cu = int((160 * 1024) / G::LDS_BYTES) >= 2 ? 2 : 1;
@@ -578,7 +633,7 @@ static int launch_cp2d(const ConvPlan &p, const float *x, const float *wp, const
     const int per_row = mblocks * nblocks;
     const int sb = grid / per_row, rem = grid % per_row;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G::LDS_BYTES, st, pp, mblocks, nblocks, ntiles, rem % mblocks,
-                       rem / mblocks, sb, x, wp + p.tile_off, bias, y, add, mask);
+                       rem / mblocks, sb, x, wp + p.tile_off, bias, y, add, mask, wfs);
     return check_launch("conv_p2d");
 }
 
@@ -597,7 +652,7 @@ typedef CpGeom<2, 2, 1, 4, 16, 3, 1, 2, 1, 2> CpUp2;      // upsample x2, M = 64
 
 // Conv2d (row-folded; the kernel's row count / row stride / row padding are run-time):
 //                      MW NW WM WN CCH  J  S  Q  P NS  D2
-typedef CpGeom<2, 2, 2, 2, 16, 3, 1, 1, 1, 2, true> Cp2dK3;        // kh x 3 kernels, column stride 1, pad 1:  128 x 128
+typedef CpGeom<2, 2, 2, 2, 8, 3, 1, 1, 1, 2, true> Cp2dK3;         // kh x 3 kernels, column stride 1, pad 1:  128 x 128
 typedef CpGeom<2, 2, 1, 4, 8, 3, 1, 1, 1, 2, true> Cp2dK3M64;      // ... 64 output rows:                         64 x 256
 typedef CpGeom<1, 4, 1, 4, 8, 3, 1, 1, 1, 2, true> Cp2dK3M32;      // ... 32 output rows (= M):                   32 x 512
 typedef CpGeom<2, 2, 2, 2, 8, 4, 2, 1, 1, 2, true> Cp2dK4S2;       // kh x 4 kernels, column stride 2, pad 1:  128 x 128
@@ -658,7 +713,9 @@ bool conv_p2d_supported(const ConvPlan &p) {
     if (int64_t(p.Cout) * p.y_cstride * 4 >= (int64_t(1) << 32)) return false;
     const int bn = g == CP2D_K3M32 ? 512 : ((g == CP2D_K3M64 || g == CP2D_K4S2M64 || g == CP2D_B2M64) ? 256 : 128);
     const int lt = p.q == 1 ? p.Lt : p.Lt - 1;   // column phases: the ring runs base positions 1 .. Lt - 1
-    return lt >= 1 && 10 * int64_t(lt) >= 7 * int64_t(ceil_div(lt, bn)) * bn;
+    if (lt < 1) return false;
+    const int wf = 1 << cp2d_wf_shift(lt, bn);   // narrow maps: several rows per tile
+    return 10 * int64_t(lt) >= 7 * int64_t(ceil_div(lt, wf)) * wf;
 }
 
 const char *conv_p2d_variant(const ConvPlan &p) {

@@ -33,6 +33,12 @@ FWD = [  # cin, cout, kh, kw, sh, sw, h, w, variant
     (32, 64, 3, 4, 1, 2, 6, 500, "conv_p2d<k4s2,64x256>"), (64, 128, 4, 4, 2, 2, 10, 256, "conv_p2d<k4s2,128x128>"),
     (64, 128, 4, 4, 2, 2, 11, 250, "conv_p2d<k4s2,128x128>"), (128, 128, 3, 4, 1, 2, 5, 480, "conv_p2d<k4s2,128x128>"),
     (256, 512, 4, 4, 2, 2, 6, 241, "conv_p2d<k4s2,128x128>"), (64, 128, 5, 3, 2, 1, 9, 125, "conv_p2d<k3,128x128>"),
+    # narrow maps: several output rows per tile (columns per tile row = 64 / 32 / 128 ...)
+    (128, 128, 3, 3, 1, 1, 9, 64, "conv_p2d<k3,128x128>"), (256, 256, 3, 3, 1, 1, 7, 32, "conv_p2d<k3,128x128>"),
+    (128, 128, 3, 3, 1, 1, 6, 50, "conv_p2d<k3,128x128>"), (64, 64, 3, 3, 1, 1, 9, 128, "conv_p2d<k3,64x256>"),
+    (64, 64, 3, 3, 1, 1, 5, 64, "conv_p2d<k3,64x256>"), (32, 32, 3, 3, 1, 1, 9, 128, "conv_p2d<k3,32x512>"),
+    (128, 256, 4, 4, 2, 2, 10, 128, "conv_p2d<k4s2,128x128>"), (256, 256, 3, 4, 1, 2, 7, 64, "conv_p2d<k4s2,128x128>"),
+    (32, 64, 3, 4, 1, 2, 11, 128, "conv_p2d<k4s2,64x256>"),
 ]
 
 
@@ -63,7 +69,9 @@ def test_forward_on_the_ring_kernel(cin, cout, kh, kw, sh, sw, h, w, variant, kn
 @pytest.mark.parametrize("cin,cout,kh,h,w,variant", [
     (64, 64, 3, 7, 250, "conv_p2d<k3,64x256>"), (128, 128, 3, 6, 250, "conv_p2d<k3,128x128>"),
     (128, 128, 3, 5, 253, "conv_p2d<k3,128x128>"), (256, 256, 3, 5, 120, "conv_p2d<k3,128x128>"),
-    (128, 64, 3, 4, 500, "conv_p2d<k3,128x128>"), (128, 64, 5, 9, 125, "conv_p2d<k3,128x128>")])
+    (128, 64, 3, 4, 500, "conv_p2d<k3,128x128>"), (128, 64, 5, 9, 125, "conv_p2d<k3,128x128>"),
+    (128, 128, 3, 9, 64, "conv_p2d<k3,128x128>"), (256, 256, 3, 7, 32, "conv_p2d<k3,128x128>"),
+    (128, 128, 3, 6, 50, "conv_p2d<k3,128x128>"), (64, 64, 3, 5, 64, "conv_p2d<k3,64x256>")])
 def test_backward_data_on_the_ring_kernel(cin, cout, kh, h, w, variant, knob):
     """stride-1 layers: dx = conv(dy, flipped kernel); (cin, cout) are the FORWARD layer's."""
     torch.manual_seed(cin + cout + h + w)
@@ -91,13 +99,14 @@ def test_backward_data_on_the_ring_kernel(cin, cout, kh, h, w, variant, knob):
     close(old, (xin.grad + extra) * slope_mask, 2e-5)
 
 
-def test_narrow_maps_and_other_shapes_stay_on_the_patch_tiles():
-    for (cin, cout, kh, kw, sh, sw, h, w) in [(128, 128, 3, 3, 1, 1, 9, 64), (64, 64, 3, 3, 1, 1, 9, 128),
-                                             (32, 32, 3, 3, 1, 1, 9, 300), (64, 128, 4, 4, 2, 2, 18, 130),
-                                             (128, 128, 3, 3, 1, 1, 9, 1024 + 40)]:
+def test_half_empty_column_blocks_stay_on_the_patch_tiles():
+    """the ring takes a layer when its column blocks (whole rows of >= 32 columns for narrow maps) are >= 70 % full"""
+    for (cin, cout, kh, kw, sh, sw, h, w, ring) in [(128, 128, 3, 3, 1, 1, 9, 16, False), (64, 64, 3, 3, 1, 1, 9, 20, False),
+                                                   (32, 32, 3, 3, 1, 1, 9, 300, False), (64, 128, 4, 4, 2, 2, 18, 130, False),
+                                                   (128, 128, 3, 3, 1, 1, 9, 1024 + 40, True), (128, 128, 3, 3, 1, 1, 9, 24, True)]:
         d = ops.conv2d_desc(2, cin, cout, h, w, kh, kw, (sh, sw), ((kh - 1) // 2, 1))
         name = ops.conv2d_kernel_name(d)
-        assert name.startswith("conv_p2d") == (w == 1064), (name, cin, w)
+        assert name.startswith("conv_p2d") == ring, (name, cin, w)
 
 
 def test_packed_image_does_not_depend_on_the_feature_map_size():
@@ -110,7 +119,9 @@ def test_packed_image_does_not_depend_on_the_feature_map_size():
         real = ops.conv2d_desc(2, cin, cout, 6, 512, kh, kw, (sh, sw), (1, 1))
         pk_n, pk_r = ops.conv2d_pack(nominal, wt), ops.conv2d_pack(real, wt)
         assert pk_n.shape == pk_r.shape and torch.equal(pk_n, pk_r)
-        assert ops.conv2d_kernel_name(real).startswith("conv_p2d") and ops.conv2d_kernel_name(nominal).startswith("conv_mfma")
+        assert ops.conv2d_kernel_name(real).startswith("conv_p2d")
+        tiny = ops.conv2d_desc(1, cin, cout, 9, 8, kh, kw, (sh, sw), (1, 1))       # too narrow for the ring: same image still
+        assert ops.conv2d_kernel_name(tiny).startswith("conv_mfma") and torch.equal(ops.conv2d_pack(tiny, wt), pk_r)
         x = torch.randn(2, cin, 6, 512)
         close(ops.conv2d_forward(real, x.to(DEV), pk_n, None), F.conv2d(x, wt.cpu(), None, stride=(sh, sw), padding=(1, 1)), 1e-5)
         if (sh, sw) == (1, 1):
@@ -120,7 +131,9 @@ def test_packed_image_does_not_depend_on_the_feature_map_size():
 @pytest.mark.parametrize("cin,cout,kh,sh,h,w,variant", [
     (32, 64, 3, 1, 6, 500, "conv_p2d<bwd s(1,2),64x256>"), (128, 128, 3, 1, 5, 480, "conv_p2d<bwd s(1,2),128x128>"),
     (64, 128, 4, 2, 10, 256, "conv_p2d<bwd s(2,2),128x128>"), (64, 128, 4, 2, 11, 250, "conv_p2d<bwd s(2,2),128x128>"),
-    (256, 512, 4, 2, 6, 241, "conv_p2d<bwd s(2,2),128x128>"), (64, 32, 4, 2, 3, 256, "conv_p2d<bwd s(2,2),128x128>")])
+    (256, 512, 4, 2, 6, 241, "conv_p2d<bwd s(2,2),128x128>"), (64, 32, 4, 2, 3, 256, "conv_p2d<bwd s(2,2),128x128>"),
+    (128, 256, 4, 2, 10, 128, "conv_p2d<bwd s(2,2),128x128>"), (256, 256, 3, 1, 7, 64, "conv_p2d<bwd s(1,2),128x128>"),
+    (32, 64, 3, 1, 11, 128, "conv_p2d<bwd s(1,2),64x256>"), (64, 128, 4, 2, 9, 60, "conv_p2d<bwd s(2,2),128x128>")])
 def test_strided_backward_data_on_the_ring_kernel(cin, cout, kh, sh, h, w, variant, knob):
     """column stride 2 (kernels (3,4) stride (1,2) and (4,4) stride (2,2), padding 1): the phase GEMM on the ring for base
     positions 1 .. W/2 plus conv2d_bwd_first_cols_kernel for output column 0."""

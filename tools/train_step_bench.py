@@ -107,6 +107,19 @@ def main():
     for _ in range(2):
         step()
     torch.cuda.synchronize()
+    ab = {}
+    knob = os.environ.get("AGX_AB_KNOB")          # in-process A/B of one tuning knob (devices differ by several per cent)
+    if knob:
+        from audio_generation_amd import _lib
+        for value in (0, 1, 0, 1):
+            _lib.load().agx_set_tuning(knob.encode(), value)
+            step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            ab.setdefault(f"{knob}={value}", []).append(1e3 * (time.perf_counter() - t0) / steps)
     t0 = time.perf_counter()
     losses = [step() for _ in range(steps)]
     torch.cuda.synchronize()
@@ -125,7 +138,7 @@ def main():
                           "n_gpus": world, "batch_per_gpu": batch, "ms_per_step": ms, "replicas_in_sync": same, "update_codebook": update_cb,
                           "samples_per_s": world * batch * 72000 / ms * 1e3, "losses": losses,
                           "approx_tflops_at_3x_forward": world * 3 * fwd_flop / ms * 1e-9,
-                          "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}))
+                          "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30, **({"ab_ms_per_step": ab} if ab else {})}))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
