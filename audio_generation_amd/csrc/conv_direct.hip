@@ -192,12 +192,81 @@ __global__ __launch_bounds__(256) void conv_narrow_kernel(ConvPlan p, const floa
     }
 }
 
+// ------------------------------------------------------------------ few GEMM rows
+// Dense 1-D layers with at most 16 rows (q * Cout): backward-data of the small-hop STFTs of the mel loss (8 / 16 phase
+// channels from 514 spectrum rows: 36 + 11 ms of a training step on the tiled kernel above, whose blocks then own 16 rows
+// x 256 outputs and walk the channels through LDS), of the waveform discriminator's first conv, 1-channel heads.  One
+// thread owns ONE base position and all the rows: each x element is read once per tap (coalesced along t), the weights
+// are wave-uniform scalar loads.  Summation order: channel-major, tap-minor (as the generic kernel).
+template <int MM>
+__global__ __launch_bounds__(256) void conv_fewrows_kernel(ConvPlan p, const float *__restrict__ x, const float *__restrict__ wp,
+                                                           const float *__restrict__ bias, const float *__restrict__ res,
+                                                           float *__restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) float ws[];   // weights of one 16-channel group: [j][c16][MM]
+    __shared__ int tap_live[128];   // taps whose weights are all zero in this group are skipped (a short window inside a long
+                                    // n_fft: 60 of the 64 taps of the mel loss's 32-sample window)
+    const int t = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    const bool live = t < p.Lt;
+    const float *xb = x + size_t(b) * p.cin_real * p.Lin;
+    float acc[MM];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) acc[m] = 0.f;
+    const int ngrp = (p.cin_real + kWG - 1) / kWG, gsz = p.J * p.M * kWG;
+    for (int g = 0; g < ngrp; ++g) {
+        __syncthreads();
+        for (int jj = threadIdx.x; jj < 128; jj += 256) tap_live[jj] = p.J > 128 ? 1 : 0;
+        __syncthreads();
+        for (int e = threadIdx.x; e < p.J * kWG * MM; e += 256) {   // image order of a group: [j][m][c16]
+            const int m = e % MM, c16 = (e / MM) % kWG, jj = e / (MM * kWG);
+            const float w = m < p.M ? wp[size_t(g) * gsz + (size_t(jj) * p.M + m) * kWG + c16] : 0.f;
+            ws[e] = w;
+            if (w != 0.f && jj < 128) tap_live[jj] = 1;   // benign race: every writer stores 1
+        }
+        __syncthreads();
+        const int cn = min(kWG, p.cin_real - g * kWG);
+        for (int c16 = 0; c16 < cn; ++c16) {
+            const float *xr = xb + size_t(g * kWG + c16) * p.Lin;
+            for (int jj = 0; jj < p.J; ++jj) {
+                if (jj < 128 && !tap_live[jj]) continue;   // uniform
+                const int i = t * p.s + jj * p.d - p.P;
+                const float xv = (live && i >= 0 && i < p.Lvalid) ? xr[i] : 0.f;
+                const float *wv = ws + (jj * kWG + c16) * MM;   // wave-uniform address: LDS broadcast
+#pragma unroll
+                for (int m = 0; m < MM; ++m) acc[m] = fmaf(wv[m], xv, acc[m]);
+            }
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+        if (m >= p.M) break;
+        const int co = m / p.q, ph = m - co * p.q;
+        const int u = t * p.q + ph - p.oshift;
+        if (u < 0 || u >= p.Lout) continue;
+        const size_t o = (size_t(b) * p.Cout + co) * p.Lout + u;
+        float v = acc[m] + (bias ? bias[co] : 0.f);
+        if (p.epilogue & AGX_EPI_LEAKY_PRE) v = v > 0.f ? v : v * p.slope;
+        if (p.epilogue & AGX_EPI_GELU_PRE) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+        if (p.epilogue & AGX_EPI_RESIDUAL) v += res[o];
+        if (p.epilogue & AGX_EPI_LEAKY_POST) v = v > 0.f ? v : v * p.slope;
+        if (p.epilogue & AGX_EPI_MASK) v = p.mask[o] > 0.f ? v : v * p.slope;
+        y[o] = v;
+    }
+}
+
+static inline bool fewrows_ok(const ConvPlan &p) {
+    const int mm = p.M > 8 ? 16 : (p.M > 4 ? 8 : (p.M > 1 ? 4 : 1));
+    return p.G == 1 && p.kh == 1 && p.Tout == 1 && p.M <= 16 && p.pm_R == 0 && p.prec == 0 && p.ncv == p.cin_real &&
+           p.J * mm <= 1024;   // one group of weights (J x 16 x rows) in <= 64 KB of LDS
+}
+
 const char *conv_direct_variant(const ConvPlan &p) {
     if (p.G > 1) {
         const int rpg = p.Cout / p.G;
         return rpg % 32 == 0 ? "conv_direct<32>" : (rpg % 16 == 0 ? "conv_direct<16>" : (rpg % 4 == 0 ? "conv_direct<4>" : "conv_direct<1>"));
     }
     if (narrow_ok(p)) return p.M == 32 ? "conv_narrow<16>" : (p.M == 2 ? "conv_narrow<2>" : "conv_narrow<1>");
+    if (fewrows_ok(p)) return p.M > 8 ? "conv_fewrows<16>" : (p.M > 4 ? "conv_fewrows<8>" : (p.M > 1 ? "conv_fewrows<4>" : "conv_fewrows<1>"));
     return p.M >= 32 ? "conv_direct<32>" : (p.M > 4 ? "conv_direct<16>" : (p.M > 1 ? "conv_direct<4>" : "conv_direct<1>"));
 }
 
@@ -213,6 +282,17 @@ int launch_conv_direct(const ConvPlan &p, const float *x, const float *wp, const
         else
             hipLaunchKernelGGL(conv_narrow_kernel<1>, grid, block, 0, st, p, x, wp, bias, res, y);
         return check_launch("conv_narrow");
+    }
+    if (fewrows_ok(p)) {
+        dim3 grid(ceil_div(p.Lt, 256), p.B), block(256);
+        if (grid.y > 65535) return fail(AGX_ERR_BAD_SHAPE, "conv_fewrows: grid too large");
+        const int mm = p.M > 8 ? 16 : (p.M > 4 ? 8 : (p.M > 1 ? 4 : 1));
+        const size_t lds = size_t(p.J) * kWG * mm * sizeof(float);
+        if (mm == 16) hipLaunchKernelGGL(conv_fewrows_kernel<16>, grid, block, lds, st, p, x, wp, bias, res, y);
+        else if (mm == 8) hipLaunchKernelGGL(conv_fewrows_kernel<8>, grid, block, lds, st, p, x, wp, bias, res, y);
+        else if (mm == 4) hipLaunchKernelGGL(conv_fewrows_kernel<4>, grid, block, lds, st, p, x, wp, bias, res, y);
+        else hipLaunchKernelGGL(conv_fewrows_kernel<1>, grid, block, lds, st, p, x, wp, bias, res, y);
+        return check_launch("conv_fewrows");
     }
     const int span = 255 * p.s + (p.J - 1) * p.d + 1;
     const int cpg = p.ncv / p.G;
