@@ -24,6 +24,7 @@ struct Tuning {
                         // input elements (tall tiles share the row halo), 0 = always the widest
     int bf_sched = -1;  // (-1 = per-shape table) schedule of the bf16x3 main loop in the fused residual block: 0 split after the MFMAs,
                         // 1 the same with MFMA / VALU interleave hints, 2 split before the MFMAs
+    int dw2_shared = 1; // conv2d weight gradient: 1 = workgroup-shared operand slots + one barrier per item where a variant exists, 0 = wave-private buffers
     int dw2_direct = 2; // conv2d weight gradient on the barrier-free LDS-DMA kernel: 1 = stride-1 "same" layers, 2 = also the column-strided
                         // layers (x read through its column-phase planes), 0 = the staged kernel everywhere
     int dw_direct = 3;  // 1-D weight gradient on the barrier-free kernel: 3 = every dense layer (strided / transposed ones through a

@@ -895,6 +895,182 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     direct_finish<MW, NW, WM, WN>(acc, bsum, dma_buf, wk, wr, lane, n_base, m_base, NK, M, part, bias_part, do_bias);
 }
 
+// The same item stream with the operands SHARED by the workgroup (knob dw2_shared, default on).  In the kernel above every
+// wave DMAs its own A and B blocks: on a 2 x 2 wave grid each block is fetched twice, 64 KB of L2 -> LDS traffic per item
+// of 64 MFMAs per wave -- ~10 TB/s at the full MFMA rate, which is what holds that kernel at 80-93 TFLOP/s.  Here the
+// (BM + BN) / 32 blocks of an item are fetched once (each wave issues a quarter of the DMA instructions) into one of two
+// LDS slots, and one barrier per item hands the slot over: item n + 1 streams in while item n is multiplied, exactly the
+// hand-over of conv_p.hip's two-slot ring.  Items whose DMA window could leave the tensor (head / tail rows) take the
+// element-by-element path, workgroup-uniformly.
+template <int MW, int NW, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv2d_bwd_weight_shared_kernel(Bw2dGeom g, const float *__restrict__ x,
+                                                                          const float *__restrict__ dy,
+                                                                          float *__restrict__ part,
+                                                                          float *__restrict__ bias_part) {
+    static_assert(WM * WN == 4, "4 waves, no contraction split");
+    constexpr int BM = 32 * MW * WM, BN = 32 * NW * WN, T = 32;
+    constexpr int NBA = BM / 32, NBB = BN / 32, NBLK = NBA + NBB;   // 4 KB operand blocks of an item
+    constexpr int NI = NBLK;                                        // DMA instructions per wave and item (4 per block / 4 waves)
+    constexpr int SLOTF = NBLK * 1024;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int KK = g.kh * g.kw, NK = g.Cin * KK, M = g.Cout;
+    const int Wp = g.Wp, HWo = g.Hout * g.Wout, HWi = g.Hin * Wp, FC = g.Wout / T;
+    const int plane = g.B * g.Cin * HWi;
+    const int n_base = blockIdx.x * BN, m_base = blockIdx.y * BM;
+    const int slice = blockIdx.z, n_slices = gridDim.z;
+
+    int aoff[MW], brow[NW], bdh[NW], bdw[NW];   // this lane's MFMA rows (edge path, masks)
+#pragma unroll
+    for (int i = 0; i < MW; ++i) aoff[i] = min(m_base + (wm * MW + i) * 32 + li, M - 1) * HWo;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const int n = min(n_base + (wn * NW + k) * 32 + li, NK - 1);
+        const int ci = n / KK, rem = n - ci * KK, dh = rem / g.kw;
+        const int dwp = rem - dh * g.kw - g.pw, a = floordiv_bw(dwp, g.sw);
+        brow[k] = (dwp - a * g.sw) * plane + ci * HWi;
+        bdh[k] = dh - g.ph;
+        bdw[k] = a;
+    }
+    // DMA instruction q = wave + 4 r of an item: block q / 4 (A blocks first), rows 8 (q % 4) .. + 7 of it, lane l -> row
+    // 8 (q % 4) + (l >> 3), 16-byte chunk (l & 7) ^ (l >> 3) of the row (the swizzle direct_read_lds undoes)
+    extern __shared__ __attribute__((aligned(16))) float dma_buf[];
+    const int dr = lane >> 3, dchunk = (lane & 7) ^ dr;
+    int doff[NI], ddh[NI];   // source offset (floats); B rows: dh - ph + 64, A rows: -1
+#pragma unroll
+    for (int r = 0; r < NI; ++r) {
+        const int q = wave + 4 * r, blk = q >> 2, v = q & 3;
+        if (blk < NBA) {
+            doff[r] = min(m_base + blk * 32 + 8 * v + dr, M - 1) * HWo + 4 * dchunk;
+            ddh[r] = -1;
+        } else {
+            const int n = min(n_base + (blk - NBA) * 32 + 8 * v + dr, NK - 1);
+            const int ci = n / KK, rem = n - ci * KK, dh = rem / g.kw, dwp = rem - dh * g.kw - g.pw;
+            const int a = floordiv_bw(dwp, g.sw);
+            doff[r] = (dwp - a * g.sw) * plane + ci * HWi + (dh - g.ph) * Wp + a + 4 * dchunk;
+            ddh[r] = dh - g.ph + 64;
+        }
+    }
+    const float *zsrc = bw_zero_page + 4 * (lane & 7);
+
+    f32x16 acc[MW][NW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
+    float bsum[MW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i) bsum[i] = 0.f;
+    const bool do_bias = bias_part != nullptr && blockIdx.x == 0 && wn == 0;
+
+    const int rows = g.B * g.Hout, items = rows * FC;
+    auto dma = [&](int item, float *slot) {
+        const int row = item / FC, fc = item - row * FC, b = row / g.Hout, t = row - b * g.Hout;
+        const float *dyb = dy + size_t(b) * M * HWo + t * g.Wout + fc * T;
+        const float *xb = x + size_t(b) * g.Cin * HWi + t * g.sh * Wp + fc * T;
+#pragma unroll
+        for (int r = 0; r < NI; ++r) {
+            const int q = wave + 4 * r;
+            const float *src;
+            if (ddh[r] < 0) {
+                src = dyb + doff[r];
+            } else {
+                const int rr = t * g.sh + ddh[r] - 64;
+                src = (rr >= 0 && rr < g.Hin) ? xb + doff[r] : zsrc;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(slot + q * 256), 16, 0, 0);
+        }
+    };
+    // operands of this wave's fragments out of a slot: A blocks wm MW + i, B blocks NBA + wn NW + k
+    auto read_slot = [&](const float *slot, f32x4 (&A)[MW][4], f32x4 (&Bv)[NW][4]) {
+        const int rd_off = (li >> 3) * 256 + (li & 7) * 32;
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                A[i][e] = *reinterpret_cast<const f32x4 *>(slot + (wm * MW + i) * 1024 + rd_off + 4 * ((4 * lh + e) ^ (li & 7)));
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                Bv[k][e] = *reinterpret_cast<const f32x4 *>(slot + (NBA + wn * NW + k) * 1024 + rd_off +
+                                                            4 * ((4 * lh + e) ^ (li & 7)));
+    };
+    auto mask_cols = [&](f32x4 (&Bv)[NW][4], int fc) {
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int x0 = fc * T + 16 * lh + c + bdw[k], x1 = x0 + 12;
+                Bv[k][0][c] = __uint_as_float(__float_as_uint(Bv[k][0][c]) & ((x0 >= 0 && x0 < Wp) ? ~0u : 0u));
+                Bv[k][3][c] = __uint_as_float(__float_as_uint(Bv[k][3][c]) & ((x1 >= 0 && x1 < Wp) ? ~0u : 0u));
+            }
+    };
+    auto load_edge = [&](f32x4 (&A)[MW][4], f32x4 (&Bv)[NW][4], int item) {
+        const int row = item / FC, fc = item - row * FC, b = row / g.Hout, t = row - b * g.Hout;
+        const float *dyb = dy + size_t(b) * M * HWo + t * g.Wout + fc * T + 16 * lh;
+        const float *xb = x + size_t(b) * g.Cin * HWi;
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) A[i][e] = *reinterpret_cast<const f32x4 *>(dyb + aoff[i] + 4 * e);
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int r = t * g.sh + bdh[k];
+            const bool rok = r >= 0 && r < g.Hin;
+            const float *xr = xb + brow[k] + min(max(r, 0), g.Hin - 1) * Wp;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int xi = fc * T + 16 * lh + e + bdw[k];
+                const unsigned v = __float_as_uint(xr[min(max(xi, 0), Wp - 1)]);
+                Bv[k][e >> 2][e & 3] = __uint_as_float(v & ((rok && xi >= 0 && xi < Wp) ? ~0u : 0u));
+            }
+        }
+    };
+    auto compute = [&](const f32x4 (&A)[MW][4], const f32x4 (&Bv)[NW][4]) { direct_compute<MW, NW>(acc, bsum, A, Bv, do_bias); };
+
+    f32x4 A0[MW][4], B0[NW][4];
+    const int per = (items + n_slices - 1) / n_slices;
+    int item = slice * per;
+    const int end = min(items, item + per);
+    const int head_rows = min(g.ph + 1, rows), tail_row0 = max(rows - (g.kh - g.ph), 0);
+    while (item < end) {   // (every branch below is workgroup-uniform)
+        const int row = item / FC, fc = item - row * FC;
+        const bool head = row < head_rows, tail = row >= tail_row0;
+        const bool unsafe = (head && fc == 0) || (tail && fc == FC - 1);
+        const int run_end = tail ? row * FC + FC - 1 : (head ? (row + 1) * FC : tail_row0 * FC);
+        const int run = unsafe ? 0 : min(end, run_end) - item;
+        if (run <= 0) {
+            load_edge(A0, B0, item);
+            compute(A0, B0);
+            ++item;
+            continue;
+        }
+        const int last = item + run - 1;
+        dma(item, dma_buf);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                   // item 0 of the run is complete in slot 0
+        for (int n = 0; n < run; ++n) {
+            float *cur = dma_buf + (n & 1) * SLOTF, *nxt = dma_buf + ((n + 1) & 1) * SLOTF;
+            read_slot(cur, A0, B0);
+            dma(min(item + n + 1, last), nxt);             // the other slot: everyone left it at the last barrier
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int fcn = (item + n) % FC;
+            if (fcn == 0 || fcn == FC - 1) mask_cols(B0, fcn);
+            compute(A0, B0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the next item has landed
+            __syncthreads();                                   // everyone's has, and everyone has read the current slot
+        }
+        item += run;
+    }
+    direct_finish<MW, NW, WM, WN>(acc, bsum, dma_buf, 0, wave, lane, n_base, m_base, NK, M, part, bias_part, do_bias);
+}
+
 // Gradient w.r.t. the normalised weight G[co][n] = dwp[n][co] -> dw (torch layout), and per-row <G, W>.
 __global__ __launch_bounds__(256) void bwd2d_unpack_kernel(const float *__restrict__ dwp, const float *__restrict__ w,
                                                            float *__restrict__ dw, float *__restrict__ rowdot, int NK,
@@ -979,6 +1155,12 @@ static int bw2d_geometry(const agx_conv2d_desc *d, Bw2dGeom *g, int *cfg, int *b
                                  else         { *cfg = 12; dbm = 64; dbn = 64; wk = 4; } }   // <2,2,1,1>
         else                   { if (NK > 32) { *cfg = 13; dbm = 32; dbn = 256; wk = 1; }    // <1,2,1,4>
                                  else         { *cfg = 14; dbm = 32; dbn = 32; wk = 4; } }   // <1,1,1,1>
+        // 32 rows: 96-column tiles (the four waves split the contraction) when they waste fewer columns than 256-column
+        // ones -- 32 -> 32 3x3: NK = 288 = 3 x 96, against 2 x 256
+        if (*cfg == 13 && ceil_div(NK, 96) * 96 < ceil_div(NK, 256) * 256) { *cfg = 17; dbm = 32; dbn = 96; wk = 4; }   // <1,3,1,1>
+        // (64 rows x 96 columns, <2,3,1,1>, for NK = 576 = 6 x 96: 73.8 TFLOP/s against 81 on 5 tiles of 128 -- not kept)
+        if (tuning().dw2_shared >= 2 && *cfg == 11) { *cfg = 15; dbm = 64; dbn = 128; wk = 1; }    // shared <2,1,1,4>
+        if (tuning().dw2_shared >= 2 && *cfg == 13) { *cfg = 16; dbm = 32; dbn = 256; wk = 1; }    // shared <1,2,1,4>
         const int dnt = ceil_div(NK, dbn), dmt = ceil_div(g->Cout, dbm);
         const int64_t ditems = int64_t(g->B) * g->Hout * (g->Wout / 32);
         int64_t gz = ceil_div(tuning().dw_wgs, dnt * dmt);
@@ -1213,10 +1395,21 @@ int agx_conv2d_bwd_weight(const agx_conv2d_desc *d, const float *x, const float 
                                xs, xrows, g.Win, g.Wp, g.sw);
             x = xs;
         }
-        rc = cfg == 10 ? launch_direct(conv2d_bwd_weight_direct_kernel<2, 2, 2, 2>, 4)
+        auto launch_shared = [&](auto kern, int blocks) -> int {   // two slots of (BM + BN) / 32 operand blocks of 4 KB
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+            hipLaunchKernelGGL(kern, grid, dim3(256), size_t(2) * blocks * 4096, st, g, x, dy, part, dbias ? bias_part : nullptr);
+            return AGX_OK;
+        };
+        rc = (cfg == 10 && tuning().dw2_shared) ? launch_shared(conv2d_bwd_weight_shared_kernel<2, 2, 2, 2>, 8)
+           : (cfg == 15) ? launch_shared(conv2d_bwd_weight_shared_kernel<2, 1, 1, 4>, 6)
+           : (cfg == 16) ? launch_shared(conv2d_bwd_weight_shared_kernel<1, 2, 1, 4>, 9)
+           : cfg == 10 ? launch_direct(conv2d_bwd_weight_direct_kernel<2, 2, 2, 2>, 4)
            : cfg == 11 ? launch_direct(conv2d_bwd_weight_direct_kernel<2, 2, 1, 2>, 4)
            : cfg == 12 ? launch_direct(conv2d_bwd_weight_direct_kernel<2, 2, 1, 1>, 4)
            : cfg == 13 ? launch_direct(conv2d_bwd_weight_direct_kernel<1, 2, 1, 4>, 3)
+           : cfg == 17 ? launch_direct(conv2d_bwd_weight_direct_kernel<1, 3, 1, 1>, 4)
                        : launch_direct(conv2d_bwd_weight_direct_kernel<1, 1, 1, 1>, 2);
     } else if (g.prec) {
         rc = cfg == 0 ? launch(conv2d_bwd_weight_kernel<2, 2, 2, 2, 1>)

@@ -236,6 +236,7 @@ int agx_set_tuning(const char *name, int32_t value) {
     else if (!strcmp(name, "bf_sched")) agx::tuning().bf_sched = value;
     else if (!strcmp(name, "patch_tie")) agx::tuning().patch_tie = value;
     else if (!strcmp(name, "dw2_direct")) agx::tuning().dw2_direct = value;
+    else if (!strcmp(name, "dw2_shared")) agx::tuning().dw2_shared = value;
     else if (!strcmp(name, "dw_wgs")) agx::tuning().dw_wgs = value;
     else if (!strcmp(name, "dw_direct")) agx::tuning().dw_direct = value;
     else if (!strcmp(name, "dw1_wgs")) agx::tuning().dw1_wgs = value;
@@ -261,6 +262,7 @@ int agx_get_tuning(const char *name) {
     if (!strcmp(name, "bf_sched")) return agx::tuning().bf_sched;
     if (!strcmp(name, "patch_tie")) return agx::tuning().patch_tie;
     if (!strcmp(name, "dw2_direct")) return agx::tuning().dw2_direct;
+    if (!strcmp(name, "dw2_shared")) return agx::tuning().dw2_shared;
     if (!strcmp(name, "dw_wgs")) return agx::tuning().dw_wgs;
     if (!strcmp(name, "dw_direct")) return agx::tuning().dw_direct;
     if (!strcmp(name, "dw1_wgs")) return agx::tuning().dw1_wgs;

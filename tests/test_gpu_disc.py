@@ -320,7 +320,9 @@ def test_conv2d_backward_data(cin, cout, kh, kw, sh, sw, ph, pw, h, w):
     (2, 20, 5, 5, 1, 1, 2, 2, 7, 128), (24, 200, 1, 1, 1, 1, 0, 0, 4, 64),
     # column-strided layers with whole 32-column items: the same kernel over the column-phase planes of x
     (32, 64, 3, 4, 1, 2, 1, 1, 17, 128), (64, 128, 4, 4, 2, 2, 1, 1, 10, 64), (16, 32, 3, 4, 1, 2, 1, 1, 5, 64),
-    (40, 140, 4, 4, 2, 2, 1, 1, 2, 128), (8, 16, 3, 4, 1, 2, 1, 1, 1, 64)])
+    (40, 140, 4, 4, 2, 2, 1, 1, 2, 128), (8, 16, 3, 4, 1, 2, 1, 1, 1, 64),
+    # long runs of interior items on the shared-operand kernel (two LDS slots, one barrier per item)
+    (128, 256, 3, 3, 1, 1, 1, 1, 12, 128), (96, 128, 3, 4, 1, 2, 1, 1, 9, 256), (64, 128, 4, 4, 2, 2, 1, 1, 14, 128)])
 @pytest.mark.parametrize("spectral", [False, True])
 def test_conv2d_backward_weight(cin, cout, kh, kw, sh, sw, ph, pw, h, w, spectral):
     """dW / dbias against autograd; with spectral norm the gradient w.r.t. weight_orig (sigma = u.Wv, u / v fixed)."""
