@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AGX_VERSION 114 /* 114: agx_attention_alibi_backward_ex (any T), agx_rvq_forward_ex; 113: tile images (resblock_p / conv_p), agx_attention_alibi_ex, agx_sizeof_*; 0.1.1: agx_conv_desc gained groups / padding (zero = old behaviour); 111: resample, conv2d column split */
+#define AGX_VERSION 115 /* 115: agx_rvq_ema_stats, agx_conv2d_bwd_data_kernel_name; 114: agx_attention_alibi_backward_ex (any T), agx_rvq_forward_ex; 113: tile images (resblock_p / conv_p), agx_attention_alibi_ex, agx_sizeof_*; 0.1.1: agx_conv_desc gained groups / padding (zero = old behaviour); 111: resample, conv2d column split */
 
 #define AGX_OK 0
 #define AGX_ERR_BAD_SHAPE (-1)
@@ -63,7 +63,10 @@ int32_t agx_sizeof_conv2d_desc(void);
  *   "conv_shape" 0|1   1: 128x128 conv tiles as four row-waves of 1x4 fragments
  *   "rb_impl" 0|1      fused residual block: 1 (default) the persistent ring kernel (csrc/resblock_p.hip) where it applies,
  *                      0 the first kernel (csrc/resblock_mfma.hip) everywhere
- *   "conv_impl" 0|1    resampling / stride-1 1-D layers: 1 (default) the persistent ring kernel (csrc/conv_p.hip), 0 conv_mfma.hip
+ *   "conv_impl" 0|1    resampling / stride-1 1-D layers and the Conv2d layers the ring kernel has a geometry for (forward and
+ *                      backward-data): 1 (default) the persistent ring kernel (csrc/conv_p.hip), 0 conv_mfma.hip
+ *   "dw2_shared" 0|1|2 conv2d weight gradient: 1 (default) 128 x 128 tiles fetch their operands once per workgroup (two LDS
+ *                      slots, one barrier per item), 2 also the 64- and 32-row tiles (no gain measured), 0 wave-private buffers
  *   "rb_lw" 0|1        diagnostic: resblock_p with a fifth, DMA-only wave (one workgroup per CU; d = 1 instantiations only)
  *   "rb_stagger", "rb_dbg"  retired diagnostics (accepted, no effect)                                      */
 int agx_set_tuning(const char *name, int32_t value);
