@@ -646,9 +646,9 @@ typedef CpGeom<2, 1, 2, 2, 4, 17, 8, 1, 9, 3> CpDown8;    // Conv1d k17 s8:     
 typedef CpGeom<2, 1, 2, 2, 16, 3, 1, 1, 2, 2> CpK3;       // Conv1d k3 s1:             128 x 64
 typedef CpGeom<2, 1, 2, 2, 8, 7, 1, 1, 6, 2> CpK7;        // Conv1d k7 s1 / ConvT k7 s1 (flipped kernel): 128 x 64
 typedef CpGeom<2, 1, 2, 2, 16, 3, 1, 8, 1, 2> CpUp8;      // upsample x8 (J = 3):      128 x 64
-typedef CpGeom<2, 2, 2, 2, 16, 3, 1, 5, 1, 2> CpUp5;      // upsample x5:              128 x 128
-typedef CpGeom<2, 2, 2, 2, 16, 3, 1, 4, 1, 2> CpUp4;      // upsample x4:              128 x 128
-typedef CpGeom<2, 2, 1, 4, 16, 3, 1, 2, 1, 2> CpUp2;      // upsample x2, M = 64:       64 x 256
+typedef CpGeom<2, 2, 2, 2, 8, 3, 1, 5, 1, 2> CpUp5;       // upsample x5:              128 x 128
+typedef CpGeom<2, 2, 2, 2, 8, 3, 1, 4, 1, 2> CpUp4;       // upsample x4:              128 x 128
+typedef CpGeom<2, 2, 1, 4, 8, 3, 1, 2, 1, 2> CpUp2;       // upsample x2, M = 64:       64 x 256
 
 // Conv2d (row-folded; the kernel's row count / row stride / row padding are run-time):
 //                      MW NW WM WN CCH  J  S  Q  P NS  D2
