@@ -640,6 +640,7 @@ static int launch_cp2d(const ConvPlan &p, const float *x, const float *wp, const
 // ---- layer geometries the kernel is instantiated for -------------------------------------------------------------------
 //                      MW NW WM WN CCH  J  S  Q  P NS
 typedef CpGeom<2, 2, 1, 4, 8, 5, 2, 1, 3, 2> CpDown2;     // Conv1d k5 s2, M = 64:      64 x 256 tiles
+typedef CpGeom<2, 2, 2, 2, 4, 7, 3, 1, 4, 2> CpDown3;     // Conv1d k7 s3 (the class-default strides (2, 3, 4, 4, 5), vae.py:215): 128 x 128
 typedef CpGeom<2, 2, 2, 2, 4, 9, 4, 1, 5, 2> CpDown4;     // Conv1d k9 s4:             128 x 128
 typedef CpGeom<2, 2, 2, 2, 4, 11, 5, 1, 6, 2> CpDown5;    // Conv1d k11 s5:            128 x 128
 typedef CpGeom<2, 1, 2, 2, 4, 17, 8, 1, 9, 3> CpDown8;    // Conv1d k17 s8:            128 x 64 (one workgroup per CU)
@@ -648,6 +649,7 @@ typedef CpGeom<2, 1, 2, 2, 8, 7, 1, 1, 6, 2> CpK7;        // Conv1d k7 s1 / Conv
 typedef CpGeom<2, 1, 2, 2, 16, 3, 1, 8, 1, 2> CpUp8;      // upsample x8 (J = 3):      128 x 64
 typedef CpGeom<2, 2, 2, 2, 8, 3, 1, 5, 1, 2> CpUp5;       // upsample x5:              128 x 128
 typedef CpGeom<2, 2, 2, 2, 8, 3, 1, 4, 1, 2> CpUp4;       // upsample x4:              128 x 128
+typedef CpGeom<2, 2, 1, 4, 8, 3, 1, 3, 1, 2> CpUp3;       // upsample x3 (M = 3 Cout = 192 for 128 -> 64): 64 x 256
 typedef CpGeom<2, 2, 1, 4, 8, 3, 1, 2, 1, 2> CpUp2;       // upsample x2, M = 64:       64 x 256
 
 // Conv2d (row-folded; the kernel's row count / row stride / row padding are run-time):
@@ -750,7 +752,7 @@ int launch_conv_p2d(const ConvPlan &p, const float *x, const float *wp, const fl
     }
 }
 
-enum { CP_NONE = 0, CP_DOWN2, CP_DOWN4, CP_DOWN5, CP_DOWN8, CP_K3, CP_K7, CP_UP8, CP_UP5, CP_UP4, CP_UP2 };
+enum { CP_NONE = 0, CP_DOWN2, CP_DOWN4, CP_DOWN5, CP_DOWN8, CP_K3, CP_K7, CP_UP8, CP_UP5, CP_UP4, CP_UP2, CP_DOWN3, CP_UP3 };
 
 template <class G>
 static bool cp_fits(const ConvPlan &p) {
@@ -763,6 +765,7 @@ int conv_p_geometry(const ConvPlan &p) {
     if (p.prec != 0 || p.G != 1 || p.d != 1 || p.kh != 1 || p.Tout != 1 || p.pm_R != 0) return CP_NONE;
     const int J = p.J, S = p.s, Q = p.q, P = p.P;
     if (Q == 1 && J == 5 && S == 2 && P == 3 && p.M == 64 && cp_fits<CpDown2>(p)) return CP_DOWN2;
+    if (Q == 1 && J == 7 && S == 3 && P == 4 && cp_fits<CpDown3>(p)) return CP_DOWN3;
     if (Q == 1 && J == 9 && S == 4 && P == 5 && cp_fits<CpDown4>(p)) return CP_DOWN4;
     if (Q == 1 && J == 11 && S == 5 && P == 6 && cp_fits<CpDown5>(p)) return CP_DOWN5;
     if (Q == 1 && J == 17 && S == 8 && P == 9 && cp_fits<CpDown8>(p)) return CP_DOWN8;
@@ -771,6 +774,7 @@ int conv_p_geometry(const ConvPlan &p) {
     if (Q == 8 && J == 3 && S == 1 && P == 1 && cp_fits<CpUp8>(p)) return CP_UP8;
     if (Q == 5 && J == 3 && S == 1 && P == 1 && cp_fits<CpUp5>(p)) return CP_UP5;
     if (Q == 4 && J == 3 && S == 1 && P == 1 && cp_fits<CpUp4>(p)) return CP_UP4;
+    if (Q == 3 && J == 3 && S == 1 && P == 1 && cp_fits<CpUp3>(p)) return CP_UP3;
     if (Q == 2 && J == 3 && S == 1 && P == 1 && p.M == 64 && cp_fits<CpUp2>(p)) return CP_UP2;
     return CP_NONE;
 }
@@ -796,6 +800,8 @@ const char *conv_p_variant(const ConvPlan &p) {
         case CP_UP5: return "conv_p<up5,128x128>";
         case CP_UP4: return "conv_p<up4,128x128>";
         case CP_UP2: return "conv_p<up2,64x256>";
+        case CP_DOWN3: return "conv_p<down3,128x128>";
+        case CP_UP3: return "conv_p<up3,64x256>";
         default: return "conv_p<unsupported>";
     }
 }
@@ -813,6 +819,8 @@ int launch_conv_p(const ConvPlan &p, const float *x, const float *wp, const floa
         case CP_UP5: return launch_cp<CpUp5>(p, x, wp, bias, y, st);
         case CP_UP4: return launch_cp<CpUp4>(p, x, wp, bias, y, st);
         case CP_UP2: return launch_cp<CpUp2>(p, x, wp, bias, y, st);
+        case CP_DOWN3: return launch_cp<CpDown3>(p, x, wp, bias, y, st);
+        case CP_UP3: return launch_cp<CpUp3>(p, x, wp, bias, y, st);
         default: return fail(AGX_ERR_UNSUPPORTED, "conv_p: unsupported layer");
     }
 }

@@ -18,6 +18,8 @@ LAYERS = [
     ("down8", "conv", 256, 512, 17, 8), ("k3", "conv", 512, 512, 3, 1), ("k7", "convt", 512, 512, 7, 1),
     ("k7", "conv", 128, 256, 7, 1), ("up8", "upconv", 512, 256, 17, 8), ("up5", "upconv", 256, 128, 11, 5),
     ("up4", "upconv", 128, 64, 9, 4), ("up2", "upconv", 64, 32, 5, 2),
+    # the class-default strides (2, 3, 4, 4, 5) of CausalVQAE (vae.py:215)
+    ("down3", "conv", 64, 128, 7, 3), ("up3", "upconv", 128, 64, 7, 3), ("down4", "conv", 256, 512, 9, 4), ("up4", "upconv", 512, 256, 9, 4),
 ]
 
 
