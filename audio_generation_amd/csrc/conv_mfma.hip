@@ -319,6 +319,13 @@ static const Variant *select_variant(const ConvPlan &p) {
     const int n = p.M >= 128 ? 3 : 5;
     if (p.M >= 128 && tuning().conv_shape == 1) list = kWideAlt;
     const Variant *v = pick(list, n, p, p.prec ? 16 : tuning().conv_cc);
+    // row-folded 2-D layers with few rows (the 2-channel 7x7 first conv of the STFT discriminators) on narrow maps: a tile
+    // is ONE output row, so the 512-column tile of kNarrow's first entry is 25-50 % full on 128 / 256-column maps
+    // (4.4 ms against 1.1 ms for the same work on 1024 columns): 128-column tiles there
+    if (v && list == kNarrow && !p.pm_R && (p.kh > 1 || p.Tout > 1) && p.Lt <= 256 && !p.prec && !tuning().conv_cc) {
+        const Variant *vn = pick(kNarrow + 2, 2, p, 0);
+        if (vn) v = vn;
+    }
     if (v && p.M >= 128 && tuning().conv_short && !p.pm_R) {
         // Short signals: the same channel chunk (= the same summation order, so results do not depend on
         // the batch size or the signal length) on 128 x 64 tiles.
