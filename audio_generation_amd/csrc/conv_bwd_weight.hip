@@ -988,18 +988,19 @@ __global__ __launch_bounds__(256, 2) void conv2d_bwd_weight_shared_kernel(Bw2dGe
     };
     // operands of this wave's fragments out of a slot: A blocks wm MW + i, B blocks NBA + wn NW + k
     auto read_slot = [&](const float *slot, f32x4 (&A)[MW][4], f32x4 (&Bv)[NW][4]) {
+        // position-major: the operands of the item's first MFMAs arrive first, the rest while those MFMAs issue (the DMA goes
+        // to the OTHER slot, so nothing has to be in registers before it starts)
         const int rd_off = (li >> 3) * 256 + (li & 7) * 32;
 #pragma unroll
-        for (int i = 0; i < MW; ++i)
+        for (int e = 0; e < 4; ++e) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int i = 0; i < MW; ++i)
                 A[i][e] = *reinterpret_cast<const f32x4 *>(slot + (wm * MW + i) * 1024 + rd_off + 4 * ((4 * lh + e) ^ (li & 7)));
 #pragma unroll
-        for (int k = 0; k < NW; ++k)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int k = 0; k < NW; ++k)
                 Bv[k][e] = *reinterpret_cast<const f32x4 *>(slot + (NBA + wn * NW + k) * 1024 + rd_off +
                                                             4 * ((4 * lh + e) ^ (li & 7)));
+        }
     };
     auto mask_cols = [&](f32x4 (&Bv)[NW][4], int fc) {
 #pragma unroll
@@ -1059,7 +1060,6 @@ __global__ __launch_bounds__(256, 2) void conv2d_bwd_weight_shared_kernel(Bw2dGe
             float *cur = dma_buf + (n & 1) * SLOTF, *nxt = dma_buf + ((n + 1) & 1) * SLOTF;
             read_slot(cur, A0, B0);
             dma(min(item + n + 1, last), nxt);             // the other slot: everyone left it at the last barrier
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int fcn = (item + n) % FC;
             if (fcn == 0 || fcn == FC - 1) mask_cols(B0, fcn);
             compute(A0, B0);
