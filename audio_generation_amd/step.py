@@ -111,7 +111,8 @@ def training_backward(model, x: Tensor, discriminators: Sequence = (), *, genera
                             use_commit_loss=True, update_codebook=False, prioritize_early=False, codebook_n=None),
                      **terms})
     if not discriminators:
-        loss.backward()
+        if loss.requires_grad:
+            loss.backward()
         return loss.detach(), None, {k: float(v.detach()) for k, v in parts.items()}
     y_leaf = y.detach().requires_grad_(True)
     total, d_total = loss.detach().clone(), y.new_zeros(())
@@ -124,5 +125,8 @@ def training_backward(model, x: Tensor, discriminators: Sequence = (), *, genera
         del g_i, d_i
     d_total = d_total * generator_loss_weight
     parts["discriminator_loss"] = d_total
-    torch.autograd.backward([loss, y], [torch.ones_like(loss), y_leaf.grad])
+    if loss.requires_grad:      # (every reconstruction-side term switched off: only the discriminators' gradient on y is left)
+        torch.autograd.backward([loss, y], [torch.ones_like(loss), y_leaf.grad])
+    else:
+        y.backward(y_leaf.grad)
     return total, d_total, {k: float(v.detach()) for k, v in parts.items()}
