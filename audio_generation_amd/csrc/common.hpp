@@ -35,11 +35,7 @@ struct Tuning {
     int conv_shape = 0; // diagnostic: 1 = 128x128 conv tiles as 4 row-waves x (1x4) fragments
     int conv_short = 1; // 1: 128x64 conv tiles when the 128x128 grid is under two workgroups per CU
     int rb_occ = 2;    // 3: build of the fused residual block capped at 168 VGPRs (3 waves/SIMD)
-    int rb_stagger = 0; // diagnostic: odd-slot workgroups of the fused residual block start rb_stagger x ~1k cycles late
-    int rb_dbg = 0;     // diagnostic bit mask of resblock_p.hip (timing-only builds: 1 no steady-state DMA, 2 no residual loads, 4 1/16 of the stores)
-    int rb_lw = 0;      // retired diagnostic (a fifth, DMA-only wave per workgroup: slower); accepted, no effect
     int conv_impl = 1;  // resampling / stride-1 1-D layers: 1 = persistent ring kernel (conv_p.hip) where it applies, 0 = conv_mfma.hip
-    int rb_defer = 1;   // retired diagnostic (deferred tile stores: slower, resblock_p.hip); accepted, no effect
     int rb_impl = 1;    // fused residual block: 1 = persistent ring kernel (resblock_p.hip) where it applies, 0 = resblock_mfma.hip
     int rb_sched = -1; // phase scheduling of the fused residual block (mfma_tile.hpp: 0 / 1 / 2; -1 = per-shape table)
 };

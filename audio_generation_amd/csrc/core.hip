@@ -227,12 +227,8 @@ int agx_set_tuning(const char *name, int32_t value) {
     else if (!strcmp(name, "rb_wgs")) agx::tuning().rb_wgs = value;
     else if (!strcmp(name, "rb_sched")) agx::tuning().rb_sched = value;
     else if (!strcmp(name, "rb_occ")) agx::tuning().rb_occ = value;
-    else if (!strcmp(name, "rb_stagger")) agx::tuning().rb_stagger = value;
     else if (!strcmp(name, "rb_impl")) agx::tuning().rb_impl = value;
     else if (!strcmp(name, "conv_impl")) agx::tuning().conv_impl = value;
-    else if (!strcmp(name, "rb_dbg")) agx::tuning().rb_dbg = value;
-    else if (!strcmp(name, "rb_lw")) agx::tuning().rb_lw = value;
-    else if (!strcmp(name, "rb_defer")) agx::tuning().rb_defer = value;
     else if (!strcmp(name, "bf_sched")) agx::tuning().bf_sched = value;
     else if (!strcmp(name, "patch_tie")) agx::tuning().patch_tie = value;
     else if (!strcmp(name, "dw2_direct")) agx::tuning().dw2_direct = value;
@@ -253,12 +249,8 @@ int agx_get_tuning(const char *name) {
     if (!strcmp(name, "rb_wgs")) return agx::tuning().rb_wgs;
     if (!strcmp(name, "rb_sched")) return agx::tuning().rb_sched;
     if (!strcmp(name, "rb_occ")) return agx::tuning().rb_occ;
-    if (!strcmp(name, "rb_stagger")) return agx::tuning().rb_stagger;
     if (!strcmp(name, "rb_impl")) return agx::tuning().rb_impl;
     if (!strcmp(name, "conv_impl")) return agx::tuning().conv_impl;
-    if (!strcmp(name, "rb_dbg")) return agx::tuning().rb_dbg;
-    if (!strcmp(name, "rb_lw")) return agx::tuning().rb_lw;
-    if (!strcmp(name, "rb_defer")) return agx::tuning().rb_defer;
     if (!strcmp(name, "bf_sched")) return agx::tuning().bf_sched;
     if (!strcmp(name, "patch_tie")) return agx::tuning().patch_tie;
     if (!strcmp(name, "dw2_direct")) return agx::tuning().dw2_direct;

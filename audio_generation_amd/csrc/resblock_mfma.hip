@@ -21,7 +21,7 @@
 namespace agx {
 
 template <int MW, int NW, int CC, int SCHED = kSchedDefault, int OCC = (MW <= 4 ? 2 : 1), int PREC = 0>   // PREC 1: bf16x3 (SCHED = its schedule)
-__global__ __launch_bounds__(256, OCC) void resblock_mfma_kernel(ConvPlan p, int span, int post_act, int stagger,
+__global__ __launch_bounds__(256, OCC) void resblock_mfma_kernel(ConvPlan p, int span, int post_act,
                                                             const float *__restrict__ x,
                                                             const float *__restrict__ w1,
                                                             const float *__restrict__ b1,
@@ -37,13 +37,6 @@ __global__ __launch_bounds__(256, OCC) void resblock_mfma_kernel(ConvPlan p, int
     const int b = blockIdx.y;
     const int in0 = t0 - p.P;  // stride 1
 
-    if (stagger > 0) {
-        // diagnostic (knob rb_stagger): workgroups whose waves sit in an odd wave slot of their SIMD start late, so that
-        // the two workgroups of a CU do not run prologue / DMA issue / epilogue in lockstep
-        const unsigned wslot = __builtin_amdgcn_s_getreg((3 << 11) | 4);   // HW_REG_HW_ID[3:0] = wave slot on the SIMD
-        if (wslot & 1)
-            for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(16);   // ~1k cycles each
-    }
     AGX_STAMP(0);
     f32x16 acc[MW][NW];
 #pragma unroll
@@ -215,7 +208,7 @@ static int launch_rb(const ConvPlan &p, const float *x, const float *w1, const f
     }
     dim3 grid(ceil_div(p.Lin, BN), p.B), block(256);
     if (grid.y > 65535) return fail(AGX_ERR_BAD_SHAPE, "resblock: batch too large for one launch");
-    hipLaunchKernelGGL(kern, grid, block, lds, st, p, span, post_act, tuning().rb_stagger, x, w1, b1, w2, b2, y);
+    hipLaunchKernelGGL(kern, grid, block, lds, st, p, span, post_act, x, w1, b1, w2, b2, y);
     return check_launch("resblock_mfma");
 }
 

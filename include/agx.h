@@ -67,8 +67,8 @@ int32_t agx_sizeof_conv2d_desc(void);
  *                      backward-data): 1 (default) the persistent ring kernel (csrc/conv_p.hip), 0 conv_mfma.hip
  *   "dw2_shared" 0|1|2 conv2d weight gradient: 1 (default) 128 x 128 tiles fetch their operands once per workgroup (two LDS
  *                      slots, one barrier per item), 2 also the 64- and 32-row tiles (no gain measured), 0 wave-private buffers
- *   "rb_lw" 0|1        diagnostic: resblock_p with a fifth, DMA-only wave (one workgroup per CU; d = 1 instantiations only)
- *   "rb_stagger", "rb_dbg"  retired diagnostics (accepted, no effect)                                      */
+ *   (the diagnostics of the experiments DESIGN 4.11 lists as dropped -- a DMA-only wave, start staggers, deferred stores --
+ *    were removed together with their code)                                                                */
 int agx_set_tuning(const char *name, int32_t value);
 int agx_get_tuning(const char *name);
 
