@@ -785,6 +785,10 @@ bool conv_p_supported(const ConvPlan &p) {
     if ((p.epilogue & ~AGX_EPI_LEAKY_PRE) != 0 || p.oshift != 0 || p.mask != nullptr) return false;
     if (p.Lvalid != p.Lin || p.Lin < 4 || p.Lout != p.q * p.Lt) return false;   // (ragged L: fix_ragged)
     if (p.q > 1 && p.q % 4 == 0 && (p.Lout % 4 != 0)) return false;
+    // 32-bit byte offsets inside a clip (DMA cells: row * Lin + 4 * col; stores: row * Lout + t): very long clips fall back
+    // to conv_mfma, whose addressing is 64-bit
+    if (int64_t(16) * p.Lin * 4 >= (int64_t(1) << 31)) return false;
+    if (int64_t(p.Cout) * p.Lout * 4 >= (int64_t(1) << 32)) return false;
     return true;
 }
 

@@ -500,6 +500,7 @@ bool resblock_p_supported(const ConvPlan &p) {
     if (p.prec != 0 || p.Cin != p.Cout || p.s != 1 || p.q != 1 || p.J != 7 || p.G != 1) return false;
     if (p.Lvalid != p.Lin || p.Lt != p.Lin || p.Lin % 4 != 0 || p.Lin < 4) return false;
     if (p.Cin != 32 && p.Cin != 64 && p.Cin != 128 && p.Cin != 256) return false;
+    if (int64_t(p.Cin) * p.Lin * 4 >= (int64_t(1) << 32)) return false;   // 32-bit byte offsets inside a clip
     return p.d == 1 || p.d == 3 || p.d == 9;
 }
 

@@ -56,6 +56,16 @@ def max_over_ranks(value: float, device="cpu") -> float:
     return float(t.item())
 
 
+def gather_floats(value: float, device="cpu") -> List[float]:
+    """Every rank's scalar, in rank order, on every rank (bench.py prints per-rank step times with it)."""
+    if not dist.is_initialized():
+        return [float(value)]
+    mine = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]
+
+
 def sum_over_ranks(value: float, device="cpu") -> float:
     if not dist.is_initialized():
         return float(value)

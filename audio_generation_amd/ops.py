@@ -212,10 +212,10 @@ def rvq_pack(codebooks: Tensor, sizes: Optional[Sequence[int]] = None) -> Tensor
 
 
 def rvq_forward(x: Tensor, codebooks: Tensor, packed: Tensor, q_used: int,
-                layout: str = "b l c") -> Tuple[Tensor, Tensor, Tensor]:
+                layout: str = "b l c") -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     """x: (B,T,D) for layout "b l c" or (B,D,T) for "b c l" (any strides).
-    Returns (x_q in the same layout/shape, index (B,T,q_used) int64, sq_err (q_used) f64); the commit loss
-    sum(sq_err) / x.numel() computed by the same launch is left in ``rvq_forward.last_commit`` (0-d f32 tensor)."""
+    Returns (x_q in the same layout/shape, index (B,T,q_used) int64, sq_err (q_used) f64, commit): the commit loss
+    sum(sq_err) / x.numel() is a 0-d f32 tensor written by the same launch."""
     lib = _lib.load()
     _need_gpu(x, codebooks, packed)
     if x.dtype != torch.float32:
@@ -255,8 +255,7 @@ def rvq_forward(x: Tensor, codebooks: Tensor, packed: Tensor, q_used: int,
     if q_used == 0:
         xq.zero_()
         commit.zero_()
-    rvq_forward.last_commit = commit
-    return xq, index, buf[:q_used]
+    return xq, index, buf[:q_used], commit
 
 
 def rvq_ema_stats(frames: Tensor, codebooks: Tensor, index: Tensor) -> Tensor:

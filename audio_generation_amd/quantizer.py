@@ -19,9 +19,18 @@ The forward search is the HIP kernel; the codebook *update* rules of the
 external module (EMA / SOM neighbourhoods) are unknown and training-only, so
 ``update_codebook=True`` applies a plain EMA k-means update (build-defined,
 torch bookkeeping, not on the measured path).
+
+**Not performed** (their definition lives in the absent ``som_quantizer``; parity unpinned): the SOM
+neighbourhood update (``use_som`` / ``som_kernel_type``, ``vae.py:249-250``), early-stage prioritisation
+(``prioritize_early``, ``training.py:325-328``) and stale-code replacement (``vq_cutoff_freq`` only feeds
+``get_stale_clusters()``).  The kwargs are accepted so the reference's constructor calls and shipped YAML
+(``config/training.yml``: ``use_som: True``) keep working; the first time one of them would have changed the
+result -- ``update_codebook=True`` with ``use_som=True``, or ``prioritize_early=True`` -- a
+``UserWarning`` says so, once per process.
 """
 from __future__ import annotations
 
+import warnings
 from typing import List, Optional
 
 import torch
@@ -64,6 +73,15 @@ class _Stage(nn.Module):
     def dequantize(self, idx: Tensor) -> Tensor:
         """``(..,) int -> (.., D)`` gather (call site vae.py:333)."""
         return ops.rvq_dequantize(self.codebook.detach(), idx)
+
+
+_WARNED = set()
+
+
+def _warn_once(key: str, message: str) -> None:
+    if key not in _WARNED:
+        _WARNED.add(key)
+        warnings.warn(message, UserWarning, stacklevel=3)
 
 
 class ResidualQuantizer(nn.Module):
@@ -110,10 +128,21 @@ class ResidualQuantizer(nn.Module):
     def _q_used(self, codebook_n) -> int:
         return self.num_quantizers if codebook_n is None else max(0, min(int(codebook_n), self.num_quantizers))
 
-    def _quantize(self, x: Tensor, layout: str, codebook_n, update_codebook: bool):
+    def _quantize(self, x: Tensor, layout: str, codebook_n, update_codebook: bool, prioritize_early: bool = False):
         q_used = self._q_used(codebook_n)
-        xq, index, sq_err = ops.rvq_forward(x.detach(), self.codebooks.detach(), self._packed_codebooks(), q_used,
-                                            layout)
+        if prioritize_early:
+            _warn_once("prioritize_early",
+                       "audio_generation_amd.ResidualQuantizer: prioritize_early=True is accepted but IGNORED -- its "
+                       "definition lives in the external `som_quantizer` module, which is absent from the reference tree "
+                       "(parity unpinned); every stage is treated alike.")
+        if update_codebook and self.training and self.use_som:
+            _warn_once("use_som",
+                       "audio_generation_amd.ResidualQuantizer: use_som=True is accepted but the SOM neighbourhood update "
+                       f"(som_kernel_type={self.som_kernel_type!r}) and stale-code replacement are NOT performed -- their "
+                       "definition lives in the external `som_quantizer` module, which is absent from the reference tree "
+                       "(parity unpinned); update_codebook=True applies the build-defined plain EMA k-means update only.")
+        xq, index, sq_err, commit_eval = ops.rvq_forward(x.detach(), self.codebooks.detach(), self._packed_codebooks(),
+                                                         q_used, layout)
         if torch.is_grad_enabled() and x.requires_grad:
             # training semantics (build-defined, the external module's are unknown): straight-through
             # estimator for x_q, and a commitment loss that is differentiable in the encoder output --
@@ -126,7 +155,7 @@ class ResidualQuantizer(nn.Module):
                 commit = commit + ((x - partial) ** 2).mean()
             xq = x + (xq - x).detach()
         else:
-            commit = ops.rvq_forward.last_commit          # sum(sq_err) / numel, written by the search launch itself
+            commit = commit_eval                          # sum(sq_err) / numel, written by the search launch itself
         if update_codebook and self.training:
             frames = x if layout == "b l c" else x.transpose(1, 2)
             self._ema_update(frames.reshape(-1, self.dim), index.reshape(-1, q_used))
@@ -134,11 +163,11 @@ class ResidualQuantizer(nn.Module):
 
     def quantize_bcl(self, x: Tensor, codebook_n=None, update_codebook=False, prioritize_early=False):
         """Native entry used by ``CausalVQAE.encode``: (B,D,T) in, (B,D,T) out."""
-        return self._quantize(x, "b c l", codebook_n, update_codebook)
+        return self._quantize(x, "b c l", codebook_n, update_codebook, prioritize_early)
 
     def forward(self, x: Tensor, codebook_n=None, update_codebook=False, prioritize_early=False):
         """Reference call contract (vae.py:315-318): (B,T,D) -> (x_q, index, commit_loss)."""
-        return self._quantize(x, "b l c", codebook_n, update_codebook)
+        return self._quantize(x, "b l c", codebook_n, update_codebook, prioritize_early)
 
     # --------------------------------------------------------- training bookkeeping
     def _invalidate_packed(self) -> None:
@@ -154,25 +183,32 @@ class ResidualQuantizer(nn.Module):
         Data parallel (the reference toggles ``update_codebook`` inside the step,
         training.py:305-308, 326): the per-code assignment counts (K,) and residual sums (K,D) of all
         stages travel in ONE all-reduce (sum over ranks), so every replica applies the same global-batch
-        statistics and the codebooks stay bit-identical across ranks.  ``stats`` (q_used, K, D+1): this rank's
-        statistics if the caller already holds them (host-logic tests); otherwise one ``agx_rvq_ema_stats`` launch."""
+        statistics and the codebooks stay bit-identical across ranks -- also when the ranks drew different
+        ``codebook_n`` (fixed-shape collective, see below).  ``stats`` (q_used, K, D+1): this rank's statistics if the
+        caller already holds them (host-logic tests); otherwise one ``agx_rvq_ema_stats`` launch."""
         from . import dist as agx_dist
         q_used = index.shape[1]
         cb = self.codebooks.detach()            # shares storage and version counter with the module's tensor
         # counts and sums of the residual each stage's search saw (against the PRE-update codewords), one launch,
         # added in frame order: the update is reproducible run to run (index_add_ on the device is not)
-        if stats is None:
-            stats = ops.rvq_ema_stats(frames, cb, index)
-        else:
-            stats = stats.clone()
+        own = ops.rvq_ema_stats(frames, cb, index) if stats is None else stats
+        # The collective has ONE shape whatever this step's codebook_n: the reference draws codebook_n per process
+        # (training.py:294), so ranks may run different numbers of stages -- an all-reduce whose size depends on it
+        # would hang or corrupt.  Stages this rank did not run contribute zeros.
+        stats = own.new_zeros(self.num_quantizers, self.codebook_size, self.dim + 1)
+        stats[:q_used].copy_(own)
         agx_dist.allreduce_sum_(stats)
-        for q in range(q_used):
+        for q in range(self.num_quantizers):
             counts, sums = stats[q, :, 0], stats[q, :, 1:]
-            self.cluster_frequency[q].mul_(self.ema_decay).add_(counts, alpha=1 - self.ema_decay)
+            # a stage NO rank ran (global count 0) is left untouched, as in the single-process loop over q_used stages;
+            # decided on the device from the all-reduced counts: identical on every rank, no host sync
+            ran = (counts.sum() > 0).to(counts.dtype)
+            decay = 1.0 - ran * (1.0 - self.ema_decay)
+            self.cluster_frequency[q].mul_(decay).add_(counts, alpha=1 - self.ema_decay)
             if self.quantizer_class != "base":
-                self.ema_sum[q].mul_(self.ema_decay).add_(sums, alpha=1 - self.ema_decay)
+                self.ema_sum[q].mul_(decay).add_(sums, alpha=1 - self.ema_decay)
                 denom = self.cluster_frequency[q].clamp_min(1e-5).unsqueeze(1)
-                cb[q].copy_(self.ema_sum[q] / denom)
+                cb[q].copy_(torch.where(ran > 0, self.ema_sum[q] / denom, cb[q]))
                 cb[q, self.codebook_sizes[q]:] = 0.0
         self._invalidate_packed()
 

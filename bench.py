@@ -143,6 +143,20 @@ def encoder_roofline(model, x, bsz, enc_bytes, reps=10):
 
 
 # ----------------------------------------------------------------------------- main
+def encoder_roofline_bf16x3(model, x, bsz):
+    """The encoder on the bf16x3 kernels (NOT the supported configuration: it decides integers): same byte model, the
+    FLOP ceiling is the bf16 matrix pipe at 6 bf16 flops per fp32-equivalent flop."""
+    model.set_conv_arithmetic(decoders="fp32", encoders="bf16x3")
+    try:
+        r = encoder_roofline(model, x, bsz, 4864.0)
+    finally:
+        model.set_conv_arithmetic(decoders="fp32", encoders="fp32")
+    r["arithmetic"] = "bf16x3"
+    r["frac_of_bf16_peak_executed"] = 6 * r["tflops"] / PEAK_BF16_TFLOPS
+    r.pop("frac_of_fp32_peak"), r.pop("hbm_frac_ceiling_in_fp32")
+    return r
+
+
 def make_inputs(batch, rank):
     gen = torch.Generator().manual_seed(1234 + rank)   # SURVEY 8d
     return (0.1 * torch.randn(batch, 1, CLIP, generator=gen)).clamp(-1, 1)
@@ -186,6 +200,39 @@ def pmc_entry(pmc, dom_name):
         if k.startswith(stem + ",") and (ring or k.rstrip(">").rsplit(",", 1)[1] == want):
             hits.append(k)
     return hits if ring else hits[:1]
+
+
+def parity_block(model, sd, spec, y_gpu, idx_gpu, z_gpu, cpu_run):
+    """GPU vs oracle on the bounded sample (same inputs / weights / codebooks):
+      (a) oracle RVQ on the GPU's latents must give the GPU's indices exactly;
+      (b) waveform RMS vs the oracle decode of those codes;
+      (c) the fully independent CPU path -- agreement, and the near-tie PROOF of every first disagreement
+          (oracle/neartie.py: both top-2 margins <= 2 |delta| |c_a - c_b|, delta = measured latent difference).
+    ``cpu_run`` = (z, idx, y) of the oracle's own forward on the same clips."""
+    from oracle import codec, neartie, rvq
+    cbs = model.quantizer.codebooks.detach().cpu()
+    z, idx, y = cpu_run
+    n, t = idx.shape[:2]
+    frames_gpu = z_gpu.cpu().transpose(1, 2).contiguous()
+    with torch.no_grad():
+        zq_g, idx_g, _ = rvq.residual_quantize(frames_gpu, cbs)
+        y_g = codec.decode_latents(zq_g, sd, spec)
+    rep = neartie.explain_disagreements(frames_gpu.reshape(n * t, -1).numpy(), z.reshape(n * t, -1).numpy(),
+                                        idx_gpu.cpu().reshape(n * t, -1).numpy(), idx.reshape(n * t, -1).numpy(), cbs.numpy())
+    return {
+        "distinct_stage0_codes_in_sample": int(idx_gpu[..., 0].unique().numel()),
+        "distinct_codes_per_stage_in_sample": [int(idx_gpu[..., q].unique().numel()) for q in range(idx_gpu.shape[-1])],
+        "clips": int(n), "frames": int(n * t),
+        "index_bit_exact_on_same_latents": bool(torch.equal(idx_g, idx_gpu.cpu())),
+        "waveform_rms_vs_oracle": float((y_gpu.cpu().double() - y_g.double()).pow(2).mean().sqrt()),
+        "independent_path_index_agreement": float((idx == idx_gpu.cpu()).float().mean()),
+        "independent_path_waveform_rms": float((y_gpu.cpu().double() - y.double()).pow(2).mean().sqrt()),
+        "latent_rms_vs_oracle": float((frames_gpu.double() - z.double()).pow(2).mean().sqrt()),
+        "independent_path_disagreements_proved_near_ties": rep["proved"],
+        "near_tie_report": {k: rep[k] for k in ("frames_with_a_disagreement", "codes_disagreeing", "max_margin_over_bound",
+                                                "max_relative_margin", "max_latent_error_relative", "unexplained",
+                                                "negative_margins")},
+    }
 
 
 def cpu_baseline_and_parity(model, x_cpu, y_gpu, idx_gpu, z_gpu, n_items):
@@ -236,18 +283,7 @@ def cpu_baseline_and_parity(model, x_cpu, y_gpu, idx_gpu, z_gpu, n_items):
     run(xs[:1])
     _, stage1 = run(xs[:1])
     torch.set_num_threads(cores)
-    # parity: (a) oracle RVQ on the GPU's latents must give the GPU's indices exactly;
-    #         (b) waveform RMS vs the oracle decode of those codes; (c) independent path agreement
-    with torch.no_grad():
-        zq_g, idx_g, _ = rvq.residual_quantize(z_gpu[:n_items].cpu().transpose(1, 2).contiguous(), cbs)
-        y_g = codec.decode_latents(zq_g, sd, spec)
-    parity = {
-        "index_bit_exact_on_same_latents": bool(torch.equal(idx_g, idx_gpu[:n_items].cpu())),
-        "waveform_rms_vs_oracle": float((y_gpu[:n_items].cpu().double() - y_g.double()).pow(2).mean().sqrt()),
-        "independent_path_index_agreement": float((idx == idx_gpu[:n_items].cpu()).float().mean()),
-        "independent_path_waveform_rms": float((y_gpu[:n_items].cpu().double() - y.double()).pow(2).mean().sqrt()),
-        "latent_rms_vs_oracle": float((z_gpu[:n_items].cpu().transpose(1, 2).double() - z.double()).pow(2).mean().sqrt()),
-    }
+    parity = parity_block(model, sd, spec, y_gpu[:n_items], idx_gpu[:n_items], z_gpu[:n_items], (z, idx, y))
     nsmp = n_items * CLIP
     base = {"value": nsmp / sec, "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"{n_items} clips x {CLIP} samples (same inputs/weights as the GPU run), "
@@ -255,7 +291,7 @@ def cpu_baseline_and_parity(model, x_cpu, y_gpu, idx_gpu, z_gpu, n_items):
             "cores_available": avail, "thread_probe_s": {str(k): round(v, 4) for k, v in probe.items()},
             "stages": {"encoder": nsmp / stage[0], "rvq": nsmp / stage[1], "decoder": nsmp / stage[2]},
             "one_thread": {"value": CLIP / sum(stage1), "sample": f"1 clip x {CLIP} samples, 1 thread, 1 timed after 1 warm-up"}}
-    return base, parity
+    return base, parity, (sd, spec, z)
 
 
 def main():
@@ -270,7 +306,7 @@ def main():
     ap.add_argument("--arith", choices=("fp32", "mixed"), default="fp32",
                     help="arithmetic of the MEASURED configuration: fp32 = fp32-input MFMA everywhere (bitwise an fp32 FMA "
                          "chain); mixed = encoder + RVQ as fp32, decoder on the bf16x3 kernels (fp32-class accuracy)")
-    ap.add_argument("--codebooks", choices=("survey", "latents"), default="survey",
+    ap.add_argument("--codebooks", choices=("survey", "latents"), default="latents",
                     help="synthetic codebook recipe of the measured run (see calibrate_codebooks); the other one is "
                          "measured as well and reported under other_codebooks")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurement of the other arithmetic")
@@ -326,7 +362,9 @@ def main():
     torch.cuda.synchronize()
     agx_dist.barrier()
     torch.cuda.synchronize()
-    elapsed = agx_dist.max_over_ranks(time.perf_counter() - t0, device=red_dev)
+    mine = time.perf_counter() - t0
+    elapsed = agx_dist.max_over_ranks(mine, device=red_dev)
+    per_rank_ms = agx_dist.gather_floats(1e3 * mine / args.steps, device=red_dev)   # a straggler shows up here
     y, commit, index = out
     distinct0 = int(index[..., 0].unique().numel())
 
@@ -336,6 +374,7 @@ def main():
         "metric": "24kHz samples/s encode->RVQ->decode", "value": total_samples / elapsed, "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms],
         "config": {"workload": "Soundstream default: 8-codebook RVQ (1024 x 512), strides [2,4,5,8], 24 kHz, "
                                f"batch {bsz}/GPU x {CLIP} samples, fp32, eval forward (encode->RVQ->decode)",
                    "batch_per_gpu": bsz, "global_batch": bsz * world, "clip_samples": CLIP,
@@ -393,6 +432,10 @@ def main():
                      "whole_forward_tflops_reference_count": 1e-9 * ref_flops / ms_per_step,
                      "whole_forward_frac_of_fp32_peak": 1e-9 * exec_flops / ms_per_step / PEAK_FP32_TFLOPS,
                      "encoder": encoder_roofline(model, x, bsz, enc_bytes),
+                     "kernels_note": "per-kernel times come from an EAGER instrumented pass (HIP events around every C-ABI call, "
+                                     "outside the timed region); their sum exceeds ms_per_step of the hipGraph replay by the "
+                                     "inter-launch gaps the graph removes",
+                     "kernels_sum_ms_per_step": round(sum(v["ms_per_step"] for v in per.values()), 4),
                      "kernels": {k: {"ms_per_step": round(v["ms_per_step"], 4), "avg_us": round(v["avg_us"], 2),
                                      "launches_per_step": v["launches_per_step"], "tflops": round(v["tflops"], 2),
                                      "gbps": round(v["gbps"], 1)} for k, v in sorted(per.items())}})
@@ -401,10 +444,25 @@ def main():
     if rank == 0 and world == 1 and args.cpu_items > 0:
         with torch.no_grad():
             z_gpu = model._run_encoders(x)
-        base, parity = cpu_baseline_and_parity(model, x_cpu, y, index, z_gpu, min(args.cpu_items, bsz))
+        n_cpu = min(args.cpu_items, bsz)
+        base, parity, (sd_cpu, spec_cpu, z_cpu) = cpu_baseline_and_parity(model, x_cpu, y, index, z_gpu, n_cpu)
+        parity["codebooks"] = args.codebooks
         result["cpu_baseline"] = base
         result["parity"] = parity
         result["speedup_vs_cpu_baseline"] = result["value"] / base["value"]
+        # the same parity block under the OTHER synthetic-codebook recipe (the encoder, hence z, does not depend on it)
+        from oracle import codec as _codec, rvq as _rvq
+        other = "latents" if args.codebooks == "survey" else "survey"
+        keep = {k: v.clone() for k, v in model.quantizer.state_dict().items()}
+        calibrate_codebooks(model, x[:8], other)
+        with torch.no_grad():
+            y_o, _, idx_o = model(x[:n_cpu])
+            cbs_o = model.quantizer.codebooks.detach().cpu()
+            zq_c, idx_c, _ = _rvq.residual_quantize(z_cpu, cbs_o)
+            y_c = _codec.decode_latents(zq_c, sd_cpu, spec_cpu)
+        result["parity_other_codebooks"] = dict(codebooks=other, **parity_block(model, sd_cpu, spec_cpu, y_o, idx_o,
+                                                                                z_gpu[:n_cpu], (z_cpu, idx_c, y_c)))
+        model.quantizer.load_state_dict(keep)
 
     if rank == 0 and world == 1 and not args.no_extra:
         # secondary measurements, outside the timed region and NOT the headline value: the other arithmetics
@@ -430,8 +488,25 @@ def main():
                                           "fp32 chain; the supported opt-in)", **measure("bf16x3", "fp32")))
         else:
             others.append(dict(arithmetic="fp32: fp32-input MFMA everywhere", **measure("fp32", "fp32")))
-        others.append(dict(arithmetic="all bf16x3 (encoder too): shown for the trade-off only -- near-tie indices can flip, so "
-                                      "it is NOT a supported configuration", **measure("bf16x3", "bf16x3")))
+        allbf = dict(arithmetic="all bf16x3 (encoder too): shown for the trade-off only -- near-tie indices can flip, so "
+                                "it is NOT a supported configuration", **measure("bf16x3", "bf16x3"))
+        with torch.no_grad():      # its flips against the fp32 run, put through the near-tie proof (whole batch)
+            from oracle import neartie as _neartie
+            z_bf, idx_bf = model._run_encoders(x), model(x)[2]
+            model.set_conv_arithmetic(decoders="fp32", encoders="fp32")
+            z_fp = model._run_encoders(x)
+            rep = _neartie.explain_disagreements(z_bf.cpu().transpose(1, 2).reshape(-1, z_bf.shape[1]).numpy(),
+                                                 z_fp.cpu().transpose(1, 2).reshape(-1, z_fp.shape[1]).numpy(),
+                                                 idx_bf.cpu().reshape(-1, idx_bf.shape[-1]).numpy(),
+                                                 index.cpu().reshape(-1, index.shape[-1]).numpy(),
+                                                 model.quantizer.codebooks.detach().cpu().numpy())
+            enc = encoder_roofline_bf16x3(model, x, bsz)
+        allbf["flips_vs_fp32_run_proved_near_ties"] = rep["proved"]
+        allbf["near_tie_report"] = {k: rep[k] for k in ("frames", "frames_with_a_disagreement", "codes_disagreeing",
+                                                        "max_margin_over_bound", "max_relative_margin",
+                                                        "max_latent_error_relative", "unexplained", "negative_margins")}
+        allbf["encoder"] = enc
+        others.append(allbf)
         model.set_conv_arithmetic(decoders="bf16x3" if args.arith == "mixed" else "fp32")
         result["other_arithmetic"] = others
         # the other synthetic-codebook recipe, same arithmetic as the measured run (eager)

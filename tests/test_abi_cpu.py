@@ -216,3 +216,22 @@ def test_parameter_order_matches_torch_weight_norm():
                        codebook_size=8, codebook_dim=16, wavelet_decoders=False)
     names = [n for n, _ in model.named_parameters() if n.startswith("encoders.1.")][:3]
     assert [n.rsplit(".", 1)[1] for n in names] == ["bias", "weight_g", "weight_v"]
+
+
+def test_ring_kernels_refuse_clips_beyond_their_32_bit_offsets(lib):
+    """conv_p / resblock_p address inside a clip with 32-bit byte offsets; a clip with Cout * Lout * 4 >= 2^32
+    (or 16 * Lin * 4 >= 2^31) must be lowered to the 64-bit-addressed first-round kernels, decided from the shape alone."""
+    leaky = _lib.EPI_LEAKY_PRE
+    short = ops.conv_desc(_lib.CONV_CAUSAL, 1, 32, 64, 72000, 5, 2, 1, leaky)
+    assert ops.conv_kernel_name(short).startswith("conv_p<down2")
+    for length in (1 << 24, 1 << 25):           # 16 * Lin * 4 = 2^30 (still fine) / 2^31 (must fall back)
+        name = ops.conv_kernel_name(ops.conv_desc(_lib.CONV_CAUSAL, 1, 32, 64, length, 5, 2, 1, leaky))
+        assert name.startswith("conv_p<down2") == (length == 1 << 24), (length, name)
+    up = ops.conv_desc(_lib.CONV_UPSAMPLE, 1, 64, 32, 1 << 23, 5, 2, 1, leaky)          # Cout * Lout * 4 = 2^31: ring
+    assert ops.conv_kernel_name(up).startswith("conv_p<up2")
+    up = ops.conv_desc(_lib.CONV_UPSAMPLE, 1, 64, 32, 1 << 24, 5, 2, 1, leaky)          # = 2^32: not the ring
+    assert not ops.conv_kernel_name(up).startswith("conv_p")
+    rb = ops.conv_desc(_lib.CONV_CAUSAL, 1, 256, 256, 1 << 21, 7, 1, 1)                 # C * L * 4 = 2^31: ring
+    assert ops.resblock_kernel_name(rb).startswith("resblock_p")
+    rb = ops.conv_desc(_lib.CONV_CAUSAL, 1, 256, 256, 1 << 22, 7, 1, 1)                 # = 2^32: first fused kernel
+    assert not ops.resblock_kernel_name(rb).startswith("resblock_p")

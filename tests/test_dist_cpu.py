@@ -148,3 +148,155 @@ def test_ema_update_uses_pre_update_codewords_and_invalidates_pack():
     rq._packed = torch.zeros(1)
     rq.init_randn(0.3)
     assert rq._packed is None
+
+
+# ------------------------------------------------------------------------------------------------ world 4
+def _spawn(target, world, timeout=240):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((out.get(timeout=timeout) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def _different_codebook_n_worker(rank, world, port, out):
+    """the reference draws ``codebook_n`` per PROCESS (``training.py:294``), so ranks may run a
+    different number of stages in the same step; the statistics all-reduce must have one shape regardless."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    agx_dist.init("gloo")
+    from audio_generation_amd.quantizer import ResidualQuantizer
+    from oracle import rvq
+    torch.manual_seed(0)
+    rq = ResidualQuantizer(num_quantizers=4, dim=8, codebook_sizes=16, quantizer_class="ema").train()
+    cb_start = rq.codebooks.clone()
+    gen = torch.Generator().manual_seed(100 + rank)
+    for step in range(3):
+        n = (1, 3)[rank] if step < 2 else (2, 2)[rank]          # ranks disagree on codebook_n; stage 3 never runs
+        x = torch.randn(2, 20, 8, generator=gen)
+        _, index, _ = rvq.residual_quantize(x, rq.codebooks, codebook_n=n)
+        fr, ix = x.reshape(-1, 8), index.reshape(-1, n)
+        rq._ema_update(fr, ix, stats=rvq.ema_assignment_stats(fr, rq.codebooks, ix))
+    lo, hi = agx_dist.replica_checksums(rq)
+    agx_dist.barrier()
+    out.put((rank, rq.codebooks.clone().numpy(), rq.cluster_frequency.clone().numpy(), lo, hi,
+             bool(torch.equal(rq.codebooks[3], cb_start[3])), bool(torch.equal(rq.codebooks[2], cb_start[2]))))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_with_different_codebook_n_stay_in_sync():
+    import numpy as np
+    a, b = _spawn(_different_codebook_n_worker, 2)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert a[3] == a[4] == b[3] == b[4]
+    assert a[5] and b[5]                # the stage no rank ran is untouched (no decay towards zero)
+    assert not a[6] and not b[6]        # the stage only ONE rank ran was updated, from that rank's statistics, on both
+
+
+def _train_worker(rank, world, port, out):
+    """Three data-parallel training steps on CPU: the oracle's autograd statement of the generator step
+    (``step.training_backward`` restated: encode -> RVQ straight-through + commit -> decode -> MSE + commit,
+    ``training.py:325-347, 380``) on this rank's shard of a global batch of 256 = 8 x 32, gradients through
+    ``GradBucket`` (one in-place all-reduce), Adam, EMA codebook statistics all-reduced, per-rank ``codebook_n``."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    agx_dist.init("gloo")
+    from audio_generation_amd.vae import CausalVQAE
+    from oracle import codec, rvq
+    torch.manual_seed(0)
+    kw = dict(in_channels=1, n_blocks=2, strides=(2, 4), first_block_channels=4, num_quantizers=3, codebook_size=16,
+              codebook_dim=8, input_format="n c l", wavelet_decoders=False)
+    model = CausalVQAE(**kw).train()
+    spec = codec.CodecSpec(in_channels=1, n_blocks=2, strides=(2, 4), first_block_channels=4, codebook_dim=8,
+                           wavelet_decoders=False, input_format="n c l")
+    if rank:                                                            # replicas start apart ...
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(0.01 * rank)
+    agx_dist.broadcast_([p.data for p in model.parameters()] + [b for b in model.buffers()])   # ... and are synchronised
+    lo, hi = agx_dist.shard_range(256, rank, world)
+    bucket = agx_dist.GradBucket(model.parameters())
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    data = torch.Generator().manual_seed(77)
+    draw = torch.Generator().manual_seed(500 + rank)                    # every rank draws its OWN codebook_n
+    losses = []
+    for step in range(3):
+        x_global = 0.1 * torch.randn(256, 1, 64, generator=data)        # same global batch on every rank
+        x = x_global[lo:hi]
+        n = int(torch.randint(2, 4, (1,), generator=draw))              # training.py:294: randint(2, Q + 1)
+        sd = dict(model.state_dict(keep_vars=True))
+        z = codec.encode_latents(x, sd, spec)
+        zq, index, commit = rvq.residual_quantize_train(z, model.quantizer.codebooks.detach(), codebook_n=n)
+        y = codec.decode_latents(zq, sd, spec)
+        loss = ((x - y) ** 2).mean() + commit
+        bucket.zero_()
+        loss.backward()
+        bucket.allreduce_mean_()
+        opt.step()
+        fr, ix = z.detach().reshape(-1, 8), index.reshape(-1, n)
+        model.quantizer._ema_update(fr, ix, stats=rvq.ema_assignment_stats(fr, model.quantizer.codebooks.detach(), ix))
+        losses.append(float(loss))
+    cmin, cmax = agx_dist.replica_checksums(model)
+    times = agx_dist.gather_floats(10.0 + rank)
+    agx_dist.barrier()
+    out.put((rank, lo, hi, cmin, cmax, bucket.intact(), times, losses))
+    dist.destroy_process_group()
+
+
+def test_four_rank_training_steps_keep_replicas_in_sync():
+    res = _spawn(_train_worker, 4, timeout=300)
+    spans = [(r[1], r[2]) for r in res]
+    assert spans == [(0, 64), (64, 128), (128, 192), (192, 256)]        # 256 = 8 x 32 over 4 ranks: 64 each
+    cmin = {r[3] for r in res} | {r[4] for r in res}
+    assert len(cmin) == 1                                               # min == max of the state checksum, on every rank
+    assert all(r[5] for r in res)
+    assert all(r[6] == [10.0, 11.0, 12.0, 13.0] for r in res)           # per-rank timings visible on every rank
+    assert all(all(v == v and v < 1e3 for v in r[7]) for r in res)
+    # 8 ranks x 32 clips (the config-5 layout) without running them: the split itself
+    assert [agx_dist.shard_range(256, r, 8) for r in range(8)] == [(32 * r, 32 * r + 32) for r in range(8)]
+
+
+def test_quantizer_says_what_it_ignores():
+    """``use_som`` / ``prioritize_early`` are accepted (the shipped YAML sets ``use_som: True``) but the
+    SOM update / early-stage prioritisation are not performed -- one warning each, never silence."""
+    import warnings
+    from audio_generation_amd import quantizer as qz
+    from oracle import rvq
+    qz._WARNED.clear()
+    rq = qz.ResidualQuantizer(num_quantizers=2, dim=4, codebook_sizes=8, use_som=True, som_kernel_type="hard").train()
+    x = torch.randn(1, 10, 4)
+
+    class _Ops:                                                          # host logic only: the search itself needs the GPU
+        @staticmethod
+        def rvq_forward(xx, cb, packed, q_used, layout):
+            xq, idx, commit = rvq.residual_quantize(xx, cb, codebook_n=q_used)
+            return xq, idx, None, commit
+
+        @staticmethod
+        def rvq_ema_stats(frames, cb, index):
+            return rvq.ema_assignment_stats(frames, cb, index)
+
+    real_ops, real_pack = qz.ops, rq._packed_codebooks
+    qz.ops, rq._packed_codebooks = _Ops, (lambda: None)
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            rq(x)                                                        # eval-style call: nothing ignored yet
+            assert not w
+            rq(x, update_codebook=True)                                  # SOM update would have run here
+            rq(x, update_codebook=True)                                  # ... once per process
+            rq(x, prioritize_early=True)
+            rq(x, prioritize_early=True)
+        msgs = [str(m.message) for m in w]
+    finally:
+        qz.ops, rq._packed_codebooks = real_ops, real_pack
+    assert len(msgs) == 2 and "SOM" in msgs[0] and "prioritize_early" in msgs[1], msgs
+    assert all("som_quantizer" in m and "parity unpinned" in m for m in msgs)

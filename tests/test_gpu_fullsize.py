@@ -69,7 +69,7 @@ def test_rvq_residual_identities(setup):
     cb = model.quantizer.codebooks
     # x_q is the sum of the selected codewords in stage order (bit-exact re-assembly by gather)
     with torch.no_grad():
-        zq, idx, sq = ops.rvq_forward(z, cb, ops.rvq_pack(cb), 8, "b c l")
+        zq, idx, sq, _ = ops.rvq_forward(z, cb, ops.rvq_pack(cb), 8, "b c l")
         acc = None
         for q in range(8):
             acc = ops.rvq_dequantize(cb[q], idx[..., q]) if acc is None else \
@@ -80,7 +80,7 @@ def test_rvq_residual_identities(setup):
     r = z.double() - zq.double()
     assert abs(float(sq[7]) - float((r * r).sum())) < 1e-5 * float(sq[7]) + 1e-9
     # truncating the stage loop is a prefix of the full result
-    _, idx3, _ = ops.rvq_forward(z, cb, ops.rvq_pack(cb), 3, "b c l")
+    _, idx3, _, _ = ops.rvq_forward(z, cb, ops.rvq_pack(cb), 3, "b c l")
     assert torch.equal(idx3, index[..., :3])
     # nearest-neighbour optimality spot check in float64 on 2 000 random (frame, stage-0) pairs
     frames = z.transpose(1, 2).reshape(-1, 512)
