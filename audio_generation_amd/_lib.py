@@ -94,6 +94,11 @@ SIGNATURES = {
     "agx_conv_bwd_data_gelu": (c_int, [_PD, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "agx_multires_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                      c_int32, c_int32, c_void_p]),
+    "agx_multires_backward_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "agx_multires_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_size_t, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                      c_void_p]),
+    "agx_group_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "agx_wavelet_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32,
                                  c_int32, c_int32, c_void_p]),
     "agx_wavelet_fold_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
@@ -195,3 +200,10 @@ def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().agx_last_error()
         raise AgxError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def needs_grad(x, module) -> bool:
+    """True when a forward must record what its backward kernels need (autograd on, and the input or a parameter of
+    ``module`` requires a gradient)."""
+    import torch
+    return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in module.parameters()))

@@ -16,9 +16,9 @@ Forward, all on HIP kernels through the C ABI:
 * loss           -> ``agx_reduce_mean`` / ``agx_reduce_mean_backward`` (every mean of the hinge and
   feature-matching terms, with hand-written gradients).
 
-Backward through the discriminator bodies is bridged through an ATen restatement for now
-(``autograd_bridge.py``; the conv2d / grouped-conv backward kernels are the next row) -- the forward
-never is.
+Backward through the discriminator bodies runs on the HIP kernels as well (``_STFTDiscNative``,
+``_WaveBlockNative``); an activation other than LeakyReLU has no backward kernel and raises -- there is no
+ATen fallback.
 """
 from __future__ import annotations
 
@@ -26,12 +26,10 @@ import warnings
 from typing import List, Optional, Sequence, Tuple
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from . import ops
-from ._lib import CONV_PADDED, EPI_LEAKY_PRE, IMPL_AUTO, IMPL_MFMA_BF16X3
-from .autograd_bridge import needs_grad, require_allowed
+from ._lib import CONV_PADDED, EPI_LEAKY_PRE, IMPL_AUTO, IMPL_MFMA_BF16X3, AgxError, needs_grad
 from .quantizer import tuple_checker
 
 Tensor = torch.Tensor
@@ -72,7 +70,6 @@ class _SNConv(nn.Module):
             self.bias, self.weight = conv.bias, conv.weight
         self._key, self._packed, self._iter = None, None, 0
         self.impl = IMPL_AUTO      # IMPL_MFMA_BF16X3: Conv2d layers with a bf16x3 form run on it (set_arithmetic)
-        self._uv_override = None   # (u, v) of the forward being differentiated (backward bridge only)
         self._tape = None          # (sigma, u, v) of the latest forward (native backward)
 
     @property
@@ -124,17 +121,6 @@ class _SNConv(nn.Module):
             self._key = (w.data_ptr(), w._version, self.training, self._iter, self.impl,
                          getattr(self, "_wn_key", None) if self.norm != "spectral" else (self.weight_u._version, self.weight_v._version))
         return self._packed
-
-    def aten_weight(self) -> Tensor:
-        """Differentiable normalised weight from the CURRENT buffers (no power iteration): backward bridge."""
-        if self.norm == "weight":
-            return torch._weight_norm(self.weight_v, self.weight_g, 0)
-        if self.norm != "spectral":
-            return self.weight
-        w = self.weight_orig
-        u, v = self._uv_override if self._uv_override is not None else (self.weight_u, self.weight_v)
-        sigma = torch.dot(u, torch.mv(w.reshape(w.shape[0], -1), v))
-        return w / sigma
 
     # -- 1-D --------------------------------------------------------------------------------------
     def run1d(self, x: Tensor, slope: Optional[float]) -> Tensor:
@@ -226,53 +212,6 @@ def set_arithmetic(module: nn.Module, mode: str = "fp32") -> nn.Module:
     return module
 
 
-class _MultiOutBridge(torch.autograd.Function):
-    """HIP forward returning several tensors, backward by differentiating the ATen restatement
-    (same contract as autograd_bridge._HipForwardAtenBackward)."""
-
-    @staticmethod
-    def forward(ctx, module, hip_fn, aten_fn, x: Tensor, *params: Tensor):
-        ctx.aten_fn, ctx.params = aten_fn, params
-        ctx.save_for_backward(x)
-        with torch.no_grad():
-            out = tuple(hip_fn(x.detach()))
-        # the u / v this forward normalised with (later forwards move the buffers on)
-        ctx.convs = [m for m in module.modules() if isinstance(m, _SNConv) and m.norm == "spectral"]
-        ctx.uv = [(m.weight_u.clone(), m.weight_v.clone()) for m in ctx.convs]
-        return out
-
-    @staticmethod
-    def backward(ctx, *grads: Tensor):
-        (x,) = ctx.saved_tensors
-        params = [p for p in ctx.params if p.requires_grad]
-        for m, uv in zip(ctx.convs, ctx.uv):
-            m._uv_override = uv
-        try:
-            with torch.enable_grad():
-                xl = x.detach().requires_grad_(True)
-                outs = list(ctx.aten_fn(xl))
-                pairs = [(o, g.contiguous()) for o, g in zip(outs, grads) if g is not None and o.requires_grad]
-                got = torch.autograd.grad([o for o, _ in pairs], [xl] + params, [g for _, g in pairs],
-                                          allow_unused=True)
-        finally:
-            for m in ctx.convs:
-                m._uv_override = None
-        it = iter(got[1:])
-        pg = [next(it) if p.requires_grad else None for p in ctx.params]
-        return (None, None, None, got[0], *pg)
-
-
-def _run_bridged(module: nn.Module, x: Tensor, hip_fn, aten_fn, n_out: int) -> Tuple[List[Tensor], List[Tensor]]:
-    """``hip_fn(x) -> outs + feats`` (flat list); differentiable when a gradient is needed."""
-    if needs_grad(x, module):
-        require_allowed(type(module).__name__ + " with an activation other than LeakyReLU")
-        flat = _MultiOutBridge.apply(module, hip_fn, aten_fn, x, *list(module.parameters()))
-    else:
-        flat = hip_fn(x)
-    flat = list(flat)
-    return flat[:n_out], flat[n_out:]
-
-
 class WaveformDiscriminatorBlock(nn.Module):
     """discriminator.py:7-57."""
 
@@ -312,23 +251,15 @@ class WaveformDiscriminatorBlock(nn.Module):
         out = ops.sigmoid(x) if isinstance(self.final_activation, nn.Sigmoid) else x.clone()
         return [out] + feats
 
-    def _aten(self, x: Tensor) -> List[Tensor]:  # backward bridge only
-        x = self.layers[0](x)
-        feats = [x]
-        for layer in list(self.layers)[1:]:
-            conv, act = (layer[0], layer[1]) if isinstance(layer, nn.Sequential) else (layer, None)
-            x = F.conv1d(x, conv.aten_weight(), conv.bias, stride=conv.stride, padding=conv.padding, groups=conv.groups)
-            if act is not None:
-                x = act(x)
-            feats.append(x)
-        return [self.final_activation(x)] + feats
-
     def forward(self, x: Tensor):
-        if needs_grad(x, self) and all(isinstance(l[1], nn.LeakyReLU) for l in self.layers if isinstance(l, nn.Sequential)):
+        if needs_grad(x, self):
+            if not all(isinstance(l[1], nn.LeakyReLU) for l in self.layers if isinstance(l, nn.Sequential)):
+                raise AgxError("WaveformDiscriminatorBlock: the backward kernels fuse the LeakyReLU gradient only; another "
+                               "activation can run forward (torch.no_grad) but has no backward -- there is no ATen fallback")
             flat = _WaveBlockNative.apply(self, x, *list(self.parameters()))
             return flat[0], list(flat[1:])
-        outs, feats = _run_bridged(self, x, self._hip, self._aten, 1)
-        return outs[0], feats
+        flat = self._hip(x)
+        return flat[0], list(flat[1:])
 
 
 class WaveFormDiscriminator(nn.Module):
@@ -371,11 +302,6 @@ class STFTDiscriminatorBlock(nn.Module):
         x = self.layers[0].run2d(x, _slope(self.layers[1]))
         return self.layers[2].run2d(x, None)
 
-    def _aten(self, x: Tensor) -> Tensor:  # backward bridge only
-        c0, c2 = self.layers[0], self.layers[2]
-        x = self.layers[1](F.conv2d(x, c0.aten_weight(), c0.bias, stride=c0.stride, padding=c0.padding))
-        return F.conv2d(x, c2.aten_weight(), c2.bias, stride=c2.stride, padding=c2.padding)
-
 
 class STFTDiscriminator(nn.Module):
     """discriminator.py:119-202."""
@@ -414,30 +340,15 @@ class STFTDiscriminator(nn.Module):
         out = ops.sigmoid(x) if isinstance(self.final_activation, nn.Sigmoid) else x.clone()
         return [out] + feats
 
-    def _aten(self, x: Tensor) -> List[Tensor]:  # backward bridge only
-        x = x.squeeze(1)
-        pad = self.n_fft // 2
-        xp = F.pad(x.unsqueeze(1), (pad, pad), mode="reflect").squeeze(1)
-        spec = torch.fft.fft(xp.unfold(-1, self.n_fft, self.hop_length), dim=-1)
-        if self.normalize_stft:
-            spec = spec * (self.n_fft ** -0.5)
-        x = torch.stack([spec.real, spec.imag], dim=1)
-        fc = self.first_conv
-        x = F.conv2d(x, fc.aten_weight(), fc.bias, padding=fc.padding)
-        feats = [x]
-        for block in self.blocks:
-            x = block._aten(x)
-            feats.append(x)
-        fc = self.final_conv
-        x = F.conv2d(x, fc.aten_weight(), fc.bias, padding=fc.padding)
-        return [self.final_activation(x)] + feats
-
     def forward(self, x: Tensor):
-        if needs_grad(x, self) and all(isinstance(b.layers[1], nn.LeakyReLU) for b in self.blocks):
+        if needs_grad(x, self):
+            if not all(isinstance(b.layers[1], nn.LeakyReLU) for b in self.blocks):
+                raise AgxError("STFTDiscriminator: the backward kernels fuse the LeakyReLU gradient only; another activation "
+                               "can run forward (torch.no_grad) but has no backward -- there is no ATen fallback")
             flat = _STFTDiscNative.apply(self, x, *list(self.parameters()))
             return [flat[0]], list(flat[1:])
-        outs, feats = _run_bridged(self, x, self._hip, self._aten, 1)
-        return outs, feats
+        flat = self._hip(x)
+        return [flat[0]], list(flat[1:])
 
 
 class _WaveBlockNative(torch.autograd.Function):

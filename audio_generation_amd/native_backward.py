@@ -4,6 +4,8 @@ A stack (``model.encoders`` / ``model.decoders``) is flattened into *units*:
 
 * conv unit      ``y = act(conv(x) + b)``             (act optional)
 * residual unit  ``y = act(x + conv2(act(conv1(x) + b1)) + b2)``
+* depthwise residual unit  ``y = act(x + conv2(act(conv1(dw(x)) + b1)) + b2)`` with ``dw`` the per-channel k = 1 conv
+  of ``vae.py:103-105`` (grouped-conv backward kernels of ``conv_grouped_bwd.hip``)
 * wavelet unit   ``y = act(conv_out(fold(conv_in(x))))``  (``WaveletLayer.backward_native``)
 
 Forward runs the usual fused kernels and keeps every unit's input.  Backward walks the
@@ -17,8 +19,8 @@ units in reverse with three C-ABI ops per conv:
 * (``SAVE_HIDDEN = False`` only) one ``agx_conv_forward`` per residual unit to re-materialise the hidden activation the
   fused forward kernel never wrote.
 
-Stacks containing a layer without native backward kernels (e.g. a non-LeakyReLU activation)
-use the ATen bridge of ``autograd_bridge.py`` instead.
+A stack containing a layer without backward kernels (an activation the kernels do not fuse) raises ``AgxError``:
+there is no ATen fallback.
 """
 from __future__ import annotations
 
@@ -28,7 +30,7 @@ import torch
 from torch import nn
 
 from . import ops
-from ._lib import CONV_CAUSAL, EPI_LEAKY_PRE
+from ._lib import CONV_CAUSAL, EPI_LEAKY_PRE, AgxError
 
 # Training forward of a residual unit: True = conv1 and conv2 as two launches that leave the hidden activation in
 # HBM for the backward (one C x L tensor per block: +3.5 GB at config S, batch 32); False = the fused inference
@@ -42,8 +44,8 @@ class _Unit:
     """One conv or residual unit of a stack."""
 
     def __init__(self, kind: str, convs: Sequence[nn.Module], slope: Optional[float], inner_slope: Optional[float] = None):
-        self.kind = kind            # "conv" | "res" | "wavelet"
-        self.convs = list(convs)    # [_ConvBase] or [conv1, conv2]
+        self.kind = kind            # "conv" | "res" | "resdw" | "wavelet"
+        self.convs = list(convs)    # [_ConvBase], [conv1, conv2] or [depthwise, conv1, conv2]
         self.slope = slope          # activation after the unit (None = linear output)
         self.inner_slope = inner_slope
 
@@ -59,8 +61,8 @@ class _Unit:
         return out
 
 
-def build_units(stack: nn.ModuleList) -> Optional[List[_Unit]]:
-    """Flatten a ``CausalVQAE`` encoder / decoder ModuleList; ``None`` if some layer has no native backward."""
+def build_units(stack: nn.ModuleList) -> List[_Unit]:
+    """Flatten a ``CausalVQAE`` encoder / decoder ModuleList; raises if some layer has no backward kernels."""
     from .vae import (CausalDecoderBlock, CausalEncoderBlock, CausalResidualBlock1d, _ConvBase, _leaky_slope)
 
     units: List[_Unit] = []
@@ -69,9 +71,12 @@ def build_units(stack: nn.ModuleList) -> Optional[List[_Unit]]:
         slope = _leaky_slope(act) if act is not None else None
         if isinstance(layer, CausalResidualBlock1d):
             inner = _leaky_slope(layer.activation)
-            if inner is None or getattr(layer, "depthwise", False):   # depthwise variant: ATen bridge
+            if inner is None:
                 return False
-            units.append(_Unit("res", [layer.conv1, layer.conv2], slope, inner))
+            if getattr(layer, "depthwise", False):
+                units.append(_Unit("resdw", [layer.conv1[0], layer.conv1[1], layer.conv2], slope, inner))
+            else:
+                units.append(_Unit("res", [layer.conv1, layer.conv2], slope, inner))
             return True
         if isinstance(layer, _ConvBase):
             units.append(_Unit("conv", [layer], slope))
@@ -91,7 +96,8 @@ def build_units(stack: nn.ModuleList) -> Optional[List[_Unit]]:
         else:
             ok = add(m, None)
         if not ok:
-            return None
+            raise AgxError(f"no backward kernels for a layer of {type(m).__name__} (activation or layer type the HIP "
+                           "kernels do not cover); there is no ATen fallback")
     return units
 
 
@@ -111,6 +117,33 @@ def _grads_of(conv, x: Tensor, dz: Tensor) -> List[Tensor]:
     v, g = _vg(conv)
     dv, dg, db = ops.conv_bwd_weight(_desc(conv, x), x, dz, v, g, want_bias=conv.conv.bias is not None)
     out = [dv] if g is None else [dv, dg]
+    if db is not None:
+        out.append(db)
+    return out
+
+
+def _dw_weight(conv) -> Tensor:
+    """Effective (C, 1, 1) weight of the weight-normed per-channel conv: g v / |v| (a C-element parameter fold)."""
+    v, g = _vg(conv)
+    return v if g is None else v * (g / v.abs().clamp_min(1e-30))
+
+
+def _dw_desc(conv, x: Tensor):
+    c = conv.conv
+    return ops.conv_desc(conv.kind, x.shape[0], c.in_channels, c.out_channels, x.shape[2], 1, 1, 1, groups=c.groups)
+
+
+def _dw_grads(conv, x: Tensor, du: Tensor) -> List[Tensor]:
+    """[dv, dg, dbias] / [dweight, dbias] of the per-channel conv: ``agx_conv_grouped_bwd_weight`` + the weight-norm chain
+    rule on the C-element parameter vectors (for a 1-element direction v: dg = dw sign(v), dv = 0 up to rounding)."""
+    v, g = _vg(conv)
+    dw, db = ops.conv_grouped_bwd_weight(_dw_desc(conv, x), x, du, want_bias=conv.conv.bias is not None)
+    if g is None:
+        out = [dw]
+    else:
+        n = v.abs().clamp_min(1e-30)
+        dot = dw * v
+        out = [(g / n) * (dw - v * dot / (n * n)), dot / n]
     if db is not None:
         out.append(db)
     return out
@@ -160,6 +193,17 @@ class _NativeStack(torch.autograd.Function):
                 grads[i] = _grads_of(conv, x, dz)
                 dz = ops.conv_bwd_data(_desc(conv, x), dz, conv.conv.packed_bwd(conv.kind), None, mask,
                                        prev_slope or 0.0)
+            elif u.kind == "resdw":
+                dwc, c1, c2 = u.convs
+                ux = dwc.run(x)                                           # re-materialised: one bandwidth-bound launch
+                h = c1.run(ux, EPI_LEAKY_PRE, u.inner_slope)
+                g2 = _grads_of(c2, h, dz)
+                dh = ops.conv_bwd_data(_desc(c2, h), dz, c2.conv.packed_bwd(CONV_CAUSAL), None, h, u.inner_slope)
+                g1 = _grads_of(c1, ux, dh)
+                du = ops.conv_bwd_data(_desc(c1, ux), dh, c1.conv.packed_bwd(CONV_CAUSAL))
+                g0 = _dw_grads(dwc, x, du)
+                dz = ops.conv_grouped_bwd_data(_dw_desc(dwc, x), du, _dw_weight(dwc), None, dz, mask, prev_slope or 0.0)
+                grads[i] = g0 + g1 + g2
             else:
                 c1, c2 = u.convs
                 # the hidden activation: saved by the forward, or re-materialised with one conv launch

@@ -407,6 +407,42 @@ def multires_forward(x: Tensor, h0: Tensor, h1: Tensor, w: Tensor, depth: int) -
     return y
 
 
+def multires_backward(x: Tensor, dout: Tensor, h0: Tensor, h1: Tensor, w: Tensor, depth: int):
+    """(dx, dh0, dh1, dw) of ``multires_forward``."""
+    lib = _lib.load()
+    _need_gpu(x, dout, h0, h1, w)
+    x, dout = _f32c(x), _f32c(dout)
+    b, c, length = x.shape
+    k = h0.shape[-1]
+    if dout.shape != x.shape or tuple(h0.shape) != (c, 1, k) or tuple(h1.shape) != (c, 1, k) or tuple(w.shape) != (c, depth + 2):
+        raise AgxError("multires_backward: shapes do not match (B,C,L) / (C,1,K) / (C,depth+2)")
+    dx, dh0, dh1, dw = torch.empty_like(x), torch.empty_like(h0), torch.empty_like(h1), torch.empty_like(w)
+    nbytes = int(lib.agx_multires_backward_workspace_bytes(b, c, length, k, depth))
+    ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=x.device)
+    _lib.check(lib.agx_multires_backward(_ptr(x), _ptr(dout), _ptr(_f32c(h0)), _ptr(_f32c(h1)), _ptr(_f32c(w)), _ptr(dx),
+                                         _ptr(dh0), _ptr(dh1), _ptr(dw), _ptr(ws), nbytes, b, c, length, k, depth,
+                                         _stream()), "agx_multires_backward")
+    return dx, dh0, dh1, dw
+
+
+def group_sum(g: Tensor, group: int, gelu_pre: Optional[Tensor] = None) -> Tensor:
+    """out[..., l] = sum_{j < group} g[..., l * group + j]  (adjoint of a nearest-neighbour upsample), times the exact-GELU
+    derivative at ``gelu_pre[..., l]`` when given."""
+    lib = _lib.load()
+    _need_gpu(g, gelu_pre)
+    g = _f32c(g)
+    length = g.shape[-1]
+    if group <= 0 or length % group:
+        raise AgxError(f"group_sum: last dim {length} is not a multiple of {group}")
+    out = torch.empty(*g.shape[:-1], length // group, dtype=torch.float32, device=g.device)
+    if gelu_pre is not None:
+        gelu_pre = _f32c(gelu_pre)
+        if gelu_pre.shape != out.shape:
+            raise AgxError(f"group_sum: gelu_pre is {tuple(gelu_pre.shape)}, output is {tuple(out.shape)}")
+    _lib.check(lib.agx_group_sum(_ptr(g), _ptr(gelu_pre), _ptr(out), out.numel(), group, _stream()), "agx_group_sum")
+    return out
+
+
 def wavelet_fold(h: Tensor, space: Tensor, sigma: Tensor, scale: int) -> Tensor:
     lib = _lib.load()
     _need_gpu(h, space, sigma)

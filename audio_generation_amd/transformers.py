@@ -19,12 +19,10 @@ from __future__ import annotations
 from typing import Optional
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from . import ops
-from .autograd_bridge import hip_forward_aten_backward, needs_grad
-from ._lib import CONV_CAUSAL, EPI_GELU_PRE, EPI_RESIDUAL, AgxError
+from ._lib import CONV_CAUSAL, EPI_GELU_PRE, EPI_RESIDUAL, AgxError, needs_grad
 
 Tensor = torch.Tensor
 
@@ -120,7 +118,8 @@ class Attention(nn.Module):
         self.alibi_obj = Alibi(context_x, None, n_heads=n_heads)
         self._qkv, self._o = _PackedLinear(), _PackedLinear()
         # arithmetic of the QK^T / PV contractions: "fp32" (exact, the reference's) or "bf16" (bf16 MFMA, fp32 accumulate
-        # and softmax -- BASELINE config 3); inference only: the backward kernels assume the fp32 forward
+        # and softmax -- BASELINE config 3); inference only: with autograd on, the block's forward runs the fp32 kernel
+        # (Transformer.run_bct), which is what the backward kernels differentiate
         self.attention_dtype = "fp32"
 
     def run_bct(self, x: Tensor, residual: Optional[Tensor] = None) -> Tensor:
@@ -275,32 +274,20 @@ class Transformer(nn.Module):
             x = ff.run_bct(x, residual=x)
         return x
 
-    def _aten_bct(self, x: Tensor) -> Tensor:
-        """ATen restatement for the interim backward bridge only (autograd_bridge.py)."""
-        x = x.transpose(1, 2)
-        for attention, ff in self.layers:
-            b, t, _ = x.shape
-            xn = attention.norm(x)
-            q, k, v = (lin(xn).reshape(b, t, attention.n_heads, attention.dim_head).transpose(1, 2)
-                       for lin in (attention.W_q, attention.W_k, attention.W_v))
-            s = q @ k.transpose(-1, -2) / (attention.dim_head ** 0.5) + attention.alibi_obj.get_M(crop=(t, t))
-            o = (s.softmax(dim=-1) @ v).transpose(1, 2).reshape(b, t, attention.inner_dim)
-            x = x + attention.W_o(o)
-            x = x + ff.net(x)
-        return x.transpose(1, 2)
-
     def run_bct(self, x: Tensor) -> Tensor:
         """Channel-major (B, dim, T) in and out: 7 launches per layer, both residual adds fused into
         the W_o / FFN-out conv epilogues.  With autograd on, the backward runs on the HIP kernels too
-        (_TransformerNative; head_dim > 128 has no kernel and needs the fenced ATen bridge)."""
+        (_TransformerNative: head_dim <= 128; the training forward always uses the fp32 attention arithmetic, whatever
+        ``attention_dtype`` says -- the backward kernels recompute P from fp32 scores)."""
         for attention, _ in self.layers:
             if x.shape[-1] > attention.context:
                 raise AgxError(f"sequence length {x.shape[-1]} exceeds the ALiBi context {attention.context} "
                                "(the reference fails here too, transformers.py:88-93)")
         if needs_grad(x, self):
-            if all(a.dim_head <= 128 for a, _ in self.layers):
-                return _TransformerNative.apply(self, x, *list(self.parameters()))
-            return hip_forward_aten_backward(self._hip_bct, self._aten_bct, x, list(self.parameters()))
+            if any(a.dim_head > 128 for a, _ in self.layers):
+                raise AgxError("Transformer: the attention backward kernels cover head_dim <= 128 "
+                               "(agx_attention_alibi_backward_ex); larger heads run forward only -- there is no ATen fallback")
+            return _TransformerNative.apply(self, x, *list(self.parameters()))
         return self._hip_bct(x)
 
     def forward(self, x: Tensor, y=None) -> Tensor:

@@ -10,10 +10,10 @@ called: every layer runs as a hand-written HIP kernel behind the C ABI of
 activation / padding / crop / upsample folded into the conv kernels).
 
 Differentiation: forward AND backward run on libagx (``native_backward.py``: conv
-backward-data / weight-gradient kernels, the RVQ straight-through pass).  Only
-configurations those kernels do not cover (depthwise variant, ``norm != Identity``)
-go through the fenced ATen bridge of ``autograd_bridge.py``, which raises unless
-``AGX_ALLOW_ATEN_BRIDGE=1``.
+backward-data / weight-gradient kernels incl. the ``depthwise=True`` block variant, the RVQ
+straight-through pass).  No ATen arithmetic op is differentiated anywhere: a configuration
+without backward kernels (an activation the kernels do not fuse, ``norm != Identity``)
+raises ``AgxError`` / ``NotImplementedError`` instead of falling back.
 """
 from __future__ import annotations
 
@@ -21,13 +21,11 @@ import math
 from typing import List, Optional, Sequence
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from . import ops
-from .autograd_bridge import hip_forward_aten_backward, needs_grad
 from ._lib import (CONV_CAUSAL, CONV_PADDED, CONV_TRANSPOSED, CONV_UPSAMPLE, EPI_LEAKY_POST, EPI_LEAKY_PRE,
-                   IMPL_AUTO, IMPL_MFMA_BF16X3, AgxError)
+                   IMPL_AUTO, IMPL_MFMA_BF16X3, AgxError, needs_grad)
 
 Tensor = torch.Tensor
 
@@ -91,14 +89,6 @@ class _ConvParams(nn.Module):
         self._packed: Optional[Tensor] = None
         self._packed_key = None
 
-    def aten_weight(self) -> Tensor:
-        """Plain weight as a differentiable function of the parameters (backward bridge only)."""
-        if hasattr(self, "weight_v"):
-            v, g = self.weight_v, self.weight_g
-            norm = v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, 1, 1)
-            return v * (g / norm)
-        return self.weight
-
     def packed_bwd(self, kind: int) -> Tensor:
         """Packed image of the layer's backward-data op (same invalidation rule as ``packed``)."""
         if hasattr(self, "weight_v"):
@@ -151,21 +141,9 @@ class _ConvBase(nn.Module):
         return self.run(x)
 
 
-def _act_aten(x: Tensor, slope: Optional[float]) -> Tensor:
-    return x if slope is None else F.leaky_relu(x, slope)
-
-
 class CausalConv1d(_ConvBase):
     """networks/vae.py:14-43."""
     kind = CONV_CAUSAL
-
-    def _aten(self, x: Tensor) -> Tensor:  # backward bridge only (autograd_bridge.py)
-        c = self.conv
-        k, s, d = c.kernel_size[0], c.stride[0], c.dilation[0]
-        nxt = (x.shape[-1] - k + self.pad) / s + 1
-        extra = (math.ceil(nxt) - 1) * s + k - self.pad - x.shape[-1]
-        return F.conv1d(F.pad(x, (self.pad, extra)), c.aten_weight(), c.bias, stride=s, dilation=d,
-                        groups=getattr(c, "groups", 1))
 
     def __init__(self, in_channels, out_channels, kernel_size, dilation=1, stride=1, bias=True,
                  groups=1, norm="weight"):
@@ -190,10 +168,6 @@ class CausalConvT1d(_ConvBase):
         self.conv = _ConvParams(in_channels, out_channels, kernel_size, stride, 1, bias, True, norm)
         self.right_pad = kernel_size - stride
 
-    def _aten(self, x: Tensor) -> Tensor:  # backward bridge only
-        y = F.conv_transpose1d(x, self.conv.aten_weight(), self.conv.bias, stride=self.conv.stride[0])
-        return y[..., : y.shape[-1] - self.right_pad]
-
 
 class CausalUpsampleConv1d(_ConvBase):
     """networks/vae.py:66-89 (nearest upsample + ``padding="same"`` conv; not
@@ -205,10 +179,6 @@ class CausalUpsampleConv1d(_ConvBase):
         super().__init__()
         self.scale_factor = stride
         self.conv = _ConvParams(in_channels, out_channels, kernel_size, stride, 1, bias, False, norm)
-
-    def _aten(self, x: Tensor) -> Tensor:  # backward bridge only
-        up = x.repeat_interleave(self.scale_factor, dim=-1)
-        return F.conv1d(up, self.conv.aten_weight(), self.conv.bias, padding="same")
 
 
 class CausalResidualBlock1d(nn.Module):
@@ -228,6 +198,7 @@ class CausalResidualBlock1d(nn.Module):
         if depthwise:   # vae.py:103-105: a per-channel k = 1 conv in front of the dilated conv (three launches, unfused)
             self.conv1 = nn.Sequential(CausalConv1d(in_channels, in_channels, 1, bias=bias, groups=in_channels),
                                        CausalConv1d(in_channels, out_channels, kernel_size, dilation=dilation, bias=bias))
+            object.__setattr__(self.conv1[0], "_parent_block", self)
         else:
             self.conv1 = CausalConv1d(in_channels, out_channels, kernel_size, dilation=dilation, bias=bias)
             object.__setattr__(self.conv1, "_parent_block", self)   # plain attribute: no module cycle
@@ -259,10 +230,6 @@ class CausalResidualBlock1d(nn.Module):
         return ops.resblock_forward(desc, x, c1.packed(CONV_CAUSAL, impl), b1, c2.packed(CONV_CAUSAL, impl), b2,
                                     post_act=post_slope is not None)
 
-    def _aten(self, x: Tensor) -> Tensor:  # backward bridge only
-        h = self.conv1[1]._aten(self.conv1[0]._aten(x)) if self.depthwise else self.conv1._aten(x)
-        return x + self.conv2._aten(_act_aten(h, _leaky_slope(self.activation)))
-
     def forward(self, x: Tensor) -> Tensor:
         return self.run(x, None)
 
@@ -287,11 +254,6 @@ class CausalEncoderBlock(nn.Module):
     def forward(self, x: Tensor) -> Tensor:
         for seq in self.layers:
             x = _run_fused_pair(seq[0], seq[1], x)
-        return x
-
-    def _aten(self, x: Tensor) -> Tensor:  # backward bridge only
-        for seq in self.layers:
-            x = _act_aten(seq[0]._aten(x), _leaky_slope(seq[1]))
         return x
 
 
@@ -326,16 +288,10 @@ class CausalDecoderBlock(nn.Module):
             x = _run_fused_pair(seq[0], seq[1], x)
         return x
 
-    def _aten(self, x: Tensor) -> Tensor:  # backward bridge only
-        x = _act_aten(self.in_conv[0]._aten(x), _leaky_slope(self.in_conv[1]))
-        for seq in self.layers:
-            x = _act_aten(seq[0]._aten(x), _leaky_slope(seq[1]))
-        return x
-
 
 def _run_unit_forward(unit, x: Tensor) -> Tensor:
     """Forward of one unit of native_backward.build_units (same fused kernels as inference)."""
-    if unit.kind == "res":
+    if unit.kind in ("res", "resdw"):
         res = unit.convs[0]._parent_block
         return res.run(x, unit.slope)
     if unit.kind == "wavelet":
@@ -445,47 +401,28 @@ class CausalVQAE(nn.Module):
             x = dec(x)
         return x
 
-    def _encoders_aten(self, x: Tensor) -> Tensor:  # backward bridge only
-        x = self.encoders[0][1]._aten(x)
-        for enc in list(self.encoders)[1:]:
-            x = enc._aten(x)
-        return x
-
-    def _decoders_aten(self, x: Tensor) -> Tensor:  # backward bridge only
-        for dec in self.decoders:
-            x = dec._aten(x)
-        return x
-
     def _run_encoders(self, x: Tensor) -> Tensor:
-        """Encoder stack: libagx forward; when a gradient is needed the backward is bridged
-        through ATen (autograd_bridge.py -- interim until SURVEY 8(f1))."""
+        """Encoder stack; when a gradient is needed, forward + backward on the HIP kernels (native_backward.py)."""
         if needs_grad(x, self.encoders):
-            units = self._units("encoders")
-            if units is not None:                       # native backward kernels (native_backward.py)
-                from .native_backward import run_stack
-                return run_stack(units, x)
-            return hip_forward_aten_backward(self._encoders_hip, self._encoders_aten, x,
-                                             list(self.encoders.parameters()))
+            from .native_backward import run_stack
+            return run_stack(self._units("encoders"), x)
         return self._encoders_hip(x)
 
     def _run_decoders(self, x: Tensor) -> Tensor:
         if needs_grad(x, self.decoders):
-            units = self._units("decoders")
-            if units is not None:
-                from .native_backward import run_stack
-                return run_stack(units, x)
-            return hip_forward_aten_backward(self._decoders_hip, self._decoders_aten, x,
-                                             list(self.decoders.parameters()))
+            from .native_backward import run_stack
+            return run_stack(self._units("decoders"), x)
         return self._decoders_hip(x)
 
     def _units(self, which: str):
-        """Flattened unit list of a stack for the native backward (None: some layer lacks kernels)."""
+        """Flattened unit list of a stack for the native backward; a stack with a layer the backward kernels do not
+        cover raises (there is no ATen fallback)."""
         cache = self.__dict__.setdefault("_unit_cache", {})
         if which not in cache:
             from .native_backward import build_units
-            first = self.encoders[0]
-            ok = which != "encoders" or isinstance(first[0], nn.Identity)
-            cache[which] = build_units(getattr(self, which)) if ok else None
+            if which == "encoders" and not isinstance(self.encoders[0][0], nn.Identity):
+                raise NotImplementedError("only norm=Identity (the reference default) has HIP kernels")
+            cache[which] = build_units(getattr(self, which))
         return cache[which]
 
     def encode(self, x, update_codebook=False, codebook_n=None, prioritize_early=False):

@@ -18,12 +18,10 @@ from math import sqrt
 from typing import Optional
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from . import ops
-from ._lib import CONV_CAUSAL, CONV_SAME, EPI_GELU_PRE, EPI_LEAKY_PRE
-from .autograd_bridge import hip_forward_aten_backward, needs_grad
+from ._lib import CONV_CAUSAL, CONV_SAME, EPI_GELU_PRE, EPI_LEAKY_PRE, needs_grad
 
 Tensor = torch.Tensor
 
@@ -48,21 +46,28 @@ class CausalMultiresConv1d(nn.Module):
     def _hip(self, x: Tensor) -> Tensor:
         return ops.multires_forward(x, self.h0.detach(), self.h1.detach(), self.w.detach(), self.depth)
 
-    def _aten(self, x: Tensor) -> Tensor:
-        """ATen restatement of wavelets.py:79-96 for the fenced backward bridge only (autograd_bridge.py)."""
-        def dw(t, h, dil):
-            return F.conv1d(F.pad(t, (dil * (self.kernel_size - 1), 0)), h, dilation=dil, groups=self.channels)
-        low, y, dil = x, torch.zeros_like(x), 1
-        for i in range(self.depth, 0, -1):
-            y = y + self.w[:, i:i + 1] * dw(low, self.h1, dil)
-            low = dw(low, self.h0, dil)
-            dil *= 2
-        return F.gelu(y + self.w[:, :1] * low + self.w[:, -1:] * x)
-
     def forward(self, x: Tensor) -> Tensor:
-        if needs_grad(x, self):     # no native backward for this layer (the reference never instantiates it, vae.py:7)
-            return hip_forward_aten_backward(self._hip, self._aten, x, [self.h0, self.h1, self.w])
+        if needs_grad(x, self):
+            return _MultiresNative.apply(self, x, self.h0, self.h1, self.w)
         return self._hip(x)
+
+
+class _MultiresNative(torch.autograd.Function):
+    """``agx_multires_forward`` / ``agx_multires_backward`` (the cascade is re-formed per tile in the backward kernel:
+    only the layer input is kept)."""
+
+    @staticmethod
+    def forward(ctx, mod: "CausalMultiresConv1d", x: Tensor, h0: Tensor, h1: Tensor, w: Tensor):
+        ctx.depth = mod.depth
+        ctx.save_for_backward(x.detach(), h0.detach(), h1.detach(), w.detach())
+        with torch.no_grad():
+            return mod._hip(x.detach())
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        x, h0, h1, w = ctx.saved_tensors
+        dx, dh0, dh1, dw = ops.multires_backward(x, g.contiguous(), h0, h1, w, ctx.depth)
+        return None, dx, dh0, dh1, dw
 
 
 class _PlainConv(nn.Module):
@@ -114,16 +119,40 @@ class MultiresScaleBlock(nn.Module):
 
     def _hip(self, x: Tensor) -> Tensor:
         y = self.conv.run(self.multires_conv._hip(x), CONV_CAUSAL, EPI_GELU_PRE)
-        return y.repeat_interleave(self.scale_factor, dim=-1)
-
-    def _aten(self, x: Tensor) -> Tensor:
-        y = self.multires_conv._aten(x).repeat_interleave(self.scale_factor, dim=-1)
-        return F.gelu(F.conv1d(y, self.conv.weight, self.conv.bias))
+        return y.repeat_interleave(self.scale_factor, dim=-1)          # a copy: the 1x1 conv ran on the low rate
 
     def forward(self, x: Tensor) -> Tensor:
         if needs_grad(x, self):
-            return hip_forward_aten_backward(self._hip, self._aten, x, list(self.parameters()))
+            mr = self.multires_conv
+            return _ScaleBlockNative.apply(self, x, mr.h0, mr.h1, mr.w, self.conv.weight, self.conv.bias)
         return self._hip(x)
+
+
+class _ScaleBlockNative(torch.autograd.Function):
+    """Backward of ``MultiresScaleBlock`` on the HIP kernels: the nearest upsample's adjoint (sum of each group of
+    ``scale_factor`` gradients) fused with the exact-GELU gradient (``agx_group_sum``), the k = 1 conv's backward-data /
+    weight-gradient kernels, ``agx_multires_backward``.  The two hidden tensors are re-materialised."""
+
+    @staticmethod
+    def forward(ctx, blk: "MultiresScaleBlock", x: Tensor, *params: Tensor):
+        ctx.blk = blk
+        ctx.save_for_backward(x.detach())
+        with torch.no_grad():
+            return blk._hip(x.detach())
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        blk, (x,) = ctx.blk, ctx.saved_tensors
+        mr, conv = blk.multires_conv, blk.conv
+        h0, h1, w = mr.h0.detach(), mr.h1.detach(), mr.w.detach()
+        m = ops.multires_forward(x, h0, h1, w, mr.depth)
+        pre = conv.run(m, CONV_CAUSAL)                                  # pre-activation of the 1x1 conv
+        dpre = ops.group_sum(g.contiguous(), blk.scale_factor, gelu_pre=pre)
+        desc = conv.desc(CONV_CAUSAL, m)
+        dwc, _, dbc = ops.conv_bwd_weight(desc, m, dpre, conv.weight.detach(), None)
+        dm = ops.conv_bwd_data(desc, dpre, conv.packed_bwd(CONV_CAUSAL))
+        dx, dh0, dh1, dw = ops.multires_backward(x, dm, h0, h1, w, mr.depth)
+        return None, dx, dh0, dh1, dw, dwc, dbc
 
 
 class WaveletLayer(nn.Module):
@@ -153,17 +182,6 @@ class WaveletLayer(nn.Module):
             scale = scale.repeat(hidden_channels).reshape(1, hidden_channels, 1, 1)
         self.wavelet_scale = nn.Parameter(scale)
         self.register_buffer("cos_kernel", torch.cos(self.space))
-
-    def _aten(self, x: Tensor) -> Tensor:
-        """ATen restatement for the interim backward bridge only (autograd_bridge.py)."""
-        h = F.conv1d(x, self.conv_in.weight, self.conv_in.bias, padding="same").unsqueeze(-1)
-        y = (torch.cos(self.space) * torch.exp(-(self.space ** 2) / self.wavelet_scale) * h).flatten(2)
-        expected = y.shape[-1] // self.fold_dim
-        out = y.unfold(-1, self.n_points, self.fold_dim).sum(dim=-1)
-        short = out.shape[-1] - expected
-        if short < 0:
-            out = torch.cat([out, y[..., short:]], dim=-1)
-        return F.conv1d(out, self.conv_out.weight, self.conv_out.bias, padding="same")
 
     def run_fused(self, x: Tensor, post_slope: Optional[float] = None) -> Tensor:
         h = self.conv_in.run(x, CONV_SAME)

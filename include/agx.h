@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AGX_VERSION 115 /* 115: agx_rvq_ema_stats, agx_conv2d_bwd_data_kernel_name; 114: agx_attention_alibi_backward_ex (any T), agx_rvq_forward_ex; 113: tile images (resblock_p / conv_p), agx_attention_alibi_ex, agx_sizeof_*; 0.1.1: agx_conv_desc gained groups / padding (zero = old behaviour); 111: resample, conv2d column split */
+#define AGX_VERSION 116 /* 116: agx_multires_backward, agx_layernorm_ct one-pass kernel (same signature); agx_rvq_forward (legacy form) needs the workspace of agx_rvq_workspace_bytes since 114; 115: agx_rvq_ema_stats, agx_conv2d_bwd_data_kernel_name; 114: agx_attention_alibi_backward_ex (any T), agx_rvq_forward_ex; 113: tile images (resblock_p / conv_p), agx_attention_alibi_ex, agx_sizeof_*; 0.1.1: agx_conv_desc gained groups / padding (zero = old behaviour); 111: resample, conv2d column split */
 
 #define AGX_OK 0
 #define AGX_ERR_BAD_SHAPE (-1)
@@ -282,6 +282,21 @@ int agx_attention_alibi_ex(const float *qkv, const float *slopes, float *out, in
 int agx_multires_forward(const float *x, const float *h0, const float *h1, const float *w, float *y,
                          int32_t batch, int32_t channels, int32_t length, int32_t kernel,
                          int32_t depth, void *stream);
+
+/* Backward of agx_multires_forward: dx (B, C, L), dh0 / dh1 (C, 1, K), dw (C, depth + 2) from dout (B, C, L); the
+ * cascade is re-formed per tile in LDS (nothing is kept from the forward).  Parameter sums are per-tile partials in
+ * `workspace` reduced in a fixed order (deterministic).  Needs 2 K + depth + 2 <= 64. */
+size_t agx_multires_backward_workspace_bytes(int32_t batch, int32_t channels, int32_t length, int32_t kernel,
+                                             int32_t depth);
+int agx_multires_backward(const float *x, const float *dout, const float *h0, const float *h1, const float *w,
+                          float *dx, float *dh0, float *dh1, float *dw, void *workspace, size_t workspace_bytes,
+                          int32_t batch, int32_t channels, int32_t length, int32_t kernel, int32_t depth,
+                          void *stream);
+
+/* Adjoint of a nearest-neighbour upsample by `group` (MultiresScaleBlock, wavelets.py:112-119): out[i] = sum of
+ * g[i * group .. i * group + group), i < n_out; with `gelu_pre` != NULL multiplied by the exact-GELU derivative at
+ * gelu_pre[i] (the activation of the k = 1 conv that precedes the upsample). */
+int agx_group_sum(const float *g, const float *gelu_pre, float *out, int64_t n_out, int32_t group, void *stream);
 
 /* The fold in the middle of WaveletLayer.forward (wavelets.py:221-231):
  * every input step emits an n_points-long wavelet cos(t)exp(-t^2/sigma_c) * h laid
