@@ -140,7 +140,7 @@ def test_backward_ex_rejects_bad_arguments():
 
 def test_transformer_bottleneck_trains_at_1125_frames():
     """Native backward through the whole transformer block at the inference caller's length (training.py:488-496):
-    gradients against autograd on the oracle's formulas, and the ATen bridge is never asked for."""
+    gradients against autograd on the oracle's formulas."""
     torch.manual_seed(11)
     tf = Transformer(64, depth=1, heads=4, head_dim=32, context_x=1200).to(DEV)
     x = (0.5 * torch.randn(1, 64, 1125)).to(DEV).requires_grad_(True)
@@ -149,12 +149,13 @@ def test_transformer_bottleneck_trains_at_1125_frames():
     (y * w).sum().backward()
     got = {n: p.grad.detach().cpu().clone() for n, p in tf.named_parameters()}
     gx = x.grad.detach().cpu().clone()
-    tf.zero_grad()
-    x2 = x.detach().clone().requires_grad_(True)
-    y2 = tf._aten_bct(x2)
-    assert max_abs(y2.detach().cpu(), y.detach().cpu()) < 1e-4
-    (y2 * w).sum().backward()
-    assert max_abs(gx, x2.grad.cpu()) < 2e-4 * max(1.0, float(x2.grad.abs().max()))
-    for n, p in tf.named_parameters():
-        ref = p.grad.detach().cpu()
+    # autograd on the oracle's formulas (CPU)
+    leaves = {n: p.detach().cpu().clone().requires_grad_(True) for n, p in tf.named_parameters()}
+    x2 = x.detach().cpu().clone().requires_grad_(True)
+    y2 = oattn.transformer(x2.transpose(1, 2), leaves, 4).transpose(1, 2)
+    assert max_abs(y2.detach(), y.detach().cpu()) < 1e-4
+    (y2 * w.cpu()).sum().backward()
+    assert max_abs(gx, x2.grad) < 2e-4 * max(1.0, float(x2.grad.abs().max()))
+    for n in got:
+        ref = leaves[n].grad
         assert max_abs(got[n], ref) < 5e-4 * max(1.0, float(ref.abs().max())), n
