@@ -127,6 +127,17 @@ inline bool tile_image_eligible(const ConvPlan &p, int kind) {
     return conv_p_geometry(p) != 0;
 }
 
+// "B3 tile image" (resblock_b3.hip): the bf16x3 weights of a dense layer in the layout the bf16x3 ring kernels DMA and read:
+//   Wb[((g * J + j) * 3 + plane) * 2 + lh][m][8]   bf16,  g = ci / 16, slot e of lane half lh = channel 16 g + 8 lh + e
+// -- one (group, tap) phase = one contiguous 96 M-byte block, an A fragment = one conflict-free 16-byte LDS read.  k = 1
+// layers (the second conv of the fused block) are stored in GEMM2 order instead: slot e of lane half lh = channel
+// 16 g + 4 lh + e (e < 4), 16 g + 8 + 4 lh + (e - 4) (e >= 4) -- the hidden channels a lane holds in accumulator
+// registers 8 (g % 2) .. + 7.  Same size as the standard bf16x3 image; follows it and the dim0 scale scratch.
+inline bool b3_image_eligible(const ConvPlan &p, int kind) {
+    return p.prec == 1 && p.G == 1 && kind == AGX_CONV_CAUSAL && p.s == 1 && p.q == 1 && p.Cin == p.Cout &&
+           (p.Cin == 32 || p.Cin == 64 || p.Cin == 128 || p.Cin == 256) && (p.J == 7 || p.J == 1);
+}
+
 // Lower a descriptor; returns AGX_OK or an error (message set).
 int lower_conv(const agx_conv_desc *d, ConvPlan *p);
 // Plan of the backward-data op of layer `d` (gradient w.r.t. the layer input, given the gradient

@@ -17,6 +17,10 @@ int launch_resblock_p(const ConvPlan &p, const float *x, const float *w1, const 
                       const float *b2, float *y, int post_act, hipStream_t st);
 bool resblock_p_supported(const ConvPlan &p);
 const char *resblock_p_variant(const ConvPlan &p);
+int launch_resblock_b3(const ConvPlan &p, const float *x, const float *w1, const float *b1, const float *w2,
+                       const float *b2, float *y, int post_act, hipStream_t st);
+bool resblock_b3_supported(const ConvPlan &p);
+const char *resblock_b3_variant(const ConvPlan &p);
 int launch_conv_p(const ConvPlan &p, const float *x, const float *wp, const float *bias, float *y, hipStream_t st);
 bool conv_p_supported(const ConvPlan &p);
 const char *conv_p_variant(const ConvPlan &p);
@@ -117,6 +121,8 @@ int agx_resblock_kernel_name(const agx_conv_desc *d, char *buf, size_t buf_len) 
     if (rc != AGX_OK) return rc;
     if (d->impl != AGX_IMPL_DIRECT && tuning().rb_impl == 1 && resblock_p_supported(p)) {
         snprintf(buf, buf_len, "%s", resblock_p_variant(p));
+    } else if (tuning().rb_impl == 1 && resblock_b3_supported(p)) {
+        snprintf(buf, buf_len, "%s:bf16x3", resblock_b3_variant(p));
     } else if (d->impl != AGX_IMPL_DIRECT && resblock_fused_supported(p)) {
         snprintf(buf, buf_len, "%s%s", resblock_variant(p), p.prec ? ":bf16x3" : "");
     } else {
@@ -144,6 +150,8 @@ int agx_resblock_forward(const agx_conv_desc *d, const float *x, const float *pa
     if (rc != AGX_OK) return rc;
     if (d->impl != AGX_IMPL_DIRECT && tuning().rb_impl == 1 && resblock_p_supported(p1))
         return launch_resblock_p(p1, x, packed1, bias1, packed2, bias2, y, post_act, st);
+    if (tuning().rb_impl == 1 && resblock_b3_supported(p1))
+        return launch_resblock_b3(p1, x, packed1, bias1, packed2, bias2, y, post_act, st);
     if (d->impl != AGX_IMPL_DIRECT && resblock_fused_supported(p1))
         return launch_resblock_fused(p1, x, packed1, bias1, packed2, bias2, y, post_act, st);
     // two launches: h = leaky(conv1(x)+b1) -> workspace;  y = [leaky](x + conv2(h) + b2)

@@ -148,6 +148,8 @@ int lower_conv(const agx_conv_desc *d, ConvPlan *p) {
     p->tile_off = -1;
     if (tile_image_eligible(*p, d->kind))
         p->tile_off = packed_weight_floats(p->Cin / p->G, p->J, p->M) + (d->kind == AGX_CONV_TRANSPOSED ? d->c_in : d->c_out);
+    else if (b3_image_eligible(*p, d->kind))
+        p->tile_off = packed_weight_floats_bf(p->Cin, p->J, p->M) + d->c_out;
     return AGX_OK;
 }
 
@@ -276,7 +278,7 @@ int64_t agx_conv_packed_floats(const agx_conv_desc *d) {
     if (rc != AGX_OK) return rc;
     // + dim0 floats of scratch at the tail for the weight-norm scales
     const int dim0 = (d->kind == AGX_CONV_TRANSPOSED) ? d->c_in : d->c_out;
-    if (p.prec) return agx::packed_weight_floats_bf(p.Cin, p.J, p.M) + dim0;
+    if (p.prec) return agx::packed_weight_floats_bf(p.Cin, p.J, p.M) * (p.tile_off >= 0 ? 2 : 1) + dim0;
     const int64_t tile = p.tile_off >= 0 ? agx::tile_image_floats(p.Cin, p.J, p.M) : 0;
     return agx::packed_weight_floats(p.Cin / p.G, p.J, p.M) + dim0 + tile;
 }

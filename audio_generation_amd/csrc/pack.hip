@@ -116,6 +116,38 @@ __global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float *__restric
     dst[32] = l;
 }
 
+// B3 tile image (common.hpp): [(((g * J + j) * 3 + plane) * 2 + lh) * M + m][8] bf16; stride-1 causal layers only (q = 1)
+__global__ __launch_bounds__(256) void pack_b3_tile_kernel(const float *__restrict__ v, const float *__restrict__ scale,
+                                                           __bf16 *__restrict__ timg, int kind, int Cin, int Cout, int K,
+                                                           int J, int P) {
+    const int M = Cout;
+    const int64_t total = int64_t(Cin / kWG) * J * M * kWG;   // one thread per weight
+    const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int c16 = int(e % kWG);
+    const int m = int((e / kWG) % M);
+    const int gj = int(e / (int64_t(kWG) * M));
+    const int j = gj % J, ci = (gj / J) * kWG + c16;
+    const float w = fwd_weight(v, scale, kind, Cin, Cout, K, J, P, 1, ci, j, m, 0);
+    const __bf16 h = (__bf16)w;
+    const float r1 = w - (float)h;
+    const __bf16 mm = (__bf16)r1;
+    const __bf16 l = (__bf16)(r1 - (float)mm);
+    int lh, slot;
+    if (J == 1) {   // GEMM2 order: lane half = bit 2 of the channel, slot = (bit 3) * 4 + low two bits
+        lh = (c16 >> 2) & 1;
+        slot = ((c16 >> 3) << 2) | (c16 & 3);
+    } else {
+        lh = c16 >> 3;
+        slot = c16 & 7;
+    }
+    __bf16 *dst = timg + ((size_t(gj) * 3 * 2 + lh) * M + m) * 8 + slot;
+    const size_t plane = size_t(2) * M * 8;
+    dst[0] = h;
+    dst[plane] = mm;
+    dst[2 * plane] = l;
+}
+
 // Packed image of the BACKWARD-DATA op (core.hip: lower_conv_bwd_data).  (Cin, Cout, K, q, J, P, s) are
 // the FORWARD plan's; the image has fwd-Cout "input" channels and M_b = q_b * fwd-Cin rows.
 __global__ __launch_bounds__(256) void pack_bwd_kernel(const float *__restrict__ v,
@@ -227,6 +259,9 @@ static int pack_forward(const agx_conv_desc *d, const float *v, const float *g, 
         const int64_t nthreads = int64_t(ceil_div(p.Cin, kWG)) * p.J * p.M * kWG;
         hipLaunchKernelGGL(pack_bf16x3_kernel, dim3((unsigned)ceil_div64(nthreads, 256)), dim3(256), 0, st, v, scale,
                            reinterpret_cast<__bf16 *>(packed), d->kind, p.Cin, p.Cout, d->kernel, p.q, p.J, p.P, d->stride);
+        if (p.tile_off >= 0)   // second copy in the DMA layout of resblock_b3.hip, behind the scale scratch
+            hipLaunchKernelGGL(pack_b3_tile_kernel, dim3((unsigned)ceil_div64(nthreads, 256)), dim3(256), 0, st, v, scale,
+                               reinterpret_cast<__bf16 *>(packed + p.tile_off), d->kind, p.Cin, p.Cout, d->kernel, p.J, p.P);
         return check_launch(who);
     }
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)ceil_div64(n_w, 256)), dim3(256), 0, st, v, scale,
