@@ -157,10 +157,10 @@ def test_transformer_backward_is_native():
     # heads beyond the backward kernels' reach raise instead of differentiating an ATen restatement
     from audio_generation_amd._lib import AgxError
     big = Transformer(256, depth=1, heads=1, head_dim=256, context_x=32).to(DEV).train()
-    with torch.no_grad():
-        big.run_bct(torch.randn(1, 256, 20, device=DEV))              # forward only: fine
     with pytest.raises(AgxError, match="head_dim <= 128"):
         big.run_bct(torch.randn(1, 256, 20, device=DEV, requires_grad=True))
+    with torch.no_grad(), pytest.raises(AgxError, match="head_dim"):    # (the forward kernels stop at 128 as well)
+        big.run_bct(torch.randn(1, 256, 20, device=DEV))
 
 
 def test_depthwise_variant_gradients_match_oracle_autograd():
