@@ -230,6 +230,7 @@ int agx_set_tuning(const char *name, int32_t value) {
     else if (!strcmp(name, "rb_sched")) agx::tuning().rb_sched = value;
     else if (!strcmp(name, "rb_occ")) agx::tuning().rb_occ = value;
     else if (!strcmp(name, "rb_impl")) agx::tuning().rb_impl = value;
+    else if (!strcmp(name, "b3_dbg")) agx::tuning().b3_dbg = value;
     else if (!strcmp(name, "conv_impl")) agx::tuning().conv_impl = value;
     else if (!strcmp(name, "bf_sched")) agx::tuning().bf_sched = value;
     else if (!strcmp(name, "patch_tie")) agx::tuning().patch_tie = value;
@@ -252,6 +253,7 @@ int agx_get_tuning(const char *name) {
     if (!strcmp(name, "rb_sched")) return agx::tuning().rb_sched;
     if (!strcmp(name, "rb_occ")) return agx::tuning().rb_occ;
     if (!strcmp(name, "rb_impl")) return agx::tuning().rb_impl;
+    if (!strcmp(name, "b3_dbg")) return agx::tuning().b3_dbg;
     if (!strcmp(name, "conv_impl")) return agx::tuning().conv_impl;
     if (!strcmp(name, "bf_sched")) return agx::tuning().bf_sched;
     if (!strcmp(name, "patch_tie")) return agx::tuning().patch_tie;

@@ -19,10 +19,11 @@
 //     128 NW-column tile: a wave holds its C x 32 NW accumulators for GEMM1 and feeds them back, split in registers, as
 //     the B operand of GEMM2 (k-slot <-> accumulator-register assignment: the W2 image is packed in that order);
 //   * ring: 4 one-phase weight slots (two sets of two), two plane buffers.  Phases of a chunk run in groups [0,1] [2,3]
-//     [4,5] [6]; the DMA of group n+1 is issued at the start of group n into the set group n-1 just released and is
-//     waited for before the barrier that ends group n.  The next chunk's loads are issued in phase 4, split and written in
-//     phase 6, and become visible at the chunk's last barrier.  4 barriers per 7 phases (1 wave per SIMD: no partner
-//     wave whose work a barrier could delay).
+//     [4,5] [6].  Operand reads run one MFMA step (phase, row half, column block) ahead of the MFMAs, so a group's LAST
+//     operands are in registers before its last step: the group's barrier sits BEFORE that step ("early"), the DMA of the
+//     group after next goes out right behind it into the set just released, and the next group's first operands are read
+//     while the last step's MFMAs run.  The next chunk's loads are issued with phase 4 and split + written, one task per
+//     step under that step's MFMAs, before the chunk's last barrier.  4 barriers per 7 phases (1 wave per SIMD).
 #include "mfma_tile.hpp"
 
 namespace agx {
@@ -36,7 +37,7 @@ __device__ __forceinline__ void b3_glds_b128(const void *gsrc_lane, void *lds_wa
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-template <int MW, int NW, int D>
+template <int MW, int NW, int D, int NPB = 2>
 struct B3Geom {
     static constexpr int C = 32 * MW, BN = 128 * NW, J = 7;
     static constexpr int P = (J - 1) * D;                  // causal left pad (vae.py:32)
@@ -49,18 +50,18 @@ struct B3Geom {
     static constexpr int NT = (2 * W + 255) / 256;         // conversion tasks (time step x 8 channels) per thread and chunk
     static constexpr int RH = MW > 4 ? 4 : MW;             // row blocks per MFMA sub-phase (operand register budget)
     static constexpr int HS = MW > 2 ? MW / 2 : MW;        // output row blocks per GEMM2 pass
-    static constexpr int OFF_W = 2 * PLANE_B;              // byte offsets inside the dynamic LDS
+    static constexpr int OFF_W = NPB * PLANE_B;            // byte offsets inside the dynamic LDS (NPB plane buffers)
     static constexpr int OFF_BIAS = OFF_W + 4 * WSLOT_B;
     static constexpr size_t LDS_BYTES = size_t(OFF_BIAS) + 2 * C * sizeof(float);
     static_assert(WSLOT_B % 1024 == 0, "a weight phase must be whole 1 KiB pieces");
 };
 
-// the six products of one K = 16 block for ONE column block, small terms first: mm hl lh hm mh hh
-template <int RH>
+// the six products of one K = 16 block for ONE column block, small terms first: mm hl lh hm mh hh  (products T0 .. T1-1)
+template <int RH, int T0 = 0, int T1 = 6>
 __device__ __forceinline__ void b3_products(f32x16 (&acc)[RH], const b3x8 (&a)[3][RH], const b3x8 (&b)[3]) {
     constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
 #pragma unroll
-    for (int t = 0; t < 6; ++t)
+    for (int t = T0; t < T1; ++t)
 #pragma unroll
         for (int i = 0; i < RH; ++i)
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]][i], b[PB[t]], acc[i], 0, 0, 0);
@@ -78,14 +79,17 @@ __device__ __forceinline__ void b3_split8(const float (&x)[8], b3x8 &h, b3x8 &m,
     }
 }
 
-template <int MW, int NW, int D>
-__global__ __launch_bounds__(256, 1) void resblock_b3_kernel(ConvPlan p, int tiles_per_clip, int ntiles, int step_b,
+template <int MW, int NW, int D, int NPB>
+__global__ __launch_bounds__(256, NPB == 1 ? 2 : 1) void resblock_b3_kernel(ConvPlan p, int tiles_per_clip, int ntiles, int step_b,
                                                              int step_t, int post_act, const float *__restrict__ x,
                                                              const char *__restrict__ wt1, const float *__restrict__ b1,
                                                              const char *__restrict__ wt2, const float *__restrict__ b2,
                                                              float *__restrict__ y) {
-    using G = B3Geom<MW, NW, D>;
+    using G = B3Geom<MW, NW, D, NPB>;
     constexpr int C = G::C, BN = G::BN, W = G::W, NCH = G::NCH, RH = G::RH, NT = G::NT, HS = G::HS;
+    constexpr int NHALF = MW / RH;             // operand units (row halves) per phase
+    constexpr int NU = 7 * NHALF;              // ... per chunk
+    constexpr int NSTEP = NU * NW;             // MFMA steps per chunk: (phase, row half, column block)
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -102,13 +106,13 @@ __global__ __launch_bounds__(256, 1) void resblock_b3_kernel(ConvPlan p, int til
 
     // ---- weight DMA: a linear stream of phases (tile after tile: chunk-major, tap-minor = the image's own order) ----
     // the slot of phase (chunk, j) is fixed by j alone (groups [0,1] [2,3] [4,5] [6] alternate between the two slot sets):
-    // j -> {0, 1, 2, 3, 0, 1, 2}.
+    // j -> {0, 1, 2, 3, 0, 1, 2}.  The DMA runs TWO groups ahead of the MFMAs.
     const char *zpage = reinterpret_cast<const char *>(g_b3_zero_page) + lane * 16;
-    int w_tile = 0, w_chunk = 0;                       // DMA cursor: tile index (of this workgroup) and chunk of the next group
-    auto dma_phase = [&](int j) {                      // one phase of the cursor's chunk -> its slot
-        const int slot = j < 4 ? j : j - 4;
+    int w_tile = 0, w_chunk = 0;                       // DMA cursor: tile index (of this workgroup) and chunk
+    auto dma_phase = [&](int jj) {                     // one phase of the cursor's chunk -> its slot
+        const int slot = jj < 4 ? jj : jj - 4;
         const bool live = w_tile < my_tiles;
-        const char *src0 = wt1 + (size_t(w_chunk) * G::J + j) * G::WSLOT_B;
+        const char *src0 = wt1 + (size_t(w_chunk) * G::J + jj) * G::WSLOT_B;
 #pragma unroll
         for (int r = 0; r < G::RW; ++r) {
             const int n = (wave + 4 * r) % G::NPW;
@@ -156,31 +160,50 @@ __global__ __launch_bounds__(256, 1) void resblock_b3_kernel(ConvPlan p, int til
             if (i_t >= tiles_per_clip) i_t -= tiles_per_clip, ++i_b;
         }
     };
-    auto input_store = [&](int buf) {      // split + write the staged chunk into plane buffer `buf`
-        char *pb = lds + buf * G::PLANE_B;
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            b3x8 h, m, l;
-            b3_split8(st[n], h, m, l);
-            if (st_t[n] >= 0) {
-                *reinterpret_cast<b3x8 *>(pb + (0 * 2 * W + st_t[n]) * 16) = h;
-                *reinterpret_cast<b3x8 *>(pb + (1 * 2 * W + st_t[n]) * 16) = m;
-                *reinterpret_cast<b3x8 *>(pb + (2 * 2 * W + st_t[n]) * 16) = l;
-            }
+    auto input_store_task = [&](int n, int buf) {      // split + write ONE staged task into plane buffer `buf`
+        char *pb = lds + (buf % NPB) * G::PLANE_B;
+        b3x8 h, m, l;
+        b3_split8(st[n], h, m, l);
+        if (st_t[n] >= 0) {
+            *reinterpret_cast<b3x8 *>(pb + (0 * 2 * W + st_t[n]) * 16) = h;
+            *reinterpret_cast<b3x8 *>(pb + (1 * 2 * W + st_t[n]) * 16) = m;
+            *reinterpret_cast<b3x8 *>(pb + (2 * 2 * W + st_t[n]) * 16) = l;
         }
     };
-
-    // ---- prologue: first chunk's planes, first group's weights ------------------------------------------------------------
-    input_load();
-    dma_phase(0);
-    dma_phase(1);
-    input_store(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
 
     // consumer-side lane offsets (bytes)
     const int aLane = (lh * C + li) * 16;                      // + (plane * 2 C + 32 i) * 16
     const int bLane = (lh * W + n0 + li) * 16;                 // + (plane * 2 W + 32 k + j D) * 16
+    auto load_a = [&](b3x8 (&a)[3][RH], int jj, int half) {
+        const char *wslot = lds + G::OFF_W + (jj < 4 ? jj : jj - 4) * G::WSLOT_B + aLane;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < RH; ++i)
+                a[pl][i] = *reinterpret_cast<const b3x8 *>(wslot + (pl * 2 * C + 32 * (half * RH + i)) * 16);
+    };
+    auto load_b = [&](b3x8 (&bf)[3], int buf, int jj, int kk) {
+        const char *pbuf = lds + (buf % NPB) * G::PLANE_B + bLane;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            bf[pl] = *reinterpret_cast<const b3x8 *>(pbuf + (pl * 2 * W + 32 * kk + jj * D) * 16);
+    };
+
+    // ---- prologue: first chunk's planes, the first two groups' weights (phases 0 .. 3) ---------------------------------
+    input_load();
+    dma_phase(0);
+    dma_phase(1);
+    dma_phase(2);
+    dma_phase(3);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) input_store_task(n, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // operand registers: A of the current / next (phase, row half) unit, B of the current / next step
+    b3x8 fa[2][3][RH], fb[2][3];
+    load_a(fa[0], 0, 0);
+    load_b(fb[0], 0, 0, 0);
 
     f32x16 acc[MW][NW];
     int cb = first_b, ct = first_t;
@@ -196,53 +219,105 @@ __global__ __launch_bounds__(256, 1) void resblock_b3_kernel(ConvPlan p, int til
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][kk][r] = 0.f;
 
-        // ---- GEMM1 ------------------------------------------------------------------------------------------------------
-        for (int c = 0; c < NCH; ++c) {
-            const char *pbuf = lds + (c & 1) * G::PLANE_B + bLane;     // NCH is even: the buffer parity restarts with the tile
+        // ---- GEMM1: two chunks per iteration (the unit count of a chunk may be odd: the A register sets swap roles) --------
+        for (int c2 = 0; c2 < NCH; c2 += 2) {
 #pragma unroll
-            for (int j = 0; j < G::J; ++j) {
-                const bool group_start = j == 0 || j == 2 || j == 4 || j == 6;
-                const bool group_end = j == 1 || j == 3 || j == 5 || j == 6;
-                if (group_start) {   // request the NEXT group's weights (the set the previous group released at the last barrier)
-                    if (j == 0) { dma_phase(2); dma_phase(3); }
-                    else if (j == 2) { dma_phase(4); dma_phase(5); }
-                    else if (j == 4) { dma_phase(6); dma_advance_chunk(); }
-                    else { dma_phase(0); dma_phase(1); }          // j == 6: first group of the next chunk (cursor already advanced)
-                }
-                if (j == 4) input_load();                          // next chunk: loads in flight over phases 4, 5
-                const char *wslot = lds + G::OFF_W + (j < 4 ? j : j - 4) * G::WSLOT_B + aLane;
+            for (int cc = 0; cc < 2; ++cc) {
+                // chunk c2 + cc reads plane buffer cc (NCH is even: the parity restarts with every tile)
 #pragma unroll
-                for (int half = 0; half < MW / RH; ++half) {
-                    b3x8 a[3][RH];
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                        for (int i = 0; i < RH; ++i)
-                            a[pl][i] = *reinterpret_cast<const b3x8 *>(wslot + (pl * 2 * C + 32 * (half * RH + i)) * 16);
+                for (int u = 0; u < NU; ++u) {
+                    const int j = u / NHALF, half = u % NHALF;
+                    const int ua = (cc * NU + u) & 1;                       // A register set of this unit
 #pragma unroll
                     for (int kk = 0; kk < NW; ++kk) {
-                        b3x8 bf[3];
-#pragma unroll
-                        for (int pl = 0; pl < 3; ++pl)
-                            bf[pl] = *reinterpret_cast<const b3x8 *>(pbuf + (pl * 2 * W + 32 * kk + j * D) * 16);
+                        const int step = u * NW + kk;
+                        const int sb = (cc * NSTEP + step) & 1;             // B register set of this step
+                        const bool last_of_unit = kk == NW - 1;
+                        const bool last_of_phase = last_of_unit && half == NHALF - 1;
+                        const bool group_end = last_of_phase && (j == 1 || j == 3 || j == 5 || j == 6);
+                        // the next chunk's loads are issued behind the barrier that ends phase 1 (in flight over phases 2, 3),
+                        // split + written one task per step from phase 4 on, all before the chunk's last barrier
+                        const int first_store = 4 * NHALF * NW;
+                        if (group_end) {
+                            // EARLY barrier: this group's last operands are in registers already, so its slots (and, at the
+                            // chunk's end, nothing of the plane buffer) are needed no more.  The next group's weights -- and
+                            // the next chunk's planes -- have landed once every wave has waited for its own part.
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            __syncthreads();
+                            if (j == 1) { dma_phase(4); dma_phase(5); input_load(); }
+                            else if (j == 3) { dma_phase(6); dma_advance_chunk(); }
+                            else if (j == 5) { dma_phase(0); dma_phase(1); }
+                            else { dma_phase(2); dma_phase(3); }
+                        }
                         f32x16 part[RH];
 #pragma unroll
                         for (int i = 0; i < RH; ++i) part[i] = acc[half * RH + i][kk];
-                        b3_products<RH>(part, a, bf);
+                        const bool chunk_end = group_end && j == 6;
+                        __builtin_amdgcn_sched_barrier(0);
+                        b3_products<RH, 0, 3>(part, fa[ua], fb[sb]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        // operands of the NEXT step, issued in the middle of this step's MFMAs: they have landed when the
+                        // next step starts, whatever counter value the compiler waits for there.  (One plane buffer: the
+                        // next chunk's planes only exist behind the second barrier below.)
+                        int nu = u, nk = kk + 1, ncc = cc;
+                        if (nk == NW) nk = 0, ++nu;
+                        if (nu == NU) nu = 0, ncc ^= 1;
+                        const int nj = nu / NHALF, nhalf = nu % NHALF;
+                        if (!(NPB == 1 && chunk_end)) {
+                            if (nk == 0) load_a(fa[ua ^ 1], nj, nhalf);
+                            load_b(fb[sb ^ 1], ncc, nj, nk);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        b3_products<RH, 3, 6>(part, fa[ua], fb[sb]);
 #pragma unroll
                         for (int i = 0; i < RH; ++i) acc[half * RH + i][kk] = part[i];
+                        if (NPB == 2 && step >= first_store && step < first_store + NT) {
+                            input_store_task(step - first_store, cc ^ 1);   // the buffer the previous chunk read: free since its last barrier
+                            // thread the split's vector instructions between the MFMAs (3 RH MFMAs, ~48 VALU + 3 LDS writes)
+#pragma unroll
+                            for (int g = 0; g < 3 * RH; ++g) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x002, (48 + 3 * RH - 1) / (3 * RH), 0);
+                            }
+                        }
+                        if (NPB == 1 && chunk_end) {
+                            // ONE plane buffer (two workgroups per CU: the partner's MFMAs run meanwhile): every wave is past the
+                            // chunk's barrier, i.e. holds the chunk's last operands in registers -- the buffer is free.  Split +
+                            // write the next chunk under this step's last MFMAs, barrier, then read the next step's operands.
+#pragma unroll
+                            for (int n = 0; n < NT; ++n) input_store_task(n, 0);
+#pragma unroll
+                            for (int g = 0; g < 3 * RH; ++g) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x002, (48 * NT + 3 * RH - 1) / (3 * RH), 0);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            __syncthreads();
+                            load_a(fa[ua ^ 1], nj, nhalf);
+                            load_b(fb[sb ^ 1], ncc, nj, nk);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                }
-                __builtin_amdgcn_sched_barrier(0);                 // keep the next phase's operand reads out of this one (registers)
-                if (j == 6) input_store((c + 1) & 1);              // the buffer chunk c-1 used: free since the barrier that ended it
-                if (group_end) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of the next group has landed
-                    __syncthreads();
                 }
             }
         }
+        static_assert(4 * NHALF * NW + NT <= NSTEP - 1, "the chunk's split must finish before its last (early) barrier");
 
         // ---- tile tail -------------------------------------------------------------------------------------------------
+        const char *xb = reinterpret_cast<const char *>(x + size_t(b) * C * Lin);     // uniform bases + 32-bit lane offsets
+        char *yb = reinterpret_cast<char *>(y + size_t(b) * C * Lin);
+        unsigned linv = unsigned(Lin), w2off = unsigned(aLane);
+        asm volatile("" : "+v"(linv), "+v"(w2off));   // opaque per tile: no address of the tail is hoisted over the main loop
+        auto load_w2 = [&](b3x8 (&a2)[3][HS], int kb, int pass) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int io = 0; io < HS; ++io)
+                    a2[pl][io] = *reinterpret_cast<const b3x8 *>(wt2 + (w2off + unsigned((kb * 6 * C + pl * 2 * C + 32 * (pass * HS + io)) * 16)));
+        };
+        b3x8 a2[2][3][HS];
+        load_w2(a2[0], 0, 0);          // travels while the activation runs
+        __builtin_amdgcn_sched_barrier(0);
         // hidden activation in registers (bias from LDS); rows of register r of row block i: 32 i + 8 (r / 4) + 4 lh + r % 4
 #pragma unroll
         for (int i = 0; i < MW; ++i)
@@ -260,10 +335,6 @@ __global__ __launch_bounds__(256, 1) void resblock_b3_kernel(ConvPlan p, int til
         // GEMM2: out = b2 + W2 . h, in MW / HS row passes (register budget: acc + out + W2 fragments); k-block kb = hidden
         // channels 16 kb .. 16 kb + 15 = accumulator registers 8 (kb % 2) .. + 7 of row block kb / 2.  The residual is added
         // in the epilogue (the GEMM1 accumulators are dead by then: room to have a whole pass of x in flight).
-        const char *xb = reinterpret_cast<const char *>(x + size_t(b) * C * Lin);     // uniform bases + 32-bit lane offsets
-        char *yb = reinterpret_cast<char *>(y + size_t(b) * C * Lin);
-        unsigned linv = unsigned(Lin), w2off = unsigned(aLane);
-        asm volatile("" : "+v"(linv), "+v"(w2off));   // opaque per tile: no address of the tail is hoisted over the main loop
 #pragma unroll
         for (int pass = 0; pass < MW / HS; ++pass) {
             f32x16 out[HS][NW];
@@ -277,31 +348,47 @@ __global__ __launch_bounds__(256, 1) void resblock_b3_kernel(ConvPlan p, int til
 #pragma unroll
                         for (int kk = 0; kk < NW; ++kk) out[io][kk][4 * g + s4] = bq[s4];
                 }
+            b3x8 hb[2][3];            // split hidden block of the current / next (kb, kk)
+            {
+                float hv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hv[e] = acc[0][0][e];
+                b3_split8(hv, hb[0][0], hb[0][1], hb[0][2]);
+            }
 #pragma unroll
             for (int kb = 0; kb < C / 16; ++kb) {
-                const int i = kb >> 1, r0 = 8 * (kb & 1);
-                b3x8 a2[3][HS];
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                    for (int io = 0; io < HS; ++io)
-                        a2[pl][io] = *reinterpret_cast<const b3x8 *>(wt2 + (w2off + unsigned((kb * 6 * C + pl * 2 * C + 32 * (pass * HS + io)) * 16)));
+                // weights one k-block ahead (the last block of a pass fetches the next pass's first)
+                if (kb + 1 < C / 16) load_w2(a2[(kb + 1) & 1], kb + 1, pass);
+                else if (pass + 1 < MW / HS) load_w2(a2[0], 0, pass + 1);
 #pragma unroll
                 for (int kk = 0; kk < NW; ++kk) {
-                    float hv[8];
+                    const int sidx = (kb * NW + kk) & 1;
+                    // split the NEXT block while this one's MFMAs run
+                    {
+                        int nkb = kb, nkk = kk + 1;
+                        if (nkk == NW) nkk = 0, ++nkb;
+                        if (nkb < C / 16) {
+                            float hv[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) hv[e] = acc[i][kk][r0 + e];
-                    b3x8 bf[3];
-                    b3_split8(hv, bf[0], bf[1], bf[2]);
+                            for (int e = 0; e < 8; ++e) hv[e] = acc[nkb >> 1][nkk][8 * (nkb & 1) + e];
+                            b3_split8(hv, hb[sidx ^ 1][0], hb[sidx ^ 1][1], hb[sidx ^ 1][2]);
+                        }
+                    }
                     f32x16 part[HS];
 #pragma unroll
                     for (int io = 0; io < HS; ++io) part[io] = out[io][kk];
-                    b3_products<HS>(part, a2, bf);
+                    b3_products<HS>(part, a2[kb & 1], hb[sidx]);
 #pragma unroll
                     for (int io = 0; io < HS; ++io) out[io][kk] = part[io];
+#pragma unroll
+                    for (int g = 0; g < 6 * HS; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, (48 + 6 * HS - 1) / (6 * HS), 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
+            static_assert((C / 16 * NW) % 2 == 0, "the split register sets must line up across passes");
             // residual + trailing activation + store (accumulator layout: 128-byte row segments per half wave)
 #pragma unroll
             for (int io = 0; io < HS; ++io)
@@ -329,11 +416,11 @@ __global__ __launch_bounds__(256, 1) void resblock_b3_kernel(ConvPlan p, int til
     }
 }
 
-template <int MW, int NW, int D>
+template <int MW, int NW, int D, int NPB>
 static int launch_b3(const ConvPlan &p, const float *x, const float *w1, const float *b1, const float *w2, const float *b2,
                      float *y, int post_act, hipStream_t st) {
-    using G = B3Geom<MW, NW, D>;
-    auto kern = resblock_b3_kernel<MW, NW, D>;
+    using G = B3Geom<MW, NW, D, NPB>;
+    auto kern = resblock_b3_kernel<MW, NW, D, NPB>;
     static bool attr_set = false;
     static int n_cu = 0;
     if (!attr_set) {
@@ -347,12 +434,13 @@ static int launch_b3(const ConvPlan &p, const float *x, const float *w1, const f
         n_cu = prop.multiProcessorCount;
         attr_set = true;
     }
-    static_assert(G::LDS_BYTES <= 160 * 1024, "resblock_b3: LDS budget");
+    static_assert(G::LDS_BYTES * (NPB == 1 ? 2 : 1) <= 160 * 1024, "resblock_b3: LDS budget");
     const int tiles_per_clip = ceil_div(p.Lin, G::BN);
     const int64_t ntiles64 = int64_t(tiles_per_clip) * p.B;
     if (ntiles64 > (1 << 30)) return fail(AGX_ERR_BAD_SHAPE, "resblock_b3: too many tiles");
     const int ntiles = int(ntiles64);
-    const int grid = ntiles < n_cu ? ntiles : n_cu;        // one persistent workgroup per CU
+    const int want = n_cu * (NPB == 1 ? 2 : 1);            // persistent: two workgroups per CU where the LDS / registers allow
+    const int grid = ntiles < want ? ntiles : want;
     // B3 tile images: behind the bf16x3 standard image and the dim0 scale scratch (common.hpp: b3 images)
     const char *wt1 = reinterpret_cast<const char *>(w1 + packed_weight_floats_bf(G::C, G::J, G::C) + G::C);
     const char *wt2 = reinterpret_cast<const char *>(w2 + packed_weight_floats_bf(G::C, 1, G::C) + G::C);
@@ -372,9 +460,9 @@ bool resblock_b3_supported(const ConvPlan &p) {
 
 const char *resblock_b3_variant(const ConvPlan &p) {
     switch (p.Cin) {
-        case 32: return "resblock_b3<1,4>";
-        case 64: return "resblock_b3<2,4>";
-        case 128: return "resblock_b3<4,2>";
+        case 32: return "resblock_b3<1,4,x2>";
+        case 64: return "resblock_b3<2,2,x2>";
+        case 128: return "resblock_b3<4,1,x2>";
         default: return "resblock_b3<8,1>";
     }
 }
@@ -382,15 +470,17 @@ const char *resblock_b3_variant(const ConvPlan &p) {
 int launch_resblock_b3(const ConvPlan &p, const float *x, const float *w1, const float *b1, const float *w2, const float *b2,
                        float *y, int post_act, hipStream_t st) {
     if (!resblock_b3_supported(p)) return fail(AGX_ERR_UNSUPPORTED, "resblock_b3: unsupported shape");
-#define AGX_B3(MW, NW)                                                                  \
-    (p.d == 1 ? launch_b3<MW, NW, 1>(p, x, w1, b1, w2, b2, y, post_act, st)             \
-     : p.d == 3 ? launch_b3<MW, NW, 3>(p, x, w1, b1, w2, b2, y, post_act, st)           \
-                : launch_b3<MW, NW, 9>(p, x, w1, b1, w2, b2, y, post_act, st))
+#define AGX_B3(MW, NW, NPB)                                                                  \
+    (p.d == 1 ? launch_b3<MW, NW, 1, NPB>(p, x, w1, b1, w2, b2, y, post_act, st)             \
+     : p.d == 3 ? launch_b3<MW, NW, 3, NPB>(p, x, w1, b1, w2, b2, y, post_act, st)           \
+                : launch_b3<MW, NW, 9, NPB>(p, x, w1, b1, w2, b2, y, post_act, st))
+    // <.., 1>: one plane buffer, <= 256 registers: two workgroups per CU (one covers the other's vector work and barriers);
+    // <.., 2>: double-buffered planes, one workgroup per CU with up to 512 registers (tiles too big for two)
     switch (p.Cin) {
-        case 32: return AGX_B3(1, 4);
-        case 64: return AGX_B3(2, 4);
-        case 128: return AGX_B3(4, 2);
-        default: return AGX_B3(8, 1);
+        case 32: return AGX_B3(1, 4, 1);
+        case 64: return tuning().b3_dbg == 1 ? AGX_B3(2, 4, 2) : AGX_B3(2, 2, 1);
+        case 128: return tuning().b3_dbg == 1 ? AGX_B3(4, 2, 2) : AGX_B3(4, 1, 1);
+        default: return AGX_B3(8, 1, 2);
     }
 #undef AGX_B3
 }
