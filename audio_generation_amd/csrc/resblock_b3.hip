@@ -30,6 +30,23 @@ namespace agx {
 
 typedef __bf16 b3x8 __attribute__((ext_vector_type(8)));
 
+// probe build (tools/b3_probe.hip): s_memtime stamps of the workgroup's third tile, one lane per wave
+#ifdef AGX_STAMPS
+#define B3_TSTAMP(slot)                                                                                                \
+    do {                                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if (k == 2 && lane == 0) g_stamps[(blockIdx.x * 4 + wave) * 16 + (slot)] = __builtin_amdgcn_s_memtime();       \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+    } while (0)
+#define B3_RSTAMP(slot)                                                                                                \
+    do {                                                                                                               \
+        if (lane == 0) g_stamps[(blockIdx.x * 4 + wave) * 16 + (slot)] = __builtin_amdgcn_s_memrealtime();             \
+    } while (0)
+#else
+#define B3_TSTAMP(slot) ((void)0)
+#define B3_RSTAMP(slot) ((void)0)
+#endif
+
 __device__ __attribute__((aligned(1024))) float g_b3_zero_page[256] = {0.f};
 
 __device__ __forceinline__ void b3_glds_b128(const void *gsrc_lane, void *lds_wave_base) {
@@ -81,7 +98,7 @@ __device__ __forceinline__ void b3_split8(const float (&x)[8], b3x8 &h, b3x8 &m,
 
 template <int MW, int NW, int D, int NPB>
 __global__ __launch_bounds__(256, NPB == 1 ? 2 : 1) void resblock_b3_kernel(ConvPlan p, int tiles_per_clip, int ntiles, int step_b,
-                                                             int step_t, int post_act, const float *__restrict__ x,
+                                                             int step_t, int post_act, int prio, const float *__restrict__ x,
                                                              const char *__restrict__ wt1, const float *__restrict__ b1,
                                                              const char *__restrict__ wt2, const float *__restrict__ b2,
                                                              float *__restrict__ y) {
@@ -101,6 +118,7 @@ __global__ __launch_bounds__(256, NPB == 1 ? 2 : 1) void resblock_b3_kernel(Conv
     if (my_tiles == 0) return;
     const int first_b = int(blockIdx.x) / tiles_per_clip, first_t = int(blockIdx.x) - first_b * tiles_per_clip;
 
+    B3_RSTAMP(14);
     float *bias_s = reinterpret_cast<float *>(lds + G::OFF_BIAS);
     for (int i = tid; i < 2 * C; i += 256) bias_s[i] = i < C ? (b1 ? b1[i] : 0.f) : (b2 ? b2[i - C] : 0.f);
 
@@ -219,6 +237,8 @@ __global__ __launch_bounds__(256, NPB == 1 ? 2 : 1) void resblock_b3_kernel(Conv
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][kk][r] = 0.f;
 
+        B3_TSTAMP(0);
+        if (prio) __builtin_amdgcn_s_setprio(1);      // GEMM1 outranks the partner workgroup's tail on the shared SIMD (+1..3 %; knob b3_dbg = 2: off)
         // ---- GEMM1: two chunks per iteration (the unit count of a chunk may be odd: the A register sets swap roles) --------
         for (int c2 = 0; c2 < NCH; c2 += 2) {
 #pragma unroll
@@ -299,8 +319,10 @@ __global__ __launch_bounds__(256, NPB == 1 ? 2 : 1) void resblock_b3_kernel(Conv
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+                B3_TSTAMP(1 + c2 + cc);
             }
         }
+        if (prio) __builtin_amdgcn_s_setprio(0);
         static_assert(4 * NHALF * NW + NT <= NSTEP - 1, "the chunk's split must finish before its last (early) barrier");
 
         // ---- tile tail -------------------------------------------------------------------------------------------------
@@ -332,6 +354,7 @@ __global__ __launch_bounds__(256, NPB == 1 ? 2 : 1) void resblock_b3_kernel(Conv
                         acc[i][kk][4 * g + s4] = v > 0.f ? v : v * p.slope;
                     }
             }
+        B3_TSTAMP(9);
         // GEMM2: out = b2 + W2 . h, in MW / HS row passes (register budget: acc + out + W2 fragments); k-block kb = hidden
         // channels 16 kb .. 16 kb + 15 = accumulator registers 8 (kb % 2) .. + 7 of row block kb / 2.  The residual is added
         // in the epilogue (the GEMM1 accumulators are dead by then: room to have a whole pass of x in flight).
@@ -388,6 +411,7 @@ __global__ __launch_bounds__(256, NPB == 1 ? 2 : 1) void resblock_b3_kernel(Conv
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            if (pass == 0) B3_TSTAMP(10);
             static_assert((C / 16 * NW) % 2 == 0, "the split register sets must line up across passes");
             // residual + trailing activation + store (accumulator layout: 128-byte row segments per half wave)
 #pragma unroll
@@ -412,8 +436,11 @@ __global__ __launch_bounds__(256, NPB == 1 ? 2 : 1) void resblock_b3_kernel(Conv
                         }
                     }
                 }
+            if (pass == 0) B3_TSTAMP(11);
         }
+        B3_TSTAMP(12);
     }
+    B3_RSTAMP(15);
 }
 
 template <int MW, int NW, int D, int NPB>
@@ -445,7 +472,7 @@ static int launch_b3(const ConvPlan &p, const float *x, const float *w1, const f
     const char *wt1 = reinterpret_cast<const char *>(w1 + packed_weight_floats_bf(G::C, G::J, G::C) + G::C);
     const char *wt2 = reinterpret_cast<const char *>(w2 + packed_weight_floats_bf(G::C, 1, G::C) + G::C);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G::LDS_BYTES, st, p, tiles_per_clip, ntiles, grid / tiles_per_clip,
-                       grid % tiles_per_clip, post_act, x, wt1, b1, wt2, b2, y);
+                       grid % tiles_per_clip, post_act, tuning().b3_dbg != 2, x, wt1, b1, wt2, b2, y);
     return check_launch("resblock_b3");
 }
 

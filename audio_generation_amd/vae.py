@@ -371,11 +371,19 @@ class CausalVQAE(nn.Module):
         for stack, mode in ((self.decoders, decoders), (self.encoders, encoders)):
             if mode not in ("fp32", "bf16x3"):
                 raise ValueError(f"unknown arithmetic {mode!r}")
+            in_block = {id(c_) for blk in stack.modules() if isinstance(blk, CausalResidualBlock1d)
+                        for c_ in blk.modules() if isinstance(c_, _ConvBase)}
             for m in stack.modules():
                 if isinstance(m, _ConvBase):
                     c = m.conv
                     q = c.stride[0] if m.kind in (CONV_TRANSPOSED, CONV_UPSAMPLE) else 1
                     ok = mode == "bf16x3" and c.in_channels % 16 == 0 and q * c.out_channels >= 32 and getattr(c, "groups", 1) == 1
+                    # the resampling convs only have the first-round bf16x3 kernels (no ring form yet): they beat the fp32
+                    # ring kernels on the x5 / x8 up-convs, the stride-4 down-conv and the k = 7 transposed conv, and lose
+                    # elsewhere (tools/layer_times.py bf16x3) -- those layers stay on the fp32 ring, which is at least as exact
+                    if ok and id(m) not in in_block:
+                        ok = ((m.kind == CONV_UPSAMPLE and c.stride[0] in (5, 8)) or (m.kind == CONV_CAUSAL and c.stride[0] == 4)
+                              or (m.kind == CONV_TRANSPOSED and c.kernel_size[0] == 7))
                     m.impl = IMPL_MFMA_BF16X3 if ok else IMPL_AUTO
         self.__dict__.pop("_unit_cache", None)
         return self

@@ -11,6 +11,8 @@ def main():
     model = bench.build_model(dev)
     x = bench.make_inputs(32, 0).to(dev)
     bench.calibrate_codebooks(model, x[:8], "latents")
+    arith = sys.argv[1] if len(sys.argv) > 1 else "fp32"          # fp32 | mixed (decoder bf16x3) | bf16x3 (everything)
+    model.set_conv_arithmetic(decoders="bf16x3" if arith != "fp32" else "fp32", encoders="bf16x3" if arith == "bf16x3" else "fp32")
     with torch.no_grad():
         for _ in range(2): model(x)
     agg = {}
