@@ -57,16 +57,16 @@ __global__ __launch_bounds__(256) void layernorm_ct_kernel(const float *__restri
     }
 }
 
-// One-pass form (round 3): block = 16 time steps x 16 channel groups, a thread keeps its CPT channels (c = g + 16 k) of
+// One-pass form (round 3): block = 16 time steps x NG channel groups, a thread keeps its CPT channels (c = g + NG k) of
 // one time step in registers -- x is read ONCE, every load is issued before the first use, statistics go through one
 // 16 x 16 LDS exchange each (mean, then the centred sum of squares from the registers: the two-pass formula without
 // the second pass over memory).  (B, 512, 225): 480 workgroups instead of 128, 14.7 MB moved once.
-template <int CPT>
-__global__ __launch_bounds__(256) void layernorm_ct_regs_kernel(const float *__restrict__ x,
-                                                                const float *__restrict__ weight,
-                                                                const float *__restrict__ bias,
-                                                                float *__restrict__ y, int C, int T, float eps) {
-    __shared__ float part[16][17];
+template <int CPT, int NG>   // NG channel groups x 16 time steps = 16 NG threads; channel c = g + NG k, k < CPT
+__global__ __launch_bounds__(16 * NG) void layernorm_ct_regs_kernel(const float *__restrict__ x,
+                                                                    const float *__restrict__ weight,
+                                                                    const float *__restrict__ bias,
+                                                                    float *__restrict__ y, int C, int T, float eps) {
+    __shared__ float part[NG][17];
     const int tl = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int t = blockIdx.x * 16 + tl;
     const int tc = min(t, T - 1);
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void layernorm_ct_regs_kernel(const float *__r
     float v[CPT];
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
-        const int c = g + 16 * k;
+        const int c = g + NG * k;
         v[k] = c < C ? xb[size_t(c) * T] : 0.f;
     }
     float s = 0.f;
@@ -84,26 +84,26 @@ __global__ __launch_bounds__(256) void layernorm_ct_regs_kernel(const float *__r
     __syncthreads();
     float tot = 0.f;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) tot += part[j][tl];
+    for (int j = 0; j < NG; ++j) tot += part[j][tl];
     const float mean = tot / float(C);
     __syncthreads();
     float q = 0.f;
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
-        const float d = (g + 16 * k < C) ? v[k] - mean : 0.f;
+        const float d = (g + NG * k < C) ? v[k] - mean : 0.f;
         q = fmaf(d, d, q);
     }
     part[g][tl] = q;
     __syncthreads();
     float var = 0.f;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) var += part[j][tl];
+    for (int j = 0; j < NG; ++j) var += part[j][tl];
     const float rstd = 1.f / sqrtf(var / float(C) + eps);
     if (t >= T) return;
     float *yb = y + size_t(blockIdx.y) * C * T + t;
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
-        const int c = g + 16 * k;
+        const int c = g + NG * k;
         if (c < C) {
             const float w = weight ? weight[c] : 1.f, b = bias ? bias[c] : 0.f;
             yb[size_t(c) * T] = (v[k] - mean) * rstd * w + b;
@@ -495,15 +495,15 @@ int agx_layernorm_ct(const float *x, const float *weight, const float *bias, flo
     if (!x || !y) return fail(AGX_ERR_NULL_POINTER, "layernorm_ct: NULL pointer");
     if (batch > 65535) return fail(AGX_ERR_BAD_SHAPE, "layernorm_ct: batch too large");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int cpt = ceil_div(channels, 16);
     const dim3 grid(ceil_div(t, 16), batch);
-#define AGX_LN(N) hipLaunchKernelGGL(layernorm_ct_regs_kernel<N>, grid, dim3(256), 0, st, x, weight, bias, y, channels, t, eps)
-    if (cpt <= 4) AGX_LN(4);
-    else if (cpt <= 8) AGX_LN(8);
-    else if (cpt <= 16) AGX_LN(16);
-    else if (cpt <= 32) AGX_LN(32);
-    else if (cpt <= 64) AGX_LN(64);
-    else    // > 1024 channels: the three-pass kernel (no register budget for a whole column)
+#define AGX_LN(N, NG) hipLaunchKernelGGL((layernorm_ct_regs_kernel<N, NG>), grid, dim3(16 * NG), 0, st, x, weight, bias, y, channels, t, eps)
+    if (channels <= 64) AGX_LN(4, 16);
+    else if (channels <= 128) AGX_LN(8, 16);
+    else if (channels <= 256) AGX_LN(8, 32);
+    else if (channels <= 512) AGX_LN(16, 32);          // 512 threads: 16 loads in flight per thread, one column block per workgroup
+    else if (channels <= 1024) AGX_LN(32, 32);
+    else if (channels <= 2048) AGX_LN(64, 32);
+    else    // > 2048 channels: the three-pass kernel (no register budget for a whole column)
         hipLaunchKernelGGL(layernorm_ct_kernel, dim3(ceil_div(t, 64), batch), dim3(256), 0, st, x, weight, bias, y, channels, t,
                            eps);
 #undef AGX_LN

@@ -202,6 +202,163 @@ __global__ __launch_bounds__(256) void attention_flash_kernel(const float *__res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 arithmetic with K and V of one (head, item) staged ONCE per workgroup through LDS as bf16 (round 3; BASELINE
+// config 3: T = 225).  The no-LDS kernel above reads every operand element with its own strided 4-byte load -- 128 per
+// lane and key block, repeated by each of the 4 waves -- and its 16 MFMAs per block wait on them (0.9 % MFMA
+// utilisation).  Here the workgroup's 256 threads read K and V once (8 coalesced loads -> one 16-byte LDS write per
+// task), in the fragment layouts of the two products:
+//     Ks[d / 16][lane half][key][8 d]                      S^T = K^T Q:  A fragment = one ds_read_b128
+//     Vs[key / 16][lane half][dv][8 keys, PV slot order]   O^T = V P^T:  A fragment = one ds_read_b128
+// (PV slot e of lane half lh = key 16 hb + 4 lh + (e & 3) + 8 (e >> 2): the probability registers are the B operand as
+// they stand).  No barrier inside the key loop.  Same arithmetic as PREC 1 above (operands rounded to bf16, fp32
+// accumulation and softmax).  Used when 2 * Tp * DH * 2 bytes fit the LDS (Tp = T rounded up to 64).
+template <int DVT>
+__global__ __launch_bounds__(256) void attention_bf16_lds_kernel(const float *__restrict__ qkv, const float *__restrict__ slopes,
+                                                                 float *__restrict__ out, int H, int Dh, int T, int Tp,
+                                                                 float scale_div) {
+    constexpr int KB = 64, DH = 32 * DVT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *Ks = smem;                              // [DH / 16][2][Tp][16 B]
+    char *Vs = smem + size_t(DH / 16) * 2 * Tp * 16;   // [Tp / 16][2][DH][16 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int HD = H * Dh;
+    const float *qb = qkv + (size_t(b) * 3 * HD + size_t(h) * Dh) * T;
+    const float *kb = qb + size_t(HD) * T;
+    const float *vb = kb + size_t(HD) * T;
+    // ---- stage K: task = (key j, group of 8 head dims) ----
+    for (int u = tid; u < Tp * (DH / 8); u += 256) {
+        const int j = u % Tp, g8 = u / Tp;            // consecutive threads = consecutive keys: coalesced
+        af_bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int d = 8 * g8 + e;
+            v[e] = (__bf16)((d < Dh && j < T) ? kb[size_t(d) * T + j] : 0.f);
+        }
+        *reinterpret_cast<af_bf16x8 *>(Ks + (size_t(g8) * Tp + j) * 16) = v;      // g8 = 2 (d / 16) + lane half
+    }
+    // ---- stage V: task = (dv, 16-key half block hbk, lane half): keys 16 hbk + 4 lh + {0..3, 8..11} ----
+    for (int u = tid; u < DH * (Tp / 8); u += 256) {
+        const int g = u % (Tp / 8), dv = u / (Tp / 8);   // consecutive threads walk along the keys of one row
+        const int hbk = g >> 1, vlh = g & 1;
+        af_bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int j = 16 * hbk + 4 * vlh + (e & 3) + 8 * (e >> 2);
+            v[e] = (__bf16)((dv < Dh && j < T) ? vb[size_t(dv) * T + j] : 0.f);
+        }
+        *reinterpret_cast<af_bf16x8 *>(Vs + ((size_t(hbk) * 2 + vlh) * DH + dv) * 16) = v;
+    }
+    const int i = blockIdx.x * 128 + wave * 32 + li;   // this lane's query
+    const int ic = min(i, T - 1);
+    const float slope = slopes[h], inv_scale = 1.f / scale_div;
+    af_bf16x8 qh[DH / 16];
+#pragma unroll
+    for (int kq = 0; kq < DH / 16; ++kq)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int d = 16 * kq + 8 * lh + e;
+            qh[kq][e] = (__bf16)(d < Dh ? qb[size_t(d) * T + ic] : 0.f);
+        }
+    __syncthreads();
+    if (blockIdx.x * 128 + wave * 32 >= T) return;     // (after the barrier) a wave without queries
+
+    f32x16 o[DVT];
+#pragma unroll
+    for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const int nblk = (T + KB - 1) / KB;
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int j0 = blk * KB;
+        f32x16 acc[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t2][r] = 0.f;
+#pragma unroll
+        for (int kq = 0; kq < DH / 16; ++kq)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const af_bf16x8 kh = *reinterpret_cast<const af_bf16x8 *>(Ks + (size_t(2 * kq + lh) * Tp + j0 + 32 * t2 + li) * 16);
+                acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[kq], acc[t2], 0, 0, 0);
+            }
+        float bm = -INFINITY;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = j0 + t2 * 32 + acc_row(r, lh);
+                float sv = acc[t2][r] * inv_scale - fabsf(float(ic - j)) * slope;
+                sv = j < T ? sv : -INFINITY;
+                acc[t2][r] = sv;
+                bm = fmaxf(bm, sv);
+            }
+        bm = fmaxf(bm, __shfl_xor(bm, 32));
+        const float mn = fmaxf(m, bm);
+        const float alpha = expf(m - mn);
+        float bl = 0.f;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pe = expf(acc[t2][r] - mn);
+                acc[t2][r] = pe;
+                bl += pe;
+            }
+        bl += __shfl_xor(bl, 32);
+        l = l * alpha + bl;
+        m = mn;
+#pragma unroll
+        for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                af_bf16x8 ph;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ph[e] = (__bf16)acc[t2][8 * hb + e];
+                const int hbk = (j0 + 32 * t2 + 16 * hb) >> 4;
+#pragma unroll
+                for (int dt = 0; dt < DVT; ++dt) {
+                    const af_bf16x8 vh = *reinterpret_cast<const af_bf16x8 *>(Vs + ((size_t(hbk) * 2 + lh) * DH + dt * 32 + li) * 16);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, o[dt], 0, 0, 0);
+                }
+            }
+    }
+    const float inv = 1.f / l;
+    float *ob = out + (size_t(b) * HD + size_t(h) * Dh) * T;
+    if (i < T) {
+#pragma unroll
+        for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dv = dt * 32 + acc_row(r, lh);
+                if (dv < Dh) ob[size_t(dv) * T + i] = o[dt][r] * inv;
+            }
+    }
+}
+
+template <int DVT>
+static int launch_bf16_lds(const float *qkv, const float *slopes, float *out, int B, int H, int Dh, int T, int Tp, float scale_div,
+                           hipStream_t st) {
+    const size_t lds = size_t(2) * Tp * 32 * DVT * 2;
+    auto kern = attention_bf16_lds_kernel<DVT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(ceil_div(T, 128), H, B), dim3(256), lds, st, qkv, slopes, out, H, Dh, T, Tp, scale_div);
+    return check_launch("attention_bf16_lds");
+}
+
 template <int DVT, int PREC>
 static int launch_flash(const float *qkv, const float *slopes, float *out, int B, int H, int Dh, int T, float scale_div,
                         hipStream_t st) {
@@ -222,6 +379,12 @@ static int launch_flash(const float *qkv, const float *slopes, float *out, int B
 int launch_attention_flash(const float *qkv, const float *slopes, float *out, int B, int H, int Dh, int T, float scale_div,
                            int precision, hipStream_t st) {
     const int dvt = Dh <= 32 ? 1 : (Dh <= 64 ? 2 : 4);
+    const int Tp = (T + 63) / 64 * 64;
+    if (precision && size_t(2) * Tp * 32 * dvt * 2 <= 128 * 1024) {   // K and V of a (head, item) fit the LDS as bf16
+        if (dvt == 1) return launch_bf16_lds<1>(qkv, slopes, out, B, H, Dh, T, Tp, scale_div, st);
+        if (dvt == 2) return launch_bf16_lds<2>(qkv, slopes, out, B, H, Dh, T, Tp, scale_div, st);
+        return launch_bf16_lds<4>(qkv, slopes, out, B, H, Dh, T, Tp, scale_div, st);
+    }
 #define AGX_FL(DVT)                                                                                          \
     return precision ? launch_flash<DVT, 1>(qkv, slopes, out, B, H, Dh, T, scale_div, st)                    \
                      : launch_flash<DVT, 0>(qkv, slopes, out, B, H, Dh, T, scale_div, st)
