@@ -22,6 +22,7 @@ namespace agx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 rvq_bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int FT = 32;    // frames per workgroup
 constexpr int NWV = 8;    // waves per workgroup (2 per SIMD: one computes while the other waits on L2)
@@ -31,10 +32,11 @@ constexpr int CAND = 8;   // candidate slots per frame
 constexpr int TLMAX = 8;  // |c'|^2, |c'| table entries a thread carries to the next stage: 2 K <= TLMAX * NT for the LDS copy
 constexpr int MUMAX = 2;  // same for the mean codeword: Dp <= MUMAX * NT
 
-__host__ __device__ inline int rvq_dp(int dim) { return (dim + 7) & ~7; }  // D rounded up to the 8-deep k block
+__host__ __device__ inline int rvq_dp(int dim) { return (dim + 15) & ~15; }  // D rounded up to the 16-deep k block of the bf16 MFMA
 // stage image, all on CENTRED codewords c' = fl(c - mu), mu = the stage's mean codeword:
-//   CbG[Dp/4][K][4] (4 consecutive dims of one codeword adjacent, zero padded) | c2 = |c'|^2 (K) | cn = |c'| (K)
-//   | cmax2 + pad(3) | mu (Dp)
+//   CbH[Dp/16][plane 2][lane half 2][K][8] bf16 -- c' = h + m + (error <= 2^-16 |c'_d|), the A operand of
+//   v_mfma_f32_32x32x16_bf16 as it stands: lane (code, half) reads its 8 dims 16 kq + 8 half + (0..7) of one plane with one
+//   16-byte load; same number of bytes as an fp32 image -- | c2 = |c'|^2 (K) | cn = |c'| (K) | cmax2 + pad(3) | mu (Dp)
 // Distances are translation invariant, and scoring |c'|^2 - 2 r'.c' with r' = fl(r - mu) keeps the fp32
 // error bound proportional to the SPREAD of the data instead of its offset from the origin: without the
 // centring, latents that share a large common component (any encoder with a bias) put most codewords
@@ -49,19 +51,26 @@ __host__ __device__ inline int64_t rvq_stage_floats(int k, int dim) {
 // zero in the score image; the stage's count rides in the image's tail for the kernel's full-search fallback.
 struct RvqSizes { int n[64]; };
 
-// mu[d] = mean_k c[k][d]  (thread per d; fp32 sequential over k)
+// mu[d] = mean_k c[k][d].  One wave per dimension d: lane L adds codewords L, L + 64, ... in order, the 64 partial sums are
+// combined by a fixed shuffle tree (deterministic).  (Round 2: one THREAD per d walking all K rows with a stride of D
+// floats -- 384 us per repack at 8 x 1024 x 512.)
 __global__ __launch_bounds__(256) void rvq_mean_kernel(const float *__restrict__ cb, int k, int dim,
                                                        float *__restrict__ packed, RvqSizes sizes) {
     const int q = blockIdx.y;
     const int kq = sizes.n[q];
-    const int d = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int dp = rvq_dp(dim);
-    if (d >= dp) return;
     float *mu = packed + q * rvq_stage_floats(k, dim) + size_t(dp) * k + 2 * size_t(k) + 4;
+    // 4 waves x 16 dims per block: lane = (codeword phase c0 = lane / 16, dim d0 + lane % 16) so that a wave's loads are
+    // 64-byte row segments; each lane walks codewords c0, c0 + 4, ... and the four phases are combined at the end
+    const int d = blockIdx.x * 64 + wave * 16 + (lane & 15);
+    const int c0 = lane >> 4;
     float acc = 0.f;
     if (d < dim)
-        for (int c = 0; c < kq; ++c) acc += cb[(size_t(q) * k + c) * dim + d];
-    mu[d] = d < dim ? acc / float(kq) : 0.f;
+        for (int c = c0; c < kq; c += 4) acc += cb[(size_t(q) * k + c) * dim + d];
+    acc += __shfl_xor(acc, 16);
+    acc += __shfl_xor(acc, 32);
+    if (d < dp && c0 == 0) mu[d] = d < dim ? acc / float(kq) : 0.f;
 }
 
 __global__ __launch_bounds__(256) void rvq_pack_kernel(const float *__restrict__ cb, int n_q, int k,
@@ -75,9 +84,14 @@ __global__ __launch_bounds__(256) void rvq_pack_kernel(const float *__restrict__
     const int dp = rvq_dp(dim);
     const float *mu = img + size_t(dp) * k + 2 * size_t(k) + 4;
     float acc = 0.f;
+    __bf16 *imgb = reinterpret_cast<__bf16 *>(img);
     for (int d = 0; d < dp; ++d) {
         const float v = (d < dim && !pad) ? row[d] - mu[d] : 0.f;
-        img[(size_t(d >> 2) * k + code) * 4 + (d & 3)] = v;
+        const __bf16 h = (__bf16)v;
+        const __bf16 m = (__bf16)(v - (float)h);
+        const size_t base = ((size_t(d >> 4) * 4 + ((d >> 3) & 1)) * k + code) * 8 + (d & 7);   // plane 0 (h), lane half (d/8)%2
+        imgb[base] = h;
+        imgb[base + size_t(2) * k * 8] = m;                                                      // plane 1 (m)
         acc = fmaf(v, v, acc);
     }
     img[size_t(dp) * k + code] = pad ? INFINITY : acc;
@@ -160,6 +174,7 @@ struct RvqArgs {
     int64_t *index;  // (B*T, Q)
     double *sq_err;  // (Q) [unused by the kernel since the partials moved to `part`]
     double *part;    // (workgroups, Q) squared error of each workgroup's 32 frames per stage
+    float acc_scale; // 1; a diagnostic knob (b3_dbg = 7: 4) widens the accumulation term of the score error bound
 };
 
 template <int MT, bool TAIL_LDS>   // TAIL_LDS: the stage's |c'|^2 and |c'| tables are copied to LDS (they fit beside R / O)
@@ -209,7 +224,21 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
         }
     }
     __syncthreads();
-    const float err_unit = float(D + 8) * 5.9604645e-8f * 1.25f;  // (D+8) * 2^-24 * 1.25
+    // Error of one computed score s_k = |c'_k|^2 - 2 dot_k against the exact |r - c_k|^2 - |r'|^2, in units of (|r'| + |c'_k|)^2:
+    //   * |c'|^2 table and the two centring roundings: (D + 8) 2^-24 x 1.25 (as for the fp32 score GEMM of rounds 1-2);
+    //   * the dot product on two bf16 pieces per operand: each piece pair drops <= 2^-16 of its element and the m.m product
+    //     (<= 2^-16) is not formed: <= 3 x 2^-16 |r'||c'| in all;
+    //   * its accumulation.  v_mfma_f32_32x32x16_bf16 forms c + sum of 16 exact products; measured on this hardware
+    //     (tools/mfma_bf16_err.hip: equal magnitudes, exponents spread over 2^20, heavy cancellation, large accumulators)
+    //     its result is the correctly rounded sum when the addends are of similar size and otherwise off by at most
+    //     5.3 x 2^-24 (|c| + sum |a_k b_k|) -- addends aligned to the largest and truncated.  The bound allows
+    //     18 x 2^-24 (17 truncated addends + the final rounding) per instruction, and the worst-case linear growth over the
+    //     chain of 3 Dp / 16 instructions with |c| <= the sum of all |products| <= (1 + 2^-7) |r'||c'|;
+    //   with |r'||c'| <= (|r'| + |c'|)^2 / 4 and the factor 2 of the score: x 1/2.
+    // Far above the typical error (which grows like the square root of the chain length); only the candidate selection
+    // depends on it -- a wider margin means more frames decided by the defining binary64 distance, never a different index.
+    const float acc_err = 18.f * float(3 * Dp / 16 + 1) * 5.9604645e-8f * (1.f + 0.0078125f);
+    const float err_unit = float(D + 8) * 5.9604645e-8f * 1.25f + 0.5f * (fabsf(a.acc_scale) * acc_err + 3.f * 1.5258789e-5f);
     constexpr int CHUNK = NWV * 32 * MT;  // codewords scored per pass
     const int n_chunks = (K + CHUNK - 1) / CHUNK;
 
@@ -273,58 +302,60 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) acol[i] = min(code0 + i * 32 + li, K - 1);
 
-            // ---- A: scores.  A[i=code][k=d], B[k=d][j=frame].  Within an 8-deep block of d, MFMA
-            // step ks pairs d0+ks (lane half 0) with d0+4+ks (half 1): a lane's 4 A operands are
-            // 4 consecutive dims of its codeword = one 16-byte load of the CbG image, prefetched
-            // one block ahead; B operands are conflict-free ds_read_b32 of the residual tile.
-            const float *rb = R + (4 * lh) * RS + li;
-            const float *ab = img + size_t(lh) * K * 4;
-            // The codeword operands come straight from L2 (~1 us under load) while one 8-deep block is only
-            // 4 MT MFMAs (0.2 us): they are requested three blocks ahead into a ring of four register sets
-            // (the loop is unrolled by four so that the ring is addressed statically: a register move would
-            // have to wait for its load).
+            // ---- A: scores on the bf16 matrix pipe.  A[i=code][k=d], B[k=d][j=frame].  Both operands are two bf16 pieces
+            // (x = h + m + O(2^-16 x)); a 16-deep block of d is three v_mfma_f32_32x32x16_bf16 per subtile -- m.h, h.m, h.h
+            // (small terms first; m.m is below 2^-16 of the product and goes into the error bound) -- 96 cycles against 512
+            // for the same block on the fp32-input MFMA.  The scores only SELECT candidates: every decision is still made
+            // on the rigorous bound below and, among several candidates, by the defining binary64 distance, so the indices
+            // do not depend on this arithmetic.  Lane (code, half) holds dims 16 kq + 8 half + (0..7): the codeword pieces
+            // are two 16-byte loads of the CbH image straight from L2, requested NB - 1 blocks ahead into a ring of register
+            // sets (statically addressed: the loop is unrolled by NB); the residual piece is 8 conflict-free ds_read_b32 of
+            // the tile (+ the centring) split in registers in the shadow of the previous block's MFMAs.
+            const float *rb = R + (8 * lh) * RS + li;
+            const char *ab = reinterpret_cast<const char *>(img) + size_t(lh) * K * 16;
             constexpr int NB = 4;
-            f32x4 a_r[NB][MT];
-            float b_cur[4], b_nxt[4];
-#pragma unroll
-            for (int p = 0; p < NB - 1; ++p) {
-                const int dp = 8 * p < Dp ? 8 * p : 0;
+            rvq_bf16x8 a_r[NB][MT][2];
+            rvq_bf16x8 bh_cur, bm_cur, bh_nxt, bm_nxt;
+            const int nblk = Dp / 16;
+            auto load_a = [&](rvq_bf16x8 (&dst)[MT][2], int kq) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
-                    a_r[p][i] = *reinterpret_cast<const f32x4 *>(ab + size_t(dp >> 2) * K * 4 + size_t(acol[i]) * 4);
-            }
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) b_cur[ks] = rb[ks * RS] - mus[4 * lh + ks];
-            __builtin_amdgcn_s_waitcnt(0xC07F);  // retire the LDS reads here, not in front of every block's MFMAs
-            for (int d0 = 0; d0 < Dp; d0 += 8 * NB) {
+                    for (int pl = 0; pl < 2; ++pl)
+                        dst[i][pl] = *reinterpret_cast<const rvq_bf16x8 *>(ab + (size_t(kq * 2 + pl) * 2 * K + acol[i]) * 16);
+            };
+            auto load_b = [&](rvq_bf16x8 &bh, rvq_bf16x8 &bm, int kq) {
+                float xv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xv[e] = rb[(16 * kq + e) * RS] - mus[16 * kq + 8 * lh + e];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const __bf16 hh = (__bf16)xv[e];
+                    bh[e] = hh;
+                    bm[e] = (__bf16)(xv[e] - (float)hh);
+                }
+            };
+#pragma unroll
+            for (int pb = 0; pb < NB - 1; ++pb) load_a(a_r[pb], pb < nblk ? pb : 0);
+            load_b(bh_cur, bm_cur, 0);
+            for (int k0 = 0; k0 < nblk; k0 += NB) {
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
-                    const int d8 = d0 + 8 * u;
-                    if (d8 < Dp) {      // wave-uniform
-                        // operands of later blocks are requested while this block's MFMAs issue (threaded
-                        // between them by the scheduler); past the end the prefetch re-reads block 0
-                        const int dn = d8 + 8 < Dp ? d8 + 8 : 0;
-                        const int df = d8 + 8 * (NB - 1) < Dp ? d8 + 8 * (NB - 1) : 0;
-                        const float *an = ab + size_t(df >> 2) * K * 4;
+                    const int kq = k0 + u;
+                    if (kq < nblk) {      // wave-uniform
+                        const int kf = kq + NB - 1 < nblk ? kq + NB - 1 : 0;      // past the end the prefetch re-reads block 0
+                        const int kn = kq + 1 < nblk ? kq + 1 : 0;
+                        load_a(a_r[(u + NB - 1) % NB], kf);
+                        load_b(bh_nxt, bm_nxt, kn);
 #pragma unroll
-                        for (int i = 0; i < MT; ++i)
-                            a_r[(u + NB - 1) % NB][i] = *reinterpret_cast<const f32x4 *>(an + size_t(acol[i]) * 4);
+                        for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_r[u][i][1], bh_cur, acc[i], 0, 0, 0);
 #pragma unroll
-                        for (int ks = 0; ks < 4; ++ks) b_nxt[ks] = rb[(dn + ks) * RS] - mus[dn + 4 * lh + ks];
+                        for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_r[u][i][0], bm_cur, acc[i], 0, 0, 0);
 #pragma unroll
-                        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                            for (int i = 0; i < MT; ++i)
-                                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_r[u][i][ks], b_cur[ks], acc[i], 0, 0, 0);
-#pragma unroll
-                        for (int gidx = 0; gidx < 4; ++gidx) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);  // MFMA
-                            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
-                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read (residual + mean)
-                        }
+                        for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_r[u][i][0], bh_cur, acc[i], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int ks = 0; ks < 4; ++ks) b_cur[ks] = b_nxt[ks];
+                        bh_cur = bh_nxt;
+                        bm_cur = bm_nxt;
                     }
                 }
             }
@@ -374,7 +405,11 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
         if (tid < FT) {  // wave 0, lane == li == frame
             const int f = tid;
             const int n = cnt[f];
-            if (n > CAND) {
+            if (n0 + f >= N) {          // padding frame of the last workgroup (its residual is not a latent): nothing to decide
+                best[f] = 0;
+                state[f] = 0;
+                cnt[f] = 0;
+            } else if (n > CAND) {
                 state[f] = 2;
                 flags[1] = 1;
             } else {
@@ -521,6 +556,13 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
                 if (n0 + f < N) a.index[(n0 + f) * a.Q + q] = idx;
             }
         }
+        if (a.acc_scale < 0.f && tid == 0) {   // DIAGNOSTIC (knob b3_dbg = 9): the stage's "squared error" output = largest candidate count
+            int mx = 0;
+            for (int f = 0; f < FT; ++f) mx = max(mx, state[f] == 2 ? 1000 + cnt[f] : cnt[f]);
+            wmin[0] = float(mx);
+            for (int f = 1; f < FT; ++f) wmin[f] = 0.f;
+        }
+        __syncthreads();
         if (tid < FT) cnt[tid] = 0;       // (read last by the decide step)
         if (tid < 2) flags[tid] = 0;
         __syncthreads();
@@ -722,7 +764,7 @@ int agx_rvq_pack_sized(const float *codebooks, const int32_t *sizes, int32_t n_q
         sz.n[q] = sizes[q];
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(rvq_mean_kernel, dim3(ceil_div(rvq_dp(dim), 256), n_q), dim3(256), 0, st, codebooks, k, dim, packed, sz);
+    hipLaunchKernelGGL(rvq_mean_kernel, dim3(ceil_div(rvq_dp(dim), 64), n_q), dim3(256), 0, st, codebooks, k, dim, packed, sz);
     hipLaunchKernelGGL(rvq_pack_kernel, dim3(ceil_div(k, 256), n_q), dim3(256), 0, st, codebooks, n_q, k, dim, packed, sz);
     hipLaunchKernelGGL(rvq_cmax_kernel, dim3(n_q), dim3(256), 0, st, k, dim, packed, sz);
     return check_launch("agx_rvq_pack");
@@ -761,7 +803,7 @@ int agx_rvq_forward_ex(const float *x, int64_t x_sb, int64_t x_st, int64_t x_sd,
     const size_t lds = rvq_lds_bytes(dim, k, &tail_lds);
     if (lds > 160 * 1024) return fail(AGX_ERR_UNSUPPORTED, "rvq_forward: D=%d needs %zu B of LDS", dim, lds);
     RvqArgs a{x, x_sb, x_st, x_sd, codebooks, packed, batch, t, dim, k, q_used, xq, q_sb, q_st, q_sd, index, sq_err,
-              static_cast<double *>(workspace)};
+              static_cast<double *>(workspace), tuning().b3_dbg == 7 ? 4.f : (tuning().b3_dbg == 8 ? 0.f : (tuning().b3_dbg == 9 ? -1.f : 1.f))};
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t n = int64_t(batch) * t;
     dim3 grid((unsigned)ceil_div64(n, FT)), block(NT);

@@ -1,0 +1,104 @@
+// Diagnostic (not part of libagx): how does v_mfma_f32_32x32x16_bf16 round?  Every output element is c + sum_{k<16} a_k b_k
+// with exact bf16 x bf16 products; the program compares the instruction's result with the exactly rounded sum (computed on
+// the host in long double / exact integer arithmetic where needed) and reports the worst error in units of
+// 2^-24 x (|c| + sum |a_k b_k|), over several operand distributions (equal magnitudes, wide exponent spread, heavy
+// cancellation, a large accumulator with small products).  The RVQ score bound (csrc/rvq.hip) assumes 4 of those units
+// per MFMA instruction.
+//   hipcc --offload-arch=gfx950 -O2 tools/mfma_bf16_err.hip -o tools/mfma_bf16_err_bin && tools/mfma_bf16_err_bin
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__global__ void run(const uint16_t *a, const uint16_t *b, const float *c, float *d, int trials) {
+    const int lane = threadIdx.x, li = lane & 31, lh = lane >> 5;
+    for (int t = blockIdx.x; t < trials; t += gridDim.x) {
+        bf16x8 av, bv;
+        f32x16 acc;
+        for (int e = 0; e < 8; ++e) {
+            uint16_t ua = a[(size_t(t) * 32 + li) * 16 + 8 * lh + e], ub = b[(size_t(t) * 16 + 8 * lh + e) * 32 + li];
+            __bf16 fa, fb;
+            memcpy(&fa, &ua, 2); memcpy(&fb, &ub, 2);
+            av[e] = fa; bv[e] = fb;
+        }
+        for (int r = 0; r < 16; ++r) acc[r] = c[(size_t(t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) d[(size_t(t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = acc[r];
+    }
+}
+
+static float bf2f(uint16_t u) { uint32_t v = uint32_t(u) << 16; float f; memcpy(&f, &v, 4); return f; }
+static uint16_t f2bf(float f) { uint32_t v; memcpy(&v, &f, 4); v += 0x7FFF + ((v >> 16) & 1); return uint16_t(v >> 16); }
+
+int main() {
+    const int trials = 4096;
+    std::vector<uint16_t> ha(size_t(trials) * 32 * 16), hb(size_t(trials) * 16 * 32);
+    std::vector<float> hc(size_t(trials) * 1024), hd(hc.size());
+    uint16_t *da, *db; float *dc, *dd;
+    hipMalloc(&da, ha.size() * 2); hipMalloc(&db, hb.size() * 2); hipMalloc(&dc, hc.size() * 4); hipMalloc(&dd, hd.size() * 4);
+    uint64_t s = 88172645463325252ull;
+    auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return double(s >> 11) / 9007199254740992.0; };
+    const char *names[5] = {"equal magnitudes, random signs, c = 0", "exponents spread over 2^20", "heavy cancellation (pairs +x, -x(1+2^-7))",
+                            "large accumulator, small products", "accumulator ~ -sum (cancels at the end)"};
+    for (int mode = 0; mode < 5; ++mode) {
+        for (int t = 0; t < trials; ++t) {
+            for (int i = 0; i < 32; ++i)
+                for (int k = 0; k < 16; ++k) {
+                    double v = (rnd() + 0.5) * (rnd() < 0.5 ? -1 : 1);
+                    if (mode == 1) v *= std::ldexp(1.0, int(rnd() * 20) - 10);
+                    if (mode == 2) v = (k & 1) ? -(0.5 + 0.001 * k) * (1 + 1.0 / 128) : (0.5 + 0.001 * (k - 1 + 1));
+                    ha[(size_t(t) * 32 + i) * 16 + k] = f2bf(float(v));
+                }
+            for (int k = 0; k < 16; ++k)
+                for (int j = 0; j < 32; ++j) {
+                    double v = (rnd() + 0.5) * (rnd() < 0.5 ? -1 : 1);
+                    if (mode == 1) v *= std::ldexp(1.0, int(rnd() * 20) - 10);
+                    if (mode == 2) v = 0.75 + 0.01 * j;
+                    hb[(size_t(t) * 16 + k) * 32 + j] = f2bf(float(v));
+                }
+            for (int e = 0; e < 1024; ++e) {
+                float cv = 0.f;
+                if (mode == 3) cv = float((rnd() + 0.5) * 4096.0 * (rnd() < 0.5 ? -1 : 1));
+                if (mode == 1) cv = float((rnd() - 0.5) * std::ldexp(1.0, int(rnd() * 20) - 10));
+                hc[size_t(t) * 1024 + e] = cv;
+            }
+            if (mode == 4)
+                for (int i = 0; i < 32; ++i)
+                    for (int j = 0; j < 32; ++j) {
+                        double sum = 0;
+                        for (int k = 0; k < 16; ++k) sum += double(bf2f(ha[(size_t(t) * 32 + i) * 16 + k])) * double(bf2f(hb[(size_t(t) * 16 + k) * 32 + j]));
+                        hc[(size_t(t) * 32 + i) * 32 + j] = float(-sum * (1 + (rnd() - 0.5) * 1e-3));
+                    }
+        }
+        hipMemcpy(da, ha.data(), ha.size() * 2, hipMemcpyHostToDevice);
+        hipMemcpy(db, hb.data(), hb.size() * 2, hipMemcpyHostToDevice);
+        hipMemcpy(dc, hc.data(), hc.size() * 4, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(run, dim3(256), dim3(64), 0, 0, da, db, dc, dd, trials);
+        hipMemcpy(hd.data(), dd, hd.size() * 4, hipMemcpyDeviceToHost);
+        double worst = 0, worst_vs_rn = 0, worst_vs_max = 0;
+        long n_exact_rn = 0, n = 0;
+        for (int t = 0; t < trials; ++t)
+            for (int i = 0; i < 32; ++i)
+                for (int j = 0; j < 32; ++j) {
+                    long double sum = hc[(size_t(t) * 32 + i) * 32 + j], mag = fabsl(sum), mx = fabsl(sum);
+                    for (int k = 0; k < 16; ++k) {
+                        const long double pr = (long double)bf2f(ha[(size_t(t) * 32 + i) * 16 + k]) * (long double)bf2f(hb[(size_t(t) * 16 + k) * 32 + j]);
+                        sum += pr; mag += fabsl(pr); mx = fabsl(pr) > mx ? fabsl(pr) : mx;
+                    }
+                    const float got = hd[(size_t(t) * 32 + i) * 32 + j];
+                    const float rn = float(sum);
+                    const double err = double(fabsl((long double)got - sum));
+                    if (mag > 0) worst = std::fmax(worst, err / (double(mag) * 5.9604645e-8));
+                    if (mx > 0) worst_vs_max = std::fmax(worst_vs_max, err / (double(mx) * 5.9604645e-8));
+                    if (sum != 0) worst_vs_rn = std::fmax(worst_vs_rn, err / (std::fabs(double(sum)) * 5.9604645e-8));
+                    n_exact_rn += got == rn; ++n;
+                }
+        printf("%-46s worst |err| = %7.3f x 2^-24 (|c| + sum|a b|) = %7.3f x 2^-24 max addend;  equal to the correctly rounded sum: %5.1f %%\n",
+               names[mode], worst, worst_vs_max, 100.0 * n_exact_rn / n);
+    }
+    return 0;
+}
