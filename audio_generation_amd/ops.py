@@ -26,6 +26,32 @@ def set_observer(obs) -> None:
     _observer = obs
 
 
+def count_macs(kind: str, macs: int) -> None:
+    """Report the executed multiply-accumulates of a launch that has no timing hook (backward, 2-D and spectral ops) to the
+    observer's optional ``macs(kind, n)`` method -- bench.py's FLOP account of the training step."""
+    if _observer is not None and hasattr(_observer, "macs"):
+        _observer.macs(kind, int(macs))
+
+
+def _conv_macs(desc: "ConvDesc") -> int:
+    """Executed (polyphase) MACs of a 1-D conv layer: B * Cin/groups * J * (q * Cout) * Lt."""
+    b, cin, cout, lin, k, s = desc.batch, desc.c_in, desc.c_out, desc.l_in, desc.kernel, desc.stride
+    g = max(getattr(desc, "groups", 1), 1)
+    if desc.kind == CONV_UPSAMPLE:
+        pl = (k - 1) // 2
+        jmin, jmax = (-pl) // s, (s - 1 + k - 1 - pl) // s
+        return b * cin * (jmax - jmin + 1) * s * cout * lin
+    if desc.kind == CONV_TRANSPOSED:
+        return b * cin * (-(-k // s)) * s * cout * lin
+    return b * (cin // g) * cout * k * conv_out_len(desc)
+
+
+def _conv2d_macs(desc) -> int:
+    ho = (desc.h_in + 2 * desc.pad_h - desc.kh) // desc.stride_h + 1
+    wo = (desc.w_in + 2 * desc.pad_w - desc.kw) // desc.stride_w + 1
+    return desc.batch * desc.c_in * desc.c_out * desc.kh * desc.kw * ho * wo
+
+
 def conv_kernel_name(desc: "ConvDesc") -> str:
     buf = ctypes.create_string_buffer(96)
     _lib.check(_lib.load().agx_conv_kernel_name(ctypes.byref(desc), buf, len(buf)), "agx_conv_kernel_name")
@@ -147,6 +173,7 @@ def conv_bwd_data(desc: ConvDesc, dy: Tensor, packed_bwd: Tensor, add: Optional[
             raise AgxError(f"conv_bwd_data: {nm} is {tuple(t.shape)}, dx is {tuple(dx.shape)}")
     add = None if add is None else _f32c(add)
     mask = None if mask is None else _f32c(mask)
+    count_macs("conv_bwd_data", _conv_macs(desc))
     _lib.check(lib.agx_conv_bwd_data(ctypes.byref(desc), _ptr(dy), _ptr(packed_bwd), _ptr(add), _ptr(mask),
                                      float(slope), _ptr(dx), _stream()), "agx_conv_bwd_data")
     return dx
@@ -163,6 +190,7 @@ def conv_bwd_weight(desc: ConvDesc, x: Tensor, dy: Tensor, v: Tensor, g: Optiona
     db = torch.empty(desc.c_out, dtype=torch.float32, device=x.device) if want_bias else None
     ws_bytes = int(lib.agx_conv_bwd_weight_workspace_bytes(ctypes.byref(desc)))
     ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=x.device)
+    count_macs("conv_bwd_weight", _conv_macs(desc))
     _lib.check(lib.agx_conv_bwd_weight(ctypes.byref(desc), _ptr(x), _ptr(dy), _ptr(v), _ptr(g), _ptr(dv), _ptr(dg),
                                        _ptr(db), _ptr(ws), ws_bytes, _stream()), "agx_conv_bwd_weight")
     return dv, dg, db
@@ -387,6 +415,7 @@ def conv_bwd_data_gelu(desc: ConvDesc, dy: Tensor, packed_bwd: Tensor, pre: Tens
     dy, pre = _f32c(dy), _f32c(pre)
     add = None if add is None else _f32c(add)
     dx = torch.empty(desc.batch, desc.c_in, desc.l_in, dtype=torch.float32, device=dy.device)
+    count_macs("conv_bwd_data", _conv_macs(desc))
     _lib.check(lib.agx_conv_bwd_data_gelu(ctypes.byref(desc), _ptr(dy), _ptr(packed_bwd), _ptr(add), _ptr(pre), _ptr(dx),
                                           _stream()), "agx_conv_bwd_data_gelu")
     return dx
@@ -523,6 +552,7 @@ def conv_grouped_bwd_data(desc: ConvDesc, dz: Tensor, w: Tensor, sigma: Optional
     add = None if add is None else _f32c(add)
     mask = None if mask is None else _f32c(mask)
     dx = torch.empty(desc.batch, desc.c_in, desc.l_in, dtype=torch.float32, device=dz.device)
+    count_macs("conv_bwd_data", _conv_macs(desc))
     _lib.check(lib.agx_conv_grouped_bwd_data(ctypes.byref(desc), _ptr(dz), _ptr(w), _ptr(sigma), _ptr(add), _ptr(mask),
                                              slope, _ptr(dx), _stream()), "agx_conv_grouped_bwd_data")
     return dx
@@ -538,6 +568,7 @@ def conv_grouped_bwd_weight(desc: ConvDesc, x: Tensor, dz: Tensor, want_bias: bo
     db = torch.empty(desc.c_out, dtype=torch.float32, device=x.device) if want_bias else None
     nbytes = int(lib.agx_conv_grouped_bwd_weight_workspace_bytes(ctypes.byref(desc)))
     ws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=x.device)
+    count_macs("conv_bwd_weight", _conv_macs(desc))
     _lib.check(lib.agx_conv_grouped_bwd_weight(ctypes.byref(desc), _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), _ptr(ws),
                                                nbytes, _stream()), "agx_conv_grouped_bwd_weight")
     return dw, db
@@ -584,7 +615,7 @@ def conv2d_forward(desc, x: Tensor, packed: Tensor, bias: Optional[Tensor]) -> T
     _lib.check(lib.agx_conv2d_out_shape(ctypes.byref(desc), ctypes.byref(ho), ctypes.byref(wo)), "agx_conv2d_out_shape")
     y = torch.empty(desc.batch, desc.c_out, ho.value, wo.value, dtype=torch.float32, device=x.device)
     bias = None if bias is None else _f32c(bias)
-    tok = _observer.begin("other", ("conv2d", 4 * (x.numel() + y.numel()))) if _observer is not None else None
+    tok = _observer.begin("other", ("conv2d", 4 * (x.numel() + y.numel()), _conv2d_macs(desc))) if _observer is not None else None
     _lib.check(lib.agx_conv2d_forward(ctypes.byref(desc), _ptr(x), _ptr(packed), _ptr(bias), _ptr(y), _stream()),
                "agx_conv2d_forward")
     if tok is not None:
@@ -615,6 +646,7 @@ def conv2d_bwd_data(desc, dy: Tensor, packed_bwd: Tensor, mask: Optional[Tensor]
     mask = None if mask is None else _f32c(mask)
     add = None if add is None else _f32c(add)
     dx = torch.empty(desc.batch, desc.c_in, desc.h_in, desc.w_in, dtype=torch.float32, device=dy.device)
+    count_macs("conv2d_bwd_data", _conv2d_macs(desc))
     _lib.check(lib.agx_conv2d_bwd_data(ctypes.byref(desc), _ptr(dy), _ptr(packed_bwd), _ptr(add), _ptr(mask), slope,
                                        _ptr(dx), _stream()), "agx_conv2d_bwd_data")
     return dx
@@ -631,6 +663,7 @@ def conv2d_bwd_weight(desc, x: Tensor, dy: Tensor, w: Optional[Tensor] = None, s
     nbytes = int(lib.agx_conv2d_bwd_weight_workspace_bytes(ctypes.byref(desc)))
     ws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=x.device)
     w = None if w is None else _f32c(w)
+    count_macs("conv2d_bwd_weight", _conv2d_macs(desc))
     _lib.check(lib.agx_conv2d_bwd_weight(ctypes.byref(desc), _ptr(x), _ptr(dy), _ptr(w), _ptr(sigma), _ptr(u), _ptr(v),
                                          _ptr(dw), _ptr(db), _ptr(ws), nbytes, _stream()), "agx_conv2d_bwd_weight")
     return dw, db
@@ -686,7 +719,7 @@ def stft(x: Tensor, n_fft: int, normalized: bool = True) -> Tensor:
         _STFT_IMAGES[key] = img
     ws = torch.empty(int(lib.agx_stft_workspace_bytes(b, length, n_fft)) // 4, dtype=torch.float32, device=x.device)
     y = torch.empty(b, 2, int(t), n_fft, dtype=torch.float32, device=x.device)
-    tok = _observer.begin("other", ("stft", 4 * (x.numel() + y.numel()))) if _observer is not None else None
+    tok = _observer.begin("other", ("stft", 4 * (x.numel() + y.numel()), b * 2 * n_fft * n_fft * int(t))) if _observer is not None else None
     _lib.check(lib.agx_stft_forward(_ptr(x), _ptr(_STFT_IMAGES[key]), _ptr(y), _ptr(ws), b, length, n_fft, _stream()),
                "agx_stft_forward")
     if tok is not None:
@@ -707,6 +740,7 @@ def stft_backward(dy: Tensor, length: int, n_fft: int, normalized: bool = True) 
         _STFT_IMAGES[key] = img
     ws = torch.empty(int(lib.agx_stft_workspace_bytes(b, length, n_fft)) // 4, dtype=torch.float32, device=dy.device)
     dx = torch.empty(b, length, dtype=torch.float32, device=dy.device)
+    count_macs("stft_backward", b * 2 * n_fft * n_fft * dy.shape[2])
     _lib.check(lib.agx_stft_backward(_ptr(dy), _ptr(_STFT_IMAGES[key]), _ptr(dx), _ptr(ws), b, length, n_fft, _stream()),
                "agx_stft_backward")
     return dx

@@ -310,6 +310,8 @@ def main():
                     help="synthetic codebook recipe of the measured run (see calibrate_codebooks); the other one is "
                          "measured as well and reported under other_codebooks")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurement of the other arithmetic")
+    ap.add_argument("--no-train-step", action="store_true",
+                    help="skip the config-5 training-step measurement (a child process, outside the timed region)")
     args = ap.parse_args()
 
     from audio_generation_amd import dist as agx_dist
@@ -533,6 +535,21 @@ def main():
             r["distinct_stage0_codes"] = int(model(x)[2][..., 0].unique().numel())
         result["other_codebooks"] = dict(recipe=other, **r)
         model.quantizer.load_state_dict(keep)
+
+    if rank == 0 and world == 1 and not args.no_train_step:
+        # BASELINE configs[4] at its per-GPU batch (32 clips): one whole training step -- generator forward + native backward,
+        # six discriminators x three passes, low-pass / pre-emphasis / 7-window mel terms, seven Adam steps -- measured by
+        # tools/train_step_bench.py in a CHILD process after everything above (never inside the timed region); its JSON line
+        # carries ms/step, the executed FLOPs summed per launch, the fraction of the fp32 MFMA peak and the peak memory.
+        import subprocess
+        env = dict(os.environ, AGX_GAN="1")
+        try:
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_step_bench.py"), str(bsz), "2"], env=env,
+                                 capture_output=True, text=True, timeout=600)
+            line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+            result["training_step"] = json.loads(line[-1]) if line else {"error": (out.stderr or out.stdout)[-400:]}
+        except Exception as exc:    # the headline line must not depend on the secondary measurement
+            result["training_step"] = {"error": repr(exc)[:400]}
 
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -19,7 +19,40 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from audio_generation_amd import dist as agx_dist  # noqa: E402
+from audio_generation_amd import ops  # noqa: E402
 from audio_generation_amd.vae import CausalVQAE  # noqa: E402
+
+
+class FlopCounter:
+    """ops observer that only counts: executed MACs of every compute launch of a step (no events, no sync)."""
+
+    def __init__(self):
+        self.total, self.by_kind = 0, {}
+
+    def _add(self, kind, n):
+        self.total += n
+        self.by_kind[kind] = self.by_kind.get(kind, 0) + n
+
+    def begin(self, kind, info):
+        import bench
+        if kind == "rvq":
+            b, t, d, k, q = info
+            self._add("rvq", b * t * q * k * d)
+        elif kind == "other":
+            self._add(info[0].split(":")[0], info[2] if len(info) > 2 else 0)
+        elif kind == "resblock":
+            e1, _, _ = bench.conv_work(info)
+            e2, _, _ = bench.conv_work(ops.conv_desc(info.kind, info.batch, info.c_out, info.c_out, info.l_in, 1))
+            self._add("conv_forward", e1 + e2)
+        else:
+            self._add("conv_forward", ops._conv_macs(info))
+        return None
+
+    def end(self, tok):
+        pass
+
+    def macs(self, kind, n):
+        self._add(kind, n)
 
 
 def main():
@@ -124,7 +157,14 @@ def main():
     losses = [step() for _ in range(steps)]
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / steps
-    fwd_flop = 2 * (195194 + 13107 + 208713) * 72000 * batch          # executed (polyphase) MACs of the forward
+    # executed FLOPs of one step, summed per launch by the ops observer (forward convs / blocks / RVQ / Conv2d / STFT + every
+    # backward-data and weight-gradient launch; elementwise, reduction and optimizer work is not counted)
+    counter = FlopCounter()
+    ops.set_observer(counter)
+    step()
+    ops.set_observer(None)
+    torch.cuda.synchronize()
+    step_flop = 2.0 * counter.total
     ms = agx_dist.max_over_ranks(ms, device=dev if backend == "nccl" else "cpu")
     # replicas must stay identical: min and max over ranks of a checksum of parameters AND buffers (EMA codebooks)
     lo, hi = zip(*[agx_dist.replica_checksums(m) for m in [model] + discs])
@@ -137,7 +177,9 @@ def main():
                           "backward_order": ("two calls (training.py:374, 380)" if (two_calls or not signal) else "step.training_backward"),
                           "n_gpus": world, "batch_per_gpu": batch, "ms_per_step": ms, "replicas_in_sync": same, "update_codebook": update_cb,
                           "samples_per_s": world * batch * 72000 / ms * 1e3, "losses": losses,
-                          "approx_tflops_at_3x_forward": world * 3 * fwd_flop / ms * 1e-9,
+                          "executed_tflop_per_step_per_gpu": step_flop * 1e-12,
+                          "executed_tflops": world * step_flop / ms * 1e-9, "frac_of_fp32_mfma_peak": step_flop / ms * 1e-9 / 157.3,
+                          "flop_groups_tflop": {k: round(2e-12 * v, 3) for k, v in sorted(counter.by_kind.items())},
                           "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30, **({"ab_ms_per_step": ab} if ab else {})}))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
