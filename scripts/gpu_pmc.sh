@@ -6,7 +6,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 run() { # name counters...
   name=$1; shift
-  timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/$name -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-items 0 --no-roofline --no-graph > $out/$name.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/$name -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-items 0 --no-roofline --no-graph --no-extra --no-train-step > $out/$name.log 2>&1
   rc=$?
   echo "$name rc=$rc"; tail -2 $out/$name.log
   if [ $rc -ge 124 ]; then exit $rc; fi

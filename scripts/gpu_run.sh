@@ -11,14 +11,14 @@ timeout -k 10 400 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_$tag.
 rc=$?
 tail -3 gpurun_out/bench_$tag.err
 if [ $rc -ne 0 ]; then echo "bench failed rc=$rc"; exit $rc; fi
-timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-graph --cpu-items 0 --no-roofline > gpurun_out/bench_eager_$tag.json 2>/dev/null
+timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-graph --cpu-items 0 --no-roofline --no-extra --no-train-step > gpurun_out/bench_eager_$tag.json 2>/dev/null
 python -c "
 import json
 for f in ('bench_$tag.json','bench_eager_$tag.json'):
     r=json.load(open('gpurun_out/'+f)); print(f, r['ms_per_step'], r['value']/1e6, r['config'].get('launch'))
 "
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$tag -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --cpu-items 0 --no-roofline --no-graph > $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$tag -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --cpu-items 0 --no-roofline --no-graph --no-extra --no-train-step > $GRAFT_REPO_ROOT/gpurun_out/prof_$tag.log 2>&1
 rc=$?
 if [ $rc -ge 124 ]; then exit $rc; fi
 cd $GRAFT_REPO_ROOT && ./scripts/gpu_pmc.sh $tag > gpurun_out/pmc_$tag.log 2>&1
