@@ -135,9 +135,13 @@ inline bool tile_image_eligible(const ConvPlan &p, int kind) {
 // layers (the second conv of the fused block) are stored in GEMM2 order instead: slot e of lane half lh = channel
 // 16 g + 4 lh + e (e < 4), 16 g + 8 + 4 lh + (e - 4) (e >= 4) -- the hidden channels a lane holds in accumulator
 // registers 8 (g % 2) .. + 7.  Same size as the standard bf16x3 image; follows it and the dim0 scale scratch.
+int conv_b3_geometry(const ConvPlan &p);   // conv_b3.hip: bf16x3 ring form of a stride-1 polyphase layer (0 = none)
 inline bool b3_image_eligible(const ConvPlan &p, int kind) {
-    return p.prec == 1 && p.G == 1 && kind == AGX_CONV_CAUSAL && p.s == 1 && p.q == 1 && p.Cin == p.Cout &&
-           (p.Cin == 32 || p.Cin == 64 || p.Cin == 128 || p.Cin == 256) && (p.J == 7 || p.J == 1);
+    if (p.prec != 1 || p.G != 1) return false;
+    if (kind == AGX_CONV_CAUSAL && p.s == 1 && p.q == 1 && p.Cin == p.Cout &&
+        (p.Cin == 32 || p.Cin == 64 || p.Cin == 128 || p.Cin == 256) && (p.J == 7 || p.J == 1))
+        return true;
+    return conv_b3_geometry(p) != 0;
 }
 
 // Lower a descriptor; returns AGX_OK or an error (message set).

@@ -21,6 +21,9 @@ int launch_resblock_b3(const ConvPlan &p, const float *x, const float *w1, const
                        const float *b2, float *y, int post_act, hipStream_t st);
 bool resblock_b3_supported(const ConvPlan &p);
 const char *resblock_b3_variant(const ConvPlan &p);
+int launch_conv_b3(const ConvPlan &p, const float *x, const float *wp, const float *bias, float *y, hipStream_t st);
+bool conv_b3_supported(const ConvPlan &p);
+const char *conv_b3_variant(const ConvPlan &p);
 int launch_conv_p(const ConvPlan &p, const float *x, const float *wp, const float *bias, float *y, hipStream_t st);
 bool conv_p_supported(const ConvPlan &p);
 const char *conv_p_variant(const ConvPlan &p);
@@ -37,6 +40,7 @@ static int run_conv(const ConvPlan &p, int impl, const float *x, const float *wp
                     const float *res, float *y, hipStream_t st) {
     if ((impl == AGX_IMPL_AUTO || impl == AGX_IMPL_MFMA) && tuning().conv_impl == 1 && conv_p_supported(p))
         return launch_conv_p(p, x, wp, bias, y, st);
+    if (impl == AGX_IMPL_MFMA_BF16X3 && tuning().conv_impl == 1 && conv_b3_supported(p)) return launch_conv_b3(p, x, wp, bias, y, st);
     if (impl == AGX_IMPL_AUTO) impl = conv_mfma_supported(p) ? AGX_IMPL_MFMA : AGX_IMPL_DIRECT;
     if (impl == AGX_IMPL_MFMA || impl == AGX_IMPL_MFMA_BF16X3) return launch_conv_mfma(p, x, wp, bias, res, y, st);
     if (impl == AGX_IMPL_DIRECT) return launch_conv_direct(p, x, wp, bias, res, y, st);
@@ -96,6 +100,10 @@ int agx_conv_kernel_name(const agx_conv_desc *d, char *buf, size_t buf_len) {
     if (rc != AGX_OK) return rc;
     if (!buf || buf_len == 0) return fail(AGX_ERR_NULL_POINTER, "agx_conv_kernel_name: NULL buffer");
     int impl = d->impl;
+    if (impl == AGX_IMPL_MFMA_BF16X3 && tuning().conv_impl == 1 && conv_b3_supported(p)) {
+        snprintf(buf, buf_len, "%s:bf16x3", conv_b3_variant(p));
+        return AGX_OK;
+    }
     if ((impl == AGX_IMPL_AUTO || impl == AGX_IMPL_MFMA) && tuning().conv_impl == 1 && conv_p_supported(p)) {
         snprintf(buf, buf_len, "%s", conv_p_variant(p));
         return AGX_OK;

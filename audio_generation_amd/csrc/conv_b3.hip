@@ -1,0 +1,371 @@
+// Stride-1 polyphase convolutions on the bf16 matrix pipe with fp32-class accuracy ("bf16x3"), persistent ring form: the
+// decoder's resampling layers -- CausalUpsampleConv1d x2 / x4 / x5 / x8 (networks/vae.py:66-89) as their q polyphase 3-tap
+// filters on the low-rate signal, the stride-1 CausalConvT1d k = 7 (vae.py:45-64) -- with bias and LeakyReLU fused:
+//
+//     y[b, m / q, q t + m % q] = leaky( bias[m / q] + sum_{ci, j < J} Wp[ci, j][m] x[b, ci, t + j - P] ),   m < M = q Cout
+//
+// Same machinery as resblock_b3.hip (see there): the weights come from the layer's B3 tile image ([16-channel group][tap]
+// [piece][lane half][M rows][8 bf16]; a phase's BM-row block is 6 contiguous BM x 16-byte pieces) through four one-phase
+// LDS slots, the input chunk (16 channels x (BN + J - 1) time steps) is split ONCE per tile into three bf16 planes in LDS,
+// operand reads run one MFMA step ahead, the group barrier sits before the group's last step, the DMA runs two groups
+// ahead.  What differs: a tile is (clip, time block, ROW block) -- BM = 128 rows x 128 columns on 2 x 2 waves, 64 x 256 on
+// 1 x 4 for the 64-row layer -- there is no second GEMM, and the epilogue writes the polyphase rows to their output
+// samples (row m -> channel m / q, sample q t + m % q).  Two workgroups per CU (one plane buffer, <= 256 registers).
+// A row block re-splits the input its neighbours split as well (x2 .. x16): the tiles of one (clip, time block) are
+// consecutive, so those reads hit L2, and the split hides under the partner workgroup's MFMAs.
+#include "mfma_tile.hpp"
+
+namespace agx {
+
+typedef __bf16 cb3x8 __attribute__((ext_vector_type(8)));
+
+__device__ __attribute__((aligned(1024))) float g_cb3_zero_page[256] = {0.f};
+
+__device__ __forceinline__ void cb3_glds_b128(const void *gsrc_lane, void *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc_lane,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+template <int MW, int NW, int WM, int J_, int Q_, int P_>
+struct Cb3Geom {
+    static constexpr int WN = 4 / WM;                      // waves along the columns
+    static constexpr int BM = 32 * MW * WM, BN = 32 * NW * WN, J = J_, Q = Q_, P = P_;
+    static constexpr int W = BN + J - 1;                   // time steps per plane row (tile + halo)
+    static constexpr int PLANE_B = 6 * W * 16;             // one chunk: [piece 3][lane half 2][W][8 bf16]
+    static constexpr int WSLOT_B = 96 * BM;                // one phase of weights: [piece 3][lane half 2][BM][8 bf16]
+    static constexpr int NPW = WSLOT_B / 1024;             // 1 KiB DMA pieces per phase (BM / 64 per (piece, half))
+    static constexpr int RW = (NPW + 3) / 4;
+    static constexpr int NT = (2 * W + 255) / 256;         // split tasks (time step x 8 channels) per thread and chunk
+    static constexpr int NGRP = (J + 1) / 2;               // weight groups per chunk: [0,1] [2,3] .. (the last one single)
+    static constexpr int OFF_W = PLANE_B;
+    static constexpr size_t LDS_BYTES = size_t(OFF_W) + 4 * WSLOT_B;
+    static_assert(NGRP % 2 == 0, "an even number of groups per chunk keeps the slot sets alternating");
+    static_assert(J % 2 == 1, "taps come in pairs plus one");
+};
+
+template <int N>
+__device__ __forceinline__ void cb3_products(f32x16 (&acc)[N], const cb3x8 (&a)[3][N], const cb3x8 (&b)[3], int t0, int t1) {
+    constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};      // m.m  h.l  l.h  h.m  m.h  h.h
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+        if (t >= t0 && t < t1) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t]][i], b[PB[t]], acc[i], 0, 0, 0);
+        }
+}
+
+template <int MW, int NW, int WM, int J_, int Q_, int P_>
+__global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_clip, int mb_count, int ntiles,
+                                                         const float *__restrict__ x, const char *__restrict__ wt,
+                                                         const float *__restrict__ bias, float *__restrict__ y) {
+    using G = Cb3Geom<MW, NW, WM, J_, Q_, P_>;
+    constexpr int BM = G::BM, BN = G::BN, W = G::W, J = G::J, Q = G::Q, NT = G::NT;
+    constexpr int NSTEP = J * NW;                         // MFMA steps per chunk: (tap, column block); all MW row blocks per step
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / G::WN, wn = wave % G::WN;
+    const int r0w = wm * (32 * MW), n0 = wn * (32 * NW);  // this wave's rows / columns inside the tile
+    const int Lin = p.Lin, M = p.M, Lout = p.Lout;
+    const int nch = p.Cin / 16;                           // chunks per tile (even: checked by the launcher)
+
+    const int my_tiles = int(blockIdx.x) < ntiles ? (ntiles - 1 - int(blockIdx.x)) / int(gridDim.x) + 1 : 0;
+    if (my_tiles == 0) return;
+    // tile id -> (clip b, time block tb, row block mb): row blocks of one (clip, time block) are consecutive ids
+    auto decode = [&](int tile, int &b, int &tb, int &mb) {
+        mb = tile % mb_count;
+        const int r = tile / mb_count;
+        tb = r % tb_per_clip;
+        b = r / tb_per_clip;
+    };
+
+    // ---- weight DMA: one stream of groups (tile after tile, chunk after chunk); every group-end barrier issues one ----
+    const char *zpage = reinterpret_cast<const char *>(g_cb3_zero_page) + lane * 16;
+    int w_k = 0, w_g = 0;                                 // DMA cursor: the workgroup's w_k-th tile, group w_g of that tile
+    int w_m0 = 0;
+    {
+        int b_, tb_, mb_;
+        decode(int(blockIdx.x), b_, tb_, mb_);
+        w_m0 = mb_ * BM;
+    }
+    auto dma_next_group = [&]() {
+        const bool live = w_k < my_tiles;
+        const int chunk = w_g / G::NGRP, which = w_g % G::NGRP;
+        const int set2 = (which & 1) * 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = 2 * which + i;
+            const bool valid = live && j < J;
+            // phase (chunk, j): [(chunk J + j) 6 + plh][M][16 B]; this tile's rows start at w_m0
+            const char *src0 = wt + (size_t(chunk) * J + (valid ? j : 0)) * 6 * size_t(M) * 16 + size_t(w_m0) * 16;
+            char *dst0 = lds + G::OFF_W + (set2 + i) * G::WSLOT_B;
+#pragma unroll
+            for (int r = 0; r < G::RW; ++r) {
+                const int n = (wave + 4 * r) % G::NPW;                       // piece n: (piece, half) = n / (BM / 64), part n % (BM / 64)
+                const int plh = n / (BM / 64), part = n % (BM / 64);
+                const char *src = valid ? src0 + (size_t(plh) * M + 64 * part) * 16 + lane * 16 : zpage;
+                cb3_glds_b128(src, dst0 + n * 1024);
+            }
+        }
+        if (++w_g == nch * G::NGRP) {
+            w_g = 0;
+            ++w_k;
+            int b_, tb_, mb_;
+            decode(min(int(blockIdx.x) + w_k * int(gridDim.x), ntiles - 1), b_, tb_, mb_);
+            w_m0 = mb_ * BM;
+        }
+    };
+
+    // ---- input stream ----
+    int i_k = 0, i_chunk = 0;                             // the next chunk to load: tile index, chunk
+    float st[NT][8];
+    int st_t[NT];
+    auto input_load = [&]() {
+        const bool live = i_k < my_tiles;
+        int b_, tb_, mb_;
+        decode(min(int(blockIdx.x) + i_k * int(gridDim.x), ntiles - 1), b_, tb_, mb_);
+        const int in0 = tb_ * BN - G::P;
+        const char *xc = reinterpret_cast<const char *>(x + (size_t(b_) * p.Cin + i_chunk * 16) * Lin);
+        unsigned lin4 = unsigned(Lin) * 4u;
+        asm volatile("" : "+s"(lin4));
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int u = tid + 256 * n;
+            const int uh = u >= W ? 1 : 0;
+            const int t = u - uh * W;
+            const int pos = in0 + t;
+            const bool task = u < 2 * W;
+            const bool ok = live && task && pos >= 0 && pos < p.Lvalid;
+            const int posc = min(max(pos, 0), Lin - 1);
+            const unsigned off = unsigned(8 * uh) * lin4 + unsigned(posc) * 4u;
+            st_t[n] = task ? (uh * W + t) : -1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = *reinterpret_cast<const float *>(xc + (off + unsigned(e) * lin4));
+                st[n][e] = ok ? v : 0.f;
+            }
+        }
+        if (++i_chunk == nch) i_chunk = 0, ++i_k;
+    };
+    auto input_store_all = [&]() {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            cb3x8 h, m, l;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const __bf16 hh = (__bf16)st[n][e];
+                const float r1 = st[n][e] - (float)hh;
+                const __bf16 mm = (__bf16)r1;
+                h[e] = hh;
+                m[e] = mm;
+                l[e] = (__bf16)(r1 - (float)mm);
+            }
+            if (st_t[n] >= 0) {
+                *reinterpret_cast<cb3x8 *>(lds + (0 * 2 * W + st_t[n]) * 16) = h;
+                *reinterpret_cast<cb3x8 *>(lds + (1 * 2 * W + st_t[n]) * 16) = m;
+                *reinterpret_cast<cb3x8 *>(lds + (2 * 2 * W + st_t[n]) * 16) = l;
+            }
+        }
+    };
+
+    const int aLane = (lh * BM + r0w + li) * 16;          // + (piece * 2 BM + 32 i) * 16
+    const int bLane = (lh * W + n0 + li) * 16;            // + (piece * 2 W + 32 k + j) * 16
+    auto load_a = [&](cb3x8 (&a)[3][MW], int j) {
+        const char *ws = lds + G::OFF_W + (((j >> 1) & 1) * 2 + (j & 1)) * G::WSLOT_B + aLane;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < MW; ++i) a[pl][i] = *reinterpret_cast<const cb3x8 *>(ws + (pl * 2 * BM + 32 * i) * 16);
+    };
+    auto load_b = [&](cb3x8 (&bf)[3], int j, int kk) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bf[pl] = *reinterpret_cast<const cb3x8 *>(lds + bLane + (pl * 2 * W + 32 * kk + j) * 16);
+    };
+
+    // ---- prologue ----
+    input_load();
+    dma_next_group();
+    dma_next_group();
+    input_store_all();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    input_load();
+
+    cb3x8 fa[2][3][MW], fb[2][3];
+    for (int k = 0; k < my_tiles; ++k) {
+        int b, tb, mb;
+        decode(int(blockIdx.x) + k * int(gridDim.x), b, tb, mb);
+        const int t0 = tb * BN, m0 = mb * BM;
+        f32x16 acc[MW][NW];
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int kk = 0; kk < NW; ++kk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][kk][r] = 0.f;
+        load_a(fa[0], 0);
+        load_b(fb[0], 0, 0);
+
+        for (int c2 = 0; c2 < nch; c2 += 2) {
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    const int ua = (cc * J + j) & 1;
+#pragma unroll
+                    for (int kk = 0; kk < NW; ++kk) {
+                        const int step = j * NW + kk;
+                        const int sb = (cc * NSTEP + step) & 1;
+                        const bool last_of_phase = kk == NW - 1;
+                        const bool group_end = last_of_phase && ((j & 1) == 1 || j == J - 1);
+                        const bool chunk_end = last_of_phase && j == J - 1;
+                        if (group_end) {      // early barrier: this group's last operands are in registers
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            __syncthreads();
+                            dma_next_group();
+                        }
+                        f32x16 part[MW];
+#pragma unroll
+                        for (int i = 0; i < MW; ++i) part[i] = acc[i][kk];
+                        __builtin_amdgcn_sched_barrier(0);
+                        cb3_products<MW>(part, fa[ua], fb[sb], 0, 3);
+                        __builtin_amdgcn_sched_barrier(0);
+                        int nj = j, nk = kk + 1;
+                        if (nk == NW) nk = 0, ++nj;
+                        if (nj == J) nj = 0;
+                        if (!chunk_end) {      // (the next chunk's planes only exist behind the second barrier below)
+                            if (nk == 0) load_a(fa[ua ^ 1], nj);
+                            load_b(fb[sb ^ 1], nj, nk);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        cb3_products<MW>(part, fa[ua], fb[sb], 3, 6);
+#pragma unroll
+                        for (int i = 0; i < MW; ++i) acc[i][kk] = part[i];
+                        if (chunk_end) {
+                            // one plane buffer: every wave is past the chunk's barrier (holds its last operands in registers);
+                            // split + write the next chunk, barrier, read the next step's operands
+                            input_store_all();
+                            __builtin_amdgcn_sched_barrier(0);
+                            __syncthreads();
+                            load_a(fa[ua ^ 1], 0);
+                            load_b(fb[sb ^ 1], 0, 0);
+                            input_load();                  // the chunk after next: a whole chunk of flight time
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+
+        // ---- epilogue: bias, LeakyReLU, polyphase store.  Register r of row block i: row m0 + r0w + 32 i + 8 (r / 4) + 4 lh + r % 4 ----
+        const bool pre = (p.epilogue & AGX_EPI_LEAKY_PRE) != 0;
+        float *yb = y + size_t(b) * p.Cout * Lout;
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int kk = 0; kk < NW; ++kk) {
+                const int t = t0 + n0 + 32 * kk + li;
+                if (t < p.Lt) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int mrow = m0 + r0w + 32 * i + 8 * g + 4 * lh;    // + s4; a multiple of 4
+                        if (Q % 4 == 0) {         // the 4 rows are 4 consecutive output samples of one channel: one 16-byte store
+                            const int co = mrow / Q, ph = mrow % Q;
+                            const float bv = bias ? bias[co] : 0.f;
+                            f32x4 v;
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; ++s4) {
+                                float a = acc[i][kk][4 * g + s4] + bv;
+                                v[s4] = pre ? leaky(a, p.slope) : a;
+                            }
+                            *reinterpret_cast<f32x4 *>(yb + size_t(co) * Lout + size_t(Q) * t + ph) = v;
+                        } else {
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; ++s4) {
+                                const int m = mrow + s4, co = m / Q, ph = m % Q;
+                                float a = acc[i][kk][4 * g + s4] + (bias ? bias[co] : 0.f);
+                                yb[size_t(co) * Lout + size_t(Q) * t + ph] = pre ? leaky(a, p.slope) : a;
+                            }
+                        }
+                    }
+                }
+            }
+    }
+}
+
+enum { CB3_NONE = 0, CB3_UP2, CB3_UP4, CB3_UP5, CB3_UP8, CB3_K7 };
+
+// shape-only test (also decides whether agx_conv_pack of a bf16x3 descriptor appends the B3 tile image: common.hpp)
+int conv_b3_geometry(const ConvPlan &p) {
+    if (p.prec != 1 || p.G != 1 || p.d != 1 || p.s != 1 || p.kh != 1 || p.Tout != 1 || p.pm_R != 0) return CB3_NONE;
+    if (p.Cin % 32 != 0) return CB3_NONE;                      // whole 16-channel chunks, an even number of them
+    if (p.q == 2 && p.J == 3 && p.P == 1 && p.M == 64) return CB3_UP2;
+    if (p.q == 4 && p.J == 3 && p.P == 1 && p.M % 128 == 0) return CB3_UP4;
+    if (p.q == 5 && p.J == 3 && p.P == 1 && p.M % 128 == 0) return CB3_UP5;
+    if (p.q == 8 && p.J == 3 && p.P == 1 && p.M % 128 == 0) return CB3_UP8;
+    if (p.q == 1 && p.J == 7 && p.P == 6 && p.M % 128 == 0) return CB3_K7;
+    return CB3_NONE;
+}
+
+bool conv_b3_supported(const ConvPlan &p) {
+    if (p.tile_off < 0 || conv_b3_geometry(p) == CB3_NONE) return false;
+    if ((p.epilogue & ~AGX_EPI_LEAKY_PRE) != 0 || p.oshift != 0 || p.mask != nullptr) return false;
+    if (p.Lvalid != p.Lin || p.Lin < 1 || p.Lout != p.q * p.Lt || p.Lt != p.Lin) return false;
+    if (int64_t(p.Cin) * p.Lin * 4 >= (int64_t(1) << 32)) return false;     // 32-bit byte offsets of the input loads
+    return true;
+}
+
+const char *conv_b3_variant(const ConvPlan &p) {
+    switch (conv_b3_geometry(p)) {
+        case CB3_UP2: return "conv_b3<up2,64x256>";
+        case CB3_UP4: return "conv_b3<up4,128x128>";
+        case CB3_UP5: return "conv_b3<up5,128x128>";
+        case CB3_UP8: return "conv_b3<up8,128x128>";
+        case CB3_K7: return "conv_b3<k7,128x128>";
+        default: return "conv_b3<unsupported>";
+    }
+}
+
+template <int MW, int NW, int WM, int J_, int Q_, int P_>
+static int launch_cb3(const ConvPlan &p, const float *x, const float *wp, const float *bias, float *y, hipStream_t st) {
+    using G = Cb3Geom<MW, NW, WM, J_, Q_, P_>;
+    auto kern = conv_b3_kernel<MW, NW, WM, J_, Q_, P_>;
+    static bool attr_set = false;
+    static int n_cu = 0;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024);
+        if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return fail(AGX_ERR_LAUNCH, "conv_b3: cannot query the device");
+        n_cu = prop.multiProcessorCount;
+        attr_set = true;
+    }
+    static_assert(2 * G::LDS_BYTES <= 160 * 1024, "conv_b3: LDS budget of two workgroups per CU");
+    const int tb = ceil_div(p.Lt, G::BN), mb = p.M / G::BM;
+    const int64_t ntiles64 = int64_t(tb) * mb * p.B;
+    if (ntiles64 > (1 << 30)) return fail(AGX_ERR_BAD_SHAPE, "conv_b3: too many tiles");
+    const int ntiles = int(ntiles64);
+    const int grid = ntiles < 2 * n_cu ? ntiles : 2 * n_cu;
+    // B3 tile image: behind the bf16x3 standard image and the dim0 scale scratch
+    const char *wt = reinterpret_cast<const char *>(wp + p.tile_off);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G::LDS_BYTES, st, p, tb, mb, ntiles, x, wt, bias, y);
+    return check_launch("conv_b3");
+}
+
+int launch_conv_b3(const ConvPlan &p, const float *x, const float *wp, const float *bias, float *y, hipStream_t st) {
+    if (!conv_b3_supported(p)) return fail(AGX_ERR_UNSUPPORTED, "conv_b3: unsupported layer");
+    switch (conv_b3_geometry(p)) {
+        case CB3_UP2: return launch_cb3<2, 2, 1, 3, 2, 1>(p, x, wp, bias, y, st);
+        case CB3_UP4: return launch_cb3<2, 2, 2, 3, 4, 1>(p, x, wp, bias, y, st);
+        case CB3_UP5: return launch_cb3<2, 2, 2, 3, 5, 1>(p, x, wp, bias, y, st);
+        case CB3_UP8: return launch_cb3<2, 2, 2, 3, 8, 1>(p, x, wp, bias, y, st);
+        case CB3_K7: return launch_cb3<2, 2, 2, 7, 1, 6>(p, x, wp, bias, y, st);
+        default: return fail(AGX_ERR_UNSUPPORTED, "conv_b3: unsupported layer");
+    }
+}
+
+}  // namespace agx

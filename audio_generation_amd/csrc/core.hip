@@ -149,7 +149,7 @@ int lower_conv(const agx_conv_desc *d, ConvPlan *p) {
     if (tile_image_eligible(*p, d->kind))
         p->tile_off = packed_weight_floats(p->Cin / p->G, p->J, p->M) + (d->kind == AGX_CONV_TRANSPOSED ? d->c_in : d->c_out);
     else if (b3_image_eligible(*p, d->kind))
-        p->tile_off = packed_weight_floats_bf(p->Cin, p->J, p->M) + d->c_out;
+        p->tile_off = packed_weight_floats_bf(p->Cin, p->J, p->M) + (d->kind == AGX_CONV_TRANSPOSED ? d->c_in : d->c_out);
     return AGX_OK;
 }
 

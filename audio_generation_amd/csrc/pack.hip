@@ -116,11 +116,11 @@ __global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float *__restric
     dst[32] = l;
 }
 
-// B3 tile image (common.hpp): [(((g * J + j) * 3 + plane) * 2 + lh) * M + m][8] bf16; stride-1 causal layers only (q = 1)
+// B3 tile image (common.hpp): [(((g * J + j) * 3 + plane) * 2 + lh) * M + m][8] bf16, rows m = co * q + ph as in the standard image
 __global__ __launch_bounds__(256) void pack_b3_tile_kernel(const float *__restrict__ v, const float *__restrict__ scale,
                                                            __bf16 *__restrict__ timg, int kind, int Cin, int Cout, int K,
-                                                           int J, int P) {
-    const int M = Cout;
+                                                           int q, int J, int P, int up) {
+    const int M = q * Cout;
     const int64_t total = int64_t(Cin / kWG) * J * M * kWG;   // one thread per weight
     const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (e >= total) return;
@@ -128,13 +128,13 @@ __global__ __launch_bounds__(256) void pack_b3_tile_kernel(const float *__restri
     const int m = int((e / kWG) % M);
     const int gj = int(e / (int64_t(kWG) * M));
     const int j = gj % J, ci = (gj / J) * kWG + c16;
-    const float w = fwd_weight(v, scale, kind, Cin, Cout, K, J, P, 1, ci, j, m, 0);
+    const float w = fwd_weight(v, scale, kind, Cin, Cout, K, J, P, up, ci, j, m / q, m % q);
     const __bf16 h = (__bf16)w;
     const float r1 = w - (float)h;
     const __bf16 mm = (__bf16)r1;
     const __bf16 l = (__bf16)(r1 - (float)mm);
     int lh, slot;
-    if (J == 1) {   // GEMM2 order: lane half = bit 2 of the channel, slot = (bit 3) * 4 + low two bits
+    if (J == 1 && q == 1) {   // GEMM2 order: lane half = bit 2 of the channel, slot = (bit 3) * 4 + low two bits
         lh = (c16 >> 2) & 1;
         slot = ((c16 >> 3) << 2) | (c16 & 3);
     } else {
@@ -261,7 +261,8 @@ static int pack_forward(const agx_conv_desc *d, const float *v, const float *g, 
                            reinterpret_cast<__bf16 *>(packed), d->kind, p.Cin, p.Cout, d->kernel, p.q, p.J, p.P, d->stride);
         if (p.tile_off >= 0)   // second copy in the DMA layout of resblock_b3.hip, behind the scale scratch
             hipLaunchKernelGGL(pack_b3_tile_kernel, dim3((unsigned)ceil_div64(nthreads, 256)), dim3(256), 0, st, v, scale,
-                               reinterpret_cast<__bf16 *>(packed + p.tile_off), d->kind, p.Cin, p.Cout, d->kernel, p.J, p.P);
+                               reinterpret_cast<__bf16 *>(packed + p.tile_off), d->kind, p.Cin, p.Cout, d->kernel, p.q, p.J, p.P,
+                               d->stride);
         return check_launch(who);
     }
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)ceil_div64(n_w, 256)), dim3(256), 0, st, v, scale,

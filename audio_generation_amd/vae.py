@@ -378,12 +378,13 @@ class CausalVQAE(nn.Module):
                     c = m.conv
                     q = c.stride[0] if m.kind in (CONV_TRANSPOSED, CONV_UPSAMPLE) else 1
                     ok = mode == "bf16x3" and c.in_channels % 16 == 0 and q * c.out_channels >= 32 and getattr(c, "groups", 1) == 1
-                    # the resampling convs only have the first-round bf16x3 kernels (no ring form yet): they beat the fp32
-                    # ring kernels on the x5 / x8 up-convs, the stride-4 down-conv and the k = 7 transposed conv, and lose
-                    # elsewhere (tools/layer_times.py bf16x3) -- those layers stay on the fp32 ring, which is at least as exact
+                    # resampling convs: bf16x3 where the layer has the ring form (conv_b3.hip: the decoder's up-convs and
+                    # the k = 7 transposed conv) or where the first-round bf16x3 kernel beats the fp32 ring kernel (the
+                    # stride-4 down-conv; tools/layer_times.py bf16x3); the others stay on the fp32 ring, which is at least as exact
                     if ok and id(m) not in in_block:
-                        ok = ((m.kind == CONV_UPSAMPLE and c.stride[0] in (5, 8)) or (m.kind == CONV_CAUSAL and c.stride[0] == 4)
-                              or (m.kind == CONV_TRANSPOSED and c.kernel_size[0] == 7))
+                        nominal = ops.conv_desc(m.kind, 1, c.in_channels, c.out_channels, 4096, c.kernel_size[0], c.stride[0],
+                                                c.dilation[0], EPI_LEAKY_PRE, 0.1, IMPL_MFMA_BF16X3)
+                        ok = ops.conv_kernel_name(nominal).startswith("conv_b3") or (m.kind == CONV_CAUSAL and c.stride[0] == 4)
                     m.impl = IMPL_MFMA_BF16X3 if ok else IMPL_AUTO
         self.__dict__.pop("_unit_cache", None)
         return self

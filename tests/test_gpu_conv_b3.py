@@ -1,0 +1,72 @@
+"""The bf16x3 ring form of the decoder's stride-1 polyphase convolutions (csrc/conv_b3.hip) against the oracle
+(fp32-class tolerance: three bf16 pieces per operand, six bf16 MFMAs per product block, fp32 accumulation) and against the
+fp32 ring kernel: the four up-convs and the k = 7 transposed conv of config S, ragged lengths, clips shorter than one tile,
+more tiles than resident workgroups, with and without the fused LeakyReLU."""
+import pytest
+import torch
+
+from audio_generation_amd import _lib, ops
+from oracle import codec
+from tests.helpers import max_abs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+KIND = {"convt": _lib.CONV_TRANSPOSED, "upconv": _lib.CONV_UPSAMPLE}
+LAYERS = [("up8", "upconv", 512, 256, 17, 8), ("up5", "upconv", 256, 128, 11, 5), ("up4", "upconv", 128, 64, 9, 4),
+          ("up2", "upconv", 64, 32, 5, 2), ("k7", "convt", 512, 512, 7, 1), ("up4", "upconv", 512, 256, 9, 4)]
+TOL = 1e-5
+
+
+def _case(kind, cin, cout, k, s, b, length, gen, act=True):
+    wshape = (cin, cout, k) if kind == "convt" else (cout, cin, k)
+    v = torch.randn(wshape, generator=gen) / (cin * k) ** 0.5
+    g = torch.rand((wshape[0], 1, 1), generator=gen) + 0.5
+    bias = torch.randn(cout, generator=gen) * 0.1
+    x = torch.randn(b, cin, length, generator=gen)
+    w = codec.fold_weight_norm(g, v)
+    want = codec.causal_conv_t1d(x, w, bias, stride=s) if kind == "convt" else codec.upsample_conv1d(x, w, bias, s)
+    if act:
+        want = codec.leaky(want)
+    out = {}
+    for impl in (_lib.IMPL_MFMA_BF16X3, _lib.IMPL_AUTO):
+        desc = ops.conv_desc(KIND[kind], b, cin, cout, length, k, s, 1, _lib.EPI_LEAKY_PRE if act else 0, 0.1, impl)
+        packed = ops.conv_pack(desc, v.to(DEV), g.to(DEV))
+        out[impl] = (ops.conv_kernel_name(desc), ops.conv_forward(desc, x.to(DEV), packed, bias.to(DEV)))
+    return out, want
+
+
+@pytest.mark.parametrize("variant,kind,cin,cout,k,s", LAYERS)
+def test_every_geometry_against_the_oracle_and_the_fp32_ring(variant, kind, cin, cout, k, s):
+    gen = torch.Generator().manual_seed(sum(map(ord, variant)) + cin)
+    for b, length, act in ((1, 3, True), (2, 60, False), (1, 128, True), (3, 129, True), (2, 225, True), (1, 515, False)):
+        out, want = _case(kind, cin, cout, k, s, b, length, gen, act)
+        name, y = out[_lib.IMPL_MFMA_BF16X3]
+        assert name.startswith(f"conv_b3<{variant},") and name.endswith(":bf16x3"), name
+        tol = TOL * max(1.0, float(want.abs().max()))
+        assert tuple(y.shape) == tuple(want.shape)
+        assert max_abs(y.cpu(), want) < tol, (variant, b, length, max_abs(y.cpu(), want))
+        assert max_abs(y, out[_lib.IMPL_AUTO][1]) < tol
+
+
+@pytest.mark.parametrize("variant,kind,cin,cout,k,s,b,length", [
+    ("up8", "upconv", 512, 256, 17, 8, 10, 450),      # 16 x 4 x 10 = 640 tiles of 128 x 128
+    ("up5", "upconv", 256, 128, 11, 5, 9, 1800),      # 5 x 15 x 9 = 675
+    ("up4", "upconv", 128, 64, 9, 4, 4, 9000),        # 2 x 71 x 4 = 568
+    ("up2", "upconv", 64, 32, 5, 2, 5, 36000),        # 141 x 5 = 705 tiles of 64 x 256
+    ("k7", "convt", 512, 512, 7, 1, 40, 450),         # 4 x 4 x 40 = 640
+])
+def test_more_tiles_than_workgroups(variant, kind, cin, cout, k, s, b, length):
+    gen = torch.Generator().manual_seed(7 + cin)
+    out, want = _case(kind, cin, cout, k, s, b, length, gen, True)
+    name, y = out[_lib.IMPL_MFMA_BF16X3]
+    assert name.startswith(f"conv_b3<{variant},")
+    assert max_abs(y.cpu(), want) < TOL * max(1.0, float(want.abs().max()))
+    out2, _ = _case(kind, cin, cout, k, s, b, length, torch.Generator().manual_seed(7 + cin), True)
+    assert torch.equal(y, out2[_lib.IMPL_MFMA_BF16X3][1])              # run to run, bit for bit
+
+
+def test_other_layers_keep_their_kernels():
+    d = ops.conv_desc(_lib.CONV_CAUSAL, 2, 64, 128, 4000, 9, 4, 1, _lib.EPI_LEAKY_PRE, 0.1, _lib.IMPL_MFMA_BF16X3)
+    assert ops.conv_kernel_name(d).startswith("conv_mfma") and ops.conv_kernel_name(d).endswith(":bf16x3")
+    d = ops.conv_desc(_lib.CONV_UPSAMPLE, 2, 48, 32, 400, 5, 2, 1, 0, 0.1, _lib.IMPL_MFMA_BF16X3)   # Cin % 32 != 0
+    assert not ops.conv_kernel_name(d).startswith("conv_b3")
