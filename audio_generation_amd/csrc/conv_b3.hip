@@ -18,6 +18,7 @@
 namespace agx {
 
 typedef __bf16 cb3x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2c __attribute__((ext_vector_type(2)));
 
 __device__ __attribute__((aligned(1024))) float g_cb3_zero_page[256] = {0.f};
 
@@ -280,6 +281,19 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_
                                 v[s4] = pre ? leaky(a, p.slope) : a;
                             }
                             *reinterpret_cast<f32x4 *>(yb + size_t(co) * Lout + size_t(Q) * t + ph) = v;
+                        } else if (Q == 2) {      // rows (0,1) and (2,3): two channels x two phases -> two 8-byte stores
+#pragma unroll
+                            for (int h2 = 0; h2 < 2; ++h2) {
+                                const int co = mrow / 2 + h2;
+                                const float bv = bias ? bias[co] : 0.f;
+                                f32x2c v;
+#pragma unroll
+                                for (int e = 0; e < 2; ++e) {
+                                    float a = acc[i][kk][4 * g + 2 * h2 + e] + bv;
+                                    v[e] = pre ? leaky(a, p.slope) : a;
+                                }
+                                *reinterpret_cast<f32x2c *>(yb + size_t(co) * Lout + size_t(2) * t) = v;
+                            }
                         } else {
 #pragma unroll
                             for (int s4 = 0; s4 < 4; ++s4) {
