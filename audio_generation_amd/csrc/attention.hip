@@ -61,14 +61,14 @@ __global__ __launch_bounds__(256) void layernorm_ct_kernel(const float *__restri
 // one time step in registers -- x is read ONCE, every load is issued before the first use, statistics go through one
 // 16 x 16 LDS exchange each (mean, then the centred sum of squares from the registers: the two-pass formula without
 // the second pass over memory).  (B, 512, 225): 480 workgroups instead of 128, 14.7 MB moved once.
-template <int CPT, int NG>   // NG channel groups x 16 time steps = 16 NG threads; channel c = g + NG k, k < CPT
-__global__ __launch_bounds__(16 * NG) void layernorm_ct_regs_kernel(const float *__restrict__ x,
+template <int CPT, int NG, int TS = 16>   // NG channel groups x TS time steps = TS NG threads; channel c = g + NG k, k < CPT
+__global__ __launch_bounds__(TS * NG) void layernorm_ct_regs_kernel(const float *__restrict__ x,
                                                                     const float *__restrict__ weight,
                                                                     const float *__restrict__ bias,
                                                                     float *__restrict__ y, int C, int T, float eps) {
-    __shared__ float part[NG][17];
-    const int tl = threadIdx.x & 15, g = threadIdx.x >> 4;
-    const int t = blockIdx.x * 16 + tl;
+    __shared__ float part[NG][TS + 1];
+    const int tl = threadIdx.x % TS, g = threadIdx.x / TS;
+    const int t = blockIdx.x * TS + tl;
     const int tc = min(t, T - 1);
     const float *xb = x + size_t(blockIdx.y) * C * T + tc;
     float v[CPT];
