@@ -175,7 +175,14 @@ struct RvqArgs {
     double *sq_err;  // (Q) [unused by the kernel since the partials moved to `part`]
     double *part;    // (workgroups, Q) squared error of each workgroup's 32 frames per stage
     float acc_scale; // 1; a diagnostic knob (b3_dbg = 7: 4) widens the accumulation term of the score error bound
+    unsigned long long *stamps;   // diagnostic (agx_rvq_debug_stamps): [workgroup][16] s_memtime at the phase boundaries of stage stamp_q
+    int stamp_q;
 };
+// thread 0 of every workgroup: kernel-level slots (0, 1, 15) and the phase boundaries of ONE stage (a null pointer costs a scalar branch)
+#define RVQ_STAMP(slot, cond)                                                                                      \
+    do {                                                                                                           \
+        if (a.stamps != nullptr && tid == 0 && (cond)) a.stamps[size_t(blockIdx.x) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
 
 template <int MT, bool TAIL_LDS>   // TAIL_LDS: the stage's |c'|^2 and |c'| tables are copied to LDS (they fit beside R / O)
 __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
@@ -202,6 +209,7 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
     const int64_t n0 = int64_t(blockIdx.x) * FT;
     const int D = a.D, K = a.K;
 
+    RVQ_STAMP(0, true);
     // ---- stage the latents: R[d][f] = x[n0+f][d], O = 0; pick the coalesced order ----
     for (int e = tid; e < Dp * RS; e += NT) O[e] = 0.f;
     if (a.x_st == 1 || a.x_sd != 1) {  // time-contiguous ("b c l"): frames fastest
@@ -290,6 +298,8 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
         const float rnorm = sqrtf(rn2[li]);
         const float eu = 1.01f * err_unit;
         float running = INFINITY;
+        const bool stq = q == a.stamp_q;
+        RVQ_STAMP(2, stq);
 
         for (int ch = 0; ch < n_chunks; ++ch) {
             const int code0 = ch * CHUNK + wave * (32 * MT);
@@ -359,6 +369,7 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
                     }
                 }
             }
+            RVQ_STAMP(3 + 3 * min(ch, 1), stq);
             // lower bounds in place; rows of register r: (r&3) + 8*(r>>2) + 4*lh.  One subtile at a
             // time (the sched_barrier keeps hipcc from hoisting all 2*16*MT table loads at once,
             // which spills at 2 waves/SIMD).
@@ -380,6 +391,7 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
             m = fminf(m, __shfl_xor(m, 32));
             if (lh == 0) wmin[wave * FT + li] = m;
             __syncthreads();
+            RVQ_STAMP(4 + 3 * min(ch, 1), stq);
             float cm = wmin[li];
 #pragma unroll
             for (int w = 1; w < NWV; ++w) cm = fminf(cm, wmin[w * FT + li]);
@@ -400,6 +412,7 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
                     }
                 }
             __syncthreads();
+            RVQ_STAMP(5 + 3 * min(ch, 1), stq);
         }
         // ---- B: decide ----
         if (tid < FT) {  // wave 0, lane == li == frame
@@ -438,12 +451,15 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
             }
         }
         __syncthreads();
+        RVQ_STAMP(9, stq);
+        if (a.stamps != nullptr && tid == 0 && stq) a.stamps[size_t(blockIdx.x) * 16 + 14] = (unsigned long long)flags[0];
         for (int w = wave; w < flags[0]; w += NWV) {  // one listed (frame, candidate) pair per wave at a time
             const int fc = work[w], f = fc >> 3;
             const double dist = exact_dist_wave(R + f, cbq + size_t(ccode[fc]) * D, D, lane);
             if (lane == 0) cdist[fc] = dist;
         }
         __syncthreads();
+        RVQ_STAMP(10, stq);
         if (tid < FT && state[tid] == 1) {
             const int f = tid;
             double bd = cdist[f * CAND];
@@ -468,6 +484,7 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
         for (int u = 0; u < MUMAX; ++u)
             if (tid + u * NT < Dp) mus[tid + u * NT] = mu_next[u];
         __syncthreads();
+        RVQ_STAMP(11, stq);
         // candidate overflow (degenerate codebooks): full defining search, whole block per frame
         const int any_overflow = flags[1];
         const int kq_bits = __float_as_int(c2[2 * size_t(K) + 1]);
@@ -499,6 +516,7 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
             }
             __syncthreads();
         }
+        RVQ_STAMP(12, stq);
         // ---- C: r -= c, out += c, index, squared residual ----
         // (the codeword rows of all of a wave's frames are requested together: one L2 latency, not one per frame)
         constexpr int FPW = FT / NWV;
@@ -571,7 +589,9 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
             for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off);
             if (lane == 0) a.part[size_t(blockIdx.x) * a.Q + q] = s;   // reduced in a fixed order by rvq_sqerr_kernel
         }
+        RVQ_STAMP(13, stq);
     }
+    RVQ_STAMP(1, true);
     // ---- write x_q ----
     if (a.q_st == 1 || a.q_sd != 1) {
         for (int e = tid; e < D * FT; e += NT) {
@@ -591,6 +611,7 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
             for (int d = lane; d < D; d += 64) dst[d] = O[d * RS + f];
         }
     }
+    RVQ_STAMP(15, true);
 }
 
 static size_t rvq_lds_bytes(int dim, int k, bool *tail_in_lds) {
@@ -779,6 +800,15 @@ size_t agx_rvq_workspace_bytes(int32_t batch, int32_t t, int32_t, int32_t, int32
     return size_t(agx::ceil_div64(int64_t(batch) * t, agx::FT)) * q_used * sizeof(double);
 }
 
+// diagnostic: device buffer of (workgroups x 16) 64-bit stamps the next rvq_forward launches fill (NULL switches it off)
+static unsigned long long *g_rvq_stamps = nullptr;
+static int g_rvq_stamp_q = 0;
+int agx_rvq_debug_stamps(void *device_buffer, int32_t stage) {
+    g_rvq_stamps = static_cast<unsigned long long *>(device_buffer);
+    g_rvq_stamp_q = stage;
+    return AGX_OK;
+}
+
 int agx_rvq_forward(const float *x, int64_t x_sb, int64_t x_st, int64_t x_sd, const float *codebooks,
                     const float *packed, int32_t batch, int32_t t, int32_t dim, int32_t k, int32_t q_used,
                     float *xq, int64_t q_sb, int64_t q_st, int64_t q_sd, int64_t *index, double *sq_err,
@@ -803,7 +833,8 @@ int agx_rvq_forward_ex(const float *x, int64_t x_sb, int64_t x_st, int64_t x_sd,
     const size_t lds = rvq_lds_bytes(dim, k, &tail_lds);
     if (lds > 160 * 1024) return fail(AGX_ERR_UNSUPPORTED, "rvq_forward: D=%d needs %zu B of LDS", dim, lds);
     RvqArgs a{x, x_sb, x_st, x_sd, codebooks, packed, batch, t, dim, k, q_used, xq, q_sb, q_st, q_sd, index, sq_err,
-              static_cast<double *>(workspace), tuning().b3_dbg == 7 ? 4.f : (tuning().b3_dbg == 8 ? 0.f : (tuning().b3_dbg == 9 ? -1.f : 1.f))};
+              static_cast<double *>(workspace), tuning().b3_dbg == 7 ? 4.f : (tuning().b3_dbg == 8 ? 0.f : (tuning().b3_dbg == 9 ? -1.f : 1.f)),
+              g_rvq_stamps, g_rvq_stamp_q};
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t n = int64_t(batch) * t;
     dim3 grid((unsigned)ceil_div64(n, FT)), block(NT);

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AGX_VERSION 116 /* 116: agx_multires_backward, agx_layernorm_ct one-pass kernel (same signature); agx_rvq_forward (legacy form) needs the workspace of agx_rvq_workspace_bytes since 114; 115: agx_rvq_ema_stats, agx_conv2d_bwd_data_kernel_name; 114: agx_attention_alibi_backward_ex (any T), agx_rvq_forward_ex; 113: tile images (resblock_p / conv_p), agx_attention_alibi_ex, agx_sizeof_*; 0.1.1: agx_conv_desc gained groups / padding (zero = old behaviour); 111: resample, conv2d column split */
+#define AGX_VERSION 117 /* 117: agx_rvq_debug_stamps (diagnostic); 116: agx_multires_backward, agx_layernorm_ct one-pass kernel (same signature); agx_rvq_forward (legacy form) needs the workspace of agx_rvq_workspace_bytes since 114; 115: agx_rvq_ema_stats, agx_conv2d_bwd_data_kernel_name; 114: agx_attention_alibi_backward_ex (any T), agx_rvq_forward_ex; 113: tile images (resblock_p / conv_p), agx_attention_alibi_ex, agx_sizeof_*; 0.1.1: agx_conv_desc gained groups / padding (zero = old behaviour); 111: resample, conv2d column split */
 
 #define AGX_OK 0
 #define AGX_ERR_BAD_SHAPE (-1)
@@ -237,6 +237,11 @@ int agx_rvq_forward_ex(const float *x, int64_t x_sb, int64_t x_st, int64_t x_sd,
 size_t agx_rvq_ema_workspace_bytes(int64_t n_frames, int32_t dim, int32_t q_used);
 int agx_rvq_ema_stats(const float *frames, const float *codebooks, const int64_t *index, float *stats, int64_t n_frames,
                       int32_t dim, int32_t k, int32_t q_used, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Diagnostic (not part of the reference surface): the next agx_rvq_forward launches write s_memtime stamps of workgroup w into
+ * device_buffer[w * 16 + slot] (64-bit each; slots 0 / 1 / 15 = kernel start / end of the stage loop / kernel end, 2..13 = the
+ * phase boundaries of residual stage `stage`, 14 = the (frame, candidate) pairs that went to the binary64 distance).  NULL = off. */
+int agx_rvq_debug_stamps(void *device_buffer, int32_t stage);
 
 /* quantizers[i].dequantize(idx) (vae.py:333): out[n,:] (+)= codebook[idx[n],:].
  * out element (n,d) at n*stride_n + d*stride_d. */
