@@ -4,18 +4,17 @@
 // calls at networks/vae.py:315-318 (source absent from the reference tree; the
 // arithmetic reproduced bit-for-bit is the one fixed in oracle/rvq_exact.c).
 //
-// One workgroup (4 waves) owns 32 frames for the whole stage loop.  The
-// residual tile R[d][frame] and the running output O[d][frame] live in LDS
-// (2 x 66 KB at D = 512), so latents are read once and x_q / indices written
-// once.  Per stage:
-//   A. scores s[k] = |c_k|^2 - 2 r.c_k for all K codewords with the fp32-input
-//      MFMA (rows = codewords streamed from the transposed codebook image in L2,
-//      columns = the 32 frames from LDS), per-frame minimum by in-lane min over
-//      the accumulator registers + one lane shuffle + a 4-entry LDS exchange;
-//   B. every codeword whose score is within a rigorous fp32 error margin of the
-//      minimum is a candidate; a frame with one candidate is decided, the rest
-//      are decided by the defining binary64 distance (sequential, unfused);
-//   C. r -= c, out += c, index written, squared residual accumulated.
+// One workgroup (8 waves) owns 32 frames for the whole stage loop.  The fp32 residual tile R[frame][d] (frame-major) and
+// the two bf16 planes of the centred residual live in LDS, so latents are read once and x_q / indices written once
+// (x_q is rebuilt at the end from the chosen codewords, added in stage order).  Per stage:
+//   A. scores s[k] = |c'_k|^2 - 2 r'.c'_k for all K codewords on the bf16 matrix pipe (three products of two bf16 pieces
+//      per operand; rows = codewords streamed from the stage image in L2 -- the phase is bound by the CU's L2 port: 2 MB per
+//      stage and workgroup --, columns = the 32 frames read from the planes), per-frame minimum by in-lane min over the
+//      accumulator registers + one lane shuffle + an 8-entry LDS exchange;
+//   B. every codeword whose score is within a rigorous error margin of the minimum is a candidate; a frame with one
+//      candidate is decided, the rest are decided by the defining binary64 distance (sequential, unfused): squares by all
+//      lanes, the d-ordered sums of up to 16 pairs side by side, one lane each;
+//   C. r -= c, index written, squared residual accumulated, and the next stage's r' = fl(r - mu) split into the planes.
 #include "common.hpp"
 
 namespace agx {
@@ -29,8 +28,6 @@ constexpr int NWV = 8;    // waves per workgroup (2 per SIMD: one computes while
 constexpr int NT = 64 * NWV;
 constexpr int RS = 33;    // LDS row stride of R / O (conflict-free in both access patterns)
 constexpr int CAND = 8;   // candidate slots per frame
-constexpr int TLMAX = 8;  // |c'|^2, |c'| table entries a thread carries to the next stage: 2 K <= TLMAX * NT for the LDS copy
-constexpr int MUMAX = 2;  // same for the mean codeword: Dp <= MUMAX * NT
 
 __host__ __device__ inline int rvq_dp(int dim) { return (dim + 15) & ~15; }  // D rounded up to the 16-deep k block of the bf16 MFMA
 // stage image, all on CENTRED codewords c' = fl(c - mu), mu = the stage's mean codeword:
@@ -124,7 +121,7 @@ __global__ __launch_bounds__(256) void rvq_cmax_kernel(int k, int dim, float *__
 // contiguous dims [L*blk, (L+1)*blk) (coalesced codeword load), forms its squares,
 // and the running sum is handed from lane to lane in d order.  Returns the
 // distance in every lane.
-__device__ __forceinline__ double exact_dist_wave(const float *r_col /* LDS, stride RS */,
+__device__ __forceinline__ double exact_dist_wave(const float *r_col /* LDS row of the frame */,
                                                const float *__restrict__ c, int dim, int lane) {
     constexpr int BLK_MAX = 8;  // dims per lane held in registers: D <= 512
     const int blk = (dim + 63) >> 6;
@@ -132,7 +129,7 @@ __device__ __forceinline__ double exact_dist_wave(const float *r_col /* LDS, str
     if (blk > BLK_MAX) {  // wider frames (wave-uniform): plain sequential evaluation, every lane redundantly
         double acc = 0.0;
         for (int d = 0; d < dim; ++d) {
-            const double diff = double(r_col[d * RS]) - double(c[d]);
+            const double diff = double(r_col[d]) - double(c[d]);
             const double sq = diff * diff;
             acc = acc + sq;
         }
@@ -144,7 +141,7 @@ __device__ __forceinline__ double exact_dist_wave(const float *r_col /* LDS, str
     for (int j = 0; j < BLK_MAX; ++j) {
         const int d = d0 + j;
         const bool ok = j < blk && d < dim;
-        const double diff = double(ok ? r_col[d * RS] : 0.f) - double(ok ? c[d] : 0.f);
+        const double diff = double(ok ? r_col[d] : 0.f) - double(ok ? c[d] : 0.f);
         sq[j] = diff * diff;
     }
     // ... then the running sum walks the lanes in d order: acc = (..((0 + sq_0) + sq_1) + ..)
@@ -184,36 +181,147 @@ struct RvqArgs {
         if (a.stamps != nullptr && tid == 0 && (cond)) a.stamps[size_t(blockIdx.x) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 
-template <int MT, bool TAIL_LDS>   // TAIL_LDS: the stage's |c'|^2 and |c'| tables are copied to LDS (they fit beside R / O)
+// LDS map (byte offsets).  R is FRAME-major (a frame's residual is one contiguous row: the update, the centring / split and the
+// binary64 distances walk it with 16-byte accesses); the score GEMM reads its B operand from the two bf16 PLANES
+//   PL[piece 2][Dp / 8][frame][8 bf16]      r' = fl(r - mu) = h + m + O(2^-16 r'),
+// written ONCE per stage by the update phase (round 3, first form: every wave re-read R, centred and split its B fragments
+// itself -- 16 x redundant, ~50 vector instructions per 6 MFMAs).  The plane region is dead between a stage's score passes and
+// its update: the binary64 distances use it for their squares.  x_q is not accumulated in LDS any more: it is rebuilt at the end
+// from the chosen codewords, added in stage order (the same fp32 sums).
+struct RvqLds {
+    int R, PL, wmin, rn2, sqf, mus, cnt, state, best, ccode, cscore, cdist, work, flags, hist, tails, total;
+};
+constexpr int SQ_PAIRS = 16;   // (frame, candidate) pairs whose squares fit the plane region at a time: 128 Dp / (8 Dp)
+constexpr int PROW = (FT + 1) * 16;   // bytes per 8-dim group of a plane: 32 frames x 16 B + 16 B, so that the update's writes (lane = group)
+                                      // land 4 banks apart (4-way instead of 64-way conflicts); the GEMM's reads stay contiguous
+__host__ __device__ inline int rvq_pad64(int n) { return (n + 63) & ~63; }
+__host__ __device__ inline int rvq_rsf(int Dp) { return Dp + 4; }   // floats per row of R (rows stay 16-byte aligned, 4 banks apart)
+__host__ __device__ inline RvqLds rvq_lds_map(int Dp, int K, int Q, bool tail) {
+    RvqLds m;
+    int o = 0;
+    m.R = o;      o += FT * rvq_rsf(Dp) * 4;
+    m.PL = o;     o += 2 * (Dp / 8) * PROW;      // >= SQ_PAIRS x Dp doubles
+    m.cdist = o;  o += FT * CAND * 8;            // (8-byte aligned: everything above is a multiple of 16)
+    m.wmin = o;   o += 2 * NWV * FT * 4;      // one buffer per score-pass parity
+    m.rn2 = o;    o += FT * 4;
+    m.sqf = o;    o += FT * 4;
+    m.mus = o;    o += 2 * rvq_pad64(Dp) * 4;   // two buffers: the next stage's mean streams in (LDS-DMA) during the search
+    m.cnt = o;    o += FT * 4;
+    m.state = o;  o += FT * 4;
+    m.best = o;   o += FT * 4;
+    m.ccode = o;  o += FT * CAND * 4;
+    m.cscore = o; o += FT * CAND * 4;
+    m.work = o;   o += FT * CAND * 4;
+    m.flags = o;  o += 16;
+    m.hist = o;   o += Q * FT * 4;
+    m.tails = o;  o += tail ? 2 * rvq_pad64(2 * K) * 4 : 0;   // two buffers, as mus
+    m.total = o;
+    return m;
+}
+
+// sum over the 64 lanes, the same value in every lane: four DPP steps inside the 16-lane rows (quad swaps, half-row and row mirrors
+// -- no LDS crossbar), then the four row sums through v_readlane.  (Six ds_bpermute rounds per sum before: 2.9 k cycles for the
+// eight sums of an update phase.)
+#define RVQ_DPP(x, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), (ctrl), 0xf, 0xf, true))
+__device__ __forceinline__ float rvq_wave_sum(float v) {
+    v += RVQ_DPP(v, 0xB1);    // quad_perm [1,0,3,2]
+    v += RVQ_DPP(v, 0x4E);    // quad_perm [2,3,0,1]
+    v += RVQ_DPP(v, 0x141);   // row_half_mirror
+    v += RVQ_DPP(v, 0x140);   // row_mirror
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+#pragma clang fp contract(off)
+// squares of one (frame, codeword) pair in the DEFINING arithmetic (binary64, never fused), all lanes in parallel: lane L forms
+// dims 8 L .. 8 L + 7 (+ 512 per round) and leaves them in sq[d]; dims >= D give +0.0.
+__device__ __forceinline__ void rvq_pair_squares(double *__restrict__ sq, const float *__restrict__ r_row,
+                                                 const float *__restrict__ c, int D, int Dp, int lane) {
+    for (int d0 = 8 * lane; d0 < Dp; d0 += 512) {
+        const f32x4 r0 = *reinterpret_cast<const f32x4 *>(r_row + d0), r1 = *reinterpret_cast<const f32x4 *>(r_row + d0 + 4);
+        float cv[8];
+        if ((D & 3) == 0) {   // rows are 16-byte aligned
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 c0 = d0 < D ? *reinterpret_cast<const f32x4 *>(c + d0) : z;
+            const f32x4 c1 = d0 + 4 < D ? *reinterpret_cast<const f32x4 *>(c + d0 + 4) : z;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cv[e] = c0[e], cv[4 + e] = c1[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cv[e] = d0 + e < D ? c[d0 + e] : 0.f;
+        }
+        double s[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const double diff = double(e < 4 ? r0[e] : r1[e - 4]) - double(cv[e]);
+            s[e] = diff * diff;
+        }
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            f64x2 v = {s[e], s[e + 1]};
+            *reinterpret_cast<f64x2 *>(sq + d0 + e) = v;
+        }
+    }
+}
+// ... and their sum in d order, ONE lane per pair: acc = (..((0 + sq_0) + sq_1) + ..) + sq_{D-1}
+__device__ __forceinline__ double rvq_chain_sum(const double *__restrict__ sq, int D) {
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    double acc = 0.0;
+    int d = 0;
+    for (; d + 16 <= D; d += 16) {
+        f64x2 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f64x2 *>(sq + d + 2 * j);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc = acc + v[j][0];
+            acc = acc + v[j][1];
+        }
+    }
+    for (; d < D; ++d) acc = acc + sq[d];
+    return acc;
+}
+#pragma clang fp contract(fast)
+
+template <int MT, bool TAIL_LDS>   // TAIL_LDS: the stage's |c'|^2 and |c'| tables are copied to LDS (they fit beside R / the planes)
 __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int Dp = rvq_dp(a.D);
-    float *R = smem;                 // [Dp][RS]
-    float *O = R + Dp * RS;          // [Dp][RS]
-    float *wmin = O + Dp * RS;       // [NWV][FT]
-    float *rn2 = wmin + NWV * FT;    // [FT]   ||r - mu||^2 of the current stage
-    float *mus = rn2 + FT;           // [Dp]   the current stage's mean codeword
-    int *cnt = reinterpret_cast<int *>(mus + Dp);         // [FT]
-    int *state = cnt + FT;                                 // [FT] 0 decided / 1 exact among cands / 2 full
-    int *best = state + FT;                                // [FT]
-    int *ccode = best + FT;                                // [FT][CAND]
-    float *cscore = reinterpret_cast<float *>(ccode + FT * CAND);  // [FT][CAND]
-    double *cdist = reinterpret_cast<double *>(cscore + FT * CAND);  // [FT][CAND] (8-byte aligned: offsets are even)
-    int *work = reinterpret_cast<int *>(cdist + FT * CAND);  // [FT * CAND] (frame, candidate) pairs that need the exact distance
-    int *flags = work + FT * CAND;                            // [0] number of pairs, [1] any frame in candidate overflow
-    float *tails = reinterpret_cast<float *>(flags + 2);     // [2 K] c2 | cn of the current stage (TAIL_LDS)
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+    const int Dp = rvq_dp(a.D), RSF = rvq_rsf(Dp), NG = Dp / 8;
+    const RvqLds L = rvq_lds_map(Dp, a.K, a.Q, TAIL_LDS);
+    float *R = reinterpret_cast<float *>(smem_b + L.R);           // [FT][RSF]
+    char *PL = smem_b + L.PL;                                     // [2][NG][PROW]: frame f of group g at g PROW + 16 f
+    double *SQ = reinterpret_cast<double *>(smem_b + L.PL);       // [SQ_PAIRS][Dp]  (between the score passes and the update)
+    float *wmin = reinterpret_cast<float *>(smem_b + L.wmin);     // [2][NWV][FT]
+    float *rn2 = reinterpret_cast<float *>(smem_b + L.rn2);       // [FT]   ||r - mu||^2 of the current stage
+    float *sqf = reinterpret_cast<float *>(smem_b + L.sqf);       // [FT]   ||r||^2 after the stage's update
+    float *musb = reinterpret_cast<float *>(smem_b + L.mus);      // [2][MP] mean codeword of stage q in buffer q & 1
+    int *cnt = reinterpret_cast<int *>(smem_b + L.cnt);           // [FT]
+    int *state = reinterpret_cast<int *>(smem_b + L.state);       // [FT] 0 decided / 1 exact among cands / 2 full
+    int *best = reinterpret_cast<int *>(smem_b + L.best);         // [FT]
+    int *ccode = reinterpret_cast<int *>(smem_b + L.ccode);       // [FT][CAND]
+    float *cscore = reinterpret_cast<float *>(smem_b + L.cscore); // [FT][CAND]
+    double *cdist = reinterpret_cast<double *>(smem_b + L.cdist); // [FT][CAND]
+    int *work = reinterpret_cast<int *>(smem_b + L.work);         // [FT * CAND] (frame, candidate) pairs that need the exact distance
+    int *flags = reinterpret_cast<int *>(smem_b + L.flags);       // [0] number of pairs, [1] any frame in candidate overflow
+    int *hist = reinterpret_cast<int *>(smem_b + L.hist);         // [Q][FT] the chosen codes (x_q is rebuilt from them)
+    float *tailsb = reinterpret_cast<float *>(smem_b + L.tails);  // [2][TP] c2 | cn of stage q in buffer q & 1 (TAIL_LDS)
+    const int MP = rvq_pad64(Dp), TP = rvq_pad64(2 * a.K);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int64_t N = int64_t(a.B) * a.T;
     const int64_t n0 = int64_t(blockIdx.x) * FT;
     const int D = a.D, K = a.K;
+    constexpr int FPW = FT / NWV;
 
     RVQ_STAMP(0, true);
-    // ---- stage the latents: R[d][f] = x[n0+f][d], O = 0; pick the coalesced order ----
-    for (int e = tid; e < Dp * RS; e += NT) O[e] = 0.f;
+    // ---- stage the latents: R[f][d] = x[n0+f][d] (zero for d >= D and for frames past the end); pick the coalesced order ----
     if (a.x_st == 1 || a.x_sd != 1) {  // time-contiguous ("b c l"): frames fastest
-        for (int e = tid; e < Dp * FT; e += NT) {
+        for (int e = tid; e < RSF * FT; e += NT) {
             const int d = e >> 5, f = e & 31;
             const int64_t n = n0 + f;
             float v = 0.f;
@@ -221,17 +329,94 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
                 const int64_t b = n / a.T, t = n - b * a.T;
                 v = a.x[b * a.x_sb + t * a.x_st + d * a.x_sd];
             }
-            R[d * RS + f] = v;
+            R[f * RSF + d] = v;
         }
     } else {  // channel-contiguous ("b l c"): d fastest
         for (int f = wave; f < FT; f += NWV) {
             const int64_t n = n0 + f;
             const int64_t b = n < N ? n / a.T : 0, t = n < N ? n - b * a.T : 0;
             const float *src = a.x + b * a.x_sb + t * a.x_st;
-            for (int d = lane; d < Dp; d += 64) R[d * RS + f] = (d < D && n < N) ? src[d] : 0.f;
+            for (int d = lane; d < RSF; d += 64) R[f * RSF + d] = (d < D && n < N) ? src[d] : 0.f;
         }
     }
-    __syncthreads();
+    // the 8 dims d0 .. d0 + 7 of a codeword row: the LOADS only, from clamped addresses (a select on the loaded value would make
+    // the wave wait for each row in turn -- four serial L2 round trips per update phase, measured); the elements past D are
+    // zeroed by mask_code8 where the row is used
+    auto load_code8 = [&](float (&cv)[8], const float *__restrict__ c, int d0) {
+        if ((D & 3) == 0) {
+            const f32x4 c0 = *reinterpret_cast<const f32x4 *>(c + (d0 < D ? d0 : 0));
+            const f32x4 c1 = *reinterpret_cast<const f32x4 *>(c + (d0 + 4 < D ? d0 + 4 : 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cv[e] = c0[e], cv[4 + e] = c1[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cv[e] = c[min(d0 + e, D - 1)];
+        }
+    };
+    auto mask_code8 = [&](float (&cv)[8], int d0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cv[e] = d0 + e < D ? cv[e] : 0.f;
+    };
+    // The pass between two stages over a wave's FPW frames (w, w + NWV, ...), lane L on dims d0 = 8 L .. 8 L + 7 (+ 512 per round):
+    //   r -= c (c = the chosen codeword; not before stage 0), squared residual, r' = fl(r - mu) with the NEXT stage's mean,
+    //   ||r'||^2, and the two bf16 pieces of r' into the planes.  All frames' loads first, then the arithmetic, then the stores:
+    //   the frames' latencies overlap instead of adding up.  red[2 j] += sum r^2, red[2 j + 1] += sum r'^2 of frame j (this lane's part).
+    auto frames_pass = [&](float (&cv)[FPW][8], bool sub, const float *mus, int d0, float (&red)[2 * FPW]) {
+        f32x4 r0[FPW], r1[FPW];
+#pragma unroll
+        for (int j = 0; j < FPW; ++j) {
+            const float *rr = R + (wave + j * NWV) * RSF + d0;
+            r0[j] = *reinterpret_cast<const f32x4 *>(rr), r1[j] = *reinterpret_cast<const f32x4 *>(rr + 4);
+        }
+        f32x4 m0 = {0.f, 0.f, 0.f, 0.f}, m1 = m0;
+        if (mus != nullptr) m0 = *reinterpret_cast<const f32x4 *>(mus + d0), m1 = *reinterpret_cast<const f32x4 *>(mus + d0 + 4);
+#pragma unroll
+        for (int j = 0; j < FPW; ++j) {
+            const int f = wave + j * NWV;
+            if (sub) {
+                mask_code8(cv[j], d0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r0[j][e] -= cv[j][e], r1[j][e] -= cv[j][4 + e];
+                float *rr = R + f * RSF + d0;
+                *reinterpret_cast<f32x4 *>(rr) = r0[j];
+                *reinterpret_cast<f32x4 *>(rr + 4) = r1[j];
+            }
+            rvq_bf16x8 h8, m8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float rv = e < 4 ? r0[j][e] : r1[j][e - 4];
+                red[2 * j] = fmaf(rv, rv, red[2 * j]);
+                const float v = rv - (e < 4 ? m0[e] : m1[e - 4]);
+                red[2 * j + 1] = fmaf(v, v, red[2 * j + 1]);
+                const __bf16 hh = (__bf16)v;
+                h8[e] = hh;
+                m8[e] = (__bf16)(v - (float)hh);
+            }
+            if (mus != nullptr) {   // (after the last stage only the squared residual is wanted)
+                const int g = d0 >> 3;
+                *reinterpret_cast<rvq_bf16x8 *>(PL + g * PROW + f * 16) = h8;
+                *reinterpret_cast<rvq_bf16x8 *>(PL + (NG + g) * PROW + f * 16) = m8;
+            }
+        }
+    };
+    auto wave_sums = [&](float (&red)[2 * FPW]) {      // the 2 FPW sums over the lanes (uniform results), chains side by side
+#pragma unroll
+        for (int i = 0; i < 2 * FPW; ++i) red[i] = rvq_wave_sum(red[i]);
+    };
+    // |c'|^2 | |c'| (adjacent in the image) and the mean codeword of stage qn -> buffer qn & 1, by LDS-DMA (a dword per lane, 256 B
+    // per instruction, issued by all waves in turn): no registers are held across the search and nothing is copied afterwards.
+    // Lanes past the end re-read the last element into the buffer's padding.
+    auto dma_tables = [&](int qn) {
+        const float *c2n = a.packed + qn * rvq_stage_floats(K, D) + size_t(Dp) * K;
+        const float *mun = c2n + 2 * size_t(K) + 4;
+        if (TAIL_LDS)
+            for (int i = wave; i * 64 < 2 * K; i += NWV)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(c2n + min(i * 64 + lane, 2 * K - 1)),
+                                                 (__attribute__((address_space(3))) void *)(tailsb + (qn & 1) * TP + i * 64), 4, 0, 0);
+        for (int i = wave; i * 64 < Dp; i += NWV)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(mun + min(i * 64 + lane, Dp - 1)),
+                                             (__attribute__((address_space(3))) void *)(musb + (qn & 1) * MP + i * 64), 4, 0, 0);
+    };
     // Error of one computed score s_k = |c'_k|^2 - 2 dot_k against the exact |r - c_k|^2 - |r'|^2, in units of (|r'| + |c'_k|)^2:
     //   * |c'|^2 table and the two centring roundings: (D + 8) 2^-24 x 1.25 (as for the fp32 score GEMM of rounds 1-2);
     //   * the dot product on two bf16 pieces per operand: each piece pair drops <= 2^-16 of its element and the m.m product
@@ -259,37 +444,28 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
         if (q == 0) {   // later stages: all of this is prepared by the previous stage's update phase (C)
             if (tid < FT) cnt[tid] = 0;
             if (tid < 2) flags[tid] = 0;
-            if (TAIL_LDS)
-                for (int e = tid; e < 2 * K; e += NT) tails[e] = c2[e];   // c2 and cn are adjacent in the image
-            const float *mu_g = c2 + 2 * size_t(K) + 4;
-            for (int d = tid; d < Dp; d += NT) mus[d] = mu_g[d];
+            dma_tables(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            // ||r - mu||^2 per frame (wave w owns frames w, w+NWV, ...)
-            for (int f = wave; f < FT; f += NWV) {
-                float part = 0.f;
-                for (int d = lane; d < D; d += 64) {
-                    const float v = R[d * RS + f] - mus[d];
-                    part = fmaf(v, v, part);
+            // r' = fl(r - mu), ||r'||^2 and the planes of stage 0 (wave w owns frames w, w + NWV, ...)
+            {
+                float red[2 * FPW], none[FPW][8];
+#pragma unroll
+                for (int i = 0; i < 2 * FPW; ++i) red[i] = 0.f;
+                for (int d0 = 8 * lane; d0 < Dp; d0 += 512) frames_pass(none, false, musb, d0, red);
+                wave_sums(red);
+                if (lane == 0) {
+#pragma unroll
+                    for (int j = 0; j < FPW; ++j) rn2[wave + j * NWV] = red[2 * j + 1];
                 }
-                for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-                if (lane == 0) rn2[f] = part;
             }
             __syncthreads();
         }
-        // The next stage's mean and |c'|^2 / |c'| tables are requested now and sit in registers until this stage's
-        // search is over (their latency hides behind the score GEMM).
-        float tl_next[TLMAX], mu_next[MUMAX];
+        // The next stage's tables stream into the other buffers during this stage's search (everyone left them at the barrier
+        // that ended stage q - 1's search).
         const bool more = q + 1 < a.Q;
-        {
-            const float *c2n = c2 + (more ? rvq_stage_floats(K, D) : 0);
-            if (TAIL_LDS) {
-#pragma unroll
-                for (int u = 0; u < TLMAX; ++u) tl_next[u] = c2n[min(tid + u * NT, 2 * K - 1)];
-            }
-            const float *mun = c2n + 2 * size_t(K) + 4;
-#pragma unroll
-            for (int u = 0; u < MUMAX; ++u) mu_next[u] = mun[min(tid + u * NT, Dp - 1)];
-        }
+        if (more) dma_tables(q + 1);
+        const float *tails = tailsb + (q & 1) * TP;
         // Error bound of one computed score: |s_k + |r'|^2 - |r - c_k|^2| <= E_k = eu (|r'| + |c'_k|)^2
         // (fp32 MFMA chain and |c'|^2: (D+2) u (c'^2 + 2 r'c'); the two centring roundings: 2 u (r'+c')^2).
         // Per CODEWORD, not per codebook: one far-away outlier codeword must not widen the margin of
@@ -319,9 +495,9 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
             // on the rigorous bound below and, among several candidates, by the defining binary64 distance, so the indices
             // do not depend on this arithmetic.  Lane (code, half) holds dims 16 kq + 8 half + (0..7): the codeword pieces
             // are two 16-byte loads of the CbH image straight from L2, requested NB - 1 blocks ahead into a ring of register
-            // sets (statically addressed: the loop is unrolled by NB); the residual piece is 8 conflict-free ds_read_b32 of
-            // the tile (+ the centring) split in registers in the shadow of the previous block's MFMAs.
-            const float *rb = R + (8 * lh) * RS + li;
+            // sets (statically addressed: the loop is unrolled by NB); the residual pieces are two conflict-free
+            // ds_read_b128 of the planes, one block ahead.
+            const char *pb = PL + lh * PROW + li * 16;
             const char *ab = reinterpret_cast<const char *>(img) + size_t(lh) * K * 16;
             constexpr int NB = 4;
             rvq_bf16x8 a_r[NB][MT][2];
@@ -335,18 +511,11 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
                         dst[i][pl] = *reinterpret_cast<const rvq_bf16x8 *>(ab + (size_t(kq * 2 + pl) * 2 * K + acol[i]) * 16);
             };
             auto load_b = [&](rvq_bf16x8 &bh, rvq_bf16x8 &bm, int kq) {
-                float xv[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) xv[e] = rb[(16 * kq + e) * RS] - mus[16 * kq + 8 * lh + e];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const __bf16 hh = (__bf16)xv[e];
-                    bh[e] = hh;
-                    bm[e] = (__bf16)(xv[e] - (float)hh);
-                }
+                bh = *reinterpret_cast<const rvq_bf16x8 *>(pb + 2 * kq * PROW);
+                bm = *reinterpret_cast<const rvq_bf16x8 *>(pb + (NG + 2 * kq) * PROW);
             };
 #pragma unroll
-            for (int pb = 0; pb < NB - 1; ++pb) load_a(a_r[pb], pb < nblk ? pb : 0);
+            for (int pb0 = 0; pb0 < NB - 1; ++pb0) load_a(a_r[pb0], pb0 < nblk ? pb0 : 0);
             load_b(bh_cur, bm_cur, 0);
             for (int k0 = 0; k0 < nblk; k0 += NB) {
 #pragma unroll
@@ -374,6 +543,26 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
             // time (the sched_barrier keeps hipcc from hoisting all 2*16*MT table loads at once,
             // which spills at 2 waves/SIMD).
             float m = INFINITY;
+            if (TAIL_LDS && (K & 3) == 0) {   // the four codes of a register group are consecutive: one 16-byte read per table
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int cb0 = code0 + i * 32 + 8 * g + 4 * lh;
+                        const int cc = min(cb0, K - 4);
+                        const f32x4 t2 = *reinterpret_cast<const f32x4 *>(tails + cc), tn = *reinterpret_cast<const f32x4 *>(tails + K + cc);
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) {
+                            const int r = 4 * g + e4;
+                            const float s = (cb0 < K) ? (t2[e4] - 2.f * acc[i][r]) : INFINITY;
+                            const float rc = rnorm + tn[e4];
+                            const float e = eu * rc * rc;
+                            acc[i][r] = s - e;          // keep the lower bound
+                            m = fminf(m, s + e);        // reduce the upper bound
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -389,12 +578,15 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             m = fminf(m, __shfl_xor(m, 32));
-            if (lh == 0) wmin[wave * FT + li] = m;
+            // (one buffer per pass parity: a wave may post pass ch + 1's minima while another still reads pass ch's -- the only
+            // barrier of a pass is the one below)
+            float *wm = wmin + (ch & 1) * (NWV * FT);
+            if (lh == 0) wm[wave * FT + li] = m;
             __syncthreads();
             RVQ_STAMP(4 + 3 * min(ch, 1), stq);
-            float cm = wmin[li];
+            float cm = wm[li];
 #pragma unroll
-            for (int w = 1; w < NWV; ++w) cm = fminf(cm, wmin[w * FT + li]);
+            for (int w = 1; w < NWV; ++w) cm = fminf(cm, wm[w * FT + li]);
             running = fminf(running, cm);
             const float thr = running;
 #pragma unroll
@@ -411,9 +603,9 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
                         }
                     }
                 }
-            __syncthreads();
             RVQ_STAMP(5 + 3 * min(ch, 1), stq);
         }
+        __syncthreads();
         // ---- B: decide ----
         if (tid < FT) {  // wave 0, lane == li == frame
             const int f = tid;
@@ -453,12 +645,36 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
         __syncthreads();
         RVQ_STAMP(9, stq);
         if (a.stamps != nullptr && tid == 0 && stq) a.stamps[size_t(blockIdx.x) * 16 + 14] = (unsigned long long)flags[0];
-        for (int w = wave; w < flags[0]; w += NWV) {  // one listed (frame, candidate) pair per wave at a time
-            const int fc = work[w], f = fc >> 3;
-            const double dist = exact_dist_wave(R + f, cbq + size_t(ccode[fc]) * D, D, lane);
-            if (lane == 0) cdist[fc] = dist;
+        // The update phase (C) needs the chosen codeword rows: those of the frames decided by the bounds alone are requested NOW,
+        // an L2 round trip (~4 k cycles with every other CU streaming codebooks) that then hides behind the binary64 phase.
+        // (before that: this wave's pieces of the next stage's tables, DMA'd at the start of the stage, have long landed -- the wait
+        // is free here, and the pick barrier below then publishes them without waiting for the loads issued now)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float cv[FPW][8];
+        bool early[FPW];
+#pragma unroll
+        for (int j = 0; j < FPW; ++j) {
+            const int f = wave + j * NWV;
+            early[j] = state[f] == 0;                  // (wave-uniform)
+            if (early[j]) load_code8(cv[j], cbq + size_t(best[f]) * D, 8 * lane);
         }
-        __syncthreads();
+        // The listed (frame, candidate) pairs, SQ_PAIRS at a time: every wave forms the squares of its pairs with all lanes
+        // (coalesced codeword loads) into the plane region, then ONE lane per pair adds them in d order -- the pairs' 512-long
+        // dependent chains run side by side (lane p / 8 of wave p % 8) instead of one after the other.
+        {
+            const int n_pairs = flags[0];
+            for (int base = 0; base < n_pairs; base += SQ_PAIRS) {   // (uniform)
+                const int np = min(SQ_PAIRS, n_pairs - base);
+                for (int pp = wave; pp < np; pp += NWV) {
+                    const int fc = work[base + pp], f = fc >> 3;
+                    rvq_pair_squares(SQ + size_t(pp) * Dp, R + f * RSF, cbq + size_t(ccode[fc]) * D, D, Dp, lane);
+                }
+                __syncthreads();
+                const int pp = lane * NWV + wave;
+                if (lane < SQ_PAIRS / NWV && pp < np) cdist[work[base + pp]] = rvq_chain_sum(SQ + size_t(pp) * Dp, D);
+                __syncthreads();
+            }
+        }
         RVQ_STAMP(10, stq);
         if (tid < FT && state[tid] == 1) {
             const int f = tid;
@@ -474,17 +690,11 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
             }
             best[f] = bc;
         }
-        // this stage's search is over: the next stage's tables replace the current ones
-        if (TAIL_LDS) {
-#pragma unroll
-            for (int u = 0; u < TLMAX; ++u)
-                if (tid + u * NT < 2 * K) tails[tid + u * NT] = tl_next[u];
-        }
-#pragma unroll
-        for (int u = 0; u < MUMAX; ++u)
-            if (tid + u * NT < Dp) mus[tid + u * NT] = mu_next[u];
         __syncthreads();
         RVQ_STAMP(11, stq);
+        int diag_mx = 0;
+        if (a.acc_scale < 0.f && tid == 0)     // DIAGNOSTIC (knob b3_dbg = 9): the stage's "squared error" output = largest candidate count
+            for (int f = 0; f < FT; ++f) diag_mx = max(diag_mx, state[f] == 2 ? 1000 + cnt[f] : cnt[f]);
         // candidate overflow (degenerate codebooks): full defining search, whole block per frame
         const int any_overflow = flags[1];
         const int kq_bits = __float_as_int(c2[2 * size_t(K) + 1]);
@@ -494,7 +704,7 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
             double bd = INFINITY;
             int bc = 0x7fffffff;
             for (int code = wave; code < Kq; code += NWV) {  // every lane of the wave gets the same distance
-                const double dc = exact_dist_wave(R + f, cbq + size_t(code) * D, D, lane);
+                const double dc = exact_dist_wave(R + f * RSF, cbq + size_t(code) * D, D, lane);
                 if (dc < bd || (dc == bd && code < bc)) {
                     bd = dc;
                     bc = code;
@@ -517,112 +727,112 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
             __syncthreads();
         }
         RVQ_STAMP(12, stq);
-        // ---- C: r -= c, out += c, index, squared residual ----
-        // (the codeword rows of all of a wave's frames are requested together: one L2 latency, not one per frame)
-        constexpr int FPW = FT / NWV;
-        if (D <= 512) {
-            float cv[FPW][8];
+        // ---- C: r -= c, index, squared residual; the next stage's r' = fl(r - mu), its norm and its planes ----
+        {
+            float red[2 * FPW];
 #pragma unroll
-            for (int j = 0; j < FPW; ++j) {
-                const float *c = cbq + size_t(best[wave + j * NWV]) * D;
+            for (int i = 0; i < 2 * FPW; ++i) red[i] = 0.f;
+            for (int db = 0; db < Dp; db += 512) {
+                const int d0 = db + 8 * lane;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) cv[j][u] = lane + 64 * u < D ? c[lane + 64 * u] : 0.f;
+                for (int j = 0; j < FPW; ++j)
+                    if (db > 0 || !early[j]) load_code8(cv[j], cbq + size_t(best[wave + j * NWV]) * D, d0);
+                if (d0 < Dp) frames_pass(cv, true, more ? musb + ((q + 1) & 1) * MP : nullptr, d0, red);
             }
+            wave_sums(red);
+            if (lane == 0) {
 #pragma unroll
-            for (int j = 0; j < FPW; ++j) {
-                const int f = wave + j * NWV;
-                float part = 0.f, pnext = 0.f;    // pnext: ||r - mu||^2 of the NEXT stage, same order as at q == 0
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int d = lane + 64 * u;
-                    if (d < D) {
-                        const float rv = R[d * RS + f] - cv[j][u];
-                        R[d * RS + f] = rv;
-                        O[d * RS + f] = O[d * RS + f] + cv[j][u];
-                        part = fmaf(rv, rv, part);
-                        const float v = rv - mus[d];
-                        pnext = fmaf(v, v, pnext);
-                    }
-                }
-                for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-                for (int off = 32; off > 0; off >>= 1) pnext += __shfl_xor(pnext, off);
-                if (lane == 0) {
-                    wmin[f] = part;  // squared residual of this frame (wmin row 0 is free between score passes)
-                    rn2[f] = pnext;
+                for (int j = 0; j < FPW; ++j) {
+                    const int f = wave + j * NWV;
+                    sqf[f] = red[2 * j];       // the squared residual of this frame
+                    rn2[f] = red[2 * j + 1];
+                    cnt[f] = 0;                // (read last by the pick step, before the barrier above)
+                    hist[q * FT + f] = best[f];
                     if (n0 + f < N) a.index[(n0 + f) * a.Q + q] = best[f];
                 }
             }
-        } else
-        for (int f = wave; f < FT; f += NWV) {
-            const int idx = best[f];
-            const float *c = cbq + size_t(idx) * D;
-            float part = 0.f, pnext = 0.f;
-            for (int d = lane; d < D; d += 64) {
-                const float cv = c[d];
-                const float rv = R[d * RS + f] - cv;
-                R[d * RS + f] = rv;
-                O[d * RS + f] = O[d * RS + f] + cv;
-                part = fmaf(rv, rv, part);
-                const float v = rv - mus[d];
-                pnext = fmaf(v, v, pnext);
-            }
-            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-            for (int off = 32; off > 0; off >>= 1) pnext += __shfl_xor(pnext, off);
-            if (lane == 0) {
-                wmin[f] = part;
-                rn2[f] = pnext;
-                if (n0 + f < N) a.index[(n0 + f) * a.Q + q] = idx;
+            if (tid == 0) flags[0] = 0;        // (read last at the start of the binary64 phase)
+        }
+        __syncthreads();                       // the ONE barrier between the update and the next stage's search
+        if (tid == 0) {
+            flags[1] = 0;                      // (everyone read it right after the pick barrier)
+            if (a.acc_scale < 0.f) {
+                sqf[0] = float(diag_mx);
+                for (int f = 1; f < FT; ++f) sqf[f] = 0.f;
             }
         }
-        if (a.acc_scale < 0.f && tid == 0) {   // DIAGNOSTIC (knob b3_dbg = 9): the stage's "squared error" output = largest candidate count
-            int mx = 0;
-            for (int f = 0; f < FT; ++f) mx = max(mx, state[f] == 2 ? 1000 + cnt[f] : cnt[f]);
-            wmin[0] = float(mx);
-            for (int f = 1; f < FT; ++f) wmin[f] = 0.f;
-        }
-        __syncthreads();
-        if (tid < FT) cnt[tid] = 0;       // (read last by the decide step)
-        if (tid < 2) flags[tid] = 0;
-        __syncthreads();
         if (wave == 0) {                  // the stage's squared error: 32 frames, pairwise in double
-            double s = (lane < FT && n0 + lane < N) ? double(wmin[lane]) : 0.0;
+            double s = (lane < FT && n0 + lane < N) ? double(sqf[lane]) : 0.0;
             for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off);
             if (lane == 0) a.part[size_t(blockIdx.x) * a.Q + q] = s;   // reduced in a fixed order by rvq_sqerr_kernel
         }
         RVQ_STAMP(13, stq);
     }
     RVQ_STAMP(1, true);
-    // ---- write x_q ----
-    if (a.q_st == 1 || a.q_sd != 1) {
+    // ---- x_q = ((0 + c_0) + c_1) + ... rebuilt from the chosen codewords, stage order ----
+    const bool q_rows = !(a.q_st == 1 || a.q_sd != 1);     // channel-contiguous output: a frame's row goes out as it is formed
+    float *Ot = reinterpret_cast<float *>(smem_b);         // [Dp][RS] transposition tile over R / the planes (both dead now)
+    __syncthreads();
+    for (int db = 0; db < Dp; db += 512) {
+        const int d0 = db + 8 * lane;
+#pragma unroll
+        for (int j = 0; j < FPW; ++j) {
+            const int f = wave + j * NWV;
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = 0.f;
+            for (int q0 = 0; q0 < a.Q; q0 += 4) {          // four stages' rows in flight
+                float cv[4][8];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = min(q0 + u, a.Q - 1);
+                    load_code8(cv[u], a.cb + (size_t(q) * K + hist[q * FT + f]) * D, d0 < Dp ? d0 : 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (q0 + u < a.Q) {
+                        mask_code8(cv[u], d0);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = o[e] + cv[u][e];
+                    }
+            }
+            if (d0 < Dp) {
+                if (q_rows) {
+                    const int64_t n = n0 + f;
+                    if (n < N) {
+                        const int64_t b = n / a.T, t = n - b * a.T;
+                        float *dst = a.xq + b * a.q_sb + t * a.q_st;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (d0 + e < D) dst[d0 + e] = o[e];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) Ot[(d0 + e) * RS + f] = o[e];
+                }
+            }
+        }
+    }
+    if (!q_rows) {
+        __syncthreads();
         for (int e = tid; e < D * FT; e += NT) {
             const int d = e >> 5, f = e & 31;
             const int64_t n = n0 + f;
             if (n < N) {
                 const int64_t b = n / a.T, t = n - b * a.T;
-                a.xq[b * a.q_sb + t * a.q_st + d * a.q_sd] = O[d * RS + f];
+                a.xq[b * a.q_sb + t * a.q_st + d * a.q_sd] = Ot[d * RS + f];
             }
-        }
-    } else {
-        for (int f = wave; f < FT; f += NWV) {
-            const int64_t n = n0 + f;
-            if (n >= N) continue;
-            const int64_t b = n / a.T, t = n - b * a.T;
-            float *dst = a.xq + b * a.q_sb + t * a.q_st;
-            for (int d = lane; d < D; d += 64) dst[d] = O[d * RS + f];
         }
     }
     RVQ_STAMP(15, true);
 }
 
-static size_t rvq_lds_bytes(int dim, int k, bool *tail_in_lds) {
+static size_t rvq_lds_bytes(int dim, int k, int q, bool *tail_in_lds) {
     const int Dp = rvq_dp(dim);
-    size_t floats = size_t(2) * Dp * RS + NWV * FT + FT /*rn2*/ + Dp /*mus*/ + 3 * FT /*cnt,state,best*/ +
-                    FT * CAND /*ccode*/ + FT * CAND /*cscore*/;
-    floats = (floats + 1) & ~size_t(1);
-    const size_t base = floats * 4 + size_t(FT) * CAND * 8 + (size_t(FT) * CAND + 2) * 4 /*work, flags*/;
-    const bool fits = base + size_t(2) * k * 4 <= 160 * 1024 && 2 * k <= TLMAX * NT;
+    const size_t with = size_t(rvq_lds_map(Dp, k, q, true).total);
+    const bool fits = with <= 160 * 1024;
     if (tail_in_lds) *tail_in_lds = fits;
-    return fits ? base + size_t(2) * k * 4 : base;
+    return fits ? with : size_t(rvq_lds_map(Dp, k, q, false).total);
 }
 
 // ------------------------------------------------------------------------ dequantize
@@ -830,7 +1040,7 @@ int agx_rvq_forward_ex(const float *x, int64_t x_sb, int64_t x_st, int64_t x_sd,
     if (!x || !codebooks || !packed || !xq || (q_used > 0 && (!index || !sq_err)))
         return fail(AGX_ERR_NULL_POINTER, "rvq_forward: NULL pointer");
     bool tail_lds = false;
-    const size_t lds = rvq_lds_bytes(dim, k, &tail_lds);
+    const size_t lds = rvq_lds_bytes(dim, k, q_used, &tail_lds);
     if (lds > 160 * 1024) return fail(AGX_ERR_UNSUPPORTED, "rvq_forward: D=%d needs %zu B of LDS", dim, lds);
     RvqArgs a{x, x_sb, x_st, x_sd, codebooks, packed, batch, t, dim, k, q_used, xq, q_sb, q_st, q_sd, index, sq_err,
               static_cast<double *>(workspace), tuning().b3_dbg == 7 ? 4.f : (tuning().b3_dbg == 8 ? 0.f : (tuning().b3_dbg == 9 ? -1.f : 1.f)),

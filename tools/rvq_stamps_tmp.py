@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Diagnostic: where one residual stage of rvq_forward spends its cycles (agx_rvq_debug_stamps), on the bench's workload
+(config S, batch 32 x 72 000, `latents` codebooks).  Thread 0 of every workgroup stamps s_memtime at the phase boundaries of
+ONE stage; printed: median [p10 .. p90] over the workgroups, per phase, for every stage in turn.
+usage: rvq_stamps.py [batch] [stage ...]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from audio_generation_amd import _lib, ops  # noqa: E402
+
+PHASES = [("score GEMM, pass 0", 2, 3), ("bounds + min exchange, pass 0", 3, 4), ("candidate lists, pass 0", 4, 5),
+          ("score GEMM, pass 1", 5, 6), ("bounds + min exchange, pass 1", 6, 7), ("candidate lists, pass 1", 7, 8),
+          ("decide (32 lanes)", 8, 9), ("binary64 distances of the listed pairs", 9, 10),
+          ("pick + next stage's tables", 10, 11), ("overflow search", 11, 12), ("update r / out / norms", 12, 13),
+          ("whole stage", 2, 13), ("C: codeword rows landed", 12, 3), ("C: arithmetic + LDS", 3, 4), ("C: wave sums", 4, 5), ("C: rest (barriers, index, sq err)", 5, 13)]
+
+
+def main():
+    batch = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    stages = [int(a) for a in sys.argv[2:]] or list(range(8))
+    dev = torch.device("cuda", 0)
+    model = bench.build_model(dev)
+    gen = torch.Generator().manual_seed(1234)
+    x = (0.1 * torch.randn(batch, 1, 72000, generator=gen)).clamp(-1, 1).to(dev)
+    bench.calibrate_codebooks(model, x[:4], "latents")
+    lib = _lib.load()
+    with torch.no_grad():
+        z = model._run_encoders(x)
+        n_wg = (z.shape[0] * z.shape[2] + 31) // 32
+        buf = torch.zeros(n_wg * 16, dtype=torch.int64, device=dev)
+
+        for _ in range(3):
+            model.quantizer.quantize_bcl(z)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            model.quantizer.quantize_bcl(z)
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"quantiser call (rvq_forward + its reductions), stamps off: {e0.elapsed_time(e1) / 10 * 1e3:.1f} us; {n_wg} workgroups")
+        for q in stages:
+            buf.zero_()
+            lib.agx_rvq_debug_stamps(buf.data_ptr(), q)
+            model.quantizer.quantize_bcl(z)
+            torch.cuda.synchronize()
+            lib.agx_rvq_debug_stamps(None, 0)
+            t = buf.cpu().numpy().reshape(n_wg, 16)
+            print(f"== stage {q}: whole kernel {np.median(t[:, 15] - t[:, 0]):.0f} ticks, stage loop {np.median(t[:, 1] - t[:, 0]):.0f}; "
+                  f"pairs sent to the binary64 distance: median {np.median(t[:, 14]):.0f}, p90 {np.percentile(t[:, 14], 90):.0f}, max {t[:, 14].max()}")
+            for name, a, b in PHASES:
+                d = (t[:, b] - t[:, a]).astype(np.float64)
+                d = d[(t[:, a] > 0) & (t[:, b] > 0)]
+                if len(d):
+                    print(f"   {name:42s} {np.median(d):8.0f}  [{np.percentile(d, 10):8.0f} .. {np.percentile(d, 90):8.0f}]")
+
+
+if __name__ == "__main__":
+    main()
