@@ -24,13 +24,16 @@ struct Tuning {
                         // input elements (tall tiles share the row halo), 0 = always the widest
     int bf_sched = -1;  // (-1 = per-shape table) schedule of the bf16x3 main loop in the fused residual block: 0 split after the MFMAs,
                         // 1 the same with MFMA / VALU interleave hints, 2 split before the MFMAs
-    int dw2_shared = 1; // conv2d weight gradient: 1 = workgroup-shared operand slots + one barrier per item where a variant exists, 0 = wave-private buffers
+    int dw2_shared = 2; // conv2d weight gradient: workgroup-shared operand slots + one barrier per item for 1 = the 128-row tiles, 2 = also the
+                        // 64- / 32-row tiles (64 -> 64 3 x 3: 81 -> 90 TFLOP/s since the DMA issue is cheap), 0 = wave-private buffers
     int dw2_direct = 2; // conv2d weight gradient on the barrier-free LDS-DMA kernel: 1 = stride-1 "same" layers, 2 = also the column-strided
                         // layers (x read through its column-phase planes), 0 = the staged kernel everywhere
     int dw_direct = 3;  // 1-D weight gradient on the barrier-free kernel: 3 = every dense layer (strided / transposed ones through a
                         // phase-split copy of x / dy), 2 = the stride-1 layers, 1 = the k = 1 layers only, 0 = none
     int dw1_wgs = 768;  // workgroups the 1-D LDS-free weight-gradient kernel aims for
     int dw_wgs = 1536;  // workgroups the conv2d weight-gradient kernel aims for (slices = dw_wgs / tiles)
+    int dw_xcd = 0;     // conv2d weight gradient: 1 = XCD-aware block order (all tiles of a contraction slice on one XCD's L2); measured
+                        // WORSE (128 -> 128 3 x 3: 106.6 -> 95.1 TFLOP/s): the slice's operands are better spread over the eight L2s
     int conv_cc = 0;    // diagnostic: force the LDS chunk (8/16/32 channels) of the MFMA conv; 0 = table
     int conv_shape = 0; // diagnostic: 1 = 128x128 conv tiles as 4 row-waves x (1x4) fragments
     int conv_short = 1; // 1: 128x64 conv tiles when the 128x128 grid is under two workgroups per CU

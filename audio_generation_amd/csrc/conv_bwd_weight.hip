@@ -13,6 +13,26 @@
 
 namespace agx {
 
+// XCD-aware block order.  The hardware hands consecutive workgroups of the launch order (x fastest, then y, z) to the 8 XCDs in
+// turn, so the n-tiles of one contraction slice -- which read the SAME dy rows -- land on 8 different L2s and each fetches
+// them from HBM again (9 x for a 128 -> 128 3 x 3 layer: ~5 GB per launch).  Renumbering gives every XCD a CONTIGUOUS range of
+// the virtual order: all tiles of a slice share one L2.  Bijective for any grid size.
+struct BlockId { int x, y, z; };
+__device__ __forceinline__ BlockId xcd_block_id(bool on) {
+    BlockId b{int(blockIdx.x), int(blockIdx.y), int(blockIdx.z)};
+    if (!on) return b;
+    const int gx = gridDim.x, gy = gridDim.y, total = gx * gy * int(gridDim.z);
+    const int L = b.x + gx * (b.y + gy * b.z);
+    const int per = total >> 3, rem = total & 7, xcd = L & 7, idx = L >> 3;
+    const int v = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + idx;
+    b.x = v % gx;
+    const int t = v / gx;
+    b.y = t % gy;
+    b.z = t / gy;
+    return b;
+}
+
+
 constexpr int BW_T = 64;        // time positions per LDS stage
 constexpr int BW_TS = BW_T + 1; // dyS row stride (odd: conflict-free column reads)
 
@@ -252,7 +272,7 @@ __device__ __forceinline__ void direct_compute(f32x16 (&acc)[MW][NW], float (&bs
 template <int MW, int NW, int WM, int WN>
 __device__ __forceinline__ void direct_finish(f32x16 (&acc)[MW][NW], float (&bsum)[MW], float *dma_buf, int wk, int wr,
                                               int lane, int n_base, int m_base, int NK, int M, float *__restrict__ part,
-                                              float *__restrict__ bias_part, bool do_bias) {
+                                              float *__restrict__ bias_part, bool do_bias, int oslice) {
     constexpr int WK = 4 / (WM * WN);
     const int li = lane & 31, lh = lane >> 5, wm = wr / WN, wn = wr % WN;
     if constexpr (WK > 1) {
@@ -286,7 +306,6 @@ __device__ __forceinline__ void direct_finish(f32x16 (&acc)[MW][NW], float (&bsu
             }
         }
     }
-    const int oslice = blockIdx.z;
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
         const int n = n_base + (wn * NW + k) * 32 + li;
@@ -443,7 +462,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (the clamped extra DMA of the last step)
         item += run;
     }
-    direct_finish<MW, NW, WM, WN>(acc, bsum, dma_buf, wk, wr, lane, n_base, m_base, NK, p.M, part, bias_part, do_bias);
+    direct_finish<MW, NW, WM, WN>(acc, bsum, dma_buf, wk, wr, lane, n_base, m_base, NK, p.M, part, bias_part, do_bias, blockIdx.z);
 }
 
 // out[e] = sum over slices of part[slice][e], in a fixed order: 4 slice groups (the 4 waves of a
@@ -537,6 +556,7 @@ struct Bw2dGeom {
     int R, WF, RH, SW, span, n_chan, n_slices;
     int prec;   // 1: bf16x3 contraction (AGX_IMPL_MFMA_BF16X3)
     int Wp;     // direct kernel: width of a column-phase plane of x (= Win when sw == 1)
+    int xcd;    // 1: XCD-aware block order (xcd_block_id)
 };
 
 template <int MW, int NW, int WM, int WN, int PREC = 0>   // PREC 1: bf16x3 contraction (mfma_tile.hpp), both operands split in registers
@@ -554,7 +574,8 @@ __global__ __launch_bounds__(256) void conv2d_bwd_weight_kernel(Bw2dGeom g, cons
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const int KK = g.kh * g.kw, NK = g.Cin * KK, M = g.Cout;
-    const int n_base = blockIdx.x * BN, m_base = blockIdx.y * BM, slice = blockIdx.z;
+    const BlockId bid = xcd_block_id(g.xcd != 0);
+    const int n_base = bid.x * BN, m_base = bid.y * BM, slice = bid.z;
     const int ci_first = n_base / KK;
     const int npos = g.R * g.WF;              // contraction positions per tile (<= BW_T)
     if (tid < BW_T) {
@@ -587,7 +608,7 @@ __global__ __launch_bounds__(256) void conv2d_bwd_weight_kernel(Bw2dGeom g, cons
             for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
     constexpr int TPR = 256 / BM, CPT = BW_T / TPR;
     float bsum = 0.f;
-    const bool do_bias = bias_part != nullptr && blockIdx.x == 0;
+    const bool do_bias = bias_part != nullptr && bid.x == 0;
 
     const int nft = (g.Wout + g.WF - 1) / g.WF, nrg = (g.Hout + g.R - 1) / g.R;
     const int items = g.B * nrg * nft;
@@ -753,8 +774,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     const int KK = g.kh * g.kw, NK = g.Cin * KK, M = g.Cout;
     const int Wp = g.Wp, HWo = g.Hout * g.Wout, HWi = g.Hin * Wp, FC = g.Wout / T;
     const int plane = g.B * g.Cin * HWi;          // floats per column-phase plane
-    const int n_base = blockIdx.x * BN, m_base = blockIdx.y * BM;
-    const int slice = blockIdx.z * WK + wk, n_slices = gridDim.z * WK;
+    const BlockId bid = xcd_block_id(g.xcd != 0);
+    const int n_base = bid.x * BN, m_base = bid.y * BM;
+    const int slice = bid.z * WK + wk, n_slices = gridDim.z * WK;
 
     // the MFMA rows of this lane (edge path, masks)
     int aoff[MW], brow[NW], bdh[NW], bdw[NW];
@@ -802,7 +824,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     float bsum[MW];
 #pragma unroll
     for (int i = 0; i < MW; ++i) bsum[i] = 0.f;
-    const bool do_bias = bias_part != nullptr && blockIdx.x == 0 && wn == 0;
+    const bool do_bias = bias_part != nullptr && bid.x == 0 && wn == 0;
 
     const int rows = g.B * g.Hout, items = rows * FC;
     auto dma = [&](int item) {
@@ -892,7 +914,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         item += run;
     }
-    direct_finish<MW, NW, WM, WN>(acc, bsum, dma_buf, wk, wr, lane, n_base, m_base, NK, M, part, bias_part, do_bias);
+    direct_finish<MW, NW, WM, WN>(acc, bsum, dma_buf, wk, wr, lane, n_base, m_base, NK, M, part, bias_part, do_bias, bid.z);
 }
 
 // The same item stream with the operands SHARED by the workgroup (knob dw2_shared, default on).  In the kernel above every
@@ -902,6 +924,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
 // LDS slots, and one barrier per item hands the slot over: item n + 1 streams in while item n is multiplied, exactly the
 // hand-over of conv_p.hip's two-slot ring.  Items whose DMA window could leave the tensor (head / tail rows) take the
 // element-by-element path, workgroup-uniformly.
+// probe build (-DAGX_STAMPS, tools/dw_stamps.py): per wave, the cycles of the item loop by segment, summed over the wave's items
+#ifdef AGX_STAMPS
+#define DW_STAMP_START() do { __builtin_amdgcn_sched_barrier(0); dws_prev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define DW_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); dws[k] += tn_ - dws_prev; dws_prev = tn_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define DW_STAMP_COUNT(n) do { dws[4] += (unsigned long long)(n); } while (0)
+#define DW_STAMP_WRITE() do { if (lane == 0) { const int L_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+        if ((L_ * 4 + wave) * 8 + 8 <= (1 << 16)) for (int k_ = 0; k_ < 5; ++k_) g_stamps[(L_ * 4 + wave) * 8 + k_] = dws[k_]; } } while (0)
+#else
+#define DW_STAMP_START() ((void)0)
+#define DW_STAMP(k) ((void)0)
+#define DW_STAMP_COUNT(n) ((void)0)
+#define DW_STAMP_WRITE() ((void)0)
+#endif
 template <int MW, int NW, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void conv2d_bwd_weight_shared_kernel(Bw2dGeom g, const float *__restrict__ x,
                                                                           const float *__restrict__ dy,
@@ -919,8 +954,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_bwd_weight_shared_kernel(Bw2dGe
     const int KK = g.kh * g.kw, NK = g.Cin * KK, M = g.Cout;
     const int Wp = g.Wp, HWo = g.Hout * g.Wout, HWi = g.Hin * Wp, FC = g.Wout / T;
     const int plane = g.B * g.Cin * HWi;
-    const int n_base = blockIdx.x * BN, m_base = blockIdx.y * BM;
-    const int slice = blockIdx.z, n_slices = gridDim.z;
+    const BlockId bid = xcd_block_id(g.xcd != 0);
+    const int n_base = bid.x * BN, m_base = bid.y * BM;
+    const int slice = bid.z, n_slices = gridDim.z;
 
     int aoff[MW], brow[NW], bdh[NW], bdw[NW];   // this lane's MFMA rows (edge path, masks)
 #pragma unroll
@@ -965,11 +1001,28 @@ __global__ __launch_bounds__(256, 2) void conv2d_bwd_weight_shared_kernel(Bw2dGe
     float bsum[MW];
 #pragma unroll
     for (int i = 0; i < MW; ++i) bsum[i] = 0.f;
-    const bool do_bias = bias_part != nullptr && blockIdx.x == 0 && wn == 0;
+    const bool do_bias = bias_part != nullptr && bid.x == 0 && wn == 0;
 
     const int rows = g.B * g.Hout, items = rows * FC;
-    auto dma = [&](int item, float *slot) {
-        const int row = item / FC, fc = item - row * FC, b = row / g.Hout, t = row - b * g.Hout;
+    // Fast path (every item whose kh input rows are all inside the image -- all but the first / last rows of an image): the
+    // instruction's address is a wave-uniform base (SGPR pair) + this lane's precomputed unsigned 32-bit offset, so an item costs two
+    // scalar base updates and NI (m0, global_load_lds saddr) pairs.  The general form below -- a select between the row and a page
+    // of zeros per instruction, 64-bit lane addresses -- took ~250 mostly dependent instructions per item: measured 22 % of the
+    // kernel (128 -> 128 3 x 3: 101 -> 129 TFLOP/s with the DMA issue removed).
+    const int BIAS = g.ph * Wp + 8;                      // makes every B offset non-negative (a >= -4, dh - ph >= -ph)
+    unsigned du[NI];
+#pragma unroll
+    for (int r = 0; r < NI; ++r) du[r] = unsigned(doff[r] + (r < NBA ? 0 : BIAS)) * 4u;
+    auto dma_fast = [&](int b, int t, int fc, float *slot) {
+        const char *dyb = reinterpret_cast<const char *>(dy + size_t(b) * M * HWo + t * g.Wout + fc * T);
+        const char *xb = reinterpret_cast<const char *>(x + size_t(b) * g.Cin * HWi + t * g.sh * Wp + fc * T) - size_t(BIAS) * 4;
+#pragma unroll
+        for (int r = 0; r < NI; ++r)      // instruction q = wave + 4 r lies in block r: A blocks first
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((r < NBA ? dyb : xb) + du[r]),
+                                             (__attribute__((address_space(3))) void *)(slot + (wave + 4 * r) * 256), 16, 0, 0);
+    };
+    auto dma = [&](int b, int t, int fc, float *slot) {
+        if (t * g.sh - g.ph >= 0 && t * g.sh + g.kh - 1 - g.ph < g.Hin) return dma_fast(b, t, fc, slot);
         const float *dyb = dy + size_t(b) * M * HWo + t * g.Wout + fc * T;
         const float *xb = x + size_t(b) * g.Cin * HWi + t * g.sh * Wp + fc * T;
 #pragma unroll
@@ -990,16 +1043,16 @@ __global__ __launch_bounds__(256, 2) void conv2d_bwd_weight_shared_kernel(Bw2dGe
     auto read_slot = [&](const float *slot, f32x4 (&A)[MW][4], f32x4 (&Bv)[NW][4]) {
         // position-major: the operands of the item's first MFMAs arrive first, the rest while those MFMAs issue (the DMA goes
         // to the OTHER slot, so nothing has to be in registers before it starts)
-        const int rd_off = (li >> 3) * 256 + (li & 7) * 32;
+        const int rd_off = (li >> 3) * 256 + (li & 7) * 32, rsw = li & 7;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
 #pragma unroll
             for (int i = 0; i < MW; ++i)
-                A[i][e] = *reinterpret_cast<const f32x4 *>(slot + (wm * MW + i) * 1024 + rd_off + 4 * ((4 * lh + e) ^ (li & 7)));
+                A[i][e] = *reinterpret_cast<const f32x4 *>(slot + (wm * MW + i) * 1024 + rd_off + 4 * ((4 * lh + e) ^ rsw));
 #pragma unroll
             for (int k = 0; k < NW; ++k)
                 Bv[k][e] = *reinterpret_cast<const f32x4 *>(slot + (NBA + wn * NW + k) * 1024 + rd_off +
-                                                            4 * ((4 * lh + e) ^ (li & 7)));
+                                                            4 * ((4 * lh + e) ^ rsw));
         }
     };
     auto mask_cols = [&](f32x4 (&Bv)[NW][4], int fc) {
@@ -1036,6 +1089,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_bwd_weight_shared_kernel(Bw2dGe
     auto compute = [&](const f32x4 (&A)[MW][4], const f32x4 (&Bv)[NW][4]) { direct_compute<MW, NW>(acc, bsum, A, Bv, do_bias); };
 
     f32x4 A0[MW][4], B0[NW][4];
+#ifdef AGX_STAMPS
+    unsigned long long dws[5] = {0, 0, 0, 0, 0}, dws_prev = 0;
+#endif
     const int per = (items + n_slices - 1) / n_slices;
     int item = slice * per;
     const int end = min(items, item + per);
@@ -1052,23 +1108,37 @@ __global__ __launch_bounds__(256, 2) void conv2d_bwd_weight_shared_kernel(Bw2dGe
             ++item;
             continue;
         }
-        const int last = item + run - 1;
-        dma(item, dma_buf);
+        // (b, t, fc) of the item being multiplied and of the one being fetched, advanced without divisions
+        int cb = row / g.Hout, ct = row - cb * g.Hout, cfc = fc;
+        dma(cb, ct, cfc, dma_buf);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                   // item 0 of the run is complete in slot 0
+        DW_STAMP_START();
         for (int n = 0; n < run; ++n) {
             float *cur = dma_buf + (n & 1) * SLOTF, *nxt = dma_buf + ((n + 1) & 1) * SLOTF;
+            const int fcn = cfc;
+            if (n + 1 < run) {                                 // (the last iteration fetches its own item again: harmless)
+                if (++cfc == FC) {
+                    cfc = 0;
+                    if (++ct == g.Hout) ct = 0, ++cb;
+                }
+            }
             read_slot(cur, A0, B0);
-            dma(min(item + n + 1, last), nxt);             // the other slot: everyone left it at the last barrier
-            const int fcn = (item + n) % FC;
+            dma(cb, ct, cfc, nxt);                             // the other slot: everyone left it at the last barrier
+            DW_STAMP(0);
             if (fcn == 0 || fcn == FC - 1) mask_cols(B0, fcn);
             compute(A0, B0);
+            DW_STAMP(1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the next item has landed
+            DW_STAMP(2);
             __syncthreads();                                   // everyone's has, and everyone has read the current slot
+            DW_STAMP(3);
         }
+        DW_STAMP_COUNT(run);
         item += run;
     }
-    direct_finish<MW, NW, WM, WN>(acc, bsum, dma_buf, 0, wave, lane, n_base, m_base, NK, M, part, bias_part, do_bias);
+    DW_STAMP_WRITE();
+    direct_finish<MW, NW, WM, WN>(acc, bsum, dma_buf, 0, wave, lane, n_base, m_base, NK, M, part, bias_part, do_bias, bid.z);
 }
 
 // Gradient w.r.t. the normalised weight G[co][n] = dwp[n][co] -> dw (torch layout), and per-row <G, W>.
@@ -1126,6 +1196,7 @@ static int bw2d_geometry(const agx_conv2d_desc *d, Bw2dGeom *g, int *cfg, int *b
     const int KK = g->kh * g->kw;
     g->n_chan = 127 / KK + 2;
     g->prec = d->impl == AGX_IMPL_MFMA_BF16X3 ? 1 : 0;
+    g->xcd = tuning().dw_xcd;
     *cfg = g->Cout >= 128 ? 0 : (g->Cout >= 64 ? 1 : 2);
     *bm = *cfg == 0 ? 128 : (*cfg == 1 ? 64 : 32);
     const int nt = ceil_div(g->Cin * KK, 128), mt = ceil_div(g->Cout, *bm);
@@ -1430,5 +1501,15 @@ int agx_conv2d_bwd_weight(const agx_conv2d_desc *d, const float *x, const float 
                            int64_t(M), dbias);
     return check_launch("agx_conv2d_bwd_weight");
 }
+
+#ifdef AGX_STAMPS
+int agx_debug_read_stamps(unsigned long long *host, int n) {   // probe build only: copy out and clear the stamp array
+    if (n > (1 << 16)) n = 1 << 16;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(agx::g_stamps), size_t(n) * 8) != hipSuccess) return AGX_ERR_LAUNCH;
+    static unsigned long long zeros[1 << 16];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(agx::g_stamps), zeros, sizeof(zeros)) != hipSuccess) return AGX_ERR_LAUNCH;
+    return AGX_OK;
+}
+#endif
 
 }  // extern "C"

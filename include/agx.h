@@ -60,13 +60,14 @@ int32_t agx_sizeof_conv2d_desc(void);
  *                      column-strided layers (x through its column-phase planes), 0 the staged kernel everywhere
  *   "dw1_wgs" N        workgroups the 1-D barrier-free weight-gradient kernel aims for (default 768)
  *   "dw_wgs" n         workgroups the conv2d weight-gradient kernel aims for (default 1536)
+ *   "dw_xcd" 0|1       conv2d weight gradient: 1 (default) XCD-aware block order -- the tiles of one contraction slice share an L2
  *   "conv_shape" 0|1   1: 128x128 conv tiles as four row-waves of 1x4 fragments
  *   "rb_impl" 0|1      fused residual block: 1 (default) the persistent ring kernel (csrc/resblock_p.hip) where it applies,
  *                      0 the first kernel (csrc/resblock_mfma.hip) everywhere
  *   "conv_impl" 0|1    resampling / stride-1 1-D layers and the Conv2d layers the ring kernel has a geometry for (forward and
  *                      backward-data): 1 (default) the persistent ring kernel (csrc/conv_p.hip), 0 conv_mfma.hip
- *   "dw2_shared" 0|1|2 conv2d weight gradient: 1 (default) 128 x 128 tiles fetch their operands once per workgroup (two LDS
- *                      slots, one barrier per item), 2 also the 64- and 32-row tiles (no gain measured), 0 wave-private buffers
+ *   "dw2_shared" 0|1|2 conv2d weight gradient: the tiles fetch their operands once per workgroup (two LDS slots, one barrier per
+ *                      item): 1 the 128 x 128 tiles, 2 (default) also the 64- and 32-row tiles, 0 wave-private buffers
  *   (the diagnostics of the experiments DESIGN 4.11 lists as dropped -- a DMA-only wave, start staggers, deferred stores --
  *    were removed together with their code)                                                                */
 int agx_set_tuning(const char *name, int32_t value);

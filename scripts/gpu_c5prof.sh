@@ -12,8 +12,8 @@ python3 - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-print(f"total kernel time {tot/1e6:.1f} ms over 4 steps (2 warm-up + 2 timed)")
+print(f"total kernel time {tot/1e6:.1f} ms over 5 steps (2 warm-up + 2 timed + the FLOP-count step)")
 for r in rows[:45]:
-    print(f'{float(r["TotalDurationNs"])/1e6/4:9.2f} ms/step {100*float(r["TotalDurationNs"])/tot:5.1f}%  x{int(r["Calls"])//4:5d}  {r["Name"][:110]}')
+    print(f'{float(r["TotalDurationNs"])/1e6/5:9.2f} ms/step {100*float(r["TotalDurationNs"])/tot:5.1f}%  x{int(r["Calls"])//5:5d}  {r["Name"][:110]}')
 PY
 exit $rc
