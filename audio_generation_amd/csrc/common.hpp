@@ -141,6 +141,7 @@ inline bool tile_image_eligible(const ConvPlan &p, int kind) {
 // 16 g + 4 lh + e (e < 4), 16 g + 8 + 4 lh + (e - 4) (e >= 4) -- the hidden channels a lane holds in accumulator
 // registers 8 (g % 2) .. + 7.  Same size as the standard bf16x3 image; follows it and the dim0 scale scratch.
 int conv_b3_geometry(const ConvPlan &p);   // conv_b3.hip: bf16x3 ring form of a stride-1 polyphase layer (0 = none)
+int conv2d_b3_geometry(const ConvPlan &p); // conv_b3.hip: bf16x3 ring form of a patch-mode Conv2d plan (3 x 3, stride 1, "same"; 0 = none)
 inline bool b3_image_eligible(const ConvPlan &p, int kind) {
     if (p.prec != 1 || p.G != 1) return false;
     if (kind == AGX_CONV_CAUSAL && p.s == 1 && p.q == 1 && p.Cin == p.Cout &&

@@ -20,6 +20,11 @@ bool conv_p2d_supported(const ConvPlan &p);
 const char *conv_p2d_variant(const ConvPlan &p);
 int launch_conv_p2d(const ConvPlan &p, const float *x, const float *wp, const float *bias, const float *res, float *y,
                     hipStream_t st);
+bool conv2d_b3_supported(const ConvPlan &p);
+const char *conv2d_b3_variant(const ConvPlan &p);
+int launch_conv2d_b3(const ConvPlan &p, const float *x, const float *wp, const float *bias, const float *res, float *y,
+                     hipStream_t st);
+void launch_b3_tile_from_bf(const float *img, float *timg, int64_t gj_count, int M, hipStream_t st);   // pack.hip
 
 int lower_conv2d(const agx_conv2d_desc *d, ConvPlan *p) {
     if (!d) return fail(AGX_ERR_NULL_POINTER, "conv2d descriptor is NULL");
@@ -70,6 +75,8 @@ int lower_conv2d(const agx_conv2d_desc *d, ConvPlan *p) {
     // layers the persistent ring kernel covers (conv_p.hip, D2 geometries) carry a tile image behind the scale scratch
     p->tile_off = -1;
     if (patch && d->impl == AGX_IMPL_AUTO && conv_p2d_geometry(*p) != 0) p->tile_off = packed_weight_floats(p->ncv, p->J, p->M) + p->Cout;
+    // bf16x3 layers with the ring form (conv_b3.hip: 3 x 3, stride 1) carry a B3 tile image behind the scale scratch
+    if (p->prec == 1 && conv2d_b3_geometry(*p) != 0) p->tile_off = packed_weight_floats_bf(p->ncv, p->J, p->M) + p->Cout;
     return AGX_OK;
 }
 
@@ -156,6 +163,7 @@ int lower_conv2d_bwd_data(const agx_conv2d_desc *d, ConvPlan *b) {
     b->pm_WF = 0;
     b->tile_off = -1;
     if (patch && d->impl == AGX_IMPL_AUTO && conv_p2d_geometry(*b) != 0) b->tile_off = packed_weight_floats(b->ncv, b->J, b->M);
+    if (patch && b->prec == 1 && conv2d_b3_geometry(*b) != 0) b->tile_off = packed_weight_floats_bf(b->ncv, b->J, b->M);
     return AGX_OK;
 }
 
@@ -371,7 +379,8 @@ int64_t agx_conv2d_bwd_packed_floats(const agx_conv2d_desc *d) {
     int rc = agx::lower_conv2d_bwd_data(d, &b);
     if (rc != AGX_OK) return rc;
     if (b.pm_R < 0) return int64_t(d->c_out) * d->c_in * d->kh * d->kw;
-    const int64_t tile = b.tile_off >= 0 ? agx::tile_image_floats(b.kh * b.Cin, b.J / b.kh, b.M) : 0;
+    const int64_t tile = b.tile_off < 0 ? 0 : b.prec ? agx::packed_weight_floats_bf(b.ncv, b.J, b.M)
+                                                     : agx::tile_image_floats(b.kh * b.Cin, b.J / b.kh, b.M);
     return (b.prec ? agx::packed_weight_floats_bf(b.ncv, b.J, b.M) : agx::packed_weight_floats(b.ncv, b.J, b.M)) + tile;
 }
 
@@ -391,7 +400,9 @@ int agx_conv2d_pack_bwd(const agx_conv2d_desc *d, const float *w, const float *s
     hipLaunchKernelGGL(pack_bwd2d_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), w, sigma, packed, d->c_in, d->c_out, d->kh, d->kw, d->stride_h,
                        d->stride_w, b.pm_R ? 1 : 0, b.ncv, b.J, b.M, b.prec);
-    if (b.tile_off >= 0)
+    if (b.tile_off >= 0 && b.prec)
+        launch_b3_tile_from_bf(packed, packed + b.tile_off, int64_t(ceil_div(b.ncv, kWG)) * b.J, b.M, static_cast<hipStream_t>(stream));
+    else if (b.tile_off >= 0)
         launch_pack_tile2d(w, nullptr, sigma, packed + b.tile_off, b.Cin, b.M, b.kh, b.J / b.kh, 1, static_cast<hipStream_t>(stream),
                            d->stride_h, d->stride_w, d->kh, d->kw);
     return check_launch("agx_conv2d_pack_bwd");
@@ -415,6 +426,7 @@ int agx_conv2d_bwd_data(const agx_conv2d_desc *d, const float *dy, const float *
                            d->kh, d->kw, d->stride_h, d->stride_w, d->pad_h, d->pad_w);
         return check_launch("agx_conv2d_bwd_data");
     }
+    if (b.prec == 1 && conv2d_b3_supported(b)) return launch_conv2d_b3(b, dy, packed_bwd, nullptr, add, dx, st);
     if (tuning().conv_impl == 1 && conv_p2d_supported(b)) return launch_conv_p2d(b, dy, packed_bwd, nullptr, add, dx, st);
     if (b.pm_R || (d->impl != AGX_IMPL_DIRECT && conv_mfma_supported(b)))
         return launch_conv_mfma(b, dy, packed_bwd, nullptr, add, dx, st);
@@ -473,6 +485,7 @@ int agx_conv2d_forward(const agx_conv2d_desc *d, const float *x, const float *pa
                            npos);
         return check_launch("agx_conv2d_forward");
     }
+    if (p.prec == 1 && conv2d_b3_supported(p)) return launch_conv2d_b3(p, x, packed, bias, nullptr, y, st);
     if (tuning().conv_impl == 1 && conv_p2d_supported(p)) return launch_conv_p2d(p, x, packed, bias, nullptr, y, st);
     const int impl = conv2d_impl(d, p);
     if (p.pm_R && impl != AGX_IMPL_MFMA)
@@ -488,7 +501,8 @@ int agx_conv2d_kernel_name(const agx_conv2d_desc *d, char *buf, size_t buf_len) 
     int rc = lower_conv2d(d, &p);
     if (rc != AGX_OK) return rc;
     if (!buf || buf_len == 0) return fail(AGX_ERR_NULL_POINTER, "agx_conv2d_kernel_name: NULL buffer");
-    snprintf(buf, buf_len, "%s", (agx::tuning().conv_impl == 1 && agx::conv_p2d_supported(p)) ? agx::conv_p2d_variant(p)
+    snprintf(buf, buf_len, "%s", (p.prec == 1 && agx::conv2d_b3_supported(p)) ? agx::conv2d_b3_variant(p)
+                                 : (agx::tuning().conv_impl == 1 && agx::conv_p2d_supported(p)) ? agx::conv_p2d_variant(p)
                                  : agx::conv2d_fewout(d, p) ? "conv2d_fewout<4>"
                                  : (conv2d_impl(d, p) == AGX_IMPL_MFMA ? conv_mfma_variant(p) : conv_direct_variant(p)));
     return AGX_OK;
@@ -501,6 +515,7 @@ int agx_conv2d_bwd_data_kernel_name(const agx_conv2d_desc *d, char *buf, size_t 
     if (rc != AGX_OK) return rc;
     if (!buf || buf_len == 0) return fail(AGX_ERR_NULL_POINTER, "agx_conv2d_bwd_data_kernel_name: NULL buffer");
     snprintf(buf, buf_len, "%s", b.pm_R < 0 ? "conv2d_bwd_data_gather"
+                                 : (b.prec == 1 && conv2d_b3_supported(b)) ? conv2d_b3_variant(b)
                                  : (tuning().conv_impl == 1 && conv_p2d_supported(b)) ? conv_p2d_variant(b)
                                  : (b.pm_R || (d->impl != AGX_IMPL_DIRECT && conv_mfma_supported(b))) ? conv_mfma_variant(b)
                                                                                                        : conv_direct_variant(b));

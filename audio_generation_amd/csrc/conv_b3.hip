@@ -308,6 +308,282 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Conv2d 3 x 3, stride 1, "same" padding (the STFT / waveform discriminators' stride-1 layers and their backward-data op,
+// discriminator.py:101-114, 150-167) on the same machinery.  A tile is R output rows x WF = 2^SL columns (the STFT maps are powers
+// of two wide: no padded columns), flattened: output position n = r WF + f; the input planes hold the (R + 2) x (WF + 2) patch
+// with row pitch SWP = WF + 2, so tap (dh, dw) of output position n is the plane position (n + 2 r) + dh SWP + dw -- a per-lane
+// base (n + 2 r, fixed for the whole tile loop) plus an immediate offset, exactly the 1-D kernel's "j".  Nine taps = five weight
+// groups per chunk: the slot set of a group is the parity of the tile's running group
+// count (the 1-D kernel's geometries all have an even number of groups per chunk).  Epilogue: bias, LeakyReLU (forward);
+// the arriving gradient added and the LeakyReLU-gradient mask applied (backward-data), as conv_p.hip's Conv2d epilogue.
+template <int MW, int NW, int WM, int SL>
+struct C2b3Geom {
+    static constexpr int WN = 4 / WM, KH = 3, KW = 3, J = 9;
+    static constexpr int BM = 32 * MW * WM, BN = 32 * NW * WN, WF = 1 << SL, SWP = WF + (KW - 1), R = BN >> SL;
+    static constexpr int W = (R + KH - 1) * SWP;               // plane positions
+    static constexpr int PLANE_B = 6 * W * 16;
+    static constexpr int WSLOT_B = 96 * BM;
+    static constexpr int NPW = WSLOT_B / 1024;
+    static constexpr int RW = (NPW + 3) / 4;
+    static constexpr int NT = (2 * W + 255) / 256;
+    static constexpr int NGRP = (J + 1) / 2;
+    static constexpr int OFF_W = (PLANE_B + 1023) / 1024 * 1024;
+    static constexpr size_t LDS_BYTES = size_t(OFF_W) + 4 * WSLOT_B;
+    static_assert(R >= 1 && WF >= 8, "tile rows / columns");
+    __host__ __device__ static constexpr int tap(int j) { return (j / KW) * SWP + (j % KW); }
+};
+
+template <int MW, int NW, int WM, int SL>
+__global__ __launch_bounds__(256, 2) void conv2d_b3_kernel(ConvPlan p, int cb_count, int rb_count, int mb_count, int ntiles,
+                                                           const float *__restrict__ x, const char *__restrict__ wt,
+                                                           const float *__restrict__ bias, const float *__restrict__ add,
+                                                           const float *__restrict__ mask, float *__restrict__ y) {
+    using G = C2b3Geom<MW, NW, WM, SL>;
+    constexpr int BM = G::BM, BN = G::BN, W = G::W, J = G::J, NT = G::NT, SWP = G::SWP;
+    constexpr int NSTEP = J * NW;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / G::WN, wn = wave % G::WN;
+    const int r0w = wm * (32 * MW), n0 = wn * (32 * NW);
+    const int M = p.M, Hin = p.Tin, Win = p.Lin, Hout = p.Tout, Wout = p.Lout;
+    const int nch = p.Cin / 16;
+
+    const int my_tiles = int(blockIdx.x) < ntiles ? (ntiles - 1 - int(blockIdx.x)) / int(gridDim.x) + 1 : 0;
+    if (my_tiles == 0) return;
+    // tile id -> (clip b, row block rb, column block cb, output-channel block mb): the channel blocks of one patch are consecutive
+    auto decode = [&](int tile, int &b, int &rb, int &cb, int &mb) {
+        mb = tile % mb_count;
+        int r = tile / mb_count;
+        cb = r % cb_count;
+        r /= cb_count;
+        rb = r % rb_count;
+        b = r / rb_count;
+    };
+
+    // ---- weight DMA (as conv_b3_kernel; the slot set is the parity of the tile's running group count) ----
+    const char *zpage = reinterpret_cast<const char *>(g_cb3_zero_page) + lane * 16;
+    int w_k = 0, w_g = 0, w_m0 = 0;
+    {
+        int b_, rb_, cb_, mb_;
+        decode(int(blockIdx.x), b_, rb_, cb_, mb_);
+        w_m0 = mb_ * BM;
+    }
+    auto dma_next_group = [&]() {
+        const bool live = w_k < my_tiles;
+        const int chunk = w_g / G::NGRP, which = w_g % G::NGRP;
+        const int set2 = (w_g & 1) * 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = 2 * which + i;
+            const bool valid = live && j < J;
+            const char *src0 = wt + (size_t(chunk) * J + (valid ? j : 0)) * 6 * size_t(M) * 16 + size_t(w_m0) * 16;
+            char *dst0 = lds + G::OFF_W + (set2 + i) * G::WSLOT_B;
+#pragma unroll
+            for (int r = 0; r < G::RW; ++r) {
+                const int n = (wave + 4 * r) % G::NPW;                  // 1 KiB piece n of the slot [piece, half][BM rows][16 B]
+                const int o16 = n * 64 + lane, plh = o16 / BM, row = o16 % BM;
+                const char *src = valid ? src0 + (size_t(plh) * M + row) * 16 : zpage;
+                cb3_glds_b128(src, dst0 + n * 1024);
+            }
+        }
+        if (++w_g == nch * G::NGRP) {
+            w_g = 0;
+            ++w_k;
+            int b_, rb_, cb_, mb_;
+            decode(min(int(blockIdx.x) + w_k * int(gridDim.x), ntiles - 1), b_, rb_, cb_, mb_);
+            w_m0 = mb_ * BM;
+        }
+    };
+
+    // ---- input stream: task u = (channel half, plane position); 8 channels of one position per task ----
+    int i_k = 0, i_chunk = 0;
+    float st[NT][8];
+    int st_t[NT];
+    auto input_load = [&]() {
+        const bool live = i_k < my_tiles;
+        int b_, rb_, cb_, mb_;
+        decode(min(int(blockIdx.x) + i_k * int(gridDim.x), ntiles - 1), b_, rb_, cb_, mb_);
+        const int row0 = rb_ * G::R - p.ph, col0 = cb_ * G::WF - p.P;
+        const char *xc = reinterpret_cast<const char *>(x + (size_t(b_) * p.Cin + i_chunk * 16) * p.x_cstride);
+        unsigned cs4 = unsigned(p.x_cstride) * 4u;
+        asm volatile("" : "+s"(cs4));
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int u = tid + 256 * n;
+            const int uh = u >= W ? 1 : 0;
+            const int t = u - uh * W;
+            const int pr = t / SWP, gr = row0 + pr, gc = col0 + (t - pr * SWP);
+            const bool task = u < 2 * W;
+            const bool ok = live && task && gr >= 0 && gr < Hin && gc >= 0 && gc < Win;
+            const unsigned off = unsigned(8 * uh) * cs4 + unsigned(min(max(gr, 0), Hin - 1) * Win + min(max(gc, 0), Win - 1)) * 4u;
+            st_t[n] = task ? (uh * W + t) : -1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = *reinterpret_cast<const float *>(xc + (off + unsigned(e) * cs4));
+                st[n][e] = ok ? v : 0.f;
+            }
+        }
+        if (++i_chunk == nch) i_chunk = 0, ++i_k;
+    };
+    auto input_store_all = [&]() {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            cb3x8 h, m, l;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const __bf16 hh = (__bf16)st[n][e];
+                const float r1 = st[n][e] - (float)hh;
+                const __bf16 mm = (__bf16)r1;
+                h[e] = hh;
+                m[e] = mm;
+                l[e] = (__bf16)(r1 - (float)mm);
+            }
+            if (st_t[n] >= 0) {
+                *reinterpret_cast<cb3x8 *>(lds + (0 * 2 * W + st_t[n]) * 16) = h;
+                *reinterpret_cast<cb3x8 *>(lds + (1 * 2 * W + st_t[n]) * 16) = m;
+                *reinterpret_cast<cb3x8 *>(lds + (2 * 2 * W + st_t[n]) * 16) = l;
+            }
+        }
+    };
+
+    const int aLane = (lh * BM + r0w + li) * 16;
+    int bLane[NW];                                        // this lane's plane position of output column block kk, tap (0, 0)
+#pragma unroll
+    for (int kk = 0; kk < NW; ++kk) {
+        const int n = n0 + 32 * kk + li;
+        bLane[kk] = (lh * W + n + (G::KW - 1) * (n >> SL)) * 16;
+    }
+    auto load_a = [&](cb3x8 (&a)[3][MW], int slot) {
+        const char *ws = lds + G::OFF_W + slot * G::WSLOT_B + aLane;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < MW; ++i) a[pl][i] = *reinterpret_cast<const cb3x8 *>(ws + (pl * 2 * BM + 32 * i) * 16);
+    };
+    auto load_b = [&](cb3x8 (&bf)[3], int tapoff, int kk) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bf[pl] = *reinterpret_cast<const cb3x8 *>(lds + bLane[kk] + (pl * 2 * W + tapoff) * 16);
+    };
+
+    // ---- prologue ----
+    input_load();
+    dma_next_group();
+    dma_next_group();
+    input_store_all();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    input_load();
+
+    cb3x8 fa[2][3][MW], fb[2][3];
+    for (int k = 0; k < my_tiles; ++k) {
+        int b, rb, cb, mb;
+        decode(int(blockIdx.x) + k * int(gridDim.x), b, rb, cb, mb);
+        const int m0 = mb * BM;
+        f32x16 acc[MW][NW];
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int kk = 0; kk < NW; ++kk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][kk][r] = 0.f;
+        load_a(fa[0], 0);
+        load_b(fb[0], G::tap(0), 0);
+
+        for (int c2 = 0; c2 < nch; c2 += 2) {
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    const int ua = (cc * J + j) & 1;
+#pragma unroll
+                    for (int kk = 0; kk < NW; ++kk) {
+                        const int step = j * NW + kk;
+                        const int sb = (cc * NSTEP + step) & 1;
+                        const bool last_of_phase = kk == NW - 1;
+                        const bool group_end = last_of_phase && ((j & 1) == 1 || j == J - 1);
+                        const bool chunk_end = last_of_phase && j == J - 1;
+                        if (group_end) {      // early barrier: this group's last operands are in registers
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            __syncthreads();
+                            dma_next_group();
+                        }
+                        f32x16 part[MW];
+#pragma unroll
+                        for (int i = 0; i < MW; ++i) part[i] = acc[i][kk];
+                        __builtin_amdgcn_sched_barrier(0);
+                        cb3_products<MW>(part, fa[ua], fb[sb], 0, 3);
+                        __builtin_amdgcn_sched_barrier(0);
+                        int nj = j, nk = kk + 1, ncc = cc;
+                        if (nk == NW) nk = 0, ++nj;
+                        if (nj == J) nj = 0, ncc = cc ^ 1;      // (two chunks = ten groups: the parity is back where it started)
+                        const int nslot = ((ncc * G::NGRP + (nj >> 1)) & 1) * 2 + (nj & 1);
+                        if (!chunk_end) {      // (the next chunk's planes only exist behind the second barrier below)
+                            if (nk == 0) load_a(fa[ua ^ 1], nslot);
+                            load_b(fb[sb ^ 1], G::tap(nj), nk);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        cb3_products<MW>(part, fa[ua], fb[sb], 3, 6);
+#pragma unroll
+                        for (int i = 0; i < MW; ++i) acc[i][kk] = part[i];
+                        if (chunk_end) {
+                            input_store_all();
+                            __builtin_amdgcn_sched_barrier(0);
+                            __syncthreads();
+                            load_a(fa[ua ^ 1], nslot);
+                            load_b(fb[sb ^ 1], G::tap(0), 0);
+                            input_load();
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+
+        // ---- epilogue.  Register r of row block i: row m0 + r0w + 32 i + 8 (r / 4) + 4 lh + r % 4; column n -> (row, column) of the tile ----
+        const bool pre = (p.epilogue & AGX_EPI_LEAKY_PRE) != 0;
+        const size_t ybase = size_t(b) * p.Cout * p.y_cstride;
+        float *yb = y + ybase;
+        const float *ab = add ? add + ybase : nullptr, *kb = mask ? mask + ybase : nullptr;
+        unsigned ycs = unsigned(p.y_cstride);
+        asm volatile("" : "+s"(ycs));
+#pragma unroll
+        for (int kk = 0; kk < NW; ++kk) {
+            const int n = n0 + 32 * kk + li;
+            const int orow = rb * G::R + (n >> SL), ocol = cb * G::WF + (n & (G::WF - 1));
+            const bool okp = orow < Hout && ocol < Wout;
+            const unsigned pos = okp ? unsigned(orow * Wout + ocol) : 0u;
+#pragma unroll
+            for (int i = 0; i < MW; ++i) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int mrow = m0 + r0w + 32 * i + 8 * g + 4 * lh;
+                    float rv[4], mv[4];
+                    if (ab) {
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) rv[s4] = ab[unsigned(mrow + s4) * ycs + pos];
+                    }
+                    if (kb) {
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) mv[s4] = kb[unsigned(mrow + s4) * ycs + pos];
+                    }
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        float v = acc[i][kk][4 * g + s4] + (bias ? bias[mrow + s4] : 0.f);
+                        if (pre) v = leaky(v, p.slope);
+                        if (ab) v += rv[s4];
+                        if (kb) v = mv[s4] > 0.f ? v : v * p.slope;
+                        if (okp) yb[unsigned(mrow + s4) * ycs + pos] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
 enum { CB3_NONE = 0, CB3_UP2, CB3_UP4, CB3_UP5, CB3_UP8, CB3_K7 };
 
 // shape-only test (also decides whether agx_conv_pack of a bf16x3 descriptor appends the B3 tile image: common.hpp)
@@ -379,6 +655,112 @@ int launch_conv_b3(const ConvPlan &p, const float *x, const float *wp, const flo
         case CB3_UP8: return launch_cb3<2, 2, 2, 3, 8, 1>(p, x, wp, bias, y, st);
         case CB3_K7: return launch_cb3<2, 2, 2, 7, 1, 6>(p, x, wp, bias, y, st);
         default: return fail(AGX_ERR_UNSUPPORTED, "conv_b3: unsupported layer");
+    }
+}
+
+
+// ---- Conv2d 3 x 3 (conv2d_b3_kernel) ----------------------------------------------------------------------------------
+enum { C2B3_NONE = 0, C2B3_M128, C2B3_M64, C2B3_M32 };
+
+// shape-only test (also decides whether the conv2d pack functions append the B3 tile image: conv2d.hip)
+int conv2d_b3_geometry(const ConvPlan &p) {
+    if (p.prec != 1 || p.G != 1 || p.pm_R <= 0 || p.q != 1 || p.qh != 1 || p.s != 1 || p.sh != 1 || p.d != 1) return C2B3_NONE;
+    if (p.kh != 3 || p.J != 9 || p.P != 1 || p.ph != 1 || p.oshift != 0 || p.oshift_h != 0) return C2B3_NONE;
+    if (p.Cin % 32 != 0 || p.cin_real != p.Cin || p.ncv != p.Cin) return C2B3_NONE;      // whole 16-channel chunks, an even number
+    if (p.Lt != p.Lout || p.Tt != p.Tout || p.Lout != p.Lin || p.Tout != p.Tin) return C2B3_NONE;   // "same" padding
+    if (p.M % 128 == 0) return C2B3_M128;
+    if (p.M == 64) return C2B3_M64;
+    if (p.M == 32) return C2B3_M32;
+    return C2B3_NONE;
+}
+
+static int c2b3_pick_sl(const ConvPlan &p, int BN, int sl_max);
+bool conv2d_b3_supported(const ConvPlan &p) {
+    const int geom = conv2d_b3_geometry(p);
+    if (p.tile_off < 0 || geom == C2B3_NONE) return false;
+    {   // very narrow / ragged feature maps: beyond 1.4 x padded area the fp32 ring kernel wins
+        const int BN = geom == C2B3_M128 ? 128 : 256, sl = c2b3_pick_sl(p, BN, geom == C2B3_M128 ? 6 : 7);
+        const int R = BN >> sl, WF = 1 << sl;
+        const int64_t area = int64_t(ceil_div(p.Tout, R)) * R * ceil_div(p.Lout, WF) * WF;
+        if (area * 10 > int64_t(p.Tout) * p.Lout * 14) return false;
+    }
+    if ((p.epilogue & ~(AGX_EPI_LEAKY_PRE | AGX_EPI_RESIDUAL | AGX_EPI_MASK)) != 0) return false;
+    if (p.x_cstride != int64_t(p.Tin) * p.Lin || p.y_cstride != int64_t(p.Tout) * p.Lout) return false;
+    if (p.x_cstride * 16 * 4 >= (int64_t(1) << 32) || p.y_cstride * p.Cout >= (int64_t(1) << 31)) return false;   // 32-bit offsets
+    return true;
+}
+
+// tile rows R = BN >> SL of SWP = 2^SL columns (SWP - 2 of them valid): the split with the least padded area
+static int c2b3_pick_sl(const ConvPlan &p, int BN, int sl_max) {
+    int best = 3;
+    int64_t best_area = -1;
+    for (int sl = 3; sl <= sl_max; ++sl) {
+        const int R = BN >> sl, WF = 1 << sl;
+        if (R < 1) continue;
+        const int64_t area = int64_t(ceil_div(p.Tout, R)) * R * ceil_div(p.Lout, WF) * WF;
+        if (best_area < 0 || area <= best_area) best = sl, best_area = area;     // (ties: the wider rows -- fewer halo columns)
+    }
+    return best;
+}
+
+const char *conv2d_b3_variant(const ConvPlan &p) {
+    switch (conv2d_b3_geometry(p)) {
+        case C2B3_M128: return "conv2d_b3<3x3,128x128>";
+        case C2B3_M64: return "conv2d_b3<3x3,64x256>";
+        case C2B3_M32: return "conv2d_b3<3x3,32x256>";
+        default: return "conv2d_b3<unsupported>";
+    }
+}
+
+template <int MW, int NW, int WM, int SL>
+static int launch_c2b3(const ConvPlan &p, const float *x, const float *wp, const float *bias, const float *add, const float *mask,
+                       float *y, hipStream_t st) {
+    using G = C2b3Geom<MW, NW, WM, SL>;
+    auto kern = conv2d_b3_kernel<MW, NW, WM, SL>;
+    static bool attr_set = false;
+    static int n_cu = 0;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024);
+        if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return fail(AGX_ERR_LAUNCH, "conv2d_b3: cannot query the device");
+        n_cu = prop.multiProcessorCount;
+        attr_set = true;
+    }
+    static_assert(2 * G::LDS_BYTES <= 160 * 1024, "conv2d_b3: LDS budget of two workgroups per CU");
+    const int cb = ceil_div(p.Lout, G::WF), rb = ceil_div(p.Tout, G::R), mb = p.M / G::BM;
+    const int64_t ntiles64 = int64_t(cb) * rb * mb * p.B;
+    if (ntiles64 > (1 << 30)) return fail(AGX_ERR_BAD_SHAPE, "conv2d_b3: too many tiles");
+    const int ntiles = int(ntiles64);
+    const int grid = ntiles < 2 * n_cu ? ntiles : 2 * n_cu;
+    const char *wt = reinterpret_cast<const char *>(wp + p.tile_off);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G::LDS_BYTES, st, p, cb, rb, mb, ntiles, x, wt, bias,
+                       (p.epilogue & AGX_EPI_RESIDUAL) ? add : nullptr, (p.epilogue & AGX_EPI_MASK) ? mask : nullptr, y);
+    return check_launch("conv2d_b3");
+}
+
+template <int MW, int NW, int WM, int SLMAX>
+static int launch_c2b3_sl(const ConvPlan &p, const float *x, const float *wp, const float *bias, const float *add,
+                          const float *mask, float *y, hipStream_t st) {
+    const int sl = c2b3_pick_sl(p, 32 * NW * (4 / WM), SLMAX);
+    if (sl == 3) return launch_c2b3<MW, NW, WM, 3>(p, x, wp, bias, add, mask, y, st);
+    if (sl == 4) return launch_c2b3<MW, NW, WM, 4>(p, x, wp, bias, add, mask, y, st);
+    if (sl == 5) return launch_c2b3<MW, NW, WM, 5>(p, x, wp, bias, add, mask, y, st);
+    if (sl == 6 || SLMAX == 6) return launch_c2b3<MW, NW, WM, 6>(p, x, wp, bias, add, mask, y, st);
+    return launch_c2b3<MW, NW, WM, SLMAX>(p, x, wp, bias, add, mask, y, st);
+}
+
+// res = the tensor added in the epilogue (AGX_EPI_RESIDUAL: backward-data, the gradient arriving at this feature map); p.mask as conv_p2d
+int launch_conv2d_b3(const ConvPlan &p, const float *x, const float *wp, const float *bias, const float *res, float *y, hipStream_t st) {
+    if (!conv2d_b3_supported(p)) return fail(AGX_ERR_UNSUPPORTED, "conv2d_b3: unsupported layer");
+    switch (conv2d_b3_geometry(p)) {
+        case C2B3_M128: return launch_c2b3_sl<2, 2, 2, 6>(p, x, wp, bias, res, p.mask, y, st);   // (one row of 128 columns: the planes of two workgroups do not fit)
+        case C2B3_M64: return launch_c2b3_sl<2, 2, 1, 7>(p, x, wp, bias, res, p.mask, y, st);
+        case C2B3_M32: return launch_c2b3_sl<1, 2, 1, 7>(p, x, wp, bias, res, p.mask, y, st);
+        default: return fail(AGX_ERR_UNSUPPORTED, "conv2d_b3: unsupported layer");
     }
 }
 

@@ -148,6 +148,24 @@ __global__ __launch_bounds__(256) void pack_b3_tile_kernel(const float *__restri
     dst[2 * plane] = l;
 }
 
+// B3 tile image from a finished standard bf16x3 image (any plan: the Conv2d forward / backward-data images of conv2d.hip) -- a pure
+// permutation: [((g J + j) M + m) 48 + plane 16 + c16]  ->  [(((g J + j) 3 + plane) 2 + c16 / 8) M + m][c16 % 8]
+__global__ __launch_bounds__(256) void b3_tile_from_bf_kernel(const __bf16 *__restrict__ img, __bf16 *__restrict__ timg, int64_t gj_count,
+                                                              int M) {
+    const int64_t total = gj_count * M * 48;
+    const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int c16 = int(e % 16), plane = int((e / 16) % 3);
+    const int m = int((e / 48) % M);
+    const int64_t gj = e / (int64_t(48) * M);
+    timg[(((gj * 3 + plane) * 2 + (c16 >> 3)) * M + m) * 8 + (c16 & 7)] = img[e];
+}
+void launch_b3_tile_from_bf(const float *img, float *timg, int64_t gj_count, int M, hipStream_t st) {
+    const int64_t total = gj_count * M * 48;
+    hipLaunchKernelGGL(b3_tile_from_bf_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st,
+                       reinterpret_cast<const __bf16 *>(img), reinterpret_cast<__bf16 *>(timg), gj_count, M);
+}
+
 // Packed image of the BACKWARD-DATA op (core.hip: lower_conv_bwd_data).  (Cin, Cout, K, q, J, P, s) are
 // the FORWARD plan's; the image has fwd-Cout "input" channels and M_b = q_b * fwd-Cin rows.
 __global__ __launch_bounds__(256) void pack_bwd_kernel(const float *__restrict__ v,
@@ -296,7 +314,8 @@ extern "C" int64_t agx_conv2d_packed_floats(const agx_conv2d_desc *d) {
     agx::ConvPlan p;
     int rc = agx::lower_conv2d(d, &p);
     if (rc != AGX_OK) return rc;
-    const int64_t tile = p.tile_off >= 0 ? agx::tile_image_floats(p.kh * p.Cin, p.J / p.kh, p.M) : 0;
+    const int64_t tile = p.tile_off < 0 ? 0 : p.prec ? agx::packed_weight_floats_bf(p.ncv, p.J, p.M)      // B3 tile image (conv_b3.hip)
+                                                     : agx::tile_image_floats(p.kh * p.Cin, p.J / p.kh, p.M);
     return (p.prec ? agx::packed_weight_floats_bf(p.ncv, p.J, p.M) : agx::packed_weight_floats(p.ncv, p.J, p.M)) + p.Cout + tile;
 }
 
@@ -318,6 +337,8 @@ extern "C" int agx_conv2d_pack(const agx_conv2d_desc *d, const float *w, const f
         const int64_t nthreads = int64_t(ceil_div(p.ncv, kWG)) * p.J * p.M * kWG;
         hipLaunchKernelGGL(pack_bf16x3_kernel, dim3((unsigned)ceil_div64(nthreads, 256)), dim3(256), 0, st, w, scale,
                            reinterpret_cast<__bf16 *>(packed), AGX_CONV_PADDED, p.ncv, p.Cout, p.J, 1, p.J, p.P, 1);
+        if (p.tile_off >= 0)   // second copy in the DMA layout of conv2d_b3_kernel, behind the scale scratch
+            launch_b3_tile_from_bf(packed, packed + p.tile_off, int64_t(ceil_div(p.ncv, kWG)) * p.J, p.M, st);
         return check_launch("agx_conv2d_pack");
     }
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)ceil_div64(n_w, 256)), dim3(256), 0, st, w, scale, packed,

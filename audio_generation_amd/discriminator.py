@@ -70,6 +70,8 @@ class _SNConv(nn.Module):
             self.bias, self.weight = conv.bias, conv.weight
         self._key, self._packed, self._iter = None, None, 0
         self.impl = IMPL_AUTO      # IMPL_MFMA_BF16X3: Conv2d layers with a bf16x3 form run on it (set_arithmetic)
+        self.ring_only = False     # ... only where the library has the bf16x3 RING kernel for the layer AND the feature map
+        self._impl_of = {}         #     (h, w) -> the arithmetic this layer runs at that map size
         self._tape = None          # (sigma, u, v) of the latest forward (native backward)
 
     @property
@@ -106,11 +108,23 @@ class _SNConv(nn.Module):
         self._iter += n_iter
         return ops.spectral_sigma(self.weight_orig.detach(), self.weight_u, self.weight_v, n_iter, self.eps)
 
-    def packed(self, make_desc, pack_plain, pack_sigma) -> Tensor:
+    def impl_for(self, b: int, h: int, w: int) -> int:
+        """The arithmetic of this Conv2d layer on an (h, w) map: ``self.impl``, except that in ring-only mode a layer / map the
+        bf16x3 ring kernel does not cover (or covers badly: narrow maps) stays on its fp32 kernel."""
+        if self.impl != IMPL_MFMA_BF16X3 or not self.ring_only:
+            return self.impl
+        if (h, w) not in self._impl_of:
+            d = ops.conv2d_desc(b, self.in_channels, self.out_channels, h, w, self.kernel_size[0], self.kernel_size[1],
+                                self.stride, self.padding, 0, 0.0, IMPL_MFMA_BF16X3)
+            self._impl_of[(h, w)] = IMPL_MFMA_BF16X3 if ops.conv2d_kernel_name(d).startswith("conv2d_b3") else IMPL_AUTO
+        return self._impl_of[(h, w)]
+
+    def packed(self, make_desc, pack_plain, pack_sigma, impl=None) -> Tensor:
         """Packed image; rebuilt when the weight, the buffers or the mode changed (always in training mode:
         the power iteration moves sigma)."""
         w = self.raw_weight
-        key = (w.data_ptr(), w._version, self.training, self._iter, self.impl,
+        impl = self.impl if impl is None else impl
+        key = (w.data_ptr(), w._version, self.training, self._iter, impl,
                getattr(self, "_wn_key", None) if self.norm != "spectral" else (self.weight_u._version, self.weight_v._version))
         if self.training or key != self._key:
             sigma = self._sigma()
@@ -118,7 +132,7 @@ class _SNConv(nn.Module):
             self._tape = None if sigma is None else (sigma, self.weight_u.clone(), self.weight_v.clone())
             desc = make_desc()
             self._packed = pack_plain(desc, w.detach()) if sigma is None else pack_sigma(desc, w.detach(), sigma)
-            self._key = (w.data_ptr(), w._version, self.training, self._iter, self.impl,
+            self._key = (w.data_ptr(), w._version, self.training, self._iter, impl,
                          getattr(self, "_wn_key", None) if self.norm != "spectral" else (self.weight_u._version, self.weight_v._version))
         return self._packed
 
@@ -137,13 +151,14 @@ class _SNConv(nn.Module):
     # -- 2-D --------------------------------------------------------------------------------------
     def run2d(self, x: Tensor, slope: Optional[float]) -> Tensor:
         b, _, h, w = x.shape
+        impl = self.impl_for(b, h, w)
 
         def desc(batch=b, hh=h, ww=w):
             return ops.conv2d_desc(batch, self.in_channels, self.out_channels, hh, ww, self.kernel_size[0],
                                    self.kernel_size[1], self.stride, self.padding,
-                                   EPI_LEAKY_PRE if slope is not None else 0, slope or 0.0, self.impl)
+                                   EPI_LEAKY_PRE if slope is not None else 0, slope or 0.0, impl)
 
-        packed = self.packed(lambda: desc(1, 64, 64), ops.conv2d_pack, ops.conv2d_pack)
+        packed = self.packed(lambda: desc(1, 64, 64), ops.conv2d_pack, ops.conv2d_pack, impl)
         return ops.conv2d_forward(desc(), x, packed, None if self.bias is None else self.bias.detach())
 
 
@@ -151,7 +166,7 @@ class _SNConv(nn.Module):
         b, _, h, w = x.shape
         return ops.conv2d_desc(b, self.in_channels, self.out_channels, h, w, self.kernel_size[0], self.kernel_size[1],
                                self.stride, self.padding, EPI_LEAKY_PRE if slope is not None else 0, slope or 0.0,
-                               self.impl)
+                               self.impl_for(b, h, w))
 
     def bwd2d(self, x: Tensor, dy: Tensor, tape, need_dx: bool = True, add: Optional[Tensor] = None,
               mask: Optional[Tensor] = None, slope: float = 0.2):
@@ -201,14 +216,19 @@ class _SNConv(nn.Module):
 
 
 def set_arithmetic(module: nn.Module, mode: str = "fp32") -> nn.Module:
-    """``"bf16x3"``: the Conv2d layers of the STFT discriminators that have a bf16x3 form (Cin % 16 == 0, Cout >= 32)
-    run forward and backward-data on the bf16x3 kernels (fp32-class accuracy on the bf16 MFMA); the
-    weight gradient stays on the fp32 kernel.  Default ``"fp32"``."""
-    if mode not in ("fp32", "bf16x3"):
+    """Arithmetic of the STFT discriminators' Conv2d layers (forward and backward-data; the weight gradient stays fp32):
+    ``"bf16x3_ring"``: the 3 x 3 stride-1 "same" layers with Cin % 32 == 0 and 32 / 64 / a multiple of 128 output channels run on
+    the bf16x3 ring kernel (csrc/conv_b3.hip: conv2d_b3_kernel, DESIGN 4.12: fp32-class accuracy, 1.3-1.5 x the fp32 ring) on
+    feature maps wide enough for its tiles; every other layer / map keeps its fp32 kernel; ``"bf16x3"``: every Conv2d layer with a bf16x3 form (Cin % 16 == 0, Cout >= 32) -- the ring
+    where it exists, the round-1 kernels elsewhere; default ``"fp32"``."""
+    if mode not in ("fp32", "bf16x3", "bf16x3_ring"):
         raise ValueError(f"unknown arithmetic {mode!r}")
     for m in module.modules():
         if isinstance(m, _SNConv):
-            m.impl = IMPL_MFMA_BF16X3 if (mode == "bf16x3" and m.nd == 2) else IMPL_AUTO
+            on = mode != "fp32" and m.nd == 2
+            m.impl = IMPL_MFMA_BF16X3 if on else IMPL_AUTO
+            m.ring_only = mode == "bf16x3_ring"      # decided per feature-map size by the library (impl_for)
+            m._impl_of = {}
     return module
 
 

@@ -1,0 +1,127 @@
+"""bf16x3 ring form of the discriminators' 3 x 3 stride-1 Conv2d layers (csrc/conv_b3.hip: conv2d_b3_kernel), forward and
+backward-data, against the float64 definition (torch conv2d on the CPU) -- fp32-class accuracy: 1e-5 of the output's largest
+magnitude -- and against the fp32 kernels; every tile shape (128 / 64 / 32 rows), every row pitch the launcher picks,
+ragged maps, more tiles than workgroups, spectral-norm scale, the backward-data epilogue (arriving gradient + LeakyReLU mask).
+Reference layers: discriminator.py:101-114 (STFT discriminator Conv2d stack), 150-167."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from audio_generation_amd import _lib, ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+# (batch, c_in, c_out, h, w)
+SHAPES = [
+    (2, 32, 32, 37, 128),      # 32-row tile, 2 rows x 128 columns
+    (2, 32, 64, 21, 96),       # 64-row tile, 8 rows x 32 columns, ragged height
+    (2, 64, 64, 33, 62),       # 4 rows x 64 columns, ragged width
+    (1, 64, 128, 19, 30),      # 128-row tile, 4 rows x 32 columns
+    (2, 128, 128, 9, 257),     # 2 rows x 64 columns, five column blocks (the last one almost empty)
+    (1, 128, 256, 15, 16),     # narrow map: 8 rows x 16 columns
+    (1, 256, 256, 35, 31),     # two blocks of output channels, ragged
+    (3, 64, 64, 150, 131),     # more tiles than 2 x 256 workgroups
+    (1, 256, 256, 32, 8),      # 16 rows x 8 columns
+]
+
+
+def _layer(cin, cout, seed):
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (1.5 / (cin * 9) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.1
+    return w, b
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_forward_matches_float64_and_fp32_kernels(shape):
+    bsz, cin, cout, h, w_ = shape
+    w, b = _layer(cin, cout, 11)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(bsz, cin, h, w_, generator=g)
+    want = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), padding=1), 0.2)
+    d3 = ops.conv2d_desc(bsz, cin, cout, h, w_, 3, 3, (1, 1), (1, 1), epilogue=_lib.EPI_LEAKY_PRE, slope=0.2, impl=_lib.IMPL_MFMA_BF16X3)
+    assert ops.conv2d_kernel_name(d3).startswith("conv2d_b3<3x3"), ops.conv2d_kernel_name(d3)
+    y3 = ops.conv2d_forward(d3, x.to(DEV), ops.conv2d_pack(d3, w.to(DEV)), b.to(DEV))
+    scale = float(want.abs().max())
+    assert float((y3.cpu().double() - want).abs().max()) <= 1e-5 * scale
+    d0 = ops.conv2d_desc(bsz, cin, cout, h, w_, 3, 3, (1, 1), (1, 1), epilogue=_lib.EPI_LEAKY_PRE, slope=0.2)
+    y0 = ops.conv2d_forward(d0, x.to(DEV), ops.conv2d_pack(d0, w.to(DEV)), b.to(DEV))
+    assert float((y3 - y0).abs().max()) <= 1e-5 * scale
+    # bit-reproducible run to run
+    y3b = ops.conv2d_forward(d3, x.to(DEV), ops.conv2d_pack(d3, w.to(DEV)), b.to(DEV))
+    assert torch.equal(y3, y3b)
+
+
+def test_spectral_norm_scale_and_no_bias():
+    bsz, cin, cout, h, w_ = 2, 64, 128, 21, 45
+    w, _ = _layer(cin, cout, 3)
+    sigma = torch.tensor([1.7])
+    x = torch.randn(bsz, cin, h, w_, generator=torch.Generator().manual_seed(9))
+    want = F.conv2d(x.double(), (w / sigma).double(), None, padding=1)
+    d3 = ops.conv2d_desc(bsz, cin, cout, h, w_, 3, 3, (1, 1), (1, 1), impl=_lib.IMPL_MFMA_BF16X3)
+    y3 = ops.conv2d_forward(d3, x.to(DEV), ops.conv2d_pack(d3, w.to(DEV), sigma.to(DEV)), None)
+    assert float((y3.cpu().double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("shape", SHAPES[:7] + SHAPES[8:])
+@pytest.mark.parametrize("epi", ["plain", "add+mask"])
+def test_backward_data_matches_autograd(shape, epi):
+    bsz, cin, cout, h, w_ = shape
+    w, _ = _layer(cin, cout, 21)
+    g = torch.Generator().manual_seed(6)
+    dy = torch.randn(bsz, cout, h, w_, generator=g)
+    # dx = conv_transpose of dy with w (the gradient of a stride-1 "same" conv), float64
+    want = F.conv_transpose2d(dy.double(), w.double(), padding=1)
+    add = mask = None
+    if epi == "add+mask":
+        add = torch.randn(bsz, cin, h, w_, generator=g)
+        mask = torch.randn(bsz, cin, h, w_, generator=g)
+        want = want + add.double()
+        want = torch.where(mask.double() > 0, want, want * 0.2)
+    d3 = ops.conv2d_desc(bsz, cin, cout, h, w_, 3, 3, (1, 1), (1, 1), impl=_lib.IMPL_MFMA_BF16X3)
+    assert ops.conv2d_bwd_data_kernel_name(d3).startswith("conv2d_b3<3x3"), ops.conv2d_bwd_data_kernel_name(d3)
+    pb = ops.conv2d_pack_bwd(d3, w.to(DEV))
+    dx = ops.conv2d_bwd_data(d3, dy.to(DEV), pb, mask=None if mask is None else mask.to(DEV), slope=0.2,
+                             add=None if add is None else add.to(DEV))
+    assert float((dx.cpu().double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+def test_other_layers_keep_their_kernels():
+    """Strided / 4 x 4 / few-channel layers have no ring form, and maps that would leave the tiles mostly empty (4 columns;
+    a ragged 33) are refused: a bf16x3 descriptor falls back to the kernels it had."""
+    for (cin, cout, kh, kw, sh, sw) in [(64, 128, 4, 4, 2, 2), (128, 128, 3, 4, 1, 2), (2, 32, 7, 7, 1, 1)]:
+        d = ops.conv2d_desc(2, cin, cout, 40, 64, kh, kw, (sh, sw), ((kh - 1) // 2, (kw - 1) // 2), impl=_lib.IMPL_MFMA_BF16X3)
+        assert not ops.conv2d_kernel_name(d).startswith("conv2d_b3")
+    for (h, w_) in [(562, 4), (35, 33)]:
+        d = ops.conv2d_desc(1, 256, 256, h, w_, 3, 3, (1, 1), (1, 1), impl=_lib.IMPL_MFMA_BF16X3)
+        assert not ops.conv2d_kernel_name(d).startswith("conv2d_b3")
+        assert not ops.conv2d_bwd_data_kernel_name(d).startswith("conv2d_b3")
+
+
+def test_ring_only_mode_of_the_discriminator_picks_per_map():
+    """set_arithmetic(..., "bf16x3_ring"): the 3 x 3 stride-1 layers run the ring kernel on the maps it covers well, every other
+    layer / map its fp32 kernel; the logits stay within fp32-class distance of the fp32 run, and so does the input gradient."""
+    from audio_generation_amd import discriminator as ad
+    torch.manual_seed(0)
+    d = ad.STFTDiscriminator(win_length=256).to(DEV).eval()      # eval: sigma does not move between the runs
+    x = (0.1 * torch.randn(2, 1, 9000)).to(DEV)
+
+    def run():
+        xi = x.clone().requires_grad_(True)
+        logits, feats = d(xi)
+        g, = torch.autograd.grad(logits[0].sum(), xi)
+        return logits[0].detach(), g
+
+    ref_l, ref_g = run()
+    ad.set_arithmetic(d, "bf16x3_ring")
+    ring_l, ring_g = run()
+    assert float((ring_l - ref_l).abs().max()) <= 2e-5 * float(ref_l.abs().max()) + 1e-7
+    assert float((ring_g - ref_g).abs().max()) <= 2e-5 * float(ref_g.abs().max()) + 1e-9
+    convs = [m for m in d.modules() if isinstance(m, ad._SNConv) and m.nd == 2]
+    ring_layers = [m for m in convs if _lib.IMPL_MFMA_BF16X3 in m._impl_of.values()]
+    assert ring_layers and all(tuple(m.kernel_size) == (3, 3) and tuple(m.stride) == (1, 1) for m in ring_layers)
+    assert any(_lib.IMPL_AUTO in m._impl_of.values() for m in convs)       # strided / 7 x 7 / narrow-map layers stayed fp32
+    ad.set_arithmetic(d, "fp32")
+    again_l, _ = run()
+    assert torch.equal(again_l, ref_l)

@@ -31,6 +31,8 @@ def main():
             from audio_generation_amd import _lib
             _lib.load().agx_set_tuning(kv.split("=")[0].encode(), int(kv.split("=")[1]))
     d = ad.STFTDiscriminator(win_length=win).to(dev).train()
+    if len(sys.argv) > 3:          # arithmetic: bf16x3 | bf16x3_ring
+        ad.set_arithmetic(d, sys.argv[3])
     x = 0.1 * torch.randn(b, 1, 72000, device=dev)
     with torch.no_grad():
         h = ops.stft(x.squeeze(1), win, True)

@@ -74,7 +74,8 @@ def main():
     model.quantizer.sync_from_rank0()         # every rank fed its own shard above: rank 0's codebooks win
     update_cb = os.environ.get("AGX_UPDATE_CODEBOOK", "1") == "1"     # training.py:305-308, 326
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
-    bf = os.environ.get("AGX_BF16X3", "0") == "1"     # decoder + discriminator Conv2d layers on the bf16x3 kernels
+    bf_mode = os.environ.get("AGX_BF16X3", "0")       # 1: decoder + every discriminator Conv2d layer with a bf16x3 form; 2: decoder +
+    bf = bf_mode in ("1", "2")                        #    only the discriminator layers that have the bf16x3 RING kernel (3 x 3, stride 1)
     if bf:
         model.set_conv_arithmetic(decoders="bf16x3")
     gan = os.environ.get("AGX_GAN", "0") == "1"
@@ -88,7 +89,7 @@ def main():
         if bf:
             from audio_generation_amd.discriminator import set_arithmetic
             for d in discs:
-                set_arithmetic(d, "bf16x3")
+                set_arithmetic(d, "bf16x3" if bf_mode == "1" else "bf16x3_ring")
         opt_d = [torch.optim.Adam(d.parameters(), lr=8e-4) for d in discs]
     # the reconstruction-side terms of Trainer.mini_epoch (training.py:313-359): low-pass of the input batch,
     # pre-emphasis before the MSE, the 7-window mel loss  (AGX_SIGNAL=0 switches them off)
@@ -173,7 +174,8 @@ def main():
         print(json.dumps({"what": "train step (fwd + native bwd + grad all-reduce + Adam), config S" +
                           (f" + {len(discs)} discriminators (native forward + backward)" if gan else "") +
                           (" + low-pass, pre-emphasis, 7-window mel loss" if signal else "") +
-                          (" [bf16x3: decoder forward, discriminator Conv2d forward + backward-data]" if bf else ""),
+                          (" [bf16x3: decoder forward, discriminator Conv2d forward + backward-data" +
+                           (" on the 3 x 3 stride-1 ring layers only]" if bf_mode == "2" else "]") if bf else ""),
                           "backward_order": ("two calls (training.py:374, 380)" if (two_calls or not signal) else "step.training_backward"),
                           "n_gpus": world, "batch_per_gpu": batch, "ms_per_step": ms, "replicas_in_sync": same, "update_codebook": update_cb,
                           "samples_per_s": world * batch * 72000 / ms * 1e3, "losses": losses,
