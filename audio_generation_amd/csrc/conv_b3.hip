@@ -318,9 +318,9 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_
 // groups per chunk: the slot set of a group is the parity of the tile's running group
 // count (the 1-D kernel's geometries all have an even number of groups per chunk).  Epilogue: bias, LeakyReLU (forward);
 // the arriving gradient added and the LeakyReLU-gradient mask applied (backward-data), as conv_p.hip's Conv2d epilogue.
-template <int MW, int NW, int WM, int SL>
+template <int MW, int NW, int WM, int SL, int KH_ = 3, int KW_ = 3>
 struct C2b3Geom {
-    static constexpr int WN = 4 / WM, KH = 3, KW = 3, J = 9;
+    static constexpr int WN = 4 / WM, KH = KH_, KW = KW_, J = KH_ * KW_;
     static constexpr int BM = 32 * MW * WM, BN = 32 * NW * WN, WF = 1 << SL, SWP = WF + (KW - 1), R = BN >> SL;
     static constexpr int W = (R + KH - 1) * SWP;               // plane positions
     static constexpr int PLANE_B = 6 * W * 16;
@@ -335,12 +335,17 @@ struct C2b3Geom {
     __host__ __device__ static constexpr int tap(int j) { return (j / KW) * SWP + (j % KW); }
 };
 
-template <int MW, int NW, int WM, int SL>
+// (KH, KW, Q, QH): (3, 3, 1, 1) the 3 x 3 layers and their backward-data; the backward-data of the strided layers is a stride-1
+// conv over dy with the ceil(k / s) taps per axis whose M = Cin sh sw rows carry the output phases (conv2d.hip:
+// lower_conv2d_bwd_data): (2, 2, 2, 2) for the 4 x 4 stride-(2, 2) layers, (3, 2, 2, 1) for the 3 x 4 stride-(1, 2) ones -- the tile
+// walks the BASE grid Tt x Lt, row m = (ci QH + a) Q + c of base position (t', f') goes to output (ci, QH t' + a - oshift_h,
+// Q f' + c - oshift).
+template <int MW, int NW, int WM, int SL, int KH, int KW, int Q, int QH>
 __global__ __launch_bounds__(256, 2) void conv2d_b3_kernel(ConvPlan p, int cb_count, int rb_count, int mb_count, int ntiles,
                                                            const float *__restrict__ x, const char *__restrict__ wt,
                                                            const float *__restrict__ bias, const float *__restrict__ add,
                                                            const float *__restrict__ mask, float *__restrict__ y) {
-    using G = C2b3Geom<MW, NW, WM, SL>;
+    using G = C2b3Geom<MW, NW, WM, SL, KH, KW>;
     constexpr int BM = G::BM, BN = G::BN, W = G::W, J = G::J, NT = G::NT, SWP = G::SWP;
     constexpr int NSTEP = J * NW;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -543,7 +548,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_b3_kernel(ConvPlan p, int cb_co
             }
         }
 
-        // ---- epilogue.  Register r of row block i: row m0 + r0w + 32 i + 8 (r / 4) + 4 lh + r % 4; column n -> (row, column) of the tile ----
+        // ---- epilogue.  Register r of row block i: row m0 + r0w + 32 i + 8 (r / 4) + 4 lh + r % 4; column n -> base (row, column) of the tile ----
         const bool pre = (p.epilogue & AGX_EPI_LEAKY_PRE) != 0;
         const size_t ybase = size_t(b) * p.Cout * p.y_cstride;
         float *yb = y + ybase;
@@ -553,30 +558,39 @@ __global__ __launch_bounds__(256, 2) void conv2d_b3_kernel(ConvPlan p, int cb_co
 #pragma unroll
         for (int kk = 0; kk < NW; ++kk) {
             const int n = n0 + 32 * kk + li;
-            const int orow = rb * G::R + (n >> SL), ocol = cb * G::WF + (n & (G::WF - 1));
-            const bool okp = orow < Hout && ocol < Wout;
-            const unsigned pos = okp ? unsigned(orow * Wout + ocol) : 0u;
+            const int brow = rb * G::R + (n >> SL), bcol = cb * G::WF + (n & (G::WF - 1));
+            const bool okb = brow < p.Tt && bcol < p.Lt;
 #pragma unroll
             for (int i = 0; i < MW; ++i) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int mrow = m0 + r0w + 32 * i + 8 * g + 4 * lh;
+                    unsigned off[4];
+                    bool okv[4];
                     float rv[4], mv[4];
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const int m = mrow + s4;
+                        const int co = m / (Q * QH), a = (m / Q) % QH, c = m % Q;
+                        const int orow = QH * brow + a - p.oshift_h, ocol = Q * bcol + c - p.oshift;
+                        okv[s4] = okb && orow >= 0 && orow < Hout && ocol >= 0 && ocol < Wout;
+                        off[s4] = okv[s4] ? unsigned(co) * ycs + unsigned(orow * Wout + ocol) : 0u;
+                    }
                     if (ab) {
 #pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) rv[s4] = ab[unsigned(mrow + s4) * ycs + pos];
+                        for (int s4 = 0; s4 < 4; ++s4) rv[s4] = ab[off[s4]];
                     }
                     if (kb) {
 #pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) mv[s4] = kb[unsigned(mrow + s4) * ycs + pos];
+                        for (int s4 = 0; s4 < 4; ++s4) mv[s4] = kb[off[s4]];
                     }
 #pragma unroll
                     for (int s4 = 0; s4 < 4; ++s4) {
-                        float v = acc[i][kk][4 * g + s4] + (bias ? bias[mrow + s4] : 0.f);
+                        float v = acc[i][kk][4 * g + s4] + (bias ? bias[(mrow + s4) / (Q * QH)] : 0.f);
                         if (pre) v = leaky(v, p.slope);
                         if (ab) v += rv[s4];
                         if (kb) v = mv[s4] > 0.f ? v : v * p.slope;
-                        if (okp) yb[unsigned(mrow + s4) * ycs + pos] = v;
+                        if (okv[s4]) yb[off[s4]] = v;
                     }
                 }
             }
@@ -659,30 +673,51 @@ int launch_conv_b3(const ConvPlan &p, const float *x, const float *wp, const flo
 }
 
 
-// ---- Conv2d 3 x 3 (conv2d_b3_kernel) ----------------------------------------------------------------------------------
-enum { C2B3_NONE = 0, C2B3_M128, C2B3_M64, C2B3_M32 };
+// ---- Conv2d (conv2d_b3_kernel) ---------------------------------------------------------------------------------------
+enum { C2B3_NONE = 0, C2B3_M128 = 1, C2B3_M64 = 2, C2B3_M32 = 3 };      // tile shape (low 4 bits of the geometry code)
+enum { C2B3_T33 = 0, C2B3_T22 = 1, C2B3_T32 = 2 };                      // tap shape (next 4 bits)
 
 // shape-only test (also decides whether the conv2d pack functions append the B3 tile image: conv2d.hip)
 int conv2d_b3_geometry(const ConvPlan &p) {
-    if (p.prec != 1 || p.G != 1 || p.pm_R <= 0 || p.q != 1 || p.qh != 1 || p.s != 1 || p.sh != 1 || p.d != 1) return C2B3_NONE;
-    if (p.kh != 3 || p.J != 9 || p.P != 1 || p.ph != 1 || p.oshift != 0 || p.oshift_h != 0) return C2B3_NONE;
+    if (p.prec != 1 || p.G != 1 || p.pm_R <= 0 || p.s != 1 || p.sh != 1 || p.d != 1) return C2B3_NONE;
     if (p.Cin % 32 != 0 || p.cin_real != p.Cin || p.ncv != p.Cin) return C2B3_NONE;      // whole 16-channel chunks, an even number
-    if (p.Lt != p.Lout || p.Tt != p.Tout || p.Lout != p.Lin || p.Tout != p.Tin) return C2B3_NONE;   // "same" padding
-    if (p.M % 128 == 0) return C2B3_M128;
-    if (p.M == 64) return C2B3_M64;
-    if (p.M == 32) return C2B3_M32;
-    return C2B3_NONE;
+    int taps;
+    if (p.kh == 3 && p.J == 9 && p.q == 1 && p.qh == 1) {             // 3 x 3, stride 1, "same": forward and backward-data
+        if (p.P != 1 || p.ph != 1 || p.oshift != 0 || p.oshift_h != 0) return C2B3_NONE;
+        if (p.Lt != p.Lout || p.Tt != p.Tout || p.Lout != p.Lin || p.Tout != p.Tin) return C2B3_NONE;
+        taps = C2B3_T33;
+    } else if (p.kh == 2 && p.J == 4 && p.q == 2 && p.qh == 2 && p.P == 1 && p.ph == 1) {
+        taps = C2B3_T22;                                              // backward-data of a 4 x 4 stride-(2, 2) layer
+    } else if (p.kh == 3 && p.J == 6 && p.q == 2 && p.qh == 1 && p.P == 1 && p.ph == 1 && p.oshift_h == 0 && p.Tt == p.Tout) {
+        taps = C2B3_T32;                                              // backward-data of a 3 x 4 stride-(1, 2) layer
+    } else {
+        return C2B3_NONE;
+    }
+    const int tile = p.M % 128 == 0 ? C2B3_M128 : p.M == 64 ? C2B3_M64 : p.M == 32 ? C2B3_M32 : C2B3_NONE;
+    return tile == C2B3_NONE ? C2B3_NONE : (tile | (taps << 4));
 }
 
-static int c2b3_pick_sl(const ConvPlan &p, int BN, int sl_max);
+// tile rows R = BN >> SL of WF = 2^SL columns over the base grid: the split with the least padded area
+static int c2b3_pick_sl(const ConvPlan &p, int BN, int sl_max) {
+    int best = 3;
+    int64_t best_area = -1;
+    for (int sl = 3; sl <= sl_max; ++sl) {
+        const int R = BN >> sl, WF = 1 << sl;
+        if (R < 1) continue;
+        const int64_t area = int64_t(ceil_div(p.Tt, R)) * R * ceil_div(p.Lt, WF) * WF;
+        if (best_area < 0 || area <= best_area) best = sl, best_area = area;     // (ties: the wider rows -- fewer halo columns)
+    }
+    return best;
+}
+
 bool conv2d_b3_supported(const ConvPlan &p) {
-    const int geom = conv2d_b3_geometry(p);
+    const int geom = conv2d_b3_geometry(p), tile = geom & 15;
     if (p.tile_off < 0 || geom == C2B3_NONE) return false;
     {   // very narrow / ragged feature maps: beyond 1.4 x padded area the fp32 ring kernel wins
-        const int BN = geom == C2B3_M128 ? 128 : 256, sl = c2b3_pick_sl(p, BN, geom == C2B3_M128 ? 6 : 7);
+        const int BN = tile == C2B3_M128 ? 128 : 256, sl = c2b3_pick_sl(p, BN, tile == C2B3_M128 ? 6 : 7);
         const int R = BN >> sl, WF = 1 << sl;
-        const int64_t area = int64_t(ceil_div(p.Tout, R)) * R * ceil_div(p.Lout, WF) * WF;
-        if (area * 10 > int64_t(p.Tout) * p.Lout * 14) return false;
+        const int64_t area = int64_t(ceil_div(p.Tt, R)) * R * ceil_div(p.Lt, WF) * WF;
+        if (area * 10 > int64_t(p.Tt) * p.Lt * 14) return false;
     }
     if ((p.epilogue & ~(AGX_EPI_LEAKY_PRE | AGX_EPI_RESIDUAL | AGX_EPI_MASK)) != 0) return false;
     if (p.x_cstride != int64_t(p.Tin) * p.Lin || p.y_cstride != int64_t(p.Tout) * p.Lout) return false;
@@ -690,33 +725,19 @@ bool conv2d_b3_supported(const ConvPlan &p) {
     return true;
 }
 
-// tile rows R = BN >> SL of SWP = 2^SL columns (SWP - 2 of them valid): the split with the least padded area
-static int c2b3_pick_sl(const ConvPlan &p, int BN, int sl_max) {
-    int best = 3;
-    int64_t best_area = -1;
-    for (int sl = 3; sl <= sl_max; ++sl) {
-        const int R = BN >> sl, WF = 1 << sl;
-        if (R < 1) continue;
-        const int64_t area = int64_t(ceil_div(p.Tout, R)) * R * ceil_div(p.Lout, WF) * WF;
-        if (best_area < 0 || area <= best_area) best = sl, best_area = area;     // (ties: the wider rows -- fewer halo columns)
-    }
-    return best;
-}
-
 const char *conv2d_b3_variant(const ConvPlan &p) {
-    switch (conv2d_b3_geometry(p)) {
-        case C2B3_M128: return "conv2d_b3<3x3,128x128>";
-        case C2B3_M64: return "conv2d_b3<3x3,64x256>";
-        case C2B3_M32: return "conv2d_b3<3x3,32x256>";
-        default: return "conv2d_b3<unsupported>";
-    }
+    static const char *names[3][3] = {{"conv2d_b3<3x3,128x128>", "conv2d_b3<3x3,64x256>", "conv2d_b3<3x3,32x256>"},
+                                      {"conv2d_b3<2x2 phases 2x2,128x128>", "conv2d_b3<2x2 phases 2x2,64x256>", "conv2d_b3<2x2 phases 2x2,32x256>"},
+                                      {"conv2d_b3<3x2 phases 1x2,128x128>", "conv2d_b3<3x2 phases 1x2,64x256>", "conv2d_b3<3x2 phases 1x2,32x256>"}};
+    const int geom = conv2d_b3_geometry(p);
+    return geom == C2B3_NONE ? "conv2d_b3<unsupported>" : names[geom >> 4][(geom & 15) - 1];
 }
 
-template <int MW, int NW, int WM, int SL>
+template <int MW, int NW, int WM, int SL, int KH, int KW, int Q, int QH>
 static int launch_c2b3(const ConvPlan &p, const float *x, const float *wp, const float *bias, const float *add, const float *mask,
                        float *y, hipStream_t st) {
-    using G = C2b3Geom<MW, NW, WM, SL>;
-    auto kern = conv2d_b3_kernel<MW, NW, WM, SL>;
+    using G = C2b3Geom<MW, NW, WM, SL, KH, KW>;
+    auto kern = conv2d_b3_kernel<MW, NW, WM, SL, KH, KW, Q, QH>;
     static bool attr_set = false;
     static int n_cu = 0;
     if (!attr_set) {
@@ -731,7 +752,7 @@ static int launch_c2b3(const ConvPlan &p, const float *x, const float *wp, const
         attr_set = true;
     }
     static_assert(2 * G::LDS_BYTES <= 160 * 1024, "conv2d_b3: LDS budget of two workgroups per CU");
-    const int cb = ceil_div(p.Lout, G::WF), rb = ceil_div(p.Tout, G::R), mb = p.M / G::BM;
+    const int cb = ceil_div(p.Lt, G::WF), rb = ceil_div(p.Tt, G::R), mb = p.M / G::BM;
     const int64_t ntiles64 = int64_t(cb) * rb * mb * p.B;
     if (ntiles64 > (1 << 30)) return fail(AGX_ERR_BAD_SHAPE, "conv2d_b3: too many tiles");
     const int ntiles = int(ntiles64);
@@ -742,25 +763,36 @@ static int launch_c2b3(const ConvPlan &p, const float *x, const float *wp, const
     return check_launch("conv2d_b3");
 }
 
-template <int MW, int NW, int WM, int SLMAX>
+template <int MW, int NW, int WM, int SLMAX, int KH, int KW, int Q, int QH>
 static int launch_c2b3_sl(const ConvPlan &p, const float *x, const float *wp, const float *bias, const float *add,
                           const float *mask, float *y, hipStream_t st) {
     const int sl = c2b3_pick_sl(p, 32 * NW * (4 / WM), SLMAX);
-    if (sl == 3) return launch_c2b3<MW, NW, WM, 3>(p, x, wp, bias, add, mask, y, st);
-    if (sl == 4) return launch_c2b3<MW, NW, WM, 4>(p, x, wp, bias, add, mask, y, st);
-    if (sl == 5) return launch_c2b3<MW, NW, WM, 5>(p, x, wp, bias, add, mask, y, st);
-    if (sl == 6 || SLMAX == 6) return launch_c2b3<MW, NW, WM, 6>(p, x, wp, bias, add, mask, y, st);
-    return launch_c2b3<MW, NW, WM, SLMAX>(p, x, wp, bias, add, mask, y, st);
+    if (sl == 3) return launch_c2b3<MW, NW, WM, 3, KH, KW, Q, QH>(p, x, wp, bias, add, mask, y, st);
+    if (sl == 4) return launch_c2b3<MW, NW, WM, 4, KH, KW, Q, QH>(p, x, wp, bias, add, mask, y, st);
+    if (sl == 5) return launch_c2b3<MW, NW, WM, 5, KH, KW, Q, QH>(p, x, wp, bias, add, mask, y, st);
+    if (sl == 6 || SLMAX == 6) return launch_c2b3<MW, NW, WM, 6, KH, KW, Q, QH>(p, x, wp, bias, add, mask, y, st);
+    return launch_c2b3<MW, NW, WM, SLMAX, KH, KW, Q, QH>(p, x, wp, bias, add, mask, y, st);
+}
+
+template <int KH, int KW, int Q, int QH>
+static int launch_c2b3_tile(int tile, const ConvPlan &p, const float *x, const float *wp, const float *bias, const float *res,
+                            float *y, hipStream_t st) {
+    switch (tile) {
+        case C2B3_M128: return launch_c2b3_sl<2, 2, 2, 6, KH, KW, Q, QH>(p, x, wp, bias, res, p.mask, y, st);   // (one row of 128 columns: the planes of two workgroups do not fit)
+        case C2B3_M64: return launch_c2b3_sl<2, 2, 1, 7, KH, KW, Q, QH>(p, x, wp, bias, res, p.mask, y, st);
+        case C2B3_M32: return launch_c2b3_sl<1, 2, 1, 7, KH, KW, Q, QH>(p, x, wp, bias, res, p.mask, y, st);
+        default: return fail(AGX_ERR_UNSUPPORTED, "conv2d_b3: unsupported layer");
+    }
 }
 
 // res = the tensor added in the epilogue (AGX_EPI_RESIDUAL: backward-data, the gradient arriving at this feature map); p.mask as conv_p2d
 int launch_conv2d_b3(const ConvPlan &p, const float *x, const float *wp, const float *bias, const float *res, float *y, hipStream_t st) {
     if (!conv2d_b3_supported(p)) return fail(AGX_ERR_UNSUPPORTED, "conv2d_b3: unsupported layer");
-    switch (conv2d_b3_geometry(p)) {
-        case C2B3_M128: return launch_c2b3_sl<2, 2, 2, 6>(p, x, wp, bias, res, p.mask, y, st);   // (one row of 128 columns: the planes of two workgroups do not fit)
-        case C2B3_M64: return launch_c2b3_sl<2, 2, 1, 7>(p, x, wp, bias, res, p.mask, y, st);
-        case C2B3_M32: return launch_c2b3_sl<1, 2, 1, 7>(p, x, wp, bias, res, p.mask, y, st);
-        default: return fail(AGX_ERR_UNSUPPORTED, "conv2d_b3: unsupported layer");
+    const int geom = conv2d_b3_geometry(p);
+    switch (geom >> 4) {
+        case C2B3_T33: return launch_c2b3_tile<3, 3, 1, 1>(geom & 15, p, x, wp, bias, res, y, st);
+        case C2B3_T22: return launch_c2b3_tile<2, 2, 2, 2>(geom & 15, p, x, wp, bias, res, y, st);
+        default: return launch_c2b3_tile<3, 2, 2, 1>(geom & 15, p, x, wp, bias, res, y, st);
     }
 }
 

@@ -542,14 +542,20 @@ def main():
         # tools/train_step_bench.py in a CHILD process after everything above (never inside the timed region); its JSON line
         # carries ms/step, the executed FLOPs summed per launch, the fraction of the fp32 MFMA peak and the peak memory.
         import subprocess
-        env = dict(os.environ, AGX_GAN="1")
-        try:
-            out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_step_bench.py"), str(bsz), "2"], env=env,
-                                 capture_output=True, text=True, timeout=600)
-            line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-            result["training_step"] = json.loads(line[-1]) if line else {"error": (out.stderr or out.stdout)[-400:]}
-        except Exception as exc:    # the headline line must not depend on the secondary measurement
-            result["training_step"] = {"error": repr(exc)[:400]}
+
+        def child(extra_env):
+            try:
+                out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_step_bench.py"), str(bsz), "2"],
+                                     env=dict(os.environ, AGX_GAN="1", **extra_env), capture_output=True, text=True, timeout=600)
+                line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+                return json.loads(line[-1]) if line else {"error": (out.stderr or out.stdout)[-400:]}
+            except Exception as exc:    # the headline line must not depend on the secondary measurement
+                return {"error": repr(exc)[:400]}
+
+        result["training_step"] = child({})
+        # the same step with the opt-in bf16x3 arithmetic (fp32-class accuracy) on the decoder and on the
+        # discriminators' Conv2d forward / backward-data (ring kernel for the 3 x 3 stride-1 layers); weight gradients stay fp32
+        result["training_step_bf16x3"] = child({"AGX_BF16X3": "1"})
 
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -87,9 +87,48 @@ def test_backward_data_matches_autograd(shape, epi):
     assert float((dx.cpu().double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
 
 
+# (batch, c_in, c_out, h, w, kh, kw, sh, sw): the strided layers of the STFT discriminators (discriminator.py:119-139)
+STRIDED = [          # (widths chosen so that the base grid -- ceil((w + 1) / 2) columns -- fills the tiles: the launcher refuses the rest)
+    (2, 32, 64, 21, 62, 3, 4, 1, 2),
+    (2, 64, 128, 22, 62, 4, 4, 2, 2),
+    (1, 128, 128, 17, 126, 3, 4, 1, 2),
+    (1, 128, 256, 30, 30, 4, 4, 2, 2),
+    (2, 256, 512, 10, 30, 4, 4, 2, 2),
+    (1, 256, 256, 33, 30, 3, 4, 1, 2),
+    (2, 64, 128, 61, 250, 4, 4, 2, 2),      # ragged base grid, several column blocks
+    (1, 64, 128, 282, 512, 4, 4, 2, 2),     # a real layer: base grid 142 x 257
+]
+
+
+@pytest.mark.parametrize("shape", STRIDED)
+@pytest.mark.parametrize("epi", ["plain", "add+mask"])
+def test_backward_data_of_strided_layers(shape, epi):
+    """Backward-data of the (3,4)/(1,2) and (4,4)/(2,2) layers: a stride-1 conv over dy whose rows carry the output phases."""
+    bsz, cin, cout, h, w_, kh, kw, sh, sw = shape
+    g = torch.Generator().manual_seed(31)
+    w = torch.randn(cout, cin, kh, kw, generator=g) * (1.5 / (cin * kh * kw) ** 0.5)
+    pad = ((kh - 1) // 2, (kw - 1) // 2)
+    ho, wo = (h + 2 * pad[0] - kh) // sh + 1, (w_ + 2 * pad[1] - kw) // sw + 1
+    dy = torch.randn(bsz, cout, ho, wo, generator=g)
+    x0 = torch.zeros(bsz, cin, h, w_, dtype=torch.float64, requires_grad=True)
+    want, = torch.autograd.grad(F.conv2d(x0, w.double(), None, (sh, sw), pad), x0, dy.double())
+    add = mask = None
+    if epi == "add+mask":
+        add = torch.randn(bsz, cin, h, w_, generator=g)
+        mask = torch.randn(bsz, cin, h, w_, generator=g)
+        want = want + add.double()
+        want = torch.where(mask.double() > 0, want, want * 0.2)
+    d3 = ops.conv2d_desc(bsz, cin, cout, h, w_, kh, kw, (sh, sw), pad, impl=_lib.IMPL_MFMA_BF16X3)
+    assert ops.conv2d_bwd_data_kernel_name(d3).startswith("conv2d_b3<"), ops.conv2d_bwd_data_kernel_name(d3)
+    pb = ops.conv2d_pack_bwd(d3, w.to(DEV))
+    dx = ops.conv2d_bwd_data(d3, dy.to(DEV), pb, mask=None if mask is None else mask.to(DEV), slope=0.2,
+                             add=None if add is None else add.to(DEV))
+    assert float((dx.cpu().double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
 def test_other_layers_keep_their_kernels():
-    """Strided / 4 x 4 / few-channel layers have no ring form, and maps that would leave the tiles mostly empty (4 columns;
-    a ragged 33) are refused: a bf16x3 descriptor falls back to the kernels it had."""
+    """The FORWARD of the strided layers and few-channel layers have no ring form, and maps that would leave the tiles mostly
+    empty (4 columns; a ragged 33) are refused: a bf16x3 descriptor falls back to the kernels it had."""
     for (cin, cout, kh, kw, sh, sw) in [(64, 128, 4, 4, 2, 2), (128, 128, 3, 4, 1, 2), (2, 32, 7, 7, 1, 1)]:
         d = ops.conv2d_desc(2, cin, cout, 40, 64, kh, kw, (sh, sw), ((kh - 1) // 2, (kw - 1) // 2), impl=_lib.IMPL_MFMA_BF16X3)
         assert not ops.conv2d_kernel_name(d).startswith("conv2d_b3")
