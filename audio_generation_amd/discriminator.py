@@ -108,16 +108,19 @@ class _SNConv(nn.Module):
         self._iter += n_iter
         return ops.spectral_sigma(self.weight_orig.detach(), self.weight_u, self.weight_v, n_iter, self.eps)
 
-    def impl_for(self, b: int, h: int, w: int) -> int:
-        """The arithmetic of this Conv2d layer on an (h, w) map: ``self.impl``, except that in ring-only mode a layer / map the
-        bf16x3 ring kernel does not cover (or covers badly: narrow maps) stays on its fp32 kernel."""
+    def impl_for(self, b: int, h: int, w: int, bwd: bool = False) -> int:
+        """The arithmetic of this Conv2d layer's forward (or backward-data: ``bwd``) on an (h, w) input map: ``self.impl``, except
+        that in ring-only mode an op / map the bf16x3 ring kernel does not cover (or covers badly: narrow maps) stays on its fp32
+        kernel -- forward and backward-data pack their own images, so the two directions choose independently."""
         if self.impl != IMPL_MFMA_BF16X3 or not self.ring_only:
             return self.impl
-        if (h, w) not in self._impl_of:
+        key = (h, w, bwd)
+        if key not in self._impl_of:
             d = ops.conv2d_desc(b, self.in_channels, self.out_channels, h, w, self.kernel_size[0], self.kernel_size[1],
                                 self.stride, self.padding, 0, 0.0, IMPL_MFMA_BF16X3)
-            self._impl_of[(h, w)] = IMPL_MFMA_BF16X3 if ops.conv2d_kernel_name(d).startswith("conv2d_b3") else IMPL_AUTO
-        return self._impl_of[(h, w)]
+            name = ops.conv2d_bwd_data_kernel_name(d) if bwd else ops.conv2d_kernel_name(d)
+            self._impl_of[key] = IMPL_MFMA_BF16X3 if name.startswith("conv2d_b3") else IMPL_AUTO
+        return self._impl_of[key]
 
     def packed(self, make_desc, pack_plain, pack_sigma, impl=None) -> Tensor:
         """Packed image; rebuilt when the weight, the buffers or the mode changed (always in training mode:
@@ -162,16 +165,16 @@ class _SNConv(nn.Module):
         return ops.conv2d_forward(desc(), x, packed, None if self.bias is None else self.bias.detach())
 
 
-    def desc2d(self, x: Tensor, slope: Optional[float] = None):
+    def desc2d(self, x: Tensor, slope: Optional[float] = None, bwd: bool = False):
         b, _, h, w = x.shape
         return ops.conv2d_desc(b, self.in_channels, self.out_channels, h, w, self.kernel_size[0], self.kernel_size[1],
                                self.stride, self.padding, EPI_LEAKY_PRE if slope is not None else 0, slope or 0.0,
-                               self.impl_for(b, h, w))
+                               self.impl_for(b, h, w, bwd))
 
     def bwd2d(self, x: Tensor, dy: Tensor, tape, need_dx: bool = True, add: Optional[Tensor] = None,
               mask: Optional[Tensor] = None, slope: float = 0.2):
         """(dx or None, [dbias, dweight]) of this layer for the forward that produced ``tape``."""
-        desc = self.desc2d(x)
+        desc = self.desc2d(x, bwd=True)
         w = self.raw_weight.detach()
         sigma, u, v = tape if tape is not None else (None, None, None)
         dw, db = ops.conv2d_bwd_weight(desc, x, dy, w, sigma, u, v, want_bias=self.bias is not None)
