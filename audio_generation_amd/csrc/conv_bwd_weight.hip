@@ -937,7 +937,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
 #define DW_STAMP_COUNT(n) ((void)0)
 #define DW_STAMP_WRITE() ((void)0)
 #endif
-template <int MW, int NW, int WM, int WN>
+// PREC 1: the bf16x3 contraction (mfma_tile.hpp): both operands are activations, so each lane splits the 32 + 32 values of an item
+// into three bf16 pieces in registers -- ~500 vector instructions against 48 bf16 MFMAs (1 536 cycles; the fp32 item: 64 MFMAs = 4 096
+// cycles): bound by the split, still ~1.4 x the fp32 kernel.  The contraction order of an MFMA is free as long as both operands
+// agree: k-block kb of lane half lh = positions 16 lh + 8 kb + (0 .. 7) -- the registers the fp32 path already holds.
+template <int MW, int NW, int WM, int WN, int PREC = 0>
 __global__ __launch_bounds__(256, 2) void conv2d_bwd_weight_shared_kernel(Bw2dGeom g, const float *__restrict__ x,
                                                                           const float *__restrict__ dy,
                                                                           float *__restrict__ part,
@@ -974,19 +978,23 @@ __global__ __launch_bounds__(256, 2) void conv2d_bwd_weight_shared_kernel(Bw2dGe
     // 8 (q % 4) + (l >> 3), 16-byte chunk (l & 7) ^ (l >> 3) of the row (the swizzle direct_read_lds undoes)
     extern __shared__ __attribute__((aligned(16))) float dma_buf[];
     const int dr = lane >> 3, dchunk = (lane & 7) ^ dr;
-    int doff[NI], ddh[NI];   // source offset (floats); B rows: dh - ph + 64, A rows: -1
+    // this lane's source offset of instruction r as an unsigned BYTE offset from (dy item base) resp. (x item base - BIAS floats):
+    // BIAS makes every B offset non-negative (a >= -4, dh - ph >= -ph); the kernel rows dh of the B instructions, a byte each
+    const int BIAS = g.ph * Wp + 8;
+    unsigned du[NI], dhpack[(NI + 3) / 4];
+#pragma unroll
+    for (int r = 0; r < (NI + 3) / 4; ++r) dhpack[r] = 0;
 #pragma unroll
     for (int r = 0; r < NI; ++r) {
         const int q = wave + 4 * r, blk = q >> 2, v = q & 3;
         if (blk < NBA) {
-            doff[r] = min(m_base + blk * 32 + 8 * v + dr, M - 1) * HWo + 4 * dchunk;
-            ddh[r] = -1;
+            du[r] = unsigned(min(m_base + blk * 32 + 8 * v + dr, M - 1) * HWo + 4 * dchunk) * 4u;
         } else {
             const int n = min(n_base + (blk - NBA) * 32 + 8 * v + dr, NK - 1);
             const int ci = n / KK, rem = n - ci * KK, dh = rem / g.kw, dwp = rem - dh * g.kw - g.pw;
             const int a = floordiv_bw(dwp, g.sw);
-            doff[r] = (dwp - a * g.sw) * plane + ci * HWi + (dh - g.ph) * Wp + a + 4 * dchunk;
-            ddh[r] = dh - g.ph + 64;
+            du[r] = unsigned((dwp - a * g.sw) * plane + ci * HWi + (dh - g.ph) * Wp + a + 4 * dchunk + BIAS) * 4u;
+            dhpack[r >> 2] |= unsigned(dh) << (8 * (r & 3));
         }
     }
     const float *zsrc = bw_zero_page + 4 * (lane & 7);
@@ -1009,10 +1017,6 @@ __global__ __launch_bounds__(256, 2) void conv2d_bwd_weight_shared_kernel(Bw2dGe
     // scalar base updates and NI (m0, global_load_lds saddr) pairs.  The general form below -- a select between the row and a page
     // of zeros per instruction, 64-bit lane addresses -- took ~250 mostly dependent instructions per item: measured 22 % of the
     // kernel (128 -> 128 3 x 3: 101 -> 129 TFLOP/s with the DMA issue removed).
-    const int BIAS = g.ph * Wp + 8;                      // makes every B offset non-negative (a >= -4, dh - ph >= -ph)
-    unsigned du[NI];
-#pragma unroll
-    for (int r = 0; r < NI; ++r) du[r] = unsigned(doff[r] + (r < NBA ? 0 : BIAS)) * 4u;
     auto dma_fast = [&](int b, int t, int fc, float *slot) {
         const char *dyb = reinterpret_cast<const char *>(dy + size_t(b) * M * HWo + t * g.Wout + fc * T);
         const char *xb = reinterpret_cast<const char *>(x + size_t(b) * g.Cin * HWi + t * g.sh * Wp + fc * T) - size_t(BIAS) * 4;
@@ -1023,20 +1027,20 @@ __global__ __launch_bounds__(256, 2) void conv2d_bwd_weight_shared_kernel(Bw2dGe
     };
     auto dma = [&](int b, int t, int fc, float *slot) {
         if (t * g.sh - g.ph >= 0 && t * g.sh + g.kh - 1 - g.ph < g.Hin) return dma_fast(b, t, fc, slot);
-        const float *dyb = dy + size_t(b) * M * HWo + t * g.Wout + fc * T;
-        const float *xb = x + size_t(b) * g.Cin * HWi + t * g.sh * Wp + fc * T;
+        // first / last rows of an image: B rows in the vertical padding come from a page of zeros (an address select per instruction)
+        const char *dyb = reinterpret_cast<const char *>(dy + size_t(b) * M * HWo + t * g.Wout + fc * T);
+        const char *xb = reinterpret_cast<const char *>(x + size_t(b) * g.Cin * HWi + t * g.sh * Wp + fc * T) - size_t(BIAS) * 4;
 #pragma unroll
         for (int r = 0; r < NI; ++r) {
-            const int q = wave + 4 * r;
-            const float *src;
-            if (ddh[r] < 0) {
-                src = dyb + doff[r];
+            const char *src;
+            if (r < NBA) {
+                src = dyb + du[r];
             } else {
-                const int rr = t * g.sh + ddh[r] - 64;
-                src = (rr >= 0 && rr < g.Hin) ? xb + doff[r] : zsrc;
+                const int rr = t * g.sh + int((dhpack[r >> 2] >> (8 * (r & 3))) & 255u) - g.ph;
+                src = (rr >= 0 && rr < g.Hin) ? xb + du[r] : reinterpret_cast<const char *>(zsrc);
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(slot + q * 256), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(slot + (wave + 4 * r) * 256), 16, 0, 0);
         }
     };
     // operands of this wave's fragments out of a slot: A blocks wm MW + i, B blocks NBA + wn NW + k
@@ -1086,7 +1090,41 @@ __global__ __launch_bounds__(256, 2) void conv2d_bwd_weight_shared_kernel(Bw2dGe
             }
         }
     };
-    auto compute = [&](const f32x4 (&A)[MW][4], const f32x4 (&Bv)[NW][4]) { direct_compute<MW, NW>(acc, bsum, A, Bv, do_bias); };
+    auto compute = [&](const f32x4 (&A)[MW][4], const f32x4 (&Bv)[NW][4]) {
+        if constexpr (PREC == 0) {
+            direct_compute<MW, NW>(acc, bsum, A, Bv, do_bias);
+        } else {
+            constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};   // mm hl lh hm mh hh (small terms first)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                bf16x8 a3[3][MW];
+#pragma unroll
+                for (int i = 0; i < MW; ++i) {
+                    const float xq[8] = {A[i][2 * kb][0], A[i][2 * kb][1], A[i][2 * kb][2], A[i][2 * kb][3],
+                                         A[i][2 * kb + 1][0], A[i][2 * kb + 1][1], A[i][2 * kb + 1][2], A[i][2 * kb + 1][3]};
+                    split3(xq, a3[0][i], a3[1][i], a3[2][i]);
+                }
+#pragma unroll
+                for (int k = 0; k < NW; ++k) {      // one column block's pieces at a time (12 live registers instead of 12 NW)
+                    bf16x8 b3[3];
+                    const float xq[8] = {Bv[k][2 * kb][0], Bv[k][2 * kb][1], Bv[k][2 * kb][2], Bv[k][2 * kb][3],
+                                         Bv[k][2 * kb + 1][0], Bv[k][2 * kb + 1][1], Bv[k][2 * kb + 1][2], Bv[k][2 * kb + 1][3]};
+                    split3(xq, b3[0], b3[1], b3[2]);
+#pragma unroll
+                    for (int t = 0; t < 6; ++t)
+#pragma unroll
+                        for (int i = 0; i < MW; ++i)
+                            acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[PA[t]][i], b3[PB[t]], acc[i][k], 0, 0, 0);
+                }
+            }
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < MW; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bsum[i] += (A[i][e][0] + A[i][e][1]) + (A[i][e][2] + A[i][e][3]);
+            }
+        }
+    };
 
     f32x4 A0[MW][4], B0[NW][4];
 #ifdef AGX_STAMPS
@@ -1473,8 +1511,11 @@ int agx_conv2d_bwd_weight(const agx_conv2d_desc *d, const float *x, const float 
             hipLaunchKernelGGL(kern, grid, dim3(256), size_t(2) * blocks * 4096, st, g, x, dy, part, dbias ? bias_part : nullptr);
             return AGX_OK;
         };
-        rc = (cfg == 10 && tuning().dw2_shared) ? launch_shared(conv2d_bwd_weight_shared_kernel<2, 2, 2, 2>, 8)
-           : (cfg == 15) ? launch_shared(conv2d_bwd_weight_shared_kernel<2, 1, 1, 4>, 6)
+        const bool bf = g.prec == 1 && tuning().dw2_bf;   // bf16x3 descriptors: the shared kernel's bf16x3 contraction
+        rc = (cfg == 10 && tuning().dw2_shared) ? (bf ? launch_shared(conv2d_bwd_weight_shared_kernel<2, 2, 2, 2, 1>, 8)
+                                                      : launch_shared(conv2d_bwd_weight_shared_kernel<2, 2, 2, 2>, 8))
+           : (cfg == 15) ? (bf ? launch_shared(conv2d_bwd_weight_shared_kernel<2, 1, 1, 4, 1>, 6)
+                               : launch_shared(conv2d_bwd_weight_shared_kernel<2, 1, 1, 4>, 6))
            : (cfg == 16) ? launch_shared(conv2d_bwd_weight_shared_kernel<1, 2, 1, 4>, 9)
            : cfg == 10 ? launch_direct(conv2d_bwd_weight_direct_kernel<2, 2, 2, 2>, 4)
            : cfg == 11 ? launch_direct(conv2d_bwd_weight_direct_kernel<2, 2, 1, 2>, 4)

@@ -219,7 +219,7 @@ class _SNConv(nn.Module):
 
 
 def set_arithmetic(module: nn.Module, mode: str = "fp32") -> nn.Module:
-    """Arithmetic of the STFT discriminators' Conv2d layers (forward and backward-data; the weight gradient stays fp32):
+    """Arithmetic of the STFT discriminators' Conv2d layers (forward, backward-data and the weight-gradient contraction):
     ``"bf16x3_ring"``: the 3 x 3 stride-1 "same" layers with Cin % 32 == 0 and 32 / 64 / a multiple of 128 output channels run on
     the bf16x3 ring kernel (csrc/conv_b3.hip: conv2d_b3_kernel, DESIGN 4.12: fp32-class accuracy, 1.3-1.5 x the fp32 ring) on
     feature maps wide enough for its tiles; every other layer / map keeps its fp32 kernel; ``"bf16x3"``: every Conv2d layer with a bf16x3 form (Cin % 16 == 0, Cout >= 32) -- the ring

@@ -126,6 +126,32 @@ def test_backward_data_of_strided_layers(shape, epi):
     assert float((dx.cpu().double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("shape", [(2, 128, 128, 24, 64, 3, 3, 1, 1), (2, 64, 64, 19, 96, 3, 3, 1, 1), (2, 64, 128, 22, 64, 4, 4, 2, 2),
+                                   (1, 128, 128, 17, 128, 3, 4, 1, 2), (2, 256, 256, 9, 32, 3, 3, 1, 1)])
+@pytest.mark.parametrize("knob", [1, 0])
+def test_weight_gradient_of_bf16x3_descriptors(shape, knob):
+    """The weight gradient of a bf16x3 descriptor: on the shared kernel both operands are split into three bf16 pieces in
+    registers (knob dw2_bf = 1, default) or contracted in fp32 (0); either way fp32-class against float64 autograd."""
+    bsz, cin, cout, h, w_, kh, kw, sh, sw = shape
+    g = torch.Generator().manual_seed(41)
+    pad = ((kh - 1) // 2, (kw - 1) // 2)
+    x = torch.randn(bsz, cin, h, w_, generator=g)
+    ho, wo = (h + 2 * pad[0] - kh) // sh + 1, (w_ + 2 * pad[1] - kw) // sw + 1
+    dy = torch.randn(bsz, cout, ho, wo, generator=g)
+    w0 = torch.zeros(cout, cin, kh, kw, dtype=torch.float64, requires_grad=True)
+    b0 = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    want_w, want_b = torch.autograd.grad(F.conv2d(x.double(), w0, b0, (sh, sw), pad), (w0, b0), dy.double())
+    d3 = ops.conv2d_desc(bsz, cin, cout, h, w_, kh, kw, (sh, sw), pad, impl=_lib.IMPL_MFMA_BF16X3)
+    lib = _lib.load()
+    lib.agx_set_tuning(b"dw2_bf", knob)
+    try:
+        dw, db = ops.conv2d_bwd_weight(d3, x.to(DEV), dy.to(DEV))
+    finally:
+        lib.agx_set_tuning(b"dw2_bf", 1)
+    assert float((dw.cpu().double() - want_w).abs().max()) <= 1e-5 * float(want_w.abs().max())
+    assert float((db.cpu().double() - want_b).abs().max()) <= 1e-5 * float(want_b.abs().max())
+
+
 def test_other_layers_keep_their_kernels():
     """The FORWARD of the strided layers and few-channel layers have no ring form, and maps that would leave the tiles mostly
     empty (4 columns; a ragged 33) are refused: a bf16x3 descriptor falls back to the kernels it had."""

@@ -17,7 +17,7 @@ vals = [int(v) for v in sys.argv[3:]] or [768, 512, 1024, 1536, 2048]
 for (cin, cout, kh, kw, sh, sw, h, w) in [(32, 32, 3, 3, 1, 1, 282, 1024), (64, 64, 3, 3, 1, 1, 282, 512), (128, 128, 3, 3, 1, 1, 141, 256), (64, 128, 4, 4, 2, 2, 282, 512), (256, 256, 3, 3, 1, 1, 70, 64)]:
     x = torch.randn(B, cin, h, w, device="cuda")
     pad = ((kh - 1) // 2, (kw - 1) // 2)
-    d = ops.conv2d_desc(B, cin, cout, h, w, kh, kw, (sh, sw), pad)
+    d = ops.conv2d_desc(B, cin, cout, h, w, kh, kw, (sh, sw), pad, impl=int(__import__('os').environ.get('AGX_DW_IMPL', '0')))
     ho = (h + 2 * pad[0] - kh) // sh + 1; wo = (w + 2 * pad[1] - kw) // sw + 1
     dy = torch.randn(B, cout, ho, wo, device="cuda")
     fl = 2.0 * dy.numel() * cin * kh * kw
