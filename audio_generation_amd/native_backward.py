@@ -44,7 +44,7 @@ class _Unit:
     """One conv or residual unit of a stack."""
 
     def __init__(self, kind: str, convs: Sequence[nn.Module], slope: Optional[float], inner_slope: Optional[float] = None):
-        self.kind = kind            # "conv" | "res" | "resdw" | "wavelet"
+        self.kind = kind            # "conv" | "res" | "resdw" | "wavelet" | "multires"
         self.convs = list(convs)    # [_ConvBase], [conv1, conv2] or [depthwise, conv1, conv2]
         self.slope = slope          # activation after the unit (None = linear output)
         self.inner_slope = inner_slope
@@ -52,6 +52,9 @@ class _Unit:
     def params(self) -> List[Tensor]:
         if self.kind == "wavelet":
             return self.convs[0].params()
+        if self.kind == "multires":
+            m = self.convs[0]
+            return [m.h0, m.h1, m.w]
         out = []
         for c in self.convs:
             cp = c.conv
@@ -91,8 +94,13 @@ def build_units(stack: nn.ModuleList) -> List[_Unit]:
             ok = add(m[1], None)
         elif isinstance(m, CausalEncoderBlock):
             ok = all(add(seq[0], seq[1]) for seq in m.layers)
+            if ok and hasattr(m, "multires"):      # build-defined placement: behind the strided conv (whose pair has no activation)
+                units.append(_Unit("multires", [m.multires], None))
         elif isinstance(m, CausalDecoderBlock):
-            ok = add(m.in_conv[0], m.in_conv[1]) and all(add(seq[0], seq[1]) for seq in m.layers)
+            ok = add(m.in_conv[0], m.in_conv[1])
+            if ok and hasattr(m, "multires"):
+                units.append(_Unit("multires", [m.multires], None))
+            ok = ok and all(add(seq[0], seq[1]) for seq in m.layers)
         else:
             ok = add(m, None)
         if not ok:
@@ -188,6 +196,12 @@ class _NativeStack(torch.autograd.Function):
             mask = x if prev_slope is not None else None
             if u.kind == "wavelet":
                 dz, grads[i] = u.convs[0].backward_native(x, dz, mask, prev_slope or 0.0)
+            elif u.kind == "multires":
+                if mask is not None:
+                    raise AgxError("a multires unit behind an activation has no fused mask (the blocks place it behind a linear conv)")
+                m = u.convs[0]
+                dz, dh0, dh1, dw = ops.multires_backward(x, dz, m.h0.detach(), m.h1.detach(), m.w.detach(), m.depth)
+                grads[i] = [dh0, dh1, dw]
             elif u.kind == "conv":
                 conv = u.convs[0]
                 grads[i] = _grads_of(conv, x, dz)

@@ -241,19 +241,26 @@ def _default_act():
 class CausalEncoderBlock(nn.Module):
     """networks/vae.py:119-148."""
 
-    def __init__(self, in_channels, out_channels, stride, n_layers=4, activation=None, depthwise=False):
+    def __init__(self, in_channels, out_channels, stride, n_layers=4, activation=None, depthwise=False, multires=None):
         super().__init__()
         activation = _default_act() if activation is None else activation
         layers = [nn.Sequential(CausalResidualBlock1d(in_channels, in_channels, dilation=3 ** i,
                                                       depthwise=depthwise), activation)
                   for i in range(n_layers - 1)]
+        # multires = (kernel_size, depth): BUILD-DEFINED placement of CausalMultiresConv1d (the reference imports it at vae.py:7
+        # and never wires it) -- right behind the strided conv, its GELU in place of the block's activation there
         layers.append(nn.Sequential(CausalConv1d(in_channels, out_channels, 2 * stride + 1, stride=stride),
-                                    activation))
+                                    nn.Identity() if multires else activation))
         self.layers = nn.ModuleList(layers)
+        if multires:
+            from .wavelets import CausalMultiresConv1d
+            self.multires = CausalMultiresConv1d(out_channels, multires[0], multires[1])
 
     def forward(self, x: Tensor) -> Tensor:
         for seq in self.layers:
             x = _run_fused_pair(seq[0], seq[1], x)
+        if hasattr(self, "multires"):
+            x = self.multires._hip(x)
         return x
 
 
@@ -261,7 +268,7 @@ class CausalDecoderBlock(nn.Module):
     """networks/vae.py:150-202."""
 
     def __init__(self, in_channels, out_channels, stride, n_layers=4, activation=None, depthwise=False,
-                 upsample=True, wavelet=False, wavelet_hidden_ratio=4, channelwise=True):
+                 upsample=True, wavelet=False, wavelet_hidden_ratio=4, channelwise=True, multires=None):
         super().__init__()
         activation = _default_act() if activation is None else activation
         self.wavelet = wavelet
@@ -276,7 +283,10 @@ class CausalDecoderBlock(nn.Module):
             conv_layer = CausalUpsampleConv1d(in_channels, out_channels, 2 * stride + 1, stride=stride)
         else:
             conv_layer = CausalConvT1d(in_channels, out_channels, 2 * stride + 1, stride=stride)
-        self.in_conv = nn.Sequential(conv_layer, activation)
+        self.in_conv = nn.Sequential(conv_layer, nn.Identity() if multires else activation)
+        if multires:   # build-defined placement, as in CausalEncoderBlock: behind the resampling layer, GELU instead of the activation
+            from .wavelets import CausalMultiresConv1d
+            self.multires = CausalMultiresConv1d(out_channels, multires[0], multires[1])
         self.layers = nn.ModuleList([
             nn.Sequential(CausalResidualBlock1d(out_channels, out_channels, dilation=3 ** i,
                                                 depthwise=depthwise), activation)
@@ -284,6 +294,8 @@ class CausalDecoderBlock(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         x = _run_fused_pair(self.in_conv[0], self.in_conv[1], x)
+        if hasattr(self, "multires"):
+            x = self.multires._hip(x)
         for seq in self.layers:
             x = _run_fused_pair(seq[0], seq[1], x)
         return x
@@ -296,6 +308,8 @@ def _run_unit_forward(unit, x: Tensor) -> Tensor:
         return res.run(x, unit.slope)
     if unit.kind == "wavelet":
         return unit.convs[0].run_fused(x, unit.slope)
+    if unit.kind == "multires":
+        return unit.convs[0]._hip(x)
     conv = unit.convs[0]
     return conv.run(x, EPI_LEAKY_PRE if unit.slope is not None else 0, unit.slope or 0.0)
 
@@ -319,7 +333,13 @@ class CausalVQAE(nn.Module):
                  num_quantizers=8, codebook_size=1024, codebook_dim=512, vq_cutoff_freq=1,
                  vq_type="ema", strides=(2, 3, 4, 4, 5), input_format="b l c", channel_multiplier=2,
                  norm=nn.Identity, depthwise=False, use_som=True, som_kernel_type="hard",
-                 wavelet_decoders=(False, True, False, False, False)):
+                 wavelet_decoders=(False, True, False, False, False),
+                 multires_encoders=False, multires_decoders=False, multires_kernel_size=2, multires_depth=3):
+        """The last four arguments are BUILD-DEFINED (default off: the reference's model): block i gets a
+        ``CausalMultiresConv1d(channels, multires_kernel_size, multires_depth)`` (wavelets.py:38-96 -- imported by the
+        reference at vae.py:7 and never wired) right behind its strided / upsampling conv, whose GELU takes the place of the block
+        activation there; lists are in encoder order resp. decoder order.  BASELINE config 4 ("multiresolution / wavelet layers in
+        encoder + decoder") at model level; oracle: oracle/codec.py CodecSpec."""
         super().__init__()
         from .quantizer import ResidualQuantizer
 
@@ -345,18 +365,22 @@ class CausalVQAE(nn.Module):
                                            vq_cutoff_freq=vq_cutoff_freq, use_som=use_som,
                                            som_kernel_type=som_kernel_type)
 
+        self.multires_encoders = list(tuple_checker(multires_encoders, n_blocks))
+        self.multires_decoders = list(tuple_checker(multires_decoders, n_blocks))
+        mr = (multires_kernel_size, multires_depth)
         ch = [first_block_channels * channel_multiplier ** i for i in range(n_blocks + 1)]
         encoders: List[nn.Module] = [nn.Sequential(norm(), CausalConv1d(in_channels, first_block_channels, 7))]
         for i in range(n_blocks):
             encoders.append(CausalEncoderBlock(ch[i], ch[i + 1], self.strides[i], n_layers_per_block,
-                                               depthwise=depthwise))
+                                               depthwise=depthwise, multires=mr if self.multires_encoders[i] else None))
         encoders.append(CausalConv1d(ch[-1], codebook_dim, 3))
 
         decoders: List[nn.Module] = [CausalConvT1d(codebook_dim, ch[-1], 7)]
         for i in range(n_blocks, 0, -1):
             decoders.append(CausalDecoderBlock(ch[i], ch[i - 1], self.strides[i - 1],
                                                n_layers=n_layers_per_block, depthwise=depthwise,
-                                               wavelet=self.wavelet_decoders[i - 1]))
+                                               wavelet=self.wavelet_decoders[i - 1],
+                                               multires=mr if self.multires_decoders[n_blocks - i] else None))
         decoders.append(CausalConv1d(first_block_channels, in_channels, 7))
 
         self.encoders = nn.ModuleList(encoders)

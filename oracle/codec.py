@@ -114,6 +114,12 @@ class CodecSpec:
     channel_multiplier: int = 2
     wavelet_decoders: Sequence[bool] = field(default_factory=lambda: [False, True, False, False, False])
     input_format: str = "b l c"
+    # BUILD-DEFINED (the reference imports CausalMultiresConv1d at vae.py:7 and never wires it): block i carries a multiresolution
+    # layer (wavelets.py:38-96) right behind its resampling conv, whose GELU takes the place of the block's LeakyReLU there
+    multires_encoders: Sequence[bool] = False
+    multires_decoders: Sequence[bool] = False
+    multires_kernel_size: int = 2
+    multires_depth: int = 3
 
     def __post_init__(self):
         if isinstance(self.strides, int):
@@ -122,6 +128,11 @@ class CodecSpec:
         if isinstance(self.wavelet_decoders, bool):
             self.wavelet_decoders = [self.wavelet_decoders] * self.n_blocks
         assert len(self.wavelet_decoders) == self.n_blocks
+        for name in ("multires_encoders", "multires_decoders"):
+            v = getattr(self, name)
+            if isinstance(v, bool):
+                setattr(self, name, [v] * self.n_blocks)
+            assert len(getattr(self, name)) == self.n_blocks
 
     @property
     def channel_sizes(self) -> List[int]:
@@ -162,7 +173,13 @@ def encoder_stages(x: Tensor, sd: Dict[str, Tensor], spec: CodecSpec) -> List[Te
         for j, d in enumerate(spec.dilations):
             x = leaky(residual_block(x, sd, f"{p}{j}.0.", d))
         w, b = conv_params(sd, f"{p}{len(spec.dilations)}.0.conv.")
-        x = leaky(causal_conv1d(x, w, b, stride=int(spec.strides[i])))
+        x = causal_conv1d(x, w, b, stride=int(spec.strides[i]))
+        if spec.multires_encoders[i]:      # build-defined placement (CodecSpec): multires + its GELU instead of the LeakyReLU
+            from . import wavelets as _wv
+            q = f"encoders.{i + 1}.multires."
+            x = _wv.multires_conv(x, sd[q + "h0"], sd[q + "h1"], sd[q + "w"], spec.multires_depth)
+        else:
+            x = leaky(x)
         outs.append(x)
     w, b = conv_params(sd, f"encoders.{spec.n_blocks + 1}.conv.")
     x = causal_conv1d(x, w, b)
@@ -187,7 +204,10 @@ def decoder_stages(z: Tensor, sd: Dict[str, Tensor], spec: CodecSpec) -> List[Te
         else:
             w, b = conv_params(sd, p + "in_conv.0.conv.")
             x = upsample_conv1d(x, w, b, stride)
-        x = leaky(x)
+        if spec.multires_decoders[n - 1]:  # build-defined placement (CodecSpec), decoder order
+            x = _wv.multires_conv(x, sd[p + "multires.h0"], sd[p + "multires.h1"], sd[p + "multires.w"], spec.multires_depth)
+        else:
+            x = leaky(x)
         for j, d in enumerate(spec.dilations):
             x = leaky(residual_block(x, sd, f"{p}layers.{j}.0.", d))
         outs.append(x)
@@ -252,6 +272,13 @@ def init_state_dict(spec: CodecSpec, seed: int = 0) -> Dict[str, Tensor]:
             sd[prefix + "weight"] = v
             sd[prefix + "bias"] = bias
 
+    def add_multires(prefix: str, channels: int):
+        # CausalMultiresConv1d.__init__ (wavelets.py:60-77): uniform(-1, 1) scaled by sqrt(2) / (2 k) resp. sqrt(2 / (2 depth + 4))
+        k, depth = spec.multires_kernel_size, spec.multires_depth
+        sd[prefix + "h0"] = (torch.rand(channels, 1, k, generator=gen) * 2 - 1) * (2.0 ** 0.5 / (2 * k))
+        sd[prefix + "h1"] = (torch.rand(channels, 1, k, generator=gen) * 2 - 1) * (2.0 ** 0.5 / (2 * k))
+        sd[prefix + "w"] = (torch.rand(channels, depth + 2, generator=gen) * 2 - 1) * (2.0 / (2 * depth + 4)) ** 0.5
+
     ch = spec.channel_sizes
     nd = len(spec.dilations)
     add_conv("encoders.0.1.conv.", ch[0], spec.in_channels, 7)
@@ -261,6 +288,8 @@ def init_state_dict(spec: CodecSpec, seed: int = 0) -> Dict[str, Tensor]:
             add_conv(f"{p}{j}.0.conv1.conv.", ch[i], ch[i], 7)
             add_conv(f"{p}{j}.0.conv2.conv.", ch[i], ch[i], 1)
         add_conv(f"{p}{nd}.0.conv.", ch[i + 1], ch[i], 2 * int(spec.strides[i]) + 1)
+        if spec.multires_encoders[i]:
+            add_multires(f"encoders.{i + 1}.multires.", ch[i + 1])
     add_conv(f"encoders.{spec.n_blocks + 1}.conv.", spec.codebook_dim, ch[-1], 3)
 
     add_conv("decoders.0.conv.", ch[-1], spec.codebook_dim, 7, transposed=True)
@@ -279,6 +308,8 @@ def init_state_dict(spec: CodecSpec, seed: int = 0) -> Dict[str, Tensor]:
             sd[p + "in_conv.0.wavelet_scale"] = torch.full((1, hidden, 1, 1), 40.0)
         else:
             add_conv(p + "in_conv.0.conv.", ch[i - 1], ch[i], 2 * stride + 1)
+        if spec.multires_decoders[n - 1]:
+            add_multires(p + "multires.", ch[i - 1])
         for j in range(nd):
             add_conv(f"{p}layers.{j}.0.conv1.conv.", ch[i - 1], ch[i - 1], 7)
             add_conv(f"{p}layers.{j}.0.conv2.conv.", ch[i - 1], ch[i - 1], 1)

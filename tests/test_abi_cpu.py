@@ -235,3 +235,39 @@ def test_ring_kernels_refuse_clips_beyond_their_32_bit_offsets(lib):
     assert ops.resblock_kernel_name(rb).startswith("resblock_p")
     rb = ops.conv_desc(_lib.CONV_CAUSAL, 1, 256, 256, 1 << 22, 7, 1, 1)                 # = 2^32: first fused kernel
     assert not ops.resblock_kernel_name(rb).startswith("resblock_p")
+
+
+def test_discriminator_arithmetic_modes_are_flags_only():
+    """set_arithmetic only marks the Conv2d layers (no kernel is chosen here: the library decides per feature map at call
+    time); unknown modes are refused.  discriminator.py:101-114 (STFT discriminator Conv2d stack)."""
+    import pytest
+    from audio_generation_amd import _lib, discriminator as ad
+    d = ad.STFTDiscriminator(win_length=256)
+    convs = [m for m in d.modules() if isinstance(m, ad._SNConv)]
+    assert convs and all(m.impl == _lib.IMPL_AUTO and not m.ring_only for m in convs)
+    ad.set_arithmetic(d, "bf16x3_ring")
+    assert all(m.impl == _lib.IMPL_MFMA_BF16X3 and m.ring_only for m in convs if m.nd == 2)
+    ad.set_arithmetic(d, "bf16x3")
+    assert all(m.impl == _lib.IMPL_MFMA_BF16X3 and not m.ring_only for m in convs if m.nd == 2)
+    ad.set_arithmetic(d, "fp32")
+    assert all(m.impl == _lib.IMPL_AUTO for m in convs)
+    with pytest.raises(ValueError):
+        ad.set_arithmetic(d, "fp16")
+
+
+def test_multires_placement_is_off_by_default_and_adds_only_its_own_keys():
+    """The build-defined multires placement (CausalVQAE docstring) leaves the reference's state dict untouched when off and adds
+    exactly ``{encoders,decoders}.<block>.multires.{h0,h1,w}`` when on; the oracle's init_state_dict names the same keys."""
+    from audio_generation_amd.vae import CausalVQAE
+    from oracle import codec
+    kw = dict(in_channels=1, n_blocks=2, strides=(2, 4), first_block_channels=4, codebook_dim=8, num_quantizers=1, codebook_size=16,
+              wavelet_decoders=False)
+    base = set(CausalVQAE(**kw).state_dict())
+    on = set(CausalVQAE(multires_encoders=[True, False], multires_decoders=True, multires_kernel_size=3, multires_depth=2, **kw).state_dict())
+    extra = on - base
+    assert base <= on
+    assert extra == {f"{a}.multires.{n}" for a in ("encoders.1", "decoders.1", "decoders.2") for n in ("h0", "h1", "w")}
+    spec = codec.CodecSpec(in_channels=1, n_blocks=2, strides=(2, 4), first_block_channels=4, codebook_dim=8, wavelet_decoders=False,
+                           multires_encoders=[True, False], multires_decoders=True, multires_kernel_size=3, multires_depth=2)
+    sd = codec.init_state_dict(spec)
+    assert extra <= set(sd) and sd["decoders.2.multires.w"].shape == (4, 4) and sd["encoders.1.multires.h0"].shape == (8, 1, 3)

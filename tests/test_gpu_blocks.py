@@ -175,6 +175,62 @@ def test_wavelet_vqae_config4_topology():
     assert rms(y.cpu(), want) < 1e-4
 
 
+def test_config4_multires_in_encoder_and_decoder_at_model_level():
+    """BASELINE config 4 as written: multiresolution layers in encoder AND decoder next to the reference-wired wavelet block,
+    48 kHz-style stereo.  The placement is build-defined (CausalVQAE docstring; oracle/codec.py CodecSpec restates it): forward
+    against the oracle stage by stage, then one native training backward against the oracle's autograd."""
+    torch.manual_seed(18)
+    kw = dict(in_channels=2, n_blocks=4, strides=(2, 4, 5, 8), num_quantizers=2, codebook_size=64, codebook_dim=512,
+              input_format="n c l", wavelet_decoders=[False, True, False, False],
+              multires_encoders=[True, False, True, False], multires_decoders=[False, False, True, True],
+              multires_kernel_size=3, multires_depth=4)
+    model = CausalVQAE(**kw).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    assert "encoders.1.multires.h0" in sd and "decoders.3.multires.w" in sd and "encoders.2.multires.h0" not in sd
+    spec = codec.CodecSpec(in_channels=2, n_blocks=4, strides=(2, 4, 5, 8), codebook_dim=512, input_format="n c l",
+                           wavelet_decoders=[False, True, False, False], multires_encoders=[True, False, True, False],
+                           multires_decoders=[False, False, True, True], multires_kernel_size=3, multires_depth=4)
+    x = 0.1 * torch.randn(1, 2, 6400)
+    stages = codec.encoder_stages(x, sd, spec)
+    z = stages[-1].transpose(1, 2).contiguous()
+    want = codec.decode_latents(z, sd, spec)
+    model = model.to(DEV)
+    with torch.no_grad():
+        h = x.to(DEV)
+        for i, enc in enumerate(model.encoders):
+            h = enc(h) if i else enc[1].run(h)
+            assert rms(h.cpu(), stages[i]) < 1e-5 * max(1.0, float(stages[i].abs().max())), i
+        y = model.decode(h)
+    assert rms(y.cpu(), want) < 1e-4
+    # training: gradients of sum(y * g) w.r.t. a multires filter, a conv weight next to it, and the input
+    small = dict(kw, first_block_channels=4, codebook_dim=16)
+    m2 = CausalVQAE(**small).train().to(DEV)
+    sd2 = {k: v.detach().cpu().clone() for k, v in m2.state_dict().items()}
+    spec2 = codec.CodecSpec(in_channels=2, n_blocks=4, strides=(2, 4, 5, 8), codebook_dim=16, first_block_channels=4,
+                            input_format="n c l", wavelet_decoders=[False, True, False, False],
+                            multires_encoders=[True, False, True, False], multires_decoders=[False, False, True, True],
+                            multires_kernel_size=3, multires_depth=4)
+    x2 = 0.1 * torch.randn(2, 2, 3200)
+    names = ["encoders.1.multires.h1", "encoders.3.multires.w", "decoders.3.multires.h0", "decoders.4.multires.w",
+             "encoders.1.layers.3.0.conv.weight_v", "decoders.3.in_conv.0.conv.weight_v"]
+    leaves = {k: sd2[k].clone().requires_grad_(True) for k in names}
+    sdl = dict(sd2, **leaves)
+    xl = x2.clone().requires_grad_(True)
+    zl = codec.encoder_stages(xl, sdl, spec2)[-1]
+    yl = codec.decoder_stages(zl, sdl, spec2)[-1]
+    gout = torch.randn_like(yl)
+    (yl * gout).sum().backward()
+    xg = x2.to(DEV).requires_grad_(True)
+    yg = m2._run_decoders(m2._run_encoders(xg))
+    assert yg.requires_grad and rms(yg.detach().cpu(), yl.detach()) < 1e-5
+    (yg * gout.to(DEV)).sum().backward()
+    params = dict(m2.named_parameters())
+    assert max_abs(xg.grad.cpu(), xl.grad) < 2e-3 * float(xl.grad.abs().max())
+    for k in names:
+        ref = leaves[k].grad
+        assert params[k].grad is not None and max_abs(params[k].grad.cpu(), ref) < 2e-3 * max(1e-6, float(ref.abs().max())), k
+
+
 def test_depthwise_residual_variant_matches_the_reference_goldens():
     """CausalResidualBlock1d / encoder / decoder blocks with depthwise=True (vae.py:103-105; golden G8): the
     per-channel k = 1 conv runs as a grouped AGX_CONV_PADDED layer in front of the dilated conv."""
