@@ -113,52 +113,6 @@ __global__ __launch_bounds__(256) void rvq_cmax_kernel(int k, int dim, float *__
     }
 }
 
-// ---------------------------------------------------------------- exact distance
-// The DEFINING arithmetic (oracle/rvq_exact.c): binary64, d ascending, one
-// subtract + one multiply + one add per term, never fused.
-#pragma clang fp contract(off)
-// Whole-wave evaluation, same arithmetic and SAME summation order: lane L owns the
-// contiguous dims [L*blk, (L+1)*blk) (coalesced codeword load), forms its squares,
-// and the running sum is handed from lane to lane in d order.  Returns the
-// distance in every lane.
-__device__ __forceinline__ double exact_dist_wave(const float *r_col /* LDS row of the frame */,
-                                               const float *__restrict__ c, int dim, int lane) {
-    constexpr int BLK_MAX = 8;  // dims per lane held in registers: D <= 512
-    const int blk = (dim + 63) >> 6;
-    const int d0 = lane * blk;
-    if (blk > BLK_MAX) {  // wider frames (wave-uniform): plain sequential evaluation, every lane redundantly
-        double acc = 0.0;
-        for (int d = 0; d < dim; ++d) {
-            const double diff = double(r_col[d]) - double(c[d]);
-            const double sq = diff * diff;
-            acc = acc + sq;
-        }
-        return acc;
-    }
-    // all lanes form their squares in parallel (loads issued together, no dependence on the chain) ...
-    double sq[BLK_MAX];
-#pragma unroll
-    for (int j = 0; j < BLK_MAX; ++j) {
-        const int d = d0 + j;
-        const bool ok = j < blk && d < dim;
-        const double diff = double(ok ? r_col[d] : 0.f) - double(ok ? c[d] : 0.f);
-        sq[j] = diff * diff;
-    }
-    // ... then the running sum walks the lanes in d order: acc = (..((0 + sq_0) + sq_1) + ..)
-    double acc = 0.0;
-    for (int owner = 0; owner * blk < dim; ++owner) {  // wave-uniform bounds
-        const double carry = owner == 0 ? 0.0 : __shfl(acc, owner - 1);
-        if (lane == owner) {
-            acc = carry;
-#pragma unroll
-            for (int j = 0; j < BLK_MAX; ++j)
-                if (j < blk && d0 + j < dim) acc = acc + sq[j];
-        }
-    }
-    return __shfl(acc, (dim - 1) / blk);
-}
-#pragma clang fp contract(fast)
-
 // ------------------------------------------------------------------------ forward
 struct RvqArgs {
     const float *x;
@@ -235,6 +189,8 @@ __device__ __forceinline__ float rvq_wave_sum(float v) {
     return (r0 + r1) + (r2 + r3);
 }
 
+// ---------------------------------------------------------------- exact distance
+// The DEFINING arithmetic (oracle/rvq_exact.c): binary64, d ascending, one subtract + one multiply + one add per term, never fused.
 #pragma clang fp contract(off)
 // squares of one (frame, codeword) pair in the DEFINING arithmetic (binary64, never fused), all lanes in parallel: lane L forms
 // dims 8 L .. 8 L + 7 (+ 512 per round) and leaves them in sq[d]; dims >= D give +0.0.
@@ -283,6 +239,38 @@ __device__ __forceinline__ double rvq_chain_sum(const double *__restrict__ sq, i
         }
     }
     for (; d < D; ++d) acc = acc + sq[d];
+    return acc;
+}
+// The full defining search of one frame (candidate overflow), ONE codeword per lane: every lane walks its codeword's row in d
+// order -- the defining arithmetic and its summation order per codeword, 64 codewords side by side (the wave-wide evaluation above
+// hands the running sum from lane to lane: 21 k cycles per distance, 1.5 ms per overflowing frame at K = 1024).  Returns this
+// lane's distance; the caller takes the minimum (lowest index on ties).
+__device__ __forceinline__ double rvq_dist_lane(const float *__restrict__ r_row /* LDS, the same for all lanes */,
+                                                const float *__restrict__ c /* this lane's codeword */, int D) {
+    double acc = 0.0;
+    int d = 0;
+    if ((D & 3) == 0) {
+        for (; d + 16 <= D; d += 16) {
+            f32x4 cv[4], rv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cv[j] = *reinterpret_cast<const f32x4 *>(c + d + 4 * j);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rv[j] = *reinterpret_cast<const f32x4 *>(r_row + d + 4 * j);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double diff = double(rv[j][e]) - double(cv[j][e]);
+                    const double sq = diff * diff;
+                    acc = acc + sq;
+                }
+        }
+    }
+    for (; d < D; ++d) {
+        const double diff = double(r_row[d]) - double(c[d]);
+        const double sq = diff * diff;
+        acc = acc + sq;
+    }
     return acc;
 }
 #pragma clang fp contract(fast)
@@ -703,11 +691,20 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
             if (state[f] != 2) continue;  // uniform across the block (LDS value)
             double bd = INFINITY;
             int bc = 0x7fffffff;
-            for (int code = wave; code < Kq; code += NWV) {  // every lane of the wave gets the same distance
-                const double dc = exact_dist_wave(R + f * RSF, cbq + size_t(code) * D, D, lane);
-                if (dc < bd || (dc == bd && code < bc)) {
+            for (int base = wave * 64; base < Kq; base += NWV * 64) {      // a codeword per lane (rvq_dist_lane)
+                const int code = base + lane;
+                const double dc = rvq_dist_lane(R + f * RSF, cbq + size_t(min(code, Kq - 1)) * D, D);
+                if (code < Kq && (dc < bd || (dc == bd && code < bc))) {
                     bd = dc;
                     bc = code;
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) {                        // the wave's minimum, lowest index on ties
+                const double od = __shfl_xor(bd, off);
+                const int oc = __shfl_xor(bc, off);
+                if (od < bd || (od == bd && oc < bc)) {
+                    bd = od;
+                    bc = oc;
                 }
             }
             __syncthreads();  // cdist / ccode row 0 are free to reuse as exchange

@@ -4,6 +4,7 @@
   C3  Soundstream default + attention bottleneck  Transformer(512, depth 1, 8 heads x 64, context 225)
       in place of the RVQ, batch 32 x 72 000 samples
   C4  wavelet decoder (reference wiring [F,T,F,F]), stereo, batch 8 x 144 000 samples (3 s @ 48 kHz)
+  C4m the same + a multiresolution layer in every encoder and decoder block (build-defined placement)
 
 Prints one JSON line per config: throughput (hipGraph replay), per-kernel table from HIP events,
 and parity of one clip against the CPU oracle.   usage: config_bench.py [C3|C4|all]"""
@@ -44,19 +45,21 @@ def run(name):
                                wavelet_decoders=False, input_format="n c l")
     else:
         wd = [False, True, False, False]
+        # C4m: the same + the build-defined multires placement in every encoder and decoder block (CausalVQAE docstring)
+        mr = dict(multires_encoders=True, multires_decoders=True, multires_kernel_size=2, multires_depth=3) if name == "C4m" else {}
         kw = dict(in_channels=2, n_blocks=4, strides=(2, 4, 5, 8), num_quantizers=8, codebook_size=1024,
-                  codebook_dim=512, input_format="n c l", wavelet_decoders=wd)
+                  codebook_dim=512, input_format="n c l", wavelet_decoders=wd, **mr)
         b, c, length = 8, 2, 144000
         model = CausalVQAE(**kw)
         spec = codec.CodecSpec(in_channels=2, n_blocks=4, strides=(2, 4, 5, 8), codebook_dim=512,
-                               wavelet_decoders=wd, input_format="n c l")
+                               wavelet_decoders=wd, input_format="n c l", **mr)
     model = model.eval()
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     gen = torch.Generator().manual_seed(1234)
     x_cpu = (0.1 * torch.randn(b, c, length, generator=gen)).clamp(-1, 1)
     model = model.to(DEV)
     x = x_cpu.to(DEV)
-    if name == "C4":
+    if name in ("C4", "C4m"):
         with torch.no_grad():
             model.quantizer.init_from_latents(model._run_encoders(x[:4]))
         sd["quantizer.codebooks"] = model.quantizer.codebooks.detach().cpu().clone()
@@ -113,5 +116,5 @@ def run(name):
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
-    for n in (("C3", "C3bf16", "C4") if which == "all" else (which,)):
+    for n in (("C3", "C3bf16", "C4", "C4m") if which == "all" else (which,)):
         run(n)

@@ -2,7 +2,7 @@
 """Diagnostic: where one residual stage of rvq_forward spends its cycles (agx_rvq_debug_stamps), on the bench's workload
 (config S, batch 32 x 72 000, `latents` codebooks).  Thread 0 of every workgroup stamps s_memtime at the phase boundaries of
 ONE stage; printed: median [p10 .. p90] over the workgroups, per phase, for every stage in turn.
-usage: rvq_stamps.py [batch] [stage ...]"""
+usage: rvq_stamps.py [batch | C4] [stage ...]     (C4: BASELINE config 4 -- stereo, 8 x 144 000 samples, wavelet decoder)"""
 import os
 import sys
 
@@ -21,13 +21,23 @@ PHASES = [("score GEMM, pass 0", 2, 3), ("bounds + min exchange, pass 0", 3, 4),
 
 
 def main():
-    batch = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    c4 = len(sys.argv) > 1 and sys.argv[1] == "C4"
+    batch = 8 if c4 else (int(sys.argv[1]) if len(sys.argv) > 1 else 32)
     stages = [int(a) for a in sys.argv[2:]] or list(range(8))
     dev = torch.device("cuda", 0)
-    model = bench.build_model(dev)
     gen = torch.Generator().manual_seed(1234)
-    x = (0.1 * torch.randn(batch, 1, 72000, generator=gen)).clamp(-1, 1).to(dev)
-    bench.calibrate_codebooks(model, x[:4], "latents")
+    if c4:
+        from audio_generation_amd.vae import CausalVQAE
+        torch.manual_seed(0)
+        model = CausalVQAE(in_channels=2, n_blocks=4, strides=(2, 4, 5, 8), num_quantizers=8, codebook_size=1024, codebook_dim=512,
+                           input_format="n c l", wavelet_decoders=[False, True, False, False]).eval().to(dev)
+        x = (0.1 * torch.randn(batch, 2, 144000, generator=gen)).clamp(-1, 1).to(dev)
+        with torch.no_grad():
+            model.quantizer.init_from_latents(model._run_encoders(x[:4]))
+    else:
+        model = bench.build_model(dev)
+        x = (0.1 * torch.randn(batch, 1, 72000, generator=gen)).clamp(-1, 1).to(dev)
+        bench.calibrate_codebooks(model, x[:4], "latents")
     lib = _lib.load()
     with torch.no_grad():
         z = model._run_encoders(x)
@@ -53,6 +63,10 @@ def main():
             t = buf.cpu().numpy().reshape(n_wg, 16)
             print(f"== stage {q}: whole kernel {np.median(t[:, 15] - t[:, 0]):.0f} ticks, stage loop {np.median(t[:, 1] - t[:, 0]):.0f}; "
                   f"pairs sent to the binary64 distance: median {np.median(t[:, 14]):.0f}, p90 {np.percentile(t[:, 14], 90):.0f}, max {t[:, 14].max()}")
+            tot = (t[:, 15] - t[:, 0]).astype(np.float64)
+            ovf = (t[:, 12] - t[:, 11]).astype(np.float64)
+            print(f"   slowest workgroup: whole kernel {tot.max():.0f} ticks (p99 {np.percentile(tot, 99):.0f}); workgroups whose stage-{q} "
+                  f"overflow search ran: {int((ovf > 2000).sum())} (longest {ovf.max():.0f} ticks)")
             for name, a, b in PHASES:
                 d = (t[:, b] - t[:, a]).astype(np.float64)
                 d = d[(t[:, a] > 0) & (t[:, b] > 0)]
