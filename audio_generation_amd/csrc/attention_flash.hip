@@ -213,8 +213,12 @@ __global__ __launch_bounds__(256) void attention_flash_kernel(const float *__res
 // (PV slot e of lane half lh = key 16 hb + 4 lh + (e & 3) + 8 (e >> 2): the probability registers are the B operand as
 // they stand).  No barrier inside the key loop.  Same arithmetic as PREC 1 above (operands rounded to bf16, fp32
 // accumulation and softmax).  Used when 2 * Tp * DH * 2 bytes fit the LDS (Tp = T rounded up to 64).
+// (Round 3, second pass: 8 waves = 256 queries per workgroup -- ONE workgroup stages the K / V of a (head, item) with T <= 256
+// instead of two; the staging loads are issued 32 per thread at a time on clamped addresses and masked afterwards: the
+// `cond ? load : 0` form made every load wait for its predecessor, 17 serial round trips of ~1.5 us out of 62 us.)
+constexpr int ABL_NT = 512;
 template <int DVT>
-__global__ __launch_bounds__(256) void attention_bf16_lds_kernel(const float *__restrict__ qkv, const float *__restrict__ slopes,
+__global__ __launch_bounds__(ABL_NT) void attention_bf16_lds_kernel(const float *__restrict__ qkv, const float *__restrict__ slopes,
                                                                  float *__restrict__ out, int H, int Dh, int T, int Tp,
                                                                  float scale_div) {
     constexpr int KB = 64, DH = 32 * DVT;
@@ -228,42 +232,72 @@ __global__ __launch_bounds__(256) void attention_bf16_lds_kernel(const float *__
     const float *qb = qkv + (size_t(b) * 3 * HD + size_t(h) * Dh) * T;
     const float *kb = qb + size_t(HD) * T;
     const float *vb = kb + size_t(HD) * T;
-    // ---- stage K: task = (key j, group of 8 head dims) ----
-    for (int u = tid; u < Tp * (DH / 8); u += 256) {
-        const int j = u % Tp, g8 = u / Tp;            // consecutive threads = consecutive keys: coalesced
-        af_bf16x8 v;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int d = 8 * g8 + e;
-            v[e] = (__bf16)((d < Dh && j < T) ? kb[size_t(d) * T + j] : 0.f);
-        }
-        *reinterpret_cast<af_bf16x8 *>(Ks + (size_t(g8) * Tp + j) * 16) = v;      // g8 = 2 (d / 16) + lane half
-    }
-    // ---- stage V: task = (dv, 16-key half block hbk, lane half): keys 16 hbk + 4 lh + {0..3, 8..11} ----
-    for (int u = tid; u < DH * (Tp / 8); u += 256) {
-        const int g = u % (Tp / 8), dv = u / (Tp / 8);   // consecutive threads walk along the keys of one row
-        const int hbk = g >> 1, vlh = g & 1;
-        af_bf16x8 v;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int j = 16 * hbk + 4 * vlh + (e & 3) + 8 * (e >> 2);
-            v[e] = (__bf16)((dv < Dh && j < T) ? vb[size_t(dv) * T + j] : 0.f);
-        }
-        *reinterpret_cast<af_bf16x8 *>(Vs + ((size_t(hbk) * 2 + vlh) * DH + dv) * 16) = v;
-    }
-    const int i = blockIdx.x * 128 + wave * 32 + li;   // this lane's query
+    // this lane's query operands are requested first, then K and V together: four K tasks + four V tasks = 64 loads in flight per
+    // thread on top of the 8 DH / 16 query loads -- at T <= 256 and head_dim 64 the whole staging is ONE round trip
+    const int i = blockIdx.x * (ABL_NT / 2) + wave * 32 + li;   // this lane's query
     const int ic = min(i, T - 1);
     const float slope = slopes[h], inv_scale = 1.f / scale_div;
+    float qf[DH / 16][8];
+#pragma unroll
+    for (int kq = 0; kq < DH / 16; ++kq)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[kq][e] = qb[size_t(min(16 * kq + 8 * lh + e, Dh - 1)) * T + ic];
+    // K task = (key j, group of 8 head dims); V task = (dv, 16-key half block hbk, lane half): keys 16 hbk + 4 lh + {0..3, 8..11}
+    const int nk = Tp * (DH / 8), nv = DH * (Tp / 8);       // (equal)
+    for (int u0 = tid; u0 < nk; u0 += ABL_NT * 4) {
+        float kk[4][8], vv[4][8];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int u = min(u0 + ABL_NT * it, nk - 1);
+            const int j = u % Tp, g8 = u / Tp;        // consecutive threads = consecutive keys: coalesced
+#pragma unroll
+            for (int e = 0; e < 8; ++e) kk[it][e] = kb[size_t(min(8 * g8 + e, Dh - 1)) * T + min(j, T - 1)];
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int u = min(u0 + ABL_NT * it, nv - 1);
+            const int g = u % (Tp / 8), dv = u / (Tp / 8);   // consecutive threads walk along the keys of one row
+            const int hbk = g >> 1, vlh = g & 1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int j = 16 * hbk + 4 * vlh + (e & 3) + 8 * (e >> 2);
+                vv[it][e] = vb[size_t(min(dv, Dh - 1)) * T + min(j, T - 1)];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int u = u0 + ABL_NT * it;
+            if (u < nk) {
+                const int j = u % Tp, g8 = u / Tp;
+                af_bf16x8 v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (__bf16)((8 * g8 + e < Dh && j < T) ? kk[it][e] : 0.f);
+                *reinterpret_cast<af_bf16x8 *>(Ks + (size_t(g8) * Tp + j) * 16) = v;      // g8 = 2 (d / 16) + lane half
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int u = u0 + ABL_NT * it;
+            if (u < nv) {
+                const int g = u % (Tp / 8), dv = u / (Tp / 8);
+                const int hbk = g >> 1, vlh = g & 1;
+                af_bf16x8 v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int j = 16 * hbk + 4 * vlh + (e & 3) + 8 * (e >> 2);
+                    v[e] = (__bf16)((dv < Dh && j < T) ? vv[it][e] : 0.f);
+                }
+                *reinterpret_cast<af_bf16x8 *>(Vs + ((size_t(hbk) * 2 + vlh) * DH + dv) * 16) = v;
+            }
+        }
+    }
     af_bf16x8 qh[DH / 16];
 #pragma unroll
     for (int kq = 0; kq < DH / 16; ++kq)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int d = 16 * kq + 8 * lh + e;
-            qh[kq][e] = (__bf16)(d < Dh ? qb[size_t(d) * T + ic] : 0.f);
-        }
+        for (int e = 0; e < 8; ++e) qh[kq][e] = (__bf16)(16 * kq + 8 * lh + e < Dh ? qf[kq][e] : 0.f);
     __syncthreads();
-    if (blockIdx.x * 128 + wave * 32 >= T) return;     // (after the barrier) a wave without queries
+    if (blockIdx.x * (ABL_NT / 2) + wave * 32 >= T) return;     // (after the barrier) a wave without queries
 
     f32x16 o[DVT];
 #pragma unroll
@@ -355,7 +389,7 @@ static int launch_bf16_lds(const float *qkv, const float *slopes, float *out, in
         if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(ceil_div(T, 128), H, B), dim3(256), lds, st, qkv, slopes, out, H, Dh, T, Tp, scale_div);
+    hipLaunchKernelGGL(kern, dim3(ceil_div(T, ABL_NT / 2), H, B), dim3(ABL_NT), lds, st, qkv, slopes, out, H, Dh, T, Tp, scale_div);
     return check_launch("attention_bf16_lds");
 }
 
