@@ -26,6 +26,7 @@ struct Tuning {
                         // 1 the same with MFMA / VALU interleave hints, 2 split before the MFMAs
     int dw2_shared = 2; // conv2d weight gradient: workgroup-shared operand slots + one barrier per item for 1 = the 128-row tiles, 2 = also the
                         // 64- / 32-row tiles (64 -> 64 3 x 3: 81 -> 90 TFLOP/s since the DMA issue is cheap), 0 = wave-private buffers
+    int dw2_prepad = 1; // conv2d weight gradient of maps narrower than 32 columns: 1 = the shared kernel on zero-padded flattened copies, 0 = staged kernel
     int dw2_bf = 1;     // conv2d weight gradient of bf16x3 descriptors on the shared kernel: 1 = bf16x3 contraction, 0 = fp32 (exact)
     int dw2_direct = 2; // conv2d weight gradient on the barrier-free LDS-DMA kernel: 1 = stride-1 "same" layers, 2 = also the column-strided
                         // layers (x read through its column-phase planes), 0 = the staged kernel everywhere

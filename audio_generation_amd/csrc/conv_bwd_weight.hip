@@ -557,6 +557,15 @@ struct Bw2dGeom {
     int prec;   // 1: bf16x3 contraction (AGX_IMPL_MFMA_BF16X3)
     int Wp;     // direct kernel: width of a column-phase plane of x (= Win when sw == 1)
     int xcd;    // 1: XCD-aware block order (xcd_block_id)
+    // narrow feature maps (Wout < 32) on the shared kernel: x and dy are first copied into ZERO-PADDED, phase-split planes whose
+    // flattened rows make every item 32 consecutive positions again (prepad_x_kernel / prepad_dy_kernel below):
+    //   XP[rho_h sw + rho_w][b, ci][rr Wp + cc] = x[b, ci, sh (rr + amin) + rho_h, sw (cc + bmin) + rho_w]   (0 outside the image)
+    //   DYP[b, co][t Wp + cc]                  = dy[b, co, t, cc]  (0 for cc >= Wout and behind the last row, up to pp_lpr)
+    // with dh - ph = sh ah + rho_h, dw - pw = sw aw + rho_w, amin / bmin the smallest ah / aw, Wp = Wout + (bmax - bmin): the
+    // window of B row (ci, dh, dw) is XP[phase][ci] shifted by (ah - amin) Wp + (aw - bmin) -- no masks, no padding rows, no edges.
+    int prepad;          // 1: the kernel reads such planes (one "row" of pp_lpr positions per image)
+    int pp_lpr, pp_hwi;  // positions per DYP plane (a multiple of 32) / floats per XP plane
+    int pp_amin, pp_bmin;
 };
 
 template <int MW, int NW, int WM, int WN, int PREC = 0>   // PREC 1: bf16x3 contraction (mfma_tile.hpp), both operands split in registers
@@ -956,7 +965,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_bwd_weight_shared_kernel(Bw2dGe
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const int KK = g.kh * g.kw, NK = g.Cin * KK, M = g.Cout;
-    const int Wp = g.Wp, HWo = g.Hout * g.Wout, HWi = g.Hin * Wp, FC = g.Wout / T;
+    const bool pp = g.prepad != 0;
+    const int Wp = g.Wp, HWo = pp ? g.pp_lpr : g.Hout * g.Wout, HWi = pp ? g.pp_hwi : g.Hin * Wp, FC = (pp ? g.pp_lpr : g.Wout) / T;
+    const int Hk = pp ? 1 : g.Hout;                 // item rows per image (prepadded planes: one flattened row)
     const int plane = g.B * g.Cin * HWi;
     const BlockId bid = xcd_block_id(g.xcd != 0);
     const int n_base = bid.x * BN, m_base = bid.y * BM;
@@ -993,7 +1004,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_bwd_weight_shared_kernel(Bw2dGe
             const int n = min(n_base + (blk - NBA) * 32 + 8 * v + dr, NK - 1);
             const int ci = n / KK, rem = n - ci * KK, dh = rem / g.kw, dwp = rem - dh * g.kw - g.pw;
             const int a = floordiv_bw(dwp, g.sw);
-            du[r] = unsigned((dwp - a * g.sw) * plane + ci * HWi + (dh - g.ph) * Wp + a + 4 * dchunk + BIAS) * 4u;
+            if (pp) {      // phase plane (row phase, column phase) + the tap's shift inside the padded plane
+                const int ah = floordiv_bw(dh - g.ph, g.sh), rh = (dh - g.ph) - ah * g.sh;
+                du[r] = unsigned((rh * g.sw + (dwp - a * g.sw)) * plane + ci * HWi + (ah - g.pp_amin) * Wp + (a - g.pp_bmin) +
+                                 4 * dchunk + BIAS) * 4u;
+            } else {
+                du[r] = unsigned((dwp - a * g.sw) * plane + ci * HWi + (dh - g.ph) * Wp + a + 4 * dchunk + BIAS) * 4u;
+            }
             dhpack[r >> 2] |= unsigned(dh) << (8 * (r & 3));
         }
     }
@@ -1011,7 +1028,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_bwd_weight_shared_kernel(Bw2dGe
     for (int i = 0; i < MW; ++i) bsum[i] = 0.f;
     const bool do_bias = bias_part != nullptr && bid.x == 0 && wn == 0;
 
-    const int rows = g.B * g.Hout, items = rows * FC;
+    const int rows = g.B * Hk, items = rows * FC;
     // Fast path (every item whose kh input rows are all inside the image -- all but the first / last rows of an image): the
     // instruction's address is a wave-uniform base (SGPR pair) + this lane's precomputed unsigned 32-bit offset, so an item costs two
     // scalar base updates and NI (m0, global_load_lds saddr) pairs.  The general form below -- a select between the row and a page
@@ -1026,7 +1043,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_bwd_weight_shared_kernel(Bw2dGe
                                              (__attribute__((address_space(3))) void *)(slot + (wave + 4 * r) * 256), 16, 0, 0);
     };
     auto dma = [&](int b, int t, int fc, float *slot) {
-        if (t * g.sh - g.ph >= 0 && t * g.sh + g.kh - 1 - g.ph < g.Hin) return dma_fast(b, t, fc, slot);
+        if (pp || (t * g.sh - g.ph >= 0 && t * g.sh + g.kh - 1 - g.ph < g.Hin)) return dma_fast(b, t, fc, slot);
         // first / last rows of an image: B rows in the vertical padding come from a page of zeros (an address select per instruction)
         const char *dyb = reinterpret_cast<const char *>(dy + size_t(b) * M * HWo + t * g.Wout + fc * T);
         const char *xb = reinterpret_cast<const char *>(x + size_t(b) * g.Cin * HWi + t * g.sh * Wp + fc * T) - size_t(BIAS) * 4;
@@ -1133,7 +1150,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_bwd_weight_shared_kernel(Bw2dGe
     const int per = (items + n_slices - 1) / n_slices;
     int item = slice * per;
     const int end = min(items, item + per);
-    const int head_rows = min(g.ph + 1, rows), tail_row0 = max(rows - (g.kh - g.ph), 0);
+    // (prepadded planes are surrounded by zeros and a guard: no row is unsafe)
+    const int head_rows = pp ? 0 : min(g.ph + 1, rows), tail_row0 = pp ? rows : max(rows - (g.kh - g.ph), 0);
     while (item < end) {   // (every branch below is workgroup-uniform)
         const int row = item / FC, fc = item - row * FC;
         const bool head = row < head_rows, tail = row >= tail_row0;
@@ -1147,7 +1165,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_bwd_weight_shared_kernel(Bw2dGe
             continue;
         }
         // (b, t, fc) of the item being multiplied and of the one being fetched, advanced without divisions
-        int cb = row / g.Hout, ct = row - cb * g.Hout, cfc = fc;
+        int cb = row / Hk, ct = row - cb * Hk, cfc = fc;
         dma(cb, ct, cfc, dma_buf);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                   // item 0 of the run is complete in slot 0
@@ -1158,13 +1176,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_bwd_weight_shared_kernel(Bw2dGe
             if (n + 1 < run) {                                 // (the last iteration fetches its own item again: harmless)
                 if (++cfc == FC) {
                     cfc = 0;
-                    if (++ct == g.Hout) ct = 0, ++cb;
+                    if (++ct == Hk) ct = 0, ++cb;
                 }
             }
             read_slot(cur, A0, B0);
             dma(cb, ct, cfc, nxt);                             // the other slot: everyone left it at the last barrier
             DW_STAMP(0);
-            if (fcn == 0 || fcn == FC - 1) mask_cols(B0, fcn);
+            if (!pp && (fcn == 0 || fcn == FC - 1)) mask_cols(B0, fcn);
             compute(A0, B0);
             DW_STAMP(1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the next item has landed
@@ -1218,6 +1236,30 @@ __global__ __launch_bounds__(256) void bwd2d_spectral_kernel(float *__restrict__
     }
 }
 
+// Zero-padded, phase-split copies for narrow feature maps (Bw2dGeom::prepad): one thread per element of the copy.
+__global__ __launch_bounds__(256) void prepad_x_kernel(const float *__restrict__ x, float *__restrict__ xp, int64_t nplanes, int Hin,
+                                                       int Win, int Hp, int Wp, int hwi, int sh, int sw, int amin, int bmin) {
+    const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t per_phase = nplanes * hwi;
+    if (e >= per_phase * sh * sw) return;
+    const int phase = int(e / per_phase);
+    const int64_t rem = e - phase * per_phase;
+    const int64_t pl = rem / hwi;
+    const int idx = int(rem - pl * hwi), rr = idx / Wp, cc = idx - rr * Wp;
+    const int r = sh * (rr + amin) + phase / sw, c = sw * (cc + bmin) + phase % sw;
+    const float v = x[(pl * Hin + min(max(r, 0), Hin - 1)) * Win + min(max(c, 0), Win - 1)];
+    xp[e] = (rr < Hp && r >= 0 && r < Hin && c >= 0 && c < Win) ? v : 0.f;
+}
+__global__ __launch_bounds__(256) void prepad_dy_kernel(const float *__restrict__ dy, float *__restrict__ dyp, int64_t nplanes, int Hout,
+                                                        int Wout, int Wp, int lpr) {
+    const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (e >= nplanes * lpr) return;
+    const int64_t pl = e / lpr;
+    const int idx = int(e - pl * lpr), t = idx / Wp, cc = idx - t * Wp;
+    const float v = dy[(pl * Hout + min(t, Hout - 1)) * Wout + min(cc, Wout - 1)];
+    dyp[e] = (t < Hout && cc < Wout) ? v : 0.f;
+}
+
 static int bw2d_geometry(const agx_conv2d_desc *d, Bw2dGeom *g, int *cfg, int *bm, dim3 *grid, size_t *lds) {
     ConvPlan f;
     int rc = lower_conv2d(d, &f);
@@ -1235,6 +1277,7 @@ static int bw2d_geometry(const agx_conv2d_desc *d, Bw2dGeom *g, int *cfg, int *b
     g->n_chan = 127 / KK + 2;
     g->prec = d->impl == AGX_IMPL_MFMA_BF16X3 ? 1 : 0;
     g->xcd = tuning().dw_xcd;
+    g->prepad = 0; g->pp_lpr = 0; g->pp_hwi = 0; g->pp_amin = 0; g->pp_bmin = 0;
     *cfg = g->Cout >= 128 ? 0 : (g->Cout >= 64 ? 1 : 2);
     *bm = *cfg == 0 ? 128 : (*cfg == 1 ? 64 : 32);
     const int nt = ceil_div(g->Cin * KK, 128), mt = ceil_div(g->Cout, *bm);
@@ -1280,6 +1323,33 @@ static int bw2d_geometry(const agx_conv2d_desc *d, Bw2dGeom *g, int *cfg, int *b
         *bm = dbm;
         *grid = dim3(dnt, dmt, g->n_slices);
         *lds = 0;
+    } else if (tuning().dw2_prepad && tuning().dw2_shared && g->Wout < 32 && g->Wout >= 4 && g->Cout >= 64 && g->sh <= 2 && g->sw <= 2 &&
+               g->kh <= 8 && g->kw <= 8) {
+        // narrow maps: the shared kernel on zero-padded, phase-split, flattened copies of x and dy (Bw2dGeom::prepad)
+        const int amin = -ceil_div(g->ph, g->sh), amax = (g->kh - 1 - g->ph) >= 0 ? (g->kh - 1 - g->ph) / g->sh : -ceil_div(g->ph - g->kh + 1, g->sh);
+        const int bmin = -ceil_div(g->pw, g->sw), bmax = (g->kw - 1 - g->pw) >= 0 ? (g->kw - 1 - g->pw) / g->sw : -ceil_div(g->pw - g->kw + 1, g->sw);
+        const int Wpp = g->Wout + (bmax - bmin), Hp = g->Hout + (amax - amin);
+        const int64_t lpr = ceil_div64(int64_t(g->Hout) * Wpp, 32) * 32;
+        const int64_t hwi = (int64_t(Hp) * Wpp + 64 + 3) / 4 * 4;
+        const bool fits = int64_t(g->sh) * g->sw * g->B * g->Cin * hwi < (int64_t(1) << 30) && int64_t(g->B) * g->Cout * lpr < (int64_t(1) << 30);
+        if (fits && lpr * 10 <= int64_t(g->Hout) * g->Wout * 13) {      // padded positions <= 1.3 x the real ones: 8 columns and more
+                                                                         // (measured: 16 columns 64 -> 79 TFLOP/s, 8 columns 69 -> 76, 4 columns 67 -> 61)
+            const int NK = g->Cin * KK;
+            int dbm, dbn;
+            if (g->Cout > 64) { *cfg = 10; dbm = 128; dbn = 128; }
+            else              { *cfg = 15; dbm = 64; dbn = 128; }
+            g->prepad = 1; g->Wp = Wpp; g->pp_lpr = int(lpr); g->pp_hwi = int(hwi); g->pp_amin = amin; g->pp_bmin = bmin;
+            const int dnt = ceil_div(NK, dbn), dmt = ceil_div(g->Cout, dbm);
+            const int64_t ditems = int64_t(g->B) * (lpr / 32);
+            int64_t gz = ceil_div(tuning().dw_wgs, dnt * dmt);
+            if (gz > ditems) gz = ditems;
+            if (gz < 1) gz = 1;
+            if (gz > 65535) gz = 65535;
+            g->n_slices = int(gz);
+            *bm = dbm;
+            *grid = dim3(dnt, dmt, g->n_slices);
+            *lds = 0;
+        }
     }
     return AGX_OK;
 }
@@ -1454,7 +1524,8 @@ size_t agx_conv2d_bwd_weight_workspace_bytes(const agx_conv2d_desc *d) {
     if (bw2d_geometry(d, &g, &cfg, &bm, &grid, &lds) != AGX_OK) return 0;
     const size_t nw = size_t(g.Cin) * g.kh * g.kw * g.Cout;
     size_t floats = (size_t(g.n_slices) + 1) * nw + (size_t(g.n_slices) + 2) * g.Cout;
-    if (cfg >= 10 && g.sw > 1) floats += size_t(g.sw) * g.B * g.Cin * g.Hin * g.Wp + 128;   // column-phase planes of x (+ slack)
+    if (cfg >= 10 && g.prepad) floats += size_t(g.sh) * g.sw * g.B * g.Cin * g.pp_hwi + size_t(g.B) * g.Cout * g.pp_lpr + 256;   // padded copies
+    else if (cfg >= 10 && g.sw > 1) floats += size_t(g.sw) * g.B * g.Cin * g.Hin * g.Wp + 128;   // column-phase planes of x (+ slack)
     return floats * sizeof(float);
 }
 
@@ -1497,7 +1568,19 @@ int agx_conv2d_bwd_weight(const agx_conv2d_desc *d, const float *x, const float 
         return AGX_OK;
     };
     if (cfg >= 10) {
-        if (g.sw > 1) {   // column-strided layer: x through its sw column-phase planes
+        if (g.prepad) {   // narrow map: zero-padded, phase-split, flattened copies of both operands
+            float *xp = rowdot + M + 64;
+            xp += (4 - (reinterpret_cast<uintptr_t>(xp) / 4) % 4) % 4;          // 16-byte aligned planes
+            const int64_t nx = int64_t(g.sh) * g.sw * g.B * g.Cin * g.pp_hwi, ny = int64_t(g.B) * M * g.pp_lpr;
+            float *dyp = xp + nx;
+            const int amax_rows = g.Hout + ((g.kh - 1 - g.ph) >= 0 ? (g.kh - 1 - g.ph) / g.sh : 0) - g.pp_amin;
+            hipLaunchKernelGGL(prepad_x_kernel, dim3((unsigned)ceil_div64(nx, 256)), dim3(256), 0, st, x, xp, int64_t(g.B) * g.Cin, g.Hin,
+                               g.Win, amax_rows, g.Wp, g.pp_hwi, g.sh, g.sw, g.pp_amin, g.pp_bmin);
+            hipLaunchKernelGGL(prepad_dy_kernel, dim3((unsigned)ceil_div64(ny, 256)), dim3(256), 0, st, dy, dyp, int64_t(g.B) * M, g.Hout,
+                               g.Wout, g.Wp, g.pp_lpr);
+            x = xp;
+            dy = dyp;
+        } else if (g.sw > 1) {   // column-strided layer: x through its sw column-phase planes
             float *xs = rowdot + M + 64;
             const int64_t xrows = int64_t(g.B) * g.Cin * g.Hin;
             hipLaunchKernelGGL(deinterleave_cols_kernel, dim3((unsigned)ceil_div64(xrows * g.Wp, 256)), dim3(256), 0, st, x,

@@ -152,6 +152,40 @@ def test_weight_gradient_of_bf16x3_descriptors(shape, knob):
     assert float((db.cpu().double() - want_b).abs().max()) <= 1e-5 * float(want_b.abs().max())
 
 
+NARROW = [(2, 128, 128, 40, 16, 3, 3, 1, 1), (2, 128, 256, 40, 16, 4, 4, 2, 2), (1, 256, 256, 50, 8, 3, 3, 1, 1),
+          (1, 256, 256, 50, 8, 3, 4, 1, 2), (2, 64, 64, 33, 12, 3, 3, 1, 1), (1, 128, 128, 281, 4, 3, 3, 1, 1),
+          (3, 64, 128, 37, 24, 4, 4, 2, 2)]
+
+
+@pytest.mark.parametrize("shape", NARROW)
+@pytest.mark.parametrize("impl", [_lib.IMPL_AUTO, _lib.IMPL_MFMA_BF16X3])
+def test_weight_gradient_on_narrow_maps(shape, impl):
+    """Maps narrower than 32 columns: the shared kernel on zero-padded, phase-split, flattened copies of x and dy (knob dw2_prepad;
+    conv_bwd_weight.hip: Bw2dGeom::prepad) -- weight and bias gradients against float64 autograd, and against the staged kernel."""
+    bsz, cin, cout, h, w_, kh, kw, sh, sw = shape
+    g = torch.Generator().manual_seed(43)
+    pad = ((kh - 1) // 2, (kw - 1) // 2)
+    x = torch.randn(bsz, cin, h, w_, generator=g)
+    ho, wo = (h + 2 * pad[0] - kh) // sh + 1, (w_ + 2 * pad[1] - kw) // sw + 1
+    dy = torch.randn(bsz, cout, ho, wo, generator=g)
+    w0 = torch.zeros(cout, cin, kh, kw, dtype=torch.float64, requires_grad=True)
+    b0 = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    want_w, want_b = torch.autograd.grad(F.conv2d(x.double(), w0, b0, (sh, sw), pad), (w0, b0), dy.double())
+    d = ops.conv2d_desc(bsz, cin, cout, h, w_, kh, kw, (sh, sw), pad, impl=impl)
+    lib = _lib.load()
+    got = {}
+    for knob in (1, 0):
+        lib.agx_set_tuning(b"dw2_prepad", knob)
+        try:
+            got[knob] = ops.conv2d_bwd_weight(d, x.to(DEV), dy.to(DEV))
+        finally:
+            lib.agx_set_tuning(b"dw2_prepad", 1)
+        dw, db = got[knob]
+        assert float((dw.cpu().double() - want_w).abs().max()) <= 1e-5 * float(want_w.abs().max()), knob
+        assert float((db.cpu().double() - want_b).abs().max()) <= 1e-5 * float(want_b.abs().max()), knob
+    assert torch.equal(got[1][0], ops.conv2d_bwd_weight(d, x.to(DEV), dy.to(DEV))[0])      # reproducible
+
+
 def test_other_layers_keep_their_kernels():
     """The FORWARD of the strided layers and few-channel layers have no ring form, and maps that would leave the tiles mostly
     empty (4 columns; a ragged 33) are refused: a bf16x3 descriptor falls back to the kernels it had."""

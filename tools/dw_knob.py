@@ -14,7 +14,8 @@ def timeit(fn, reps=5):
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 knob = (sys.argv[2] if len(sys.argv) > 2 else "dw_wgs").encode()
 vals = [int(v) for v in sys.argv[3:]] or [768, 512, 1024, 1536, 2048]
-for (cin, cout, kh, kw, sh, sw, h, w) in [(32, 32, 3, 3, 1, 1, 282, 1024), (64, 64, 3, 3, 1, 1, 282, 512), (128, 128, 3, 3, 1, 1, 141, 256), (64, 128, 4, 4, 2, 2, 282, 512), (256, 256, 3, 3, 1, 1, 70, 64)]:
+_narrow = [(128, 128, 3, 3, 1, 1, 1125, 16), (128, 256, 4, 4, 2, 2, 1125, 16), (256, 256, 3, 3, 1, 1, 562, 8), (256, 256, 3, 4, 1, 2, 562, 8), (256, 256, 3, 3, 1, 1, 562, 4)]
+for (cin, cout, kh, kw, sh, sw, h, w) in _narrow if __import__('os').environ.get('AGX_DW_SHAPES') == 'narrow' else [(32, 32, 3, 3, 1, 1, 282, 1024), (64, 64, 3, 3, 1, 1, 282, 512), (128, 128, 3, 3, 1, 1, 141, 256), (64, 128, 4, 4, 2, 2, 282, 512), (256, 256, 3, 3, 1, 1, 70, 64)]:
     x = torch.randn(B, cin, h, w, device="cuda")
     pad = ((kh - 1) // 2, (kw - 1) // 2)
     d = ops.conv2d_desc(B, cin, cout, h, w, kh, kw, (sh, sw), pad, impl=int(__import__('os').environ.get('AGX_DW_IMPL', '0')))
