@@ -11,7 +11,7 @@
 
 namespace agx {
 
-// Thread-local last-error message (the only mutable global state of the library).
+// Thread-local last-error message (the only mutable global state of the library besides the diagnostics: Tuning, the RVQ stamp buffer).
 void set_error(const char *fmt, ...);
 int fail(int code, const char *fmt, ...);
 const char *last_error();
