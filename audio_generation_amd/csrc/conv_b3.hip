@@ -119,10 +119,13 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_
     };
 
     // ---- input stream ----
+    // Two chunks of input are in flight in registers (two sets, addressed statically by the chunk's parity): with three taps a
+    // chunk is 72 MFMAs per wave -- 2.3 k cycles of matrix pipe, 4.6 k next to the partner workgroup --, less than a global load
+    // takes under load, and a request issued ONE chunk ahead was waited for at every chunk boundary.
     int i_k = 0, i_chunk = 0;                             // the next chunk to load: tile index, chunk
-    float st[NT][8];
-    int st_t[NT];
-    auto input_load = [&]() {
+    float st2[2][NT][8];
+    int st_t2[2][NT];
+    auto input_load = [&](float (&st)[NT][8], int (&st_t)[NT]) {
         const bool live = i_k < my_tiles;
         int b_, tb_, mb_;
         decode(min(int(blockIdx.x) + i_k * int(gridDim.x), ntiles - 1), b_, tb_, mb_);
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_
         }
         if (++i_chunk == nch) i_chunk = 0, ++i_k;
     };
-    auto input_store_all = [&]() {
+    auto input_store_all = [&](const float (&st)[NT][8], const int (&st_t)[NT]) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             cb3x8 h, m, l;
@@ -184,14 +187,15 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_
         for (int pl = 0; pl < 3; ++pl) bf[pl] = *reinterpret_cast<const cb3x8 *>(lds + bLane + (pl * 2 * W + 32 * kk + j) * 16);
     };
 
-    // ---- prologue ----
-    input_load();
+    // ---- prologue: chunk 0 -> planes, chunks 1 and 2 on their way ----
+    input_load(st2[0], st_t2[0]);
     dma_next_group();
     dma_next_group();
-    input_store_all();
+    input_store_all(st2[0], st_t2[0]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    input_load();
+    input_load(st2[1], st_t2[1]);
+    input_load(st2[0], st_t2[0]);
 
     cb3x8 fa[2][3][MW], fb[2][3];
     for (int k = 0; k < my_tiles; ++k) {
@@ -245,13 +249,14 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_
                         for (int i = 0; i < MW; ++i) acc[i][kk] = part[i];
                         if (chunk_end) {
                             // one plane buffer: every wave is past the chunk's barrier (holds its last operands in registers);
-                            // split + write the next chunk, barrier, read the next step's operands
-                            input_store_all();
+                            // split + write the next chunk (register set of its parity: nch is even, so the parity of a chunk
+                            // within its tile is its parity in the stream), barrier, read the next step's operands
+                            input_store_all(st2[cc ^ 1], st_t2[cc ^ 1]);
                             __builtin_amdgcn_sched_barrier(0);
                             __syncthreads();
                             load_a(fa[ua ^ 1], 0);
                             load_b(fb[sb ^ 1], 0, 0);
-                            input_load();                  // the chunk after next: a whole chunk of flight time
+                            input_load(st2[cc ^ 1], st_t2[cc ^ 1]);   // the chunk THREE ahead: two chunks of flight time
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
