@@ -367,7 +367,8 @@ __global__ __launch_bounds__(256) void conv2d_fewout_kernel(ConvPlan p, const fl
 }
 
 static bool conv2d_fewout(const agx_conv2d_desc *d, const ConvPlan &p) {
-    return d->impl == AGX_IMPL_AUTO && p.pm_R == 0 && p.prec == 0 && p.M <= 4 && p.q == 1 && p.d == 1;
+    // (a bf16x3 descriptor of a layer without a bf16x3 form -- prec 0 -- is an AUTO descriptor)
+    return (d->impl == AGX_IMPL_AUTO || d->impl == AGX_IMPL_MFMA_BF16X3) && p.pm_R == 0 && p.prec == 0 && p.M <= 4 && p.q == 1 && p.d == 1;
 }
 
 }  // namespace agx

@@ -417,8 +417,14 @@ __global__ __launch_bounds__(256, 2) void conv2d_b3_kernel(ConvPlan p, int cb_co
         const bool live = i_k < my_tiles;
         int b_, rb_, cb_, mb_;
         decode(min(int(blockIdx.x) + i_k * int(gridDim.x), ntiles - 1), b_, rb_, cb_, mb_);
-        const int row0 = rb_ * G::R - p.ph, col0 = cb_ * G::WF - p.P;
-        const char *xc = reinterpret_cast<const char *>(x + (size_t(b_) * p.Cin + i_chunk * 16) * p.x_cstride);
+        // FORWARD of a strided layer (p.s / p.sh = its column / row stride, p.cin_real = its channels): the kernel runs the
+        // space-to-depth form -- sh sw cin_real virtual channels (phase-major), ceil(k / s) taps, stride 1 -- and this is where the
+        // virtual planes come from: chunk -> (phase, 16 real channels), plane position (pr, pc) -> input (sh pr' + rho_h - ph,
+        // s pc' + rho_w - P).  Stride-1 plans: one phase, the identity.
+        const int cv0 = i_chunk * 16, phase = cv0 / p.cin_real, ci0 = cv0 - phase * p.cin_real;
+        const int rho_h = phase / p.s, rho_w = phase - rho_h * p.s;
+        const int row0 = p.sh * (rb_ * G::R) + rho_h - p.ph, col0 = p.s * (cb_ * G::WF) + rho_w - p.P;
+        const char *xc = reinterpret_cast<const char *>(x + (size_t(b_) * p.cin_real + ci0) * p.x_cstride);
         unsigned cs4 = unsigned(p.x_cstride) * 4u;
         asm volatile("" : "+s"(cs4));
 #pragma unroll
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_b3_kernel(ConvPlan p, int cb_co
             const int u = tid + 256 * n;
             const int uh = u >= W ? 1 : 0;
             const int t = u - uh * W;
-            const int pr = t / SWP, gr = row0 + pr, gc = col0 + (t - pr * SWP);
+            const int pr = t / SWP, gr = row0 + p.sh * pr, gc = col0 + p.s * (t - pr * SWP);
             const bool task = u < 2 * W;
             const bool ok = live && task && gr >= 0 && gr < Hin && gc >= 0 && gc < Win;
             const unsigned off = unsigned(8 * uh) * cs4 + unsigned(min(max(gr, 0), Hin - 1) * Win + min(max(gc, 0), Win - 1)) * 4u;
@@ -678,16 +684,33 @@ int launch_conv_b3(const ConvPlan &p, const float *x, const float *wp, const flo
 }
 
 
+// floats of the B3 tile image of a Conv2d plan with the ring form: the plan's own bf16x3 weights, or -- strided forward layers -- the
+// space-to-depth weights (sh sw Cin virtual channels x ceil(kh / sh) ceil(kw / sw) taps: the same count when the strides divide the
+// kernel, as they do for the two layer shapes covered)
+int64_t conv2d_b3_tile_floats(const ConvPlan &p) {
+    if (p.s == 1 && p.sh == 1) return packed_weight_floats_bf(p.ncv, p.J, p.M);
+    const int khv = ceil_div(p.kh, p.sh), kwv = ceil_div(p.J / p.kh, p.s);
+    return packed_weight_floats_bf(p.sh * p.s * p.Cin, khv * kwv, p.M);
+}
+
 // ---- Conv2d (conv2d_b3_kernel) ---------------------------------------------------------------------------------------
 enum { C2B3_NONE = 0, C2B3_M128 = 1, C2B3_M64 = 2, C2B3_M32 = 3 };      // tile shape (low 4 bits of the geometry code)
-enum { C2B3_T33 = 0, C2B3_T22 = 1, C2B3_T32 = 2 };                      // tap shape (next 4 bits)
+enum { C2B3_T33 = 0, C2B3_T22 = 1, C2B3_T32 = 2, C2B3_T22F = 3, C2B3_T32F = 4 };   // tap shape (next 4 bits); F: strided FORWARD, space-to-depth
 
 // shape-only test (also decides whether the conv2d pack functions append the B3 tile image: conv2d.hip)
 int conv2d_b3_geometry(const ConvPlan &p) {
-    if (p.prec != 1 || p.G != 1 || p.pm_R <= 0 || p.s != 1 || p.sh != 1 || p.d != 1) return C2B3_NONE;
-    if (p.Cin % 32 != 0 || p.cin_real != p.Cin || p.ncv != p.Cin) return C2B3_NONE;      // whole 16-channel chunks, an even number
+    if (p.prec != 1 || p.G != 1 || p.pm_R <= 0 || p.d != 1) return C2B3_NONE;
+    if (p.cin_real != p.Cin || p.ncv != p.Cin) return C2B3_NONE;
     int taps;
-    if (p.kh == 3 && p.J == 9 && p.q == 1 && p.qh == 1) {             // 3 x 3, stride 1, "same": forward and backward-data
+    if (p.s == 2 && p.q == 1 && p.qh == 1 && p.P == 1 && p.ph == 1 && p.oshift == 0 && p.oshift_h == 0 && p.Cin % 16 == 0 &&
+        ((p.sh == 2 && p.kh == 4 && p.J == 16) || (p.sh == 1 && p.kh == 3 && p.J == 12))) {
+        // FORWARD of the (4,4)/(2,2) and (3,4)/(1,2) layers, pad (1,1): space-to-depth = sh sw Cin virtual channels (16-channel
+        // chunks stay inside one phase), 2 x 2 resp. 3 x 2 taps, stride 1 (conv2d_b3_kernel's staging)
+        if (p.Lt != p.Lout || p.Tt != p.Tout) return C2B3_NONE;
+        taps = p.sh == 2 ? C2B3_T22F : C2B3_T32F;
+    } else if (p.s != 1 || p.sh != 1 || p.Cin % 32 != 0) {             // (stride-1 plans: whole 16-channel chunks, an even number)
+        return C2B3_NONE;
+    } else if (p.kh == 3 && p.J == 9 && p.q == 1 && p.qh == 1) {      // 3 x 3, stride 1, "same": forward and backward-data
         if (p.P != 1 || p.ph != 1 || p.oshift != 0 || p.oshift_h != 0) return C2B3_NONE;
         if (p.Lt != p.Lout || p.Tt != p.Tout || p.Lout != p.Lin || p.Tout != p.Tin) return C2B3_NONE;
         taps = C2B3_T33;
@@ -731,9 +754,11 @@ bool conv2d_b3_supported(const ConvPlan &p) {
 }
 
 const char *conv2d_b3_variant(const ConvPlan &p) {
-    static const char *names[3][3] = {{"conv2d_b3<3x3,128x128>", "conv2d_b3<3x3,64x256>", "conv2d_b3<3x3,32x256>"},
+    static const char *names[5][3] = {{"conv2d_b3<3x3,128x128>", "conv2d_b3<3x3,64x256>", "conv2d_b3<3x3,32x256>"},
                                       {"conv2d_b3<2x2 phases 2x2,128x128>", "conv2d_b3<2x2 phases 2x2,64x256>", "conv2d_b3<2x2 phases 2x2,32x256>"},
-                                      {"conv2d_b3<3x2 phases 1x2,128x128>", "conv2d_b3<3x2 phases 1x2,64x256>", "conv2d_b3<3x2 phases 1x2,32x256>"}};
+                                      {"conv2d_b3<3x2 phases 1x2,128x128>", "conv2d_b3<3x2 phases 1x2,64x256>", "conv2d_b3<3x2 phases 1x2,32x256>"},
+                                      {"conv2d_b3<4x4 s2 as 2x2 s2d,128x128>", "conv2d_b3<4x4 s2 as 2x2 s2d,64x256>", "conv2d_b3<4x4 s2 as 2x2 s2d,32x256>"},
+                                      {"conv2d_b3<3x4 s(1,2) as 3x2 s2d,128x128>", "conv2d_b3<3x4 s(1,2) as 3x2 s2d,64x256>", "conv2d_b3<3x4 s(1,2) as 3x2 s2d,32x256>"}};
     const int geom = conv2d_b3_geometry(p);
     return geom == C2B3_NONE ? "conv2d_b3<unsupported>" : names[geom >> 4][(geom & 15) - 1];
 }
@@ -794,6 +819,14 @@ static int launch_c2b3_tile(int tile, const ConvPlan &p, const float *x, const f
 int launch_conv2d_b3(const ConvPlan &p, const float *x, const float *wp, const float *bias, const float *res, float *y, hipStream_t st) {
     if (!conv2d_b3_supported(p)) return fail(AGX_ERR_UNSUPPORTED, "conv2d_b3: unsupported layer");
     const int geom = conv2d_b3_geometry(p);
+    if ((geom >> 4) == C2B3_T22F || (geom >> 4) == C2B3_T32F) {     // the virtual (space-to-depth) plan the kernel loops over
+        ConvPlan v = p;
+        v.Cin = p.sh * p.s * p.Cin;
+        v.kh = (geom >> 4) == C2B3_T22F ? 2 : 3;
+        v.J = v.kh * 2;
+        return (geom >> 4) == C2B3_T22F ? launch_c2b3_tile<2, 2, 1, 1>(geom & 15, v, x, wp, bias, res, y, st)
+                                        : launch_c2b3_tile<3, 2, 1, 1>(geom & 15, v, x, wp, bias, res, y, st);
+    }
     switch (geom >> 4) {
         case C2B3_T33: return launch_c2b3_tile<3, 3, 1, 1>(geom & 15, p, x, wp, bias, res, y, st);
         case C2B3_T22: return launch_c2b3_tile<2, 2, 2, 2>(geom & 15, p, x, wp, bias, res, y, st);

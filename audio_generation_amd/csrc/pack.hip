@@ -160,6 +160,37 @@ __global__ __launch_bounds__(256) void b3_tile_from_bf_kernel(const __bf16 *__re
     const int64_t gj = e / (int64_t(48) * M);
     timg[(((gj * 3 + plane) * 2 + (c16 >> 3)) * M + m) * 8 + (c16 & 7)] = img[e];
 }
+// B3 tile image of a STRIDED Conv2d layer's forward in space-to-depth form (conv_b3.hip: conv2d_b3_kernel): virtual channel
+// cv = (rho_h sw + rho_w) Cin + ci, tap jv = ah KWv + aw  <->  W[co][ci][sh ah + rho_h][sw aw + rho_w] (zero past the kernel).
+__global__ __launch_bounds__(256) void pack_s2d_b3_kernel(const float *__restrict__ w, const float *__restrict__ scale,
+                                                          __bf16 *__restrict__ timg, int Cin, int Cout, int kh, int kw, int sh, int sw) {
+    const int KHv = (kh + sh - 1) / sh, KWv = (kw + sw - 1) / sw, Jv = KHv * KWv, Cv = sh * sw * Cin, M = Cout;
+    const int64_t total = int64_t(Cv / kWG) * Jv * M * kWG;   // one thread per virtual weight
+    const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int c16 = int(e % kWG);
+    const int m = int((e / kWG) % M);
+    const int gj = int(e / (int64_t(kWG) * M));
+    const int jv = gj % Jv, cv = (gj / Jv) * kWG + c16;
+    const int phase = cv / Cin, ci = cv - phase * Cin, rho_h = phase / sw, rho_w = phase - rho_h * sw;
+    const int ah = jv / KWv, aw = jv - ah * KWv, dh = sh * ah + rho_h, dw = sw * aw + rho_w;
+    const float wv = (dh < kh && dw < kw) ? w[((size_t(m) * Cin + ci) * kh + dh) * kw + dw] * scale[m] : 0.f;
+    const __bf16 h = (__bf16)wv;
+    const float r1 = wv - (float)h;
+    const __bf16 mm = (__bf16)r1;
+    const __bf16 l = (__bf16)(r1 - (float)mm);
+    __bf16 *dst = timg + ((size_t(gj) * 3 * 2 + (c16 >> 3)) * M + m) * 8 + (c16 & 7);
+    const size_t plane = size_t(2) * M * 8;
+    dst[0] = h;
+    dst[plane] = mm;
+    dst[2 * plane] = l;
+}
+void launch_pack_s2d_b3(const float *w, const float *scale, float *timg, int Cin, int Cout, int kh, int kw, int sh, int sw,
+                        hipStream_t st) {
+    const int64_t total = int64_t(sh * sw * Cin) * ceil_div(kh, sh) * ceil_div(kw, sw) * Cout;
+    hipLaunchKernelGGL(pack_s2d_b3_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, w, scale,
+                       reinterpret_cast<__bf16 *>(timg), Cin, Cout, kh, kw, sh, sw);
+}
 void launch_b3_tile_from_bf(const float *img, float *timg, int64_t gj_count, int M, hipStream_t st) {
     const int64_t total = gj_count * M * 48;
     hipLaunchKernelGGL(b3_tile_from_bf_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st,
@@ -309,12 +340,13 @@ extern "C" int agx_conv_pack_sigma(const agx_conv_desc *d, const float *w, const
 namespace agx {
 void launch_pack_tile2d(const float *w, const float *scale, const float *sigma, float *timg, int C, int M, int kh, int kw,
                         int bwd, hipStream_t st, int sh, int sw, int kh_w, int kw_w);   // conv2d.hip
+int64_t conv2d_b3_tile_floats(const ConvPlan &p);   // conv_b3.hip
 }
 extern "C" int64_t agx_conv2d_packed_floats(const agx_conv2d_desc *d) {
     agx::ConvPlan p;
     int rc = agx::lower_conv2d(d, &p);
     if (rc != AGX_OK) return rc;
-    const int64_t tile = p.tile_off < 0 ? 0 : p.prec ? agx::packed_weight_floats_bf(p.ncv, p.J, p.M)      // B3 tile image (conv_b3.hip)
+    const int64_t tile = p.tile_off < 0 ? 0 : p.prec ? agx::conv2d_b3_tile_floats(p)                      // B3 tile image (conv_b3.hip)
                                                      : agx::tile_image_floats(p.kh * p.Cin, p.J / p.kh, p.M);
     return (p.prec ? agx::packed_weight_floats_bf(p.ncv, p.J, p.M) : agx::packed_weight_floats(p.ncv, p.J, p.M)) + p.Cout + tile;
 }
@@ -337,7 +369,9 @@ extern "C" int agx_conv2d_pack(const agx_conv2d_desc *d, const float *w, const f
         const int64_t nthreads = int64_t(ceil_div(p.ncv, kWG)) * p.J * p.M * kWG;
         hipLaunchKernelGGL(pack_bf16x3_kernel, dim3((unsigned)ceil_div64(nthreads, 256)), dim3(256), 0, st, w, scale,
                            reinterpret_cast<__bf16 *>(packed), AGX_CONV_PADDED, p.ncv, p.Cout, p.J, 1, p.J, p.P, 1);
-        if (p.tile_off >= 0)   // second copy in the DMA layout of conv2d_b3_kernel, behind the scale scratch
+        if (p.tile_off >= 0 && (p.s > 1 || p.sh > 1))   // strided forward layer: the space-to-depth weights
+            launch_pack_s2d_b3(w, scale, packed + p.tile_off, p.Cin, p.Cout, p.kh, p.J / p.kh, p.sh, p.s, st);
+        else if (p.tile_off >= 0)   // second copy in the DMA layout of conv2d_b3_kernel, behind the scale scratch
             launch_b3_tile_from_bf(packed, packed + p.tile_off, int64_t(ceil_div(p.ncv, kWG)) * p.J, p.M, st);
         return check_launch("agx_conv2d_pack");
     }

@@ -100,6 +100,31 @@ STRIDED = [          # (widths chosen so that the base grid -- ceil((w + 1) / 2)
 ]
 
 
+STRIDED_FWD = [(2, 32, 64, 21, 64, 3, 4, 1, 2), (2, 64, 128, 22, 64, 4, 4, 2, 2), (1, 128, 128, 17, 128, 3, 4, 1, 2),
+               (1, 128, 256, 30, 64, 4, 4, 2, 2), (2, 256, 512, 12, 64, 4, 4, 2, 2), (1, 256, 256, 33, 32, 3, 4, 1, 2),
+               (2, 64, 128, 61, 250, 4, 4, 2, 2), (1, 64, 128, 282, 512, 4, 4, 2, 2), (1, 32, 64, 9, 1024, 3, 4, 1, 2)]
+
+
+@pytest.mark.parametrize("shape", STRIDED_FWD)
+def test_forward_of_strided_layers_space_to_depth(shape):
+    """Forward of the (3,4)/(1,2) and (4,4)/(2,2) layers: the ring kernel on the space-to-depth form (sh sw Cin virtual channels,
+    ceil(k / s) taps, stride 1; the virtual planes are formed by the kernel's own staging), bias + LeakyReLU, spectral scale."""
+    bsz, cin, cout, h, w_, kh, kw, sh, sw = shape
+    g = torch.Generator().manual_seed(37)
+    w = torch.randn(cout, cin, kh, kw, generator=g) * (1.5 / (cin * kh * kw) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.1
+    sigma = torch.tensor([1.3])
+    x = torch.randn(bsz, cin, h, w_, generator=g)
+    pad = ((kh - 1) // 2, (kw - 1) // 2)
+    want = F.leaky_relu(F.conv2d(x.double(), (w / sigma).double(), b.double(), (sh, sw), pad), 0.2)
+    d3 = ops.conv2d_desc(bsz, cin, cout, h, w_, kh, kw, (sh, sw), pad, epilogue=_lib.EPI_LEAKY_PRE, slope=0.2, impl=_lib.IMPL_MFMA_BF16X3)
+    assert ops.conv2d_kernel_name(d3).startswith("conv2d_b3<"), ops.conv2d_kernel_name(d3)
+    y3 = ops.conv2d_forward(d3, x.to(DEV), ops.conv2d_pack(d3, w.to(DEV), sigma.to(DEV)), b.to(DEV))
+    assert y3.shape == want.shape
+    assert float((y3.cpu().double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    assert torch.equal(y3, ops.conv2d_forward(d3, x.to(DEV), ops.conv2d_pack(d3, w.to(DEV), sigma.to(DEV)), b.to(DEV)))
+
+
 @pytest.mark.parametrize("shape", STRIDED)
 @pytest.mark.parametrize("epi", ["plain", "add+mask"])
 def test_backward_data_of_strided_layers(shape, epi):
@@ -187,9 +212,9 @@ def test_weight_gradient_on_narrow_maps(shape, impl):
 
 
 def test_other_layers_keep_their_kernels():
-    """The FORWARD of the strided layers and few-channel layers have no ring form, and maps that would leave the tiles mostly
-    empty (4 columns; a ragged 33) are refused: a bf16x3 descriptor falls back to the kernels it had."""
-    for (cin, cout, kh, kw, sh, sw) in [(64, 128, 4, 4, 2, 2), (128, 128, 3, 4, 1, 2), (2, 32, 7, 7, 1, 1)]:
+    """Few-channel layers and other kernel shapes have no ring form, and maps that would leave the tiles mostly empty (4 columns; a
+    ragged 33) are refused: a bf16x3 descriptor falls back to the kernels it had."""
+    for (cin, cout, kh, kw, sh, sw) in [(2, 32, 7, 7, 1, 1), (64, 128, 5, 5, 1, 1), (64, 64, 3, 3, 2, 2), (40, 64, 4, 4, 2, 2)]:
         d = ops.conv2d_desc(2, cin, cout, 40, 64, kh, kw, (sh, sw), ((kh - 1) // 2, (kw - 1) // 2), impl=_lib.IMPL_MFMA_BF16X3)
         assert not ops.conv2d_kernel_name(d).startswith("conv2d_b3")
     for (h, w_) in [(562, 4), (35, 33)]:
@@ -219,7 +244,7 @@ def test_ring_only_mode_of_the_discriminator_picks_per_map():
     assert float((ring_g - ref_g).abs().max()) <= 2e-5 * float(ref_g.abs().max()) + 1e-9
     convs = [m for m in d.modules() if isinstance(m, ad._SNConv) and m.nd == 2]
     ring_fwd = [m for m in convs if any(v == _lib.IMPL_MFMA_BF16X3 and not k[2] for k, v in m._impl_of.items())]
-    assert ring_fwd and all(tuple(m.kernel_size) == (3, 3) and tuple(m.stride) == (1, 1) for m in ring_fwd)
+    assert ring_fwd and all(tuple(m.kernel_size) in ((3, 3), (3, 4), (4, 4)) for m in ring_fwd)
     assert any(_lib.IMPL_AUTO in m._impl_of.values() for m in convs)       # strided / 7 x 7 / narrow-map layers stayed fp32
     ad.set_arithmetic(d, "fp32")
     again_l, _ = run()
