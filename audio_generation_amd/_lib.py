@@ -142,6 +142,8 @@ SIGNATURES = {
                                   c_void_p]),
     "agx_reduce_mean": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "agx_reduce_mean_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "agx_feature_means": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "agx_feature_means_backward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "agx_sigmoid": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "agx_fdft_frames": (c_int64, [c_int32, c_int32, c_int32]),
     "agx_fdft_rows": (c_int64, [c_int32, c_int32]),

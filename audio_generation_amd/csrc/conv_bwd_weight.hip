@@ -481,6 +481,37 @@ __global__ __launch_bounds__(256) void bwd_slice_reduce_kernel(const float *__re
     if (grp == 0 && e < n) out[e] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
+// The same sum for short outputs (bias gradients: n <= a few hundred elements, thousands of slices): one thread per
+// element leaves a handful of waves walking a chain of n_slices / 4 dependent loads (43 us for a 256-element bias).
+// Here a block takes 16 elements x 16 slice groups (group g sums slices g, g + 16, ...; the groups are added as a
+// fixed binary tree), so the chains are 4x shorter and there are 4x the blocks.
+__global__ __launch_bounds__(256) void bwd_slice_reduce_short_kernel(const float *__restrict__ part, int n_slices,
+                                                                     int64_t n, float *__restrict__ out) {
+    __shared__ float red[16][17];
+    const int le = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int64_t e = int64_t(blockIdx.x) * 16 + le;
+    float s0 = 0.f, s1 = 0.f;
+    if (e < n) {
+        int k = grp;
+        for (; k + 16 < n_slices; k += 32) { s0 += part[size_t(k) * n + e]; s1 += part[size_t(k + 16) * n + e]; }
+        if (k < n_slices) s0 += part[size_t(k) * n + e];
+    }
+    red[grp][le] = s0 + s1;
+    __syncthreads();
+    for (int w = 8; w >= 1; w >>= 1) {
+        if (grp < w) red[grp][le] += red[grp + w][le];
+        __syncthreads();
+    }
+    if (grp == 0 && e < n) out[e] = red[0][le];
+}
+
+static void launch_slice_reduce(const float *part, int n_slices, int64_t n, float *out, hipStream_t st) {
+    if (n <= 4096 && n_slices >= 64)
+        hipLaunchKernelGGL(bwd_slice_reduce_short_kernel, dim3((unsigned)ceil_div64(n, 16)), dim3(256), 0, st, part, n_slices, n, out);
+    else
+        hipLaunchKernelGGL(bwd_slice_reduce_kernel, dim3((unsigned)ceil_div64(n, 64)), dim3(256), 0, st, part, n_slices, n, out);
+}
+
 // One block per dim-0 row r of the torch weight: fold dWp back to dw_r, then the weight-norm chain rule.
 __global__ __launch_bounds__(256) void bwd_weight_unpack_kernel(const float *__restrict__ dwp,
                                                                 const float *__restrict__ v,
@@ -1499,16 +1530,14 @@ int agx_conv_bwd_weight(const agx_conv_desc *d, const float *x, const float *dy,
            : geo.cfg == 1 ? launch(conv_bwd_weight_kernel<1, 2, 2, 2>)
                           : launch(conv_bwd_weight_kernel<1, 1, 1, 4>);
     if (rc != AGX_OK) return rc;
-    hipLaunchKernelGGL(bwd_slice_reduce_kernel, dim3((unsigned)ceil_div64(nw, 64)), dim3(256), 0, st, part,
-                       geo.n_slices, nw, dwp);
+    launch_slice_reduce(part, geo.n_slices, nw, dwp, st);
     const bool transposed = d->kind == AGX_CONV_TRANSPOSED;
     const int dim0 = transposed ? d->c_in : d->c_out;
     hipLaunchKernelGGL(bwd_weight_unpack_kernel, dim3(dim0), dim3(256), 0, st, dwp, v, g, dv, dg, d->kind, p.Cin,
                        p.Cout, d->kernel, p.q, p.J, p.P, d->stride);
     if (dbias) {
         float *rowsum = bias_part + size_t(geo.n_slices) * p.M;
-        hipLaunchKernelGGL(bwd_slice_reduce_kernel, dim3(ceil_div(p.M, 64)), dim3(256), 0, st, bias_part,
-                           geo.n_slices, int64_t(p.M), rowsum);
+        launch_slice_reduce(bias_part, geo.n_slices, int64_t(p.M), rowsum, st);
         hipLaunchKernelGGL(bwd_bias_fold_kernel, dim3(ceil_div(p.Cout, 256)), dim3(256), 0, st, rowsum, p.q, p.Cout,
                            dbias);
     }
@@ -1616,13 +1645,11 @@ int agx_conv2d_bwd_weight(const agx_conv2d_desc *d, const float *x, const float 
                       : launch(conv2d_bwd_weight_kernel<1, 1, 1, 4>);
     }
     if (rc != AGX_OK) return rc;
-    hipLaunchKernelGGL(bwd_slice_reduce_kernel, dim3((unsigned)ceil_div64(nw, 64)), dim3(256), 0, st, part, g.n_slices,
-                       nw, dwp);
+    launch_slice_reduce(part, g.n_slices, nw, dwp, st);
     hipLaunchKernelGGL(bwd2d_unpack_kernel, dim3(M), dim3(256), 0, st, dwp, sigma ? w : nullptr, dw, rowdot, NK, M);
     if (sigma) hipLaunchKernelGGL(bwd2d_spectral_kernel, dim3(M), dim3(256), 0, st, dw, rowdot, sigma, u, v, NK, M);
     if (dbias)
-        hipLaunchKernelGGL(bwd_slice_reduce_kernel, dim3(ceil_div(M, 64)), dim3(256), 0, st, bias_part, g.n_slices,
-                           int64_t(M), dbias);
+        launch_slice_reduce(bias_part, g.n_slices, int64_t(M), dbias, st);
     return check_launch("agx_conv2d_bwd_weight");
 }
 

@@ -86,8 +86,9 @@ __global__ __launch_bounds__(256) void avgpool1d_kernel(const float *__restrict_
 // Polyphase view of the framed DFT: with hop H = N / 4 and n = j H + p,
 //   Y[c, f, t] = sum_{p < H} sum_{j < 4} D_c[f, j H + p] xp[(t + j) H + p]
 // = an unpadded K = 4 conv over H channels xc[p][tau] = xp[tau H + p] (xp = reflect-padded input).
+// (tau_off: the first hop-column kept -- the framed DFT of a window shorter than n_fft skips the taps where the window is zero)
 __global__ __launch_bounds__(256) void stft_prep_kernel(const float *__restrict__ x, float *__restrict__ xc,
-                                                        int L, int N, int H, int Ttau, int chs) {
+                                                        int L, int N, int H, int Ttau, int chs, int tau_off) {
     // one block per (tau-tile of 64, batch); thread -> (p fastest over reads, tau fastest over writes)
     __shared__ float tile[64][65];
     const int b = blockIdx.z, tau0 = blockIdx.x * 64, p0 = blockIdx.y * 64;
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void stft_prep_kernel(const float *__restrict_
         const int tau = tau0 + tt, p = p0 + pp;
         float v = 0.f;
         if (tau < Ttau && p < H) {
-            const int i = tau * H + p;
+            const int i = (tau + tau_off) * H + p;
             if (i < Lp) {
                 int src = i - N / 2;
                 if (src < 0) src = -src;
@@ -157,14 +158,14 @@ __global__ __launch_bounds__(256) void stft_untranspose_kernel(const float *__re
 // (i = n + N/2 always; the reflected copies i = N/2 - n for 1 <= n <= N/2 and
 //  i = N/2 + 2(L-1) - n for L-1-N/2 <= n <= L-2), with dxc[p][tau] = dxp[tau H + p]
 __global__ __launch_bounds__(256) void stft_unprep_kernel(const float *__restrict__ dxc, float *__restrict__ dx, int L,
-                                                          int N, int H, int Ttau, int chs) {
+                                                          int N, int H, int Ttau, int chs, int tau_off) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= L) return;
     const int b = blockIdx.y, Lp = L + N, half = N / 2;
     auto at = [&](int i) -> float {
         if (i < 0 || i >= Lp) return 0.f;
-        const int tau = i / H, p = i - tau * H;
-        return tau < Ttau ? dxc[(size_t(b) * chs + p) * Ttau + tau] : 0.f;
+        const int th = i / H, p = i - th * H, tau = th - tau_off;
+        return (tau >= 0 && tau < Ttau) ? dxc[(size_t(b) * chs + p) * Ttau + tau] : 0.f;
     };
     float acc = at(n + half);
     if (n >= 1 && n <= half) acc += at(half - n);
@@ -267,20 +268,52 @@ __device__ __forceinline__ float loss_term(int mode, float a, float b) {
     }
 }
 
+// Partial sums of one loss term (PAIR = 0) or of the feature-matching pair |x - y| and |x + 1e-3| of one feature map in
+// the same pass (PAIR = 1: part[0 .. nb) and part[nb .. 2 nb)).  16-byte loads, four of them in flight per operand and
+// thread (one 4-byte load per iteration reached 1.75 TB/s on the 11.7 GB of feature maps of a config-5 step); the order
+// of the sum is fixed by (n, grid), not by timing.
+template <int PAIR>
 __global__ __launch_bounds__(256) void reduce_partial_kernel(const float *__restrict__ x, const float *__restrict__ y,
-                                                             int64_t n, int mode, float *__restrict__ part) {
+                                                             int64_t n, int mode, int vec, float *__restrict__ part) {
     __shared__ float sh[4];
-    float acc = 0.f;
-    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256)
-        acc += loss_term(mode, x[i], (mode == 3 || mode == 5) ? y[i] : 0.f);
-    const float tot = block_sum_256(acc, sh);
+    const bool two = PAIR || mode == 3 || mode == 5;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, bcc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int64_t stride = int64_t(gridDim.x) * 256, first = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t n4 = vec ? n >> 2 : 0;
+    auto term = [&](float a, float b, int u) {
+        if (PAIR) { acc[u] += fabsf(a - b); bcc[u] += fabsf(a + 1e-3f); }
+        else acc[u] += loss_term(mode, a, b);
+    };
+    auto quad = [&](const float4 a, const float4 b, int u) { term(a.x, b.x, u); term(a.y, b.y, u); term(a.z, b.z, u); term(a.w, b.w, u); };
+    const float4 *x4 = reinterpret_cast<const float4 *>(x), *y4 = reinterpret_cast<const float4 *>(y);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int64_t i = first;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        float4 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = x4[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) b[u] = two ? y4[i + u * stride] : z4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) quad(a[u], b[u], u);
+    }
+    for (; i < n4; i += stride) quad(x4[i], two ? y4[i] : z4, 0);
+    for (int64_t e = 4 * n4 + first; e < n; e += stride) term(x[e], two ? y[e] : 0.f, 0);
+    const float tot = block_sum_256((acc[0] + acc[1]) + (acc[2] + acc[3]), sh);
     if (threadIdx.x == 0) part[blockIdx.x] = tot;
+    if (PAIR) {
+        __syncthreads();
+        const float tb = block_sum_256((bcc[0] + bcc[1]) + (bcc[2] + bcc[3]), sh);
+        if (threadIdx.x == 0) part[gridDim.x + blockIdx.x] = tb;
+    }
 }
 
 __global__ __launch_bounds__(256) void reduce_final_kernel(const float *__restrict__ part, int nparts, double inv_n,
                                                            float *__restrict__ out) {
     __shared__ double shd[256];
     double acc = 0.0;
+    part += size_t(blockIdx.x) * nparts;   // (the feature-matching pair: one block per sum)
+    out += blockIdx.x;
     for (int i = threadIdx.x; i < nparts; i += 256) acc += double(part[i]);
     shd[threadIdx.x] = acc;
     __syncthreads();
@@ -291,30 +324,62 @@ __global__ __launch_bounds__(256) void reduce_final_kernel(const float *__restri
     if (threadIdx.x == 0) out[0] = float(shd[0] * inv_n);
 }
 
-// d mean(term(x, y)) / dx * g  (and / dy for the L1 term), g a device scalar
+// d mean(term(x, y)) / dx * g  (and / dy for the L1 term), g a device scalar.  PAIR = 1: the gradient of the feature-matching
+// pair in one pass, dx = g[0] sign(x - y) / n + g[1] sign(x + 1e-3) / n (each product exact, one rounding in the sum -- what
+// adding the two separate gradients gives), dy = -g[0] sign(x - y) / n.  16-byte loads and stores when the pointers allow.
+__device__ __forceinline__ float sign_of(float t) { return t > 0.f ? 1.f : (t < 0.f ? -1.f : 0.f); }
+
+template <int PAIR>
 __global__ __launch_bounds__(256) void reduce_mean_bwd_kernel(const float *__restrict__ x, const float *__restrict__ y,
-                                                              int64_t n, int mode, const float *__restrict__ g,
+                                                              int64_t n, int mode, int vec, const float *__restrict__ g,
                                                               float inv_n, float *__restrict__ dx,
                                                               float *__restrict__ dy) {
-    const float gs = g[0] * inv_n;
-    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256) {
-        const float a = x[i];
+    const float gs = g[0] * inv_n, gs2 = PAIR ? g[1] * inv_n : 0.f;
+    const bool two = PAIR || mode == 3 || mode == 5;
+    auto one = [&](float a, float b, float &ox, float &oy) {
+        if (PAIR) {
+            const float t1 = sign_of(a - b) * gs;
+            ox = t1 + sign_of(a + 1e-3f) * gs2;
+            oy = -t1;
+            return;
+        }
         float d;
         switch (mode) {
             case 0: d = 1.f; break;
             case 1: d = (a - 1.f < 0.f) ? 1.f : 0.f; break;       // torch.minimum(a - 1, 0): gradient to a where smaller
             case 2: d = (-a - 1.f < 0.f) ? -1.f : 0.f; break;
-            case 3: { const float t = a - y[i]; d = t > 0.f ? 1.f : (t < 0.f ? -1.f : 0.f); break; }
-            case 5: d = 2.f * (logf(a + 1e-8f) - logf(y[i] + 1e-8f)); break;   // times 1/(a+eps) resp. -1/(y+eps) below
-            default: { const float t = a + 1e-3f; d = t > 0.f ? 1.f : (t < 0.f ? -1.f : 0.f); break; }
+            case 3: d = sign_of(a - b); break;
+            case 5: d = 2.f * (logf(a + 1e-8f) - logf(b + 1e-8f)); break;   // times 1/(a+eps) resp. -1/(b+eps) below
+            default: d = sign_of(a + 1e-3f); break;
         }
-        if (mode == 5) {
-            dx[i] = d * gs / (a + 1e-8f);
-            if (dy) dy[i] = -d * gs / (y[i] + 1e-8f);
-            continue;
-        }
-        dx[i] = d * gs;
-        if (mode == 3 && dy) dy[i] = -d * gs;
+        if (mode == 5) { ox = d * gs / (a + 1e-8f); oy = -d * gs / (b + 1e-8f); return; }
+        ox = d * gs;
+        oy = -d * gs;
+    };
+    const int64_t stride = int64_t(gridDim.x) * 256, first = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t n4 = vec ? n >> 2 : 0;
+    const float4 *x4 = reinterpret_cast<const float4 *>(x), *y4 = reinterpret_cast<const float4 *>(y);
+    float4 *dx4 = reinterpret_cast<float4 *>(dx), *dy4 = reinterpret_cast<float4 *>(dy);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto quad = [&](int64_t i, const float4 a, const float4 b) {
+        float4 ox, oy;
+        one(a.x, b.x, ox.x, oy.x); one(a.y, b.y, ox.y, oy.y); one(a.z, b.z, ox.z, oy.z); one(a.w, b.w, ox.w, oy.w);
+        if (dx) dx4[i] = ox;
+        if (two && dy) dy4[i] = oy;
+    };
+    int64_t i = first;
+    for (; i + stride < n4; i += 2 * stride) {
+        const float4 a0 = x4[i], a1 = x4[i + stride];
+        const float4 b0 = two ? y4[i] : z4, b1 = two ? y4[i + stride] : z4;
+        quad(i, a0, b0);
+        quad(i + stride, a1, b1);
+    }
+    for (; i < n4; i += stride) quad(i, x4[i], two ? y4[i] : z4);
+    for (int64_t e = 4 * n4 + first; e < n; e += stride) {
+        float ox, oy;
+        one(x[e], two ? y[e] : 0.f, ox, oy);
+        if (dx) dx[e] = ox;
+        if (two && dy) dy[e] = oy;
     }
 }
 
@@ -323,15 +388,16 @@ __global__ __launch_bounds__(256) void sigmoid_kernel(const float *__restrict__ 
     if (i < n) y[i] = 1.f / (1.f + expf(-x[i]));
 }
 
-void launch_stft_prep(const float *x, float *xc, int batch, int L, int N, int H, int Ttau, int ch_stride, hipStream_t st) {
+void launch_stft_prep(const float *x, float *xc, int batch, int L, int N, int H, int Ttau, int ch_stride, int tau_off,
+                      hipStream_t st) {
     hipLaunchKernelGGL(stft_prep_kernel, dim3(ceil_div(Ttau, 64), ceil_div(H, 64), batch), dim3(256), 0, st, x, xc, L, N,
-                       H, Ttau, ch_stride);
+                       H, Ttau, ch_stride, tau_off);
 }
 
-void launch_stft_unprep(const float *dxc, float *dx, int batch, int L, int N, int H, int Ttau, int ch_stride,
+void launch_stft_unprep(const float *dxc, float *dx, int batch, int L, int N, int H, int Ttau, int ch_stride, int tau_off,
                         hipStream_t st) {
     hipLaunchKernelGGL(stft_unprep_kernel, dim3(ceil_div(L, 256), batch), dim3(256), 0, st, dxc, dx, L, N, H, Ttau,
-                       ch_stride);
+                       ch_stride, tau_off);
 }
 
 }  // namespace agx
@@ -420,7 +486,7 @@ int agx_stft_forward(const float *x, const float *packed, float *y, void *worksp
     const int N = n_fft, H = N / 4, T = int(T64), Ttau = T + 3;
     float *xc = static_cast<float *>(workspace);
     float *cv = xc + size_t(batch) * H * Ttau;
-    launch_stft_prep(x, xc, batch, length, N, H, Ttau, H, st);
+    launch_stft_prep(x, xc, batch, length, N, H, Ttau, H, 0, st);
     agx_conv_desc d{AGX_CONV_PADDED, batch, H, 2 * N, Ttau, 4, 1, 1, 0, 0.f, AGX_IMPL_MFMA, 1, 0};
     ConvPlan p;
     int rc = lower_conv(&d, &p);
@@ -432,14 +498,20 @@ int agx_stft_forward(const float *x, const float *packed, float *y, void *worksp
     return check_launch("agx_stft_forward");
 }
 
+static inline int aligned16(const void *a, const void *b, const void *c, const void *d) {
+    return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+             reinterpret_cast<uintptr_t>(d)) & 15) == 0;
+}
+
 int agx_reduce_mean(const float *x, const float *y, int64_t n, int32_t mode, float *out, float *workspace,
                     void *stream) {
     using namespace agx;
     if (n <= 0 || mode < 0 || mode > 5) return fail(AGX_ERR_BAD_SHAPE, "reduce_mean: bad n / mode");
     if (!x || !out || !workspace || ((mode == 3 || mode == 5) && !y)) return fail(AGX_ERR_NULL_POINTER, "reduce_mean: NULL pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int nb = int(ceil_div64(n, 256) < 1024 ? ceil_div64(n, 256) : 1024);
-    hipLaunchKernelGGL(reduce_partial_kernel, dim3(nb), dim3(256), 0, st, x, y, n, mode, workspace);
+    const int nb = int(ceil_div64(n, 4096) < 1024 ? ceil_div64(n, 4096) : 1024);
+    hipLaunchKernelGGL(reduce_partial_kernel<0>, dim3(nb), dim3(256), 0, st, x, y, n, mode, aligned16(x, y, nullptr, nullptr),
+                       workspace);
     hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, st, workspace, nb, 1.0 / double(n), out);
     return check_launch("agx_reduce_mean");
 }
@@ -449,10 +521,32 @@ int agx_reduce_mean_backward(const float *x, const float *y, int64_t n, int32_t 
     using namespace agx;
     if (n <= 0 || mode < 0 || mode > 5) return fail(AGX_ERR_BAD_SHAPE, "reduce_mean_backward: bad n / mode");
     if (!x || !grad || !dx || ((mode == 3 || mode == 5) && !y)) return fail(AGX_ERR_NULL_POINTER, "reduce_mean_backward: NULL pointer");
-    const int nb = int(ceil_div64(n, 256) < 4096 ? ceil_div64(n, 256) : 4096);
-    hipLaunchKernelGGL(reduce_mean_bwd_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, n, mode,
-                       grad, float(1.0 / double(n)), dx, dy);
+    const int nb = int(ceil_div64(n, 2048) < 8192 ? ceil_div64(n, 2048) : 8192);
+    hipLaunchKernelGGL(reduce_mean_bwd_kernel<0>, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, n, mode,
+                       aligned16(x, y, dx, dy), grad, float(1.0 / double(n)), dx, dy);
     return check_launch("agx_reduce_mean_backward");
+}
+
+int agx_feature_means(const float *x, const float *y, int64_t n, float *out, float *workspace, void *stream) {
+    using namespace agx;
+    if (n <= 0) return fail(AGX_ERR_BAD_SHAPE, "feature_means: n <= 0");
+    if (!x || !y || !out || !workspace) return fail(AGX_ERR_NULL_POINTER, "feature_means: NULL pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nb = int(ceil_div64(n, 4096) < 1024 ? ceil_div64(n, 4096) : 1024);
+    hipLaunchKernelGGL(reduce_partial_kernel<1>, dim3(nb), dim3(256), 0, st, x, y, n, 3, aligned16(x, y, nullptr, nullptr), workspace);
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(2), dim3(256), 0, st, workspace, nb, 1.0 / double(n), out);
+    return check_launch("agx_feature_means");
+}
+
+int agx_feature_means_backward(const float *x, const float *y, int64_t n, const float *grad, float *dx, float *dy,
+                               void *stream) {
+    using namespace agx;
+    if (n <= 0) return fail(AGX_ERR_BAD_SHAPE, "feature_means_backward: n <= 0");
+    if (!x || !y || !grad || (!dx && !dy)) return fail(AGX_ERR_NULL_POINTER, "feature_means_backward: NULL pointer");
+    const int nb = int(ceil_div64(n, 2048) < 8192 ? ceil_div64(n, 2048) : 8192);
+    hipLaunchKernelGGL(reduce_mean_bwd_kernel<1>, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, n, 3,
+                       aligned16(x, y, dx, dy), grad, float(1.0 / double(n)), dx, dy);
+    return check_launch("agx_feature_means_backward");
 }
 
 int agx_sigmoid(const float *x, float *y, int64_t n, void *stream) {
@@ -501,7 +595,7 @@ int agx_stft_backward(const float *dy, const float *packed_bwd, float *dx, void 
     rc = conv_mfma_supported(p) ? launch_conv_mfma(p, cv, packed_bwd, nullptr, nullptr, dxc, st)
                                 : launch_conv_direct(p, cv, packed_bwd, nullptr, nullptr, dxc, st);  // n_fft = 64: 16 rows
     if (rc != AGX_OK) return rc;
-    launch_stft_unprep(dxc, dx, batch, length, N, H, Ttau, H, st);
+    launch_stft_unprep(dxc, dx, batch, length, N, H, Ttau, H, 0, st);
     return check_launch("agx_stft_backward");
 }
 

@@ -809,6 +809,33 @@ def reduce_mean_backward(x: Tensor, mode: int, grad: Tensor, y: Optional[Tensor]
     return dx, dy
 
 
+def feature_means(x: Tensor, y: Tensor) -> Tensor:
+    """(mean|x - y|, mean|x + 1e-3|) of one feature-matching term in one pass: a 2-element device tensor."""
+    lib = _lib.load()
+    _need_gpu(x, y)
+    x, y = _f32c(x), _f32c(y)
+    if x.shape != y.shape:
+        raise AgxError(f"feature_means: shapes differ ({tuple(x.shape)} vs {tuple(y.shape)})")
+    out = torch.empty(2, dtype=torch.float32, device=x.device)
+    ws = torch.empty(2048, dtype=torch.float32, device=x.device)
+    _lib.check(lib.agx_feature_means(_ptr(x), _ptr(y), x.numel(), _ptr(out), _ptr(ws), _stream()), "agx_feature_means")
+    return out
+
+
+def feature_means_backward(x: Tensor, y: Tensor, grad: Tensor, want_dx: bool = True, want_dy: bool = True):
+    lib = _lib.load()
+    _need_gpu(x, y, grad)
+    x, y = _f32c(x), _f32c(y)
+    grad = _f32c(grad.reshape(2))
+    dx = torch.empty_like(x) if want_dx else None
+    dy = torch.empty_like(x) if want_dy else None
+    if dx is None and dy is None:
+        return None, None
+    _lib.check(lib.agx_feature_means_backward(_ptr(x), _ptr(y), x.numel(), _ptr(grad), _ptr(dx), _ptr(dy), _stream()),
+               "agx_feature_means_backward")
+    return dx, dy
+
+
 def sigmoid(x: Tensor) -> Tensor:
     lib = _lib.load()
     _need_gpu(x)

@@ -178,6 +178,9 @@ class MelSpectrogram(nn.Module):
         if n_fft % self.hop_length:
             raise NotImplementedError("the framed-DFT kernel needs hop_length | n_fft")
         self.register_buffer("fb", melscale_fbanks(n_fft // 2 + 1, sample_rate, n_mels), persistent=False)
+        # taps of the framed DFT that meet the window (spectral.hip: fdft_geom) -- only those are executed
+        left = (n_fft - self.win_length) // 2
+        self._taps = -(-(left + self.win_length) // self.hop_length) - left // self.hop_length
         self._img = {}
 
     def _image(self, backward: int, device) -> Tensor:
@@ -208,7 +211,7 @@ class MelSpectrogram(nn.Module):
             _lib.check(int(t), "agx_fdft_frames")
         rows = int(lib.agx_fdft_rows(self.n_fft, 1))
         cv = torch.empty(b, 2 * rows, int(t), dtype=torch.float32, device=x.device)
-        ops.count_macs("fdft_forward", b * self.n_fft * 2 * rows * int(t) + b * rows * self.n_mels * int(t))
+        ops.count_macs("fdft_forward", b * self._taps * self.hop_length * 2 * rows * int(t))
         _lib.check(lib.agx_fdft_forward(_ptr(x), _ptr(self._image(0, x.device)), _ptr(cv), _ptr(self._ws(b, length, x.device)),
                                         b, length, self.n_fft, self.win_length, self.hop_length, 1, _stream()),
                    "agx_fdft_forward")
@@ -224,7 +227,7 @@ class MelSpectrogram(nn.Module):
         _lib.check(lib.agx_melpower_backward(_ptr(cv), _ptr(self.fb), _ptr(dmel), _ptr(dcv), b, self.n_fft // 2 + 1, t,
                                              self.n_mels, _stream()), "agx_melpower_backward")
         dx = torch.empty(b, length, dtype=torch.float32, device=cv.device)
-        ops.count_macs("fdft_backward", b * self.n_fft * cv.shape[1] * t + b * (cv.shape[1] // 2) * self.n_mels * t)
+        ops.count_macs("fdft_backward", b * self._taps * self.hop_length * cv.shape[1] * t)
         _lib.check(lib.agx_fdft_backward(_ptr(dcv), _ptr(self._image(1, cv.device)), _ptr(dx),
                                          _ptr(self._ws(b, length, cv.device)), b, length, self.n_fft, self.win_length,
                                          self.hop_length, 1, _stream()), "agx_fdft_backward")

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AGX_VERSION 117 /* 117: agx_rvq_debug_stamps (diagnostic); 116: agx_multires_backward, agx_layernorm_ct one-pass kernel (same signature); agx_rvq_forward (legacy form) needs the workspace of agx_rvq_workspace_bytes since 114; 115: agx_rvq_ema_stats, agx_conv2d_bwd_data_kernel_name; 114: agx_attention_alibi_backward_ex (any T), agx_rvq_forward_ex; 113: tile images (resblock_p / conv_p), agx_attention_alibi_ex, agx_sizeof_*; 0.1.1: agx_conv_desc gained groups / padding (zero = old behaviour); 111: resample, conv2d column split */
+#define AGX_VERSION 118 /* 118: agx_feature_means(_backward) (the feature-matching pair in one pass); 117: agx_rvq_debug_stamps (diagnostic); 116: agx_multires_backward, agx_layernorm_ct one-pass kernel (same signature); agx_rvq_forward (legacy form) needs the workspace of agx_rvq_workspace_bytes since 114; 115: agx_rvq_ema_stats, agx_conv2d_bwd_data_kernel_name; 114: agx_attention_alibi_backward_ex (any T), agx_rvq_forward_ex; 113: tile images (resblock_p / conv_p), agx_attention_alibi_ex, agx_sizeof_*; 0.1.1: agx_conv_desc gained groups / padding (zero = old behaviour); 111: resample, conv2d column split */
 
 #define AGX_OK 0
 #define AGX_ERR_BAD_SHAPE (-1)
@@ -453,6 +453,13 @@ int agx_reduce_mean(const float *x, const float *y, int64_t n, int32_t mode, flo
 /* Gradient of the above: dx = grad[0] * d mean(term) / dx (and dy = -dx for the L1 term; dy may be NULL). */
 int agx_reduce_mean_backward(const float *x, const float *y, int64_t n, int32_t mode, const float *grad, float *dx,
                              float *dy, void *stream);
+/* The two means of one feature-matching term (discriminator.py:236-243: mean|x - y| and the scale mean|x + 1e-3| of the
+ * real feature map) in ONE pass over the pair: out[0] = mean|x - y|, out[1] = mean|x + 1e-3| -- the same values as modes 3
+ * and 4 above give.  workspace: 2048 floats.  backward: dx = grad[0] d out[0] / dx + grad[1] d out[1] / dx,
+ * dy = grad[0] d out[0] / dy (either may be NULL) -- bit for bit the sum of the two separate gradients. */
+int agx_feature_means(const float *x, const float *y, int64_t n, float *out, float *workspace, void *stream);
+int agx_feature_means_backward(const float *x, const float *y, int64_t n, const float *grad, float *dx, float *dy,
+                               void *stream);
 /* final_activation of the discriminators (torch.nn.Sigmoid, discriminator.py:46, 173). */
 int agx_sigmoid(const float *x, float *y, int64_t n, void *stream);
 

@@ -566,3 +566,73 @@ def test_weight_normalised_discriminators_match_torch():
         same(gy, yc.grad)
         for n, g in got.items():
             same(g, params[n].grad)
+
+
+@pytest.mark.parametrize("n", [1, 7, 4096, 1 << 20, (1 << 22) + 1027, 3 * 5 * 7 * 11 * 13 * 17 * 4 + 3])
+@pytest.mark.parametrize("mode", [ops.REDUCE_MEAN, ops.REDUCE_HINGE_REAL, ops.REDUCE_HINGE_FAKE, ops.REDUCE_L1,
+                                  ops.REDUCE_ABS_EPS])
+def test_reductions_16_byte_path_edges_and_misaligned_views(n, mode):
+    """The 16-byte-load form of the loss reductions: lengths that are not multiples of 4 (scalar tail), lengths below one
+    vector, and operands that start 4 bytes into an allocation (the 4-byte path) -- against float64 of the same term."""
+    g = torch.Generator().manual_seed(n % 1000 + mode)
+    for off in (0, 1):
+        xb = torch.randn(n + 1, generator=g).to(DEV)
+        yb = torch.randn(n + 1, generator=g).to(DEV)
+        x, y = xb[off:off + n], yb[off:off + n]
+        two = mode == ops.REDUCE_L1
+        out = ops.reduce_mean(x, mode, y if two else None)
+        xd, yd = x.double(), y.double()
+        ref = {ops.REDUCE_MEAN: xd, ops.REDUCE_HINGE_REAL: torch.clamp(xd - 1, max=0),
+               ops.REDUCE_HINGE_FAKE: torch.clamp(-xd - 1, max=0), ops.REDUCE_L1: (xd - yd).abs(),
+               ops.REDUCE_ABS_EPS: (xd.float() + 1e-3).double().abs()}[mode].mean()
+        assert abs(float(out) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref))) + 2e-7
+        gr = torch.tensor([0.75], device=DEV)
+        dx, dy = ops.reduce_mean_backward(x, mode, gr, y if two else None, two)
+        s = 0.75 * float(torch.tensor(1.0 / n, dtype=torch.float64).float())
+        want = {ops.REDUCE_MEAN: torch.ones_like(x), ops.REDUCE_HINGE_REAL: (x - 1 < 0).float(),
+                ops.REDUCE_HINGE_FAKE: -((-x - 1) < 0).float(), ops.REDUCE_L1: torch.sign(x - y),
+                ops.REDUCE_ABS_EPS: torch.sign(x + 1e-3)}[mode] * torch.tensor(0.75, device=DEV) * float(
+                    torch.tensor(1.0 / n, dtype=torch.float64).float())
+        assert torch.allclose(dx, want, rtol=1e-6, atol=0), (n, mode, off, s)
+        if two:
+            assert torch.equal(dy, -dx)
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 7, 9), (2, 32, 70, 64), (1, 16, 72000), (4, 1027)])
+def test_feature_means_equal_the_two_separate_means_bit_for_bit(shape):
+    """agx_feature_means: one pass over (x, y) for mean|x - y| and mean|x + 1e-3| -- values and gradients are those of
+    agx_reduce_mean modes 3 and 4 (and the sum of their two gradients), bit for bit (discriminator.py:236-243)."""
+    torch.manual_seed(sum(shape))
+    x, y = torch.randn(*shape, device=DEV), torch.randn(*shape, device=DEV)
+    y.view(-1)[::5] = x.view(-1)[::5]                        # exact ties: sign(0) = 0
+    x.view(-1)[1::7] = -1e-3                                 # ... and |x + 1e-3| at its kink
+    pair = ops.feature_means(x, y)
+    assert float(pair[0]) == float(ops.reduce_mean(x, ops.REDUCE_L1, y))
+    assert float(pair[1]) == float(ops.reduce_mean(x, ops.REDUCE_ABS_EPS))
+    g = torch.tensor([0.37, -1.9], device=DEV)
+    dx, dy = ops.feature_means_backward(x, y, g)
+    dx1, dy1 = ops.reduce_mean_backward(x, ops.REDUCE_L1, g[0:1].clone(), y, True)
+    dx2, _ = ops.reduce_mean_backward(x, ops.REDUCE_ABS_EPS, g[1:2].clone())
+    assert torch.equal(dx, dx1 + dx2) and torch.equal(dy, dy1)
+    only_dy = ops.feature_means_backward(x, y, g, want_dx=False)
+    assert only_dy[0] is None and torch.equal(only_dy[1], dy1)
+
+
+def test_feature_matching_term_through_autograd_matches_the_two_mean_form():
+    """discriminator_generator_loss's scaled feature term built from _FeatureMeans vs the same term built from the two
+    separate _mean calls: loss and both gradients identical."""
+    from audio_generation_amd.discriminator import _FeatureMeans, _mean
+    torch.manual_seed(5)
+    x0, y0 = torch.randn(2, 8, 33, 17, device=DEV), torch.randn(2, 8, 33, 17, device=DEV)
+    res = []
+    for fused in (True, False):
+        x, y = x0.clone().requires_grad_(True), y0.clone().requires_grad_(True)
+        if fused:
+            pair = _FeatureMeans.apply(x, y)
+            loss = pair[0] / 13 / pair[1]
+        else:
+            loss = _mean(ops.REDUCE_L1, x, y) / 13 / _mean(ops.REDUCE_ABS_EPS, x)
+        (100 * loss).backward()
+        res.append((loss.detach(), x.grad, y.grad))
+    assert float(res[0][0]) == float(res[1][0])
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
