@@ -26,6 +26,8 @@ struct Tuning {
                         // 1 the same with MFMA / VALU interleave hints, 2 split before the MFMAs
     int dw2_shared = 2; // conv2d weight gradient: workgroup-shared operand slots + one barrier per item for 1 = the 128-row tiles, 2 = also the
                         // 64- / 32-row tiles (64 -> 64 3 x 3: 81 -> 90 TFLOP/s since the DMA issue is cheap), 0 = wave-private buffers
+    int c2b3_sl = 0;    // conv2d_b3 tile split R x 2^SL: 0 = cost model (padded area x (matrix time + staging rounds)), -1 = least padded area
+                        // with ties to the widest rows (the first rule), 3..7 = forced where the tile has it
     int dw2_prepad = 1; // conv2d weight gradient of maps narrower than 32 columns: 1 = the shared kernel on zero-padded flattened copies, 0 = staged kernel
     int dw2_bf = 1;     // conv2d weight gradient of bf16x3 descriptors on the shared kernel: 1 = bf16x3 contraction, 0 = fp32 (exact)
     int dw2_direct = 2; // conv2d weight gradient on the barrier-free LDS-DMA kernel: 1 = stride-1 "same" layers, 2 = also the column-strided

@@ -725,27 +725,84 @@ int conv2d_b3_geometry(const ConvPlan &p) {
     return tile == C2B3_NONE ? C2B3_NONE : (tile | (taps << 4));
 }
 
-// tile rows R = BN >> SL of WF = 2^SL columns over the base grid: the split with the least padded area
-static int c2b3_pick_sl(const ConvPlan &p, int BN, int sl_max) {
+// tile rows R = BN >> SL of WF = 2^SL columns over the base grid.  A tile costs its matrix time (the same for every split) plus
+// the staging of its input planes -- (R + kh - 1)(WF + kw - 1) positions x 2 halves of 8 channels in rounds of 256 threads, ~450
+// cycles a round against 32 cycles per MFMA: two rows of 128 columns stage 1040 tasks = 5 rounds, eight rows of 32 columns 680 =
+// 3 -- so the split minimises (padded area) x (matrix cycles + rounds x (450 + 3200 / WF)) per 16-channel chunk; measured on the
+// window-1024 discriminator: 64 -> 64 3 x 3 127 -> 158 TFLOP/s, the 32-row layers 88 -> 97, the (3,4)/(1,2) forward 86 -> 123.  (c2b3_sl = -1: the first rule,
+// least padded area with ties to the widest rows.)
+// kh, kw, frags: the kernel's taps and MFMA tiles per wave (MW x NW); frags = 0: the padded area alone (the support gate)
+static int c2b3_pick_sl(const ConvPlan &p, int BN, int sl_max, int kh, int kw, int frags) {
+    const int forced = frags ? tuning().c2b3_sl : -1;
+    if (forced >= 3) return forced < sl_max ? forced : sl_max;
+    const int64_t mfma = int64_t(kh) * kw * frags * 6 * 32;      // per wave and chunk
     int best = 3;
-    int64_t best_area = -1;
+    int64_t best_cost = -1;
     for (int sl = 3; sl <= sl_max; ++sl) {
         const int R = BN >> sl, WF = 1 << sl;
         if (R < 1) continue;
         const int64_t area = int64_t(ceil_div(p.Tt, R)) * R * ceil_div(p.Lt, WF) * WF;
-        if (best_area < 0 || area <= best_area) best = sl, best_area = area;     // (ties: the wider rows -- fewer halo columns)
+        const int rounds = ceil_div(2 * (R + kh - 1) * (WF + kw - 1), 256);
+        const int64_t cost = forced < 0 ? area : area * (mfma + rounds * (450 + 3200 / WF));   // (short rows: shorter runs in memory)
+        if (best_cost < 0 || cost <= best_cost) best = sl, best_cost = cost;     // (ties: the wider rows -- longer runs in memory)
     }
     return best;
 }
+
+// Backward-data of a column-strided layer: the base grid of the phase GEMM has Lt = W / sw + 1 positions (513, 257, ...), one more
+// than whole power-of-two blocks, and its first position only produces output column 0.  As on the fp32 ring (conv_p.hip:
+// conv2d_bwd_first_cols_kernel) the ring kernel runs f' = 1 .. Lt - 1 and this kernel the first column, in fp32 on the weights
+// h + m + l of the standard bf16x3 image (exact: the three pieces hold the 24 bits of the fp32 weight):
+//   dx[ci, QH t' + a - oshift_h, 0] = sum_{co, jh} W[co][jh Jw + Jw - 1][m] dy[co, t' - ph + jh, 0],   m = (ci QH + a) Q + oshift.
+// One workgroup per (clip, base row); the dy column sits in LDS; four lanes share a row m.
+__global__ __launch_bounds__(256) void conv2d_b3_first_col_kernel(ConvPlan p, const float *__restrict__ dy,
+                                                                  const __bf16 *__restrict__ img, const float *__restrict__ add,
+                                                                  const float *__restrict__ mask, float *__restrict__ dx) {
+    extern __shared__ float dcol[];   // [kh][Cin]
+    const int bq = blockIdx.x / p.Tt, trow = blockIdx.x - bq * p.Tt;
+    const int Jw = p.J / p.kh, nv = p.kh * p.Cin;
+    for (int v = threadIdx.x; v < nv; v += 256) {
+        const int jh = v / p.Cin, co = v - jh * p.Cin;
+        const int r = trow - p.ph + jh;
+        dcol[v] = (r >= 0 && r < p.Tin) ? dy[(size_t(bq) * p.Cin + co) * p.x_cstride + size_t(r) * p.Lin] : 0.f;
+    }
+    __syncthreads();
+    const int rows = p.M / p.q, sub = threadIdx.x & 3;
+    for (int mq = threadIdx.x >> 2; mq < rows; mq += 64) {
+        const int m = mq * p.q + p.oshift;
+        const int ci = mq / p.qh, a = mq - ci * p.qh;
+        const int orow = p.qh * trow + a - p.oshift_h;
+        float acc = 0.f;
+        for (int v = sub; v < nv; v += 4) {       // (jh, co): 4 lanes x every 4th virtual channel, fixed order
+            const int jh = v / p.Cin, co = v - jh * p.Cin;
+            const __bf16 *w = img + ((size_t(co >> 4) * p.J + jh * Jw + (Jw - 1)) * p.M + m) * 48 + (co & 15);
+            acc = fmaf(((float)w[0] + (float)w[16]) + (float)w[32], dcol[v], acc);
+        }
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        if (sub != 0 || orow < 0 || orow >= p.Tout) continue;
+        const size_t o = (size_t(bq) * p.Cout + ci) * p.y_cstride + size_t(orow) * p.Lout;
+        if (add) acc += add[o];
+        if (mask) acc = mask[o] > 0.f ? acc : acc * p.slope;
+        dx[o] = acc;
+    }
+}
+
+// the plan the ring kernel runs once the first base column is peeled off (above)
+// (worth it on wide maps only: the first column is 1 / Lt of the layer's work on a scalar kernel -- base grids of 513 / 257 columns
+// 2.07 -> 1.75 ms and 2.53 -> 2.24 ms, 129 and narrower lose)
+static inline bool c2b3_peels_first_col(const ConvPlan &p) { return p.q == 2 && p.oshift == 1 && p.P == 1 && p.Lt > 192; }
 
 bool conv2d_b3_supported(const ConvPlan &p) {
     const int geom = conv2d_b3_geometry(p), tile = geom & 15;
     if (p.tile_off < 0 || geom == C2B3_NONE) return false;
     {   // very narrow / ragged feature maps: beyond 1.4 x padded area the fp32 ring kernel wins
-        const int BN = tile == C2B3_M128 ? 128 : 256, sl = c2b3_pick_sl(p, BN, tile == C2B3_M128 ? 6 : 7);
+        ConvPlan pp = p;
+        if (c2b3_peels_first_col(p)) pp.Lt = p.Lt - 1;
+        const int BN = tile == C2B3_M128 ? 128 : 256, sl = c2b3_pick_sl(pp, BN, tile == C2B3_M128 ? 6 : 7, 1, 1, 0);
         const int R = BN >> sl, WF = 1 << sl;
-        const int64_t area = int64_t(ceil_div(p.Tt, R)) * R * ceil_div(p.Lt, WF) * WF;
-        if (area * 10 > int64_t(p.Tt) * p.Lt * 14) return false;
+        const int64_t area = int64_t(ceil_div(pp.Tt, R)) * R * ceil_div(pp.Lt, WF) * WF;
+        if (area * 10 > int64_t(pp.Tt) * pp.Lt * 14) return false;
     }
     if ((p.epilogue & ~(AGX_EPI_LEAKY_PRE | AGX_EPI_RESIDUAL | AGX_EPI_MASK)) != 0) return false;
     if (p.x_cstride != int64_t(p.Tin) * p.Lin || p.y_cstride != int64_t(p.Tout) * p.Lout) return false;
@@ -796,7 +853,7 @@ static int launch_c2b3(const ConvPlan &p, const float *x, const float *wp, const
 template <int MW, int NW, int WM, int SLMAX, int KH, int KW, int Q, int QH>
 static int launch_c2b3_sl(const ConvPlan &p, const float *x, const float *wp, const float *bias, const float *add,
                           const float *mask, float *y, hipStream_t st) {
-    const int sl = c2b3_pick_sl(p, 32 * NW * (4 / WM), SLMAX);
+    const int sl = c2b3_pick_sl(p, 32 * NW * (4 / WM), SLMAX, KH, KW, MW * NW);
     if (sl == 3) return launch_c2b3<MW, NW, WM, 3, KH, KW, Q, QH>(p, x, wp, bias, add, mask, y, st);
     if (sl == 4) return launch_c2b3<MW, NW, WM, 4, KH, KW, Q, QH>(p, x, wp, bias, add, mask, y, st);
     if (sl == 5) return launch_c2b3<MW, NW, WM, 5, KH, KW, Q, QH>(p, x, wp, bias, add, mask, y, st);
@@ -827,11 +884,18 @@ int launch_conv2d_b3(const ConvPlan &p, const float *x, const float *wp, const f
         return (geom >> 4) == C2B3_T22F ? launch_c2b3_tile<2, 2, 1, 1>(geom & 15, v, x, wp, bias, res, y, st)
                                         : launch_c2b3_tile<3, 2, 1, 1>(geom & 15, v, x, wp, bias, res, y, st);
     }
-    switch (geom >> 4) {
-        case C2B3_T33: return launch_c2b3_tile<3, 3, 1, 1>(geom & 15, p, x, wp, bias, res, y, st);
-        case C2B3_T22: return launch_c2b3_tile<2, 2, 2, 2>(geom & 15, p, x, wp, bias, res, y, st);
-        default: return launch_c2b3_tile<3, 2, 2, 1>(geom & 15, p, x, wp, bias, res, y, st);
+    if ((geom >> 4) == C2B3_T33) return launch_c2b3_tile<3, 3, 1, 1>(geom & 15, p, x, wp, bias, res, y, st);
+    ConvPlan pp = p;
+    if (c2b3_peels_first_col(p)) {      // column phases: base position 0 (output column 0) on its own kernel, whole blocks for the ring
+        if (int64_t(p.B) * p.Tt > (int64_t(1) << 30)) return fail(AGX_ERR_BAD_SHAPE, "conv2d_b3: grid too large");
+        hipLaunchKernelGGL(conv2d_b3_first_col_kernel, dim3(p.B * p.Tt), dim3(256), size_t(p.kh) * p.Cin * sizeof(float), st, p, x,
+                           reinterpret_cast<const __bf16 *>(wp), res, p.mask, y);
+        pp.Lt = p.Lt - 1;
+        pp.oshift = p.oshift - 2;
+        pp.P = p.P - 1;
     }
+    return (geom >> 4) == C2B3_T22 ? launch_c2b3_tile<2, 2, 2, 2>(geom & 15, pp, x, wp, bias, res, y, st)
+                                   : launch_c2b3_tile<3, 2, 2, 1>(geom & 15, pp, x, wp, bias, res, y, st);
 }
 
 }  // namespace agx

@@ -240,6 +240,7 @@ int agx_set_tuning(const char *name, int32_t value) {
     else if (!strcmp(name, "dw_xcd")) agx::tuning().dw_xcd = value;
     else if (!strcmp(name, "dw2_bf")) agx::tuning().dw2_bf = value;
     else if (!strcmp(name, "dw2_prepad")) agx::tuning().dw2_prepad = value;
+    else if (!strcmp(name, "c2b3_sl")) agx::tuning().c2b3_sl = value;
     else if (!strcmp(name, "dw_direct")) agx::tuning().dw_direct = value;
     else if (!strcmp(name, "dw1_wgs")) agx::tuning().dw1_wgs = value;
     else if (!strcmp(name, "conv_cc")) agx::tuning().conv_cc = value;
@@ -266,6 +267,7 @@ int agx_get_tuning(const char *name) {
     if (!strcmp(name, "dw_xcd")) return agx::tuning().dw_xcd;
     if (!strcmp(name, "dw2_bf")) return agx::tuning().dw2_bf;
     if (!strcmp(name, "dw2_prepad")) return agx::tuning().dw2_prepad;
+    if (!strcmp(name, "c2b3_sl")) return agx::tuning().c2b3_sl;
     if (!strcmp(name, "dw_direct")) return agx::tuning().dw_direct;
     if (!strcmp(name, "dw1_wgs")) return agx::tuning().dw1_wgs;
     if (!strcmp(name, "conv_cc")) return agx::tuning().conv_cc;

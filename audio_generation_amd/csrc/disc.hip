@@ -280,6 +280,8 @@ __global__ __launch_bounds__(256) void reduce_partial_kernel(const float *__rest
     float acc[4] = {0.f, 0.f, 0.f, 0.f}, bcc[4] = {0.f, 0.f, 0.f, 0.f};
     const int64_t stride = int64_t(gridDim.x) * 256, first = int64_t(blockIdx.x) * 256 + threadIdx.x;
     const int64_t n4 = vec ? n >> 2 : 0;
+    // a workgroup sweeps 16 KB contiguous per operand and step, consecutive workgroups consecutive 16 KB (four loads of one
+    // thread 4 MB apart -- the grid-stride form -- land in the same memory channel)
     auto term = [&](float a, float b, int u) {
         if (PAIR) { acc[u] += fabsf(a - b); bcc[u] += fabsf(a + 1e-3f); }
         else acc[u] += loss_term(mode, a, b);
@@ -287,17 +289,19 @@ __global__ __launch_bounds__(256) void reduce_partial_kernel(const float *__rest
     auto quad = [&](const float4 a, const float4 b, int u) { term(a.x, b.x, u); term(a.y, b.y, u); term(a.z, b.z, u); term(a.w, b.w, u); };
     const float4 *x4 = reinterpret_cast<const float4 *>(x), *y4 = reinterpret_cast<const float4 *>(y);
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    int64_t i = first;
-    for (; i + 3 * stride < n4; i += 4 * stride) {
+    int64_t i = int64_t(blockIdx.x) * 1024 + threadIdx.x;
+    for (; i - threadIdx.x + 1024 <= n4; i += 4 * stride) {
         float4 a[4], b[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) a[u] = x4[i + u * stride];
+        for (int u = 0; u < 4; ++u) a[u] = x4[i + u * 256];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) b[u] = two ? y4[i + u * stride] : z4;
+        for (int u = 0; u < 4; ++u) b[u] = two ? y4[i + u * 256] : z4;
 #pragma unroll
         for (int u = 0; u < 4; ++u) quad(a[u], b[u], u);
     }
-    for (; i < n4; i += stride) quad(x4[i], two ? y4[i] : z4, 0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)      // the workgroup that meets the end of the vector part: its last, partial 16 KB
+        if (i - threadIdx.x < n4 && i + u * 256 < n4) quad(x4[i + u * 256], two ? y4[i + u * 256] : z4, u);
     for (int64_t e = 4 * n4 + first; e < n; e += stride) term(x[e], two ? y[e] : 0.f, 0);
     const float tot = block_sum_256((acc[0] + acc[1]) + (acc[2] + acc[3]), sh);
     if (threadIdx.x == 0) part[blockIdx.x] = tot;
@@ -367,14 +371,16 @@ __global__ __launch_bounds__(256) void reduce_mean_bwd_kernel(const float *__res
         if (dx) dx4[i] = ox;
         if (two && dy) dy4[i] = oy;
     };
-    int64_t i = first;
-    for (; i + stride < n4; i += 2 * stride) {
-        const float4 a0 = x4[i], a1 = x4[i + stride];
-        const float4 b0 = two ? y4[i] : z4, b1 = two ? y4[i + stride] : z4;
+    int64_t i = int64_t(blockIdx.x) * 512 + threadIdx.x;      // 8 KB contiguous per operand, workgroup and step (see above)
+    for (; i - threadIdx.x + 512 <= n4; i += 2 * stride) {
+        const float4 a0 = x4[i], a1 = x4[i + 256];
+        const float4 b0 = two ? y4[i] : z4, b1 = two ? y4[i + 256] : z4;
         quad(i, a0, b0);
-        quad(i + stride, a1, b1);
+        quad(i + 256, a1, b1);
     }
-    for (; i < n4; i += stride) quad(i, x4[i], two ? y4[i] : z4);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (i - threadIdx.x < n4 && i + u * 256 < n4) quad(i + u * 256, x4[i + u * 256], two ? y4[i + u * 256] : z4);
     for (int64_t e = 4 * n4 + first; e < n; e += stride) {
         float ox, oy;
         one(x[e], two ? y[e] : 0.f, ox, oy);

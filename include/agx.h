@@ -62,6 +62,8 @@ int32_t agx_sizeof_conv2d_desc(void);
  *   "dw_wgs" n         workgroups the conv2d weight-gradient kernel aims for (default 1536)
  *   "dw2_prepad" 0|1   conv2d weight gradient of feature maps narrower than 32 columns: 1 (default) the shared kernel on zero-padded,
  *                      phase-split, flattened copies of x and dy; 0 the staged kernel
+ *   "c2b3_sl" -1|0|3..7  bf16x3 Conv2d ring kernel, split of a tile into R rows of 2^SL columns: 0 (default) the split with the least
+ *                      padded area x (matrix time + input staging rounds), -1 the least padded area alone, 3..7 forced
  *   "dw2_bf" 0|1       conv2d weight gradient of AGX_IMPL_MFMA_BF16X3 descriptors on the shared kernel: 1 (default) bf16x3
  *                      contraction (both operands split in registers), 0 the fp32 contraction
  *   "dw_xcd" 0|1       conv2d weight gradient: 1 (default) XCD-aware block order -- the tiles of one contraction slice share an L2

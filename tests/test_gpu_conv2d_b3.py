@@ -88,7 +88,7 @@ def test_backward_data_matches_autograd(shape, epi):
 
 
 # (batch, c_in, c_out, h, w, kh, kw, sh, sw): the strided layers of the STFT discriminators (discriminator.py:119-139)
-STRIDED = [          # (widths chosen so that the base grid -- ceil((w + 1) / 2) columns -- fills the tiles: the launcher refuses the rest)
+STRIDED = [          # (narrow maps: widths chosen so that the base grid -- ceil((w + 1) / 2) columns -- fills the tiles, the launcher refuses the rest)
     (2, 32, 64, 21, 62, 3, 4, 1, 2),
     (2, 64, 128, 22, 62, 4, 4, 2, 2),
     (1, 128, 128, 17, 126, 3, 4, 1, 2),
@@ -96,7 +96,11 @@ STRIDED = [          # (widths chosen so that the base grid -- ceil((w + 1) / 2)
     (2, 256, 512, 10, 30, 4, 4, 2, 2),
     (1, 256, 256, 33, 30, 3, 4, 1, 2),
     (2, 64, 128, 61, 250, 4, 4, 2, 2),      # ragged base grid, several column blocks
+    # base grids wider than 192 columns: output column 0 on conv2d_b3_first_col_kernel, the ring on the other w / 2 (whole blocks)
     (1, 64, 128, 282, 512, 4, 4, 2, 2),     # a real layer: base grid 142 x 257
+    (1, 32, 64, 9, 512, 3, 4, 1, 2),
+    (1, 128, 128, 5, 384, 4, 4, 2, 2),      # 193 -> 1 + 192
+    (1, 64, 64, 7, 1000, 3, 4, 1, 2),       # 501 -> 1 + 500: ragged after the first column as well
 ]
 
 

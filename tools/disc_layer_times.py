@@ -42,7 +42,8 @@ def main():
         for c in convs:
             y = c.run2d(h, None)
             tape = c._tape
-            desc = c.desc2d(h)
+            desc = c.desc2d(h, bwd=True)
+            names = (ops.conv2d_kernel_name(c.desc2d(h, 0.2)).split("(")[0], ops.conv2d_bwd_data_kernel_name(desc).split("(")[0])
             w = c.raw_weight.detach()
             pk = ops.conv2d_pack_bwd(desc, w, tape[0])
             dy = torch.randn_like(y)
@@ -57,7 +58,7 @@ def main():
             fl = 2.0 * y.numel() * c.in_channels * c.kernel_size[0] * c.kernel_size[1]
             print(f"{c.in_channels:4d}->{c.out_channels:4d} k{tuple(c.kernel_size)} s{tuple(c.stride)} in {tuple(h.shape[2:])}: "
                   f"fwd {tf:7.3f} ms ({fl / tf * 1e-9:5.1f} TF)  dx {tx:7.3f} ms ({fl / tx * 1e-9:5.1f} TF)  "
-                  f"dW {tw:7.3f} ms ({fl / tw * 1e-9:5.1f} TF)")
+                  f"dW {tw:7.3f} ms ({fl / tw * 1e-9:5.1f} TF)   [{names[0]} | {names[1]}]")
             tot[0] += tf; tot[1] += tx; tot[2] += tw
             h = y
         print(f"total fwd {tot[0]:.2f}  dx {tot[1]:.2f}  dW {tot[2]:.2f} ms")
