@@ -15,6 +15,10 @@
 // consecutive, so those reads hit L2, and the split hides under the partner workgroup's MFMAs.
 #include "mfma_tile.hpp"
 
+#ifndef C2B3_GT3
+#define C2B3_GT3 1   // conv2d_b3_kernel: weight groups of three taps on the 32- / 64-row tiles
+#endif
+
 namespace agx {
 
 typedef __bf16 cb3x8 __attribute__((ext_vector_type(8)));
@@ -333,9 +337,12 @@ struct C2b3Geom {
     static constexpr int NPW = WSLOT_B / 1024;
     static constexpr int RW = (NPW + 3) / 4;
     static constexpr int NT = (2 * W + 255) / 256;
-    static constexpr int NGRP = (J + 1) / 2;
     static constexpr int OFF_W = (PLANE_B + 1023) / 1024 * 1024;
-    static constexpr size_t LDS_BYTES = size_t(OFF_W) + 4 * WSLOT_B;
+    // taps per weight group (= per workgroup barrier): 2; 3 for the 32- / 64-row tiles, whose groups of two taps are only 0.6 / 1.1 k
+    // MFMA cycles apart -- their waves spent 32-40 % of the time in barriers and waits (PMC), the 128-row tiles 18-27 %
+    static constexpr int GT = (C2B3_GT3 && BM <= 64 && J >= 6 && OFF_W + 6 * WSLOT_B <= 80 * 1024) ? 3 : 2;
+    static constexpr int NGRP = (J + GT - 1) / GT;
+    static constexpr size_t LDS_BYTES = size_t(OFF_W) + 2 * GT * WSLOT_B;
     static_assert(R >= 1 && WF >= 8, "tile rows / columns");
     __host__ __device__ static constexpr int tap(int j) { return (j / KW) * SWP + (j % KW); }
 };
@@ -385,10 +392,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_b3_kernel(ConvPlan p, int cb_co
     auto dma_next_group = [&]() {
         const bool live = w_k < my_tiles;
         const int chunk = w_g / G::NGRP, which = w_g % G::NGRP;
-        const int set2 = (w_g & 1) * 2;
+        const int set2 = (w_g & 1) * G::GT;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int j = 2 * which + i;
+        for (int i = 0; i < G::GT; ++i) {
+            const int j = G::GT * which + i;
             const bool valid = live && j < J;
             const char *src0 = wt + (size_t(chunk) * J + (valid ? j : 0)) * 6 * size_t(M) * 16 + size_t(w_m0) * 16;
             char *dst0 = lds + G::OFF_W + (set2 + i) * G::WSLOT_B;
@@ -520,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_b3_kernel(ConvPlan p, int cb_co
                         const int step = j * NW + kk;
                         const int sb = (cc * NSTEP + step) & 1;
                         const bool last_of_phase = kk == NW - 1;
-                        const bool group_end = last_of_phase && ((j & 1) == 1 || j == J - 1);
+                        const bool group_end = last_of_phase && (j % G::GT == G::GT - 1 || j == J - 1);
                         const bool chunk_end = last_of_phase && j == J - 1;
                         if (group_end) {      // early barrier: this group's last operands are in registers
                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -536,7 +543,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_b3_kernel(ConvPlan p, int cb_co
                         int nj = j, nk = kk + 1, ncc = cc;
                         if (nk == NW) nk = 0, ++nj;
                         if (nj == J) nj = 0, ncc = cc ^ 1;      // (two chunks = ten groups: the parity is back where it started)
-                        const int nslot = ((ncc * G::NGRP + (nj >> 1)) & 1) * 2 + (nj & 1);
+                        const int nslot = ((ncc * G::NGRP + nj / G::GT) & 1) * G::GT + nj % G::GT;
                         if (!chunk_end) {      // (the next chunk's planes only exist behind the second barrier below)
                             if (nk == 0) load_a(fa[ua ^ 1], nslot);
                             load_b(fb[sb ^ 1], G::tap(nj), nk);

@@ -23,6 +23,9 @@ def timeit(fn, reps=3):
 
 
 def main():
+    if os.environ.get("AGX_LIB"):      # A/B against a variant build of the library (measurement only)
+        from audio_generation_amd import _lib as _l
+        _l.LIB_PATH = os.path.abspath(os.environ["AGX_LIB"])
     win = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     b = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     dev = "cuda"
