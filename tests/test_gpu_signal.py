@@ -57,6 +57,27 @@ def test_mel_spectrogram(window):
     close(got, want, 5e-5)
 
 
+@pytest.mark.parametrize("n_fft,win,hop", [(512, 96, 32), (400, 100, 25), (512, 200, 64), (256, 256, 64), (512, 30, 8), (1024, 1000, 256)])
+def test_mel_spectrogram_windows_that_start_inside_a_tap(n_fft, win, hop):
+    """The framed DFT keeps only the taps that meet the window (spectral.hip: fdft_geom): windows whose support starts / ends
+    inside a hop (left = (n_fft - win) / 2 not a multiple of hop), odd lengths, the full window -- forward against
+    torch.stft in float64 (the call torchaudio makes), and the gradient against autograd through it."""
+    torch.manual_seed(n_fft + win)
+    x = (0.2 * torch.randn(2, 3000)).double().requires_grad_(True)
+    w = torch.hann_window(win, periodic=True, dtype=torch.float64)
+    st = torch.stft(x, n_fft, hop, win, window=w, center=True, pad_mode="reflect", normalized=False, return_complex=True)
+    fb = osg.mel_fbanks(n_fft // 2 + 1, 24000, 40).double()
+    want = torch.einsum("bft,fm->bmt", (st.real ** 2 + st.imag ** 2) / float((w * w).sum()), fb)
+    g = torch.randn_like(want)
+    want.backward(g)
+    spec = sg.MelSpectrogram(24000, n_fft, win, hop, 40, True).to(DEV)
+    xd = x.detach().float().to(DEV).requires_grad_(True)
+    got = spec(xd)
+    close(got, want.detach().float(), 5e-5)
+    got.backward(g.float().to(DEV))
+    close(xd.grad, x.grad.float(), 5e-5)
+
+
 def test_multispectral_loss_and_gradient():
     torch.manual_seed(1)
     orig = 0.2 * torch.randn(2, 1, 8000)
