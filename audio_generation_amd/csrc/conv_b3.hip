@@ -352,6 +352,18 @@ struct C2b3Geom {
 // lower_conv2d_bwd_data): (2, 2, 2, 2) for the 4 x 4 stride-(2, 2) layers, (3, 2, 2, 1) for the 3 x 4 stride-(1, 2) ones -- the tile
 // walks the BASE grid Tt x Lt, row m = (ci QH + a) Q + c of base position (t', f') goes to output (ci, QH t' + a - oshift_h,
 // Q f' + c - oshift).
+// probe build (-DC2B3_STAMPS, tools/c2b3_stamps.py): per wave, the cycles of conv2d_b3_kernel by segment, summed over the kernel
+#ifdef C2B3_STAMPS
+__device__ unsigned long long g_c2b3_stamps[1 << 16];
+#define C2S_START() do { __builtin_amdgcn_sched_barrier(0); c2s_prev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define C2S(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); c2s[k] += tn_ - c2s_prev; c2s_prev = tn_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define C2S_WRITE() do { if (lane == 0 && (int(blockIdx.x) * 4 + wave) * 8 + 8 <= (1 << 16)) for (int k_ = 0; k_ < 8; ++k_) g_c2b3_stamps[(int(blockIdx.x) * 4 + wave) * 8 + k_] = c2s[k_]; } while (0)
+#else
+#define C2S_START() ((void)0)
+#define C2S(k) ((void)0)
+#define C2S_WRITE() ((void)0)
+#endif
+
 template <int MW, int NW, int WM, int SL, int KH, int KW, int Q, int QH>
 __global__ __launch_bounds__(256, 2) void conv2d_b3_kernel(ConvPlan p, int cb_count, int rb_count, int mb_count, int ntiles,
                                                            const float *__restrict__ x, const char *__restrict__ wt,
@@ -502,6 +514,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_b3_kernel(ConvPlan p, int cb_co
     input_load();
 
     cb3x8 fa[2][3][MW], fb[2][3];
+#ifdef C2B3_STAMPS
+    unsigned long long c2s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c2s_prev = 0;
+#endif
+    C2S_START();
     for (int k = 0; k < my_tiles; ++k) {
         int b, rb, cb, mb;
         decode(int(blockIdx.x) + k * int(gridDim.x), b, rb, cb, mb);
@@ -529,10 +545,14 @@ __global__ __launch_bounds__(256, 2) void conv2d_b3_kernel(ConvPlan p, int cb_co
                         const bool last_of_phase = kk == NW - 1;
                         const bool group_end = last_of_phase && (j % G::GT == G::GT - 1 || j == J - 1);
                         const bool chunk_end = last_of_phase && j == J - 1;
+                        C2S(6);
                         if (group_end) {      // early barrier: this group's last operands are in registers
                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            C2S(0);
                             __syncthreads();
+                            C2S(1);
                             dma_next_group();
+                            C2S(6);
                         }
                         f32x16 part[MW];
 #pragma unroll
@@ -540,6 +560,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_b3_kernel(ConvPlan p, int cb_co
                         __builtin_amdgcn_sched_barrier(0);
                         cb3_products<MW>(part, fa[ua], fb[sb], 0, 3);
                         __builtin_amdgcn_sched_barrier(0);
+                        C2S(2);
                         int nj = j, nk = kk + 1, ncc = cc;
                         if (nk == NW) nk = 0, ++nj;
                         if (nj == J) nj = 0, ncc = cc ^ 1;      // (two chunks = ten groups: the parity is back where it started)
@@ -549,16 +570,22 @@ __global__ __launch_bounds__(256, 2) void conv2d_b3_kernel(ConvPlan p, int cb_co
                             load_b(fb[sb ^ 1], G::tap(nj), nk);
                         }
                         __builtin_amdgcn_sched_barrier(0);
+                        C2S(3);
                         cb3_products<MW>(part, fa[ua], fb[sb], 3, 6);
+                        C2S(2);
 #pragma unroll
                         for (int i = 0; i < MW; ++i) acc[i][kk] = part[i];
                         if (chunk_end) {
                             input_store_all();
                             __builtin_amdgcn_sched_barrier(0);
+                            C2S(4);
                             __syncthreads();
+                            C2S(1);
                             load_a(fa[ua ^ 1], nslot);
                             load_b(fb[sb ^ 1], G::tap(0), 0);
+                            C2S(3);
                             input_load();
+                            C2S(7);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -566,54 +593,71 @@ __global__ __launch_bounds__(256, 2) void conv2d_b3_kernel(ConvPlan p, int cb_co
             }
         }
 
-        // ---- epilogue.  Register r of row block i: row m0 + r0w + 32 i + 8 (r / 4) + 4 lh + r % 4; column n -> base (row, column) of the tile ----
+        C2S(6);
+        // ---- epilogue.  Register r of row block i: row m0 + r0w + 32 i + 8 (r / 4) + 4 lh + r % 4; column n -> base (row, column) of the tile.
+        // No load may sit between two stores: vmcnt counts loads and stores in order, so a bias load per element (the first version)
+        // made every store wait for the one before it -- 16 MW NW serial memory round trips per tile, a third of the 32-row layers'
+        // time (tools/c2b3_stamps.py).  The bias values of the tile are fetched in one batch, the gradient-add / mask operands of a
+        // block of 16 elements in one batch before its stores (one drain of the store queue per block instead of one per element).
         const bool pre = (p.epilogue & AGX_EPI_LEAKY_PRE) != 0;
         const size_t ybase = size_t(b) * p.Cout * p.y_cstride;
         float *yb = y + ybase;
         const float *ab = add ? add + ybase : nullptr, *kb = mask ? mask + ybase : nullptr;
         unsigned ycs = unsigned(p.y_cstride);
         asm volatile("" : "+s"(ycs));
+        float bv[MW][16];
 #pragma unroll
-        for (int kk = 0; kk < NW; ++kk) {
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                bv[i][r] = bias ? bias[(m0 + r0w + 32 * i + 8 * (r >> 2) + 4 * lh + (r & 3)) / (Q * QH)] : 0.f;
+        constexpr int NB = MW * NW;
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {      // block (kk, i): 16 elements per lane
+            const int kk = blk / MW, i = blk % MW;
             const int n = n0 + 32 * kk + li;
             const int brow = rb * G::R + (n >> SL), bcol = cb * G::WF + (n & (G::WF - 1));
             const bool okb = brow < p.Tt && bcol < p.Lt;
+            auto elem = [&](int r, bool &ok) -> unsigned {      // (recomputed where needed: 16 offsets per block do not fit the registers)
+                const int m = m0 + r0w + 32 * i + 8 * (r >> 2) + 4 * lh + (r & 3);
+                const int co = m / (Q * QH), a = (m / Q) % QH, c = m % Q;
+                const int orow = QH * brow + a - p.oshift_h, ocol = Q * bcol + c - p.oshift;
+                ok = okb && orow >= 0 && orow < Hout && ocol >= 0 && ocol < Wout;
+                return ok ? unsigned(co) * ycs + unsigned(orow * Wout + ocol) : 0u;
+            };
+            float rv[16], mv[16];
+            if (ab) {
 #pragma unroll
-            for (int i = 0; i < MW; ++i) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int mrow = m0 + r0w + 32 * i + 8 * g + 4 * lh;
-                    unsigned off[4];
-                    bool okv[4];
-                    float rv[4], mv[4];
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        const int m = mrow + s4;
-                        const int co = m / (Q * QH), a = (m / Q) % QH, c = m % Q;
-                        const int orow = QH * brow + a - p.oshift_h, ocol = Q * bcol + c - p.oshift;
-                        okv[s4] = okb && orow >= 0 && orow < Hout && ocol >= 0 && ocol < Wout;
-                        off[s4] = okv[s4] ? unsigned(co) * ycs + unsigned(orow * Wout + ocol) : 0u;
-                    }
-                    if (ab) {
-#pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) rv[s4] = ab[off[s4]];
-                    }
-                    if (kb) {
-#pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) mv[s4] = kb[off[s4]];
-                    }
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        float v = acc[i][kk][4 * g + s4] + (bias ? bias[(mrow + s4) / (Q * QH)] : 0.f);
-                        if (pre) v = leaky(v, p.slope);
-                        if (ab) v += rv[s4];
-                        if (kb) v = mv[s4] > 0.f ? v : v * p.slope;
-                        if (okv[s4]) yb[off[s4]] = v;
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    bool ok;
+                    rv[r] = ab[elem(r, ok)];
                 }
             }
+            if (kb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    bool ok;
+                    mv[r] = kb[elem(r, ok)];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                bool ok;
+                const unsigned o = elem(r, ok);
+                float v = acc[i][kk][r] + bv[i][r];
+                if (pre) v = leaky(v, p.slope);
+                if (ab) v += rv[r];
+                if (kb) v = mv[r] > 0.f ? v : v * p.slope;
+#ifdef C2B3_NOSTORE
+                if (ok && v == 12345.678f) yb[o] = v;
+#else
+                if (ok) yb[o] = v;
+#endif
+            }
         }
+        C2S(5);
     }
+    C2S_WRITE();
 }
 
 enum { CB3_NONE = 0, CB3_UP2, CB3_UP4, CB3_UP5, CB3_UP8, CB3_K7 };
@@ -906,3 +950,13 @@ int launch_conv2d_b3(const ConvPlan &p, const float *x, const float *wp, const f
 }
 
 }  // namespace agx
+
+#ifdef C2B3_STAMPS
+extern "C" int agx_debug_read_c2b3_stamps(unsigned long long *host, int n) {   // probe build only: copy out and clear
+    if (n > (1 << 16)) n = 1 << 16;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(agx::g_c2b3_stamps), size_t(n) * 8) != hipSuccess) return AGX_ERR_LAUNCH;
+    static unsigned long long zeros[1 << 16];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(agx::g_c2b3_stamps), zeros, sizeof(zeros)) != hipSuccess) return AGX_ERR_LAUNCH;
+    return AGX_OK;
+}
+#endif
