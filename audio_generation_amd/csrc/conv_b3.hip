@@ -271,6 +271,13 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_
         // ---- epilogue: bias, LeakyReLU, polyphase store.  Register r of row block i: row m0 + r0w + 32 i + 8 (r / 4) + 4 lh + r % 4 ----
         const bool pre = (p.epilogue & AGX_EPI_LEAKY_PRE) != 0;
         float *yb = y + size_t(b) * p.Cout * Lout;
+        // the tile's bias values in one batch, before the first store (a load between two stores makes the second wait for the first:
+        // vmcnt counts both in order -- see conv2d_b3_kernel)
+        float bq[MW][16];
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bq[i][r] = bias ? bias[(m0 + r0w + 32 * i + 8 * (r >> 2) + 4 * lh + (r & 3)) / Q] : 0.f;
 #pragma unroll
         for (int i = 0; i < MW; ++i)
 #pragma unroll
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_
                         const int mrow = m0 + r0w + 32 * i + 8 * g + 4 * lh;    // + s4; a multiple of 4
                         if (Q % 4 == 0) {         // the 4 rows are 4 consecutive output samples of one channel: one 16-byte store
                             const int co = mrow / Q, ph = mrow % Q;
-                            const float bv = bias ? bias[co] : 0.f;
+                            const float bv = bq[i][4 * g];
                             f32x4 v;
 #pragma unroll
                             for (int s4 = 0; s4 < 4; ++s4) {
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_
 #pragma unroll
                             for (int h2 = 0; h2 < 2; ++h2) {
                                 const int co = mrow / 2 + h2;
-                                const float bv = bias ? bias[co] : 0.f;
+                                const float bv = bq[i][4 * g + 2 * h2];
                                 f32x2c v;
 #pragma unroll
                                 for (int e = 0; e < 2; ++e) {
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_
 #pragma unroll
                             for (int s4 = 0; s4 < 4; ++s4) {
                                 const int m = mrow + s4, co = m / Q, ph = m % Q;
-                                float a = acc[i][kk][4 * g + s4] + (bias ? bias[co] : 0.f);
+                                float a = acc[i][kk][4 * g + s4] + bq[i][4 * g + s4];
                                 yb[size_t(co) * Lout + size_t(Q) * t + ph] = pre ? leaky(a, p.slope) : a;
                             }
                         }

@@ -7,6 +7,9 @@ import bench
 from audio_generation_amd import ops
 
 def main():
+    if os.environ.get("AGX_LIB"):      # A/B against a variant build of the library (measurement only)
+        from audio_generation_amd import _lib as _l
+        _l.LIB_PATH = os.path.abspath(os.environ["AGX_LIB"])
     dev = torch.device("cuda")
     model = bench.build_model(dev)
     x = bench.make_inputs(32, 0).to(dev)
