@@ -52,7 +52,9 @@ def main():
             dy = torch.randn_like(y)
             hh = h
             tf = timeit(lambda: c.run2d(hh, None))
+            am = (torch.randn_like(hh), torch.randn_like(hh))      # the op as the training step runs it: LeakyReLU mask + gradient add
             tx = timeit(lambda: ops.conv2d_bwd_data(desc, dy, pk))
+            txm = timeit(lambda: ops.conv2d_bwd_data(desc, dy, pk, am[0], 0.2, add=am[1]))
             if c is d.first_conv:    # what _SNConv.bwd2d runs for the 2-channel layer
                 tx2 = timeit(lambda: ops.conv2d_bwd_data_fewchannels(desc, dy, w, tape[0]))
                 print(f"   first conv dx: direct {tx:.3f} ms, column-split {tx2:.3f} ms")
@@ -60,7 +62,7 @@ def main():
             tw = timeit(lambda: ops.conv2d_bwd_weight(desc, hh, dy, w, *tape))
             fl = 2.0 * y.numel() * c.in_channels * c.kernel_size[0] * c.kernel_size[1]
             print(f"{c.in_channels:4d}->{c.out_channels:4d} k{tuple(c.kernel_size)} s{tuple(c.stride)} in {tuple(h.shape[2:])}: "
-                  f"fwd {tf:7.3f} ms ({fl / tf * 1e-9:5.1f} TF)  dx {tx:7.3f} ms ({fl / tx * 1e-9:5.1f} TF)  "
+                  f"fwd {tf:7.3f} ms ({fl / tf * 1e-9:5.1f} TF)  dx {tx:7.3f} ms ({fl / tx * 1e-9:5.1f} TF; +mask+add {txm:6.3f})  "
                   f"dW {tw:7.3f} ms ({fl / tw * 1e-9:5.1f} TF)   [{names[0]} | {names[1]}]")
             tot[0] += tf; tot[1] += tx; tot[2] += tw
             h = y
