@@ -3,7 +3,7 @@
 with -DC2B3_STAMPS, the other objects as they are) into audio_generation_amd/lib/libagx_c2b3_stamps.so when called with "build"
 (no GPU needed); otherwise loads it, runs the forward of a few discriminator layers (window 1024, batch 32) and prints, per wave
 (mean over the waves of the launch), the cycles (s_memtime ticks) by segment:
-   wait DMA (vmcnt) | barriers | MFMA groups | LDS operand reads issue | chunk end: split + LDS writes | epilogue | rest | chunk end: input loads issue
+   weight DMA issue | DMA wait (vmcnt) + barriers | MFMA groups | LDS operand reads issue | chunk end: split + LDS writes | epilogue | rest | chunk end: input loads issue
 (second line per layer: the same launch without a bias vector)
 usage: c2b3_stamps.py build | c2b3_stamps.py"""
 import ctypes
@@ -43,7 +43,7 @@ def main():
     lib.agx_debug_read_c2b3_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
     n = 1 << 16
     buf = np.zeros(n, dtype=np.uint64)
-    names = ["wait DMA", "barriers", "MFMA groups", "LDS reads", "split + LDS writes", "epilogue", "rest", "input loads issue"]
+    names = ["weight DMA issue", "DMA wait + barriers", "MFMA groups", "LDS reads", "split + LDS writes", "epilogue", "rest (tile start, step tails)", "input loads issue"]
     for cin, cout, h, w, kh, kw, sh, sw in [(32, 32, 282, 1024, 3, 3, 1, 1), (64, 64, 282, 512, 3, 3, 1, 1),
                                             (128, 128, 141, 256, 3, 3, 1, 1), (256, 256, 70, 64, 3, 3, 1, 1),
                                             (64, 128, 282, 512, 4, 4, 2, 2)]:
