@@ -555,11 +555,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_b3_kernel(ConvPlan p, int cb_co
                         C2S(6);
                         if (group_end) {      // early barrier: this group's last operands are in registers
                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            C2S(0);
                             __syncthreads();
                             C2S(1);
                             dma_next_group();
-                            C2S(6);
+                            C2S(0);
                         }
                         f32x16 part[MW];
 #pragma unroll
