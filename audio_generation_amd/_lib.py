@@ -77,6 +77,7 @@ SIGNATURES = {
     "agx_rvq_ema_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p,
                                   c_size_t, c_void_p]),
     "agx_rvq_debug_stamps": (c_int, [c_void_p, c_int32]),
+    "agx_rvq_verify_counts": (c_int, [POINTER(c_int64), c_int32]),
     "agx_rvq_dequantize": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p,
                                    c_int64, c_int64, c_int32, c_void_p]),
     "agx_layernorm_ct": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float,

@@ -45,9 +45,10 @@ struct Tuning {
     int conv_impl = 1;  // resampling / stride-1 1-D layers: 1 = persistent ring kernel (conv_p.hip) where it applies, 0 = conv_mfma.hip
     int rb_impl = 1;    // fused residual block: 1 = persistent ring kernel (resblock_p.hip) where it applies, 0 = resblock_mfma.hip
     int b3_dbg = 0;    // DIAGNOSTIC switchboard of round 3 (default 0 everywhere): 1 = resblock_b3 alternates (C = 64 as one 64 x 512 workgroup
-                       // per CU, C = 128 as 128 x 256 with double-buffered planes), 2 = resblock_b3 without the GEMM1 priority; RVQ score
-                       // bound: 7 = accumulation term x 4, 8 = x 0 (NOT rigorous: timing only), 9 = the stage's "squared error" output
-                       // carries the largest candidate count instead
+                       // per CU, C = 128 as 128 x 256 with double-buffered planes), 2 = resblock_b3 without the GEMM1 priority.  Values
+                       // 7 / 8 / 9 (RVQ score bound: accumulation term x 4 / x 0 / candidate counts in the squared-error output) act in
+                       // the PROBE build of rvq.hip only (-DAGX_RVQ_PROBE); agx_set_tuning refuses them otherwise
+    int rvq_verify = 0; // DEBUG: 1 = rvq_forward is followed by the checker kernel (full defining search of every (frame, stage), agx_rvq_verify_counts)
     int rb_sched = -1; // phase scheduling of the fused residual block (mfma_tile.hpp: 0 / 1 / 2; -1 = per-shape table)
 };
 Tuning &tuning();

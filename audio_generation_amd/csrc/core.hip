@@ -230,7 +230,13 @@ int agx_set_tuning(const char *name, int32_t value) {
     else if (!strcmp(name, "rb_sched")) agx::tuning().rb_sched = value;
     else if (!strcmp(name, "rb_occ")) agx::tuning().rb_occ = value;
     else if (!strcmp(name, "rb_impl")) agx::tuning().rb_impl = value;
-    else if (!strcmp(name, "b3_dbg")) agx::tuning().b3_dbg = value;
+    else if (!strcmp(name, "b3_dbg")) {
+#ifndef AGX_RVQ_PROBE
+        if (value >= 7 && value <= 9)   // they weaken / repurpose the RVQ candidate bound: never in the product library
+            return agx::fail(AGX_ERR_UNSUPPORTED, "agx_set_tuning: b3_dbg = %d exists in the probe build only (tools/rvq_stamps.py build)", value);
+#endif
+        agx::tuning().b3_dbg = value;
+    } else if (!strcmp(name, "rvq_verify")) agx::tuning().rvq_verify = value;
     else if (!strcmp(name, "conv_impl")) agx::tuning().conv_impl = value;
     else if (!strcmp(name, "bf_sched")) agx::tuning().bf_sched = value;
     else if (!strcmp(name, "patch_tie")) agx::tuning().patch_tie = value;
@@ -258,6 +264,7 @@ int agx_get_tuning(const char *name) {
     if (!strcmp(name, "rb_occ")) return agx::tuning().rb_occ;
     if (!strcmp(name, "rb_impl")) return agx::tuning().rb_impl;
     if (!strcmp(name, "b3_dbg")) return agx::tuning().b3_dbg;
+    if (!strcmp(name, "rvq_verify")) return agx::tuning().rvq_verify;
     if (!strcmp(name, "conv_impl")) return agx::tuning().conv_impl;
     if (!strcmp(name, "bf_sched")) return agx::tuning().bf_sched;
     if (!strcmp(name, "patch_tie")) return agx::tuning().patch_tie;

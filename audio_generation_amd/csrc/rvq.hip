@@ -125,15 +125,25 @@ struct RvqArgs {
     int64_t *index;  // (B*T, Q)
     double *sq_err;  // (Q) [unused by the kernel since the partials moved to `part`]
     double *part;    // (workgroups, Q) squared error of each workgroup's 32 frames per stage
-    float acc_scale; // 1; a diagnostic knob (b3_dbg = 7: 4) widens the accumulation term of the score error bound
-    unsigned long long *stamps;   // diagnostic (agx_rvq_debug_stamps): [workgroup][16] s_memtime at the phase boundaries of stage stamp_q
+    // PROBE BUILD ONLY (-DAGX_RVQ_PROBE, tools/rvq_stamps.py build): the product build fixes acc_scale = 1 and compiles no stamp.
+    float acc_scale; // 1; probe knob b3_dbg = 7: 4 (widens the accumulation term of the score error bound), 8: 0 (NOT rigorous:
+                     // timing only), 9: -1 (the stage's "squared error" output carries the largest candidate count)
+    unsigned long long *stamps;   // agx_rvq_debug_stamps: [workgroup][16] s_memtime at the phase boundaries of stage stamp_q
     int stamp_q;
 };
+#ifdef AGX_RVQ_PROBE
 // thread 0 of every workgroup: kernel-level slots (0, 1, 15) and the phase boundaries of ONE stage (a null pointer costs a scalar branch)
 #define RVQ_STAMP(slot, cond)                                                                                      \
     do {                                                                                                           \
         if (a.stamps != nullptr && tid == 0 && (cond)) a.stamps[size_t(blockIdx.x) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
+#define RVQ_ACC_SCALE(a) fabsf((a).acc_scale)
+#define RVQ_DIAG(a) ((a).acc_scale < 0.f)
+#else
+#define RVQ_STAMP(slot, cond) do { } while (0)
+#define RVQ_ACC_SCALE(a) 1.f
+#define RVQ_DIAG(a) false
+#endif
 
 // LDS map (byte offsets).  R is FRAME-major (a frame's residual is one contiguous row: the update, the centring / split and the
 // binary64 distances walk it with 16-byte accesses); the score GEMM reads its B operand from the two bf16 PLANES
@@ -409,17 +419,21 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
     //   * |c'|^2 table and the two centring roundings: (D + 8) 2^-24 x 1.25 (as for the fp32 score GEMM of rounds 1-2);
     //   * the dot product on two bf16 pieces per operand: each piece pair drops <= 2^-16 of its element and the m.m product
     //     (<= 2^-16) is not formed: <= 3 x 2^-16 |r'||c'| in all;
-    //   * its accumulation.  v_mfma_f32_32x32x16_bf16 forms c + sum of 16 exact products; measured on this hardware
-    //     (tools/mfma_bf16_err.hip: equal magnitudes, exponents spread over 2^20, heavy cancellation, large accumulators)
-    //     its result is the correctly rounded sum when the addends are of similar size and otherwise off by at most
-    //     5.3 x 2^-24 (|c| + sum |a_k b_k|) -- addends aligned to the largest and truncated.  The bound allows
-    //     18 x 2^-24 (17 truncated addends + the final rounding) per instruction, and the worst-case linear growth over the
+    //   * its accumulation.  v_mfma_f32_32x32x16_bf16 forms c + sum of 16 exact products.  MODEL of the instruction: the 17 addends
+    //     are aligned to the largest one and each is TRUNCATED at the 24th bit of that alignment (<= 2^-23 of the largest addend each),
+    //     then the sum is rounded once (<= 2^-24 of the result): |error| <= (17 x 2 + 1) 2^-24 (|c| + sum |a_k b_k|) = 35 x 2^-24 (...)
+    //     per instruction -- the constant this model PROVES, and the one used (round 3 used 18, i.e. 2.6 x the worst case measured
+    //     but not what the model proves).  The model itself is an empirical characterisation of the hardware
+    //     (tools/mfma_bf16_err.hip: equal magnitudes, exponents spread over 2^20, heavy cancellation, large accumulators: correctly
+    //     rounded when the addends are of similar size, otherwise off by at most 7.0 x 2^-24 (|c| + sum |a_k b_k|) -- 5 x inside the
+    //     constant); tests/test_gpu_rvq_adversarial.py feeds the kernel the operand patterns that would break a tighter model and the
+    //     knob rvq_verify re-runs the full defining search beside the fast path.  Worst-case linear growth over the
     //     chain of 3 Dp / 16 instructions with |c| <= the sum of all |products| <= (1 + 2^-7) |r'||c'|;
     //   with |r'||c'| <= (|r'| + |c'|)^2 / 4 and the factor 2 of the score: x 1/2.
     // Far above the typical error (which grows like the square root of the chain length); only the candidate selection
     // depends on it -- a wider margin means more frames decided by the defining binary64 distance, never a different index.
-    const float acc_err = 18.f * float(3 * Dp / 16 + 1) * 5.9604645e-8f * (1.f + 0.0078125f);
-    const float err_unit = float(D + 8) * 5.9604645e-8f * 1.25f + 0.5f * (fabsf(a.acc_scale) * acc_err + 3.f * 1.5258789e-5f);
+    const float acc_err = 35.f * float(3 * Dp / 16 + 1) * 5.9604645e-8f * (1.f + 0.0078125f);
+    const float err_unit = float(D + 8) * 5.9604645e-8f * 1.25f + 0.5f * (RVQ_ACC_SCALE(a) * acc_err + 3.f * 1.5258789e-5f);
     constexpr int CHUNK = NWV * 32 * MT;  // codewords scored per pass
     const int n_chunks = (K + CHUNK - 1) / CHUNK;
 
@@ -681,7 +695,7 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
         __syncthreads();
         RVQ_STAMP(11, stq);
         int diag_mx = 0;
-        if (a.acc_scale < 0.f && tid == 0)     // DIAGNOSTIC (knob b3_dbg = 9): the stage's "squared error" output = largest candidate count
+        if (RVQ_DIAG(a) && tid == 0)     // DIAGNOSTIC, probe build only (knob b3_dbg = 9): the stage's "squared error" output = largest candidate count
             for (int f = 0; f < FT; ++f) diag_mx = max(diag_mx, state[f] == 2 ? 1000 + cnt[f] : cnt[f]);
         // candidate overflow (degenerate codebooks): full defining search, whole block per frame
         const int any_overflow = flags[1];
@@ -753,7 +767,7 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
         __syncthreads();                       // the ONE barrier between the update and the next stage's search
         if (tid == 0) {
             flags[1] = 0;                      // (everyone read it right after the pick barrier)
-            if (a.acc_scale < 0.f) {
+            if (RVQ_DIAG(a)) {
                 sqf[0] = float(diag_mx);
                 for (int f = 1; f < FT; ++f) sqf[f] = 0.f;
             }
@@ -822,6 +836,55 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
         }
     }
     RVQ_STAMP(15, true);
+}
+
+// ------------------------------------------------------------------------ verify mode (debug knob rvq_verify)
+// The DEFINING search of every (frame, stage) next to the fast path's answer: one wave per frame, a codeword per lane
+// (rvq_dist_lane: binary64, d ascending, never fused -- oracle/rvq_exact.c), the minimum with the lowest index on ties, compared
+// with index[frame][stage]; the residual then follows the FAST path's choice (r <- r - c[index], binary32), so every stage is
+// checked on exactly the residual the fast path searched.  Counters (g_rvq_verify): [0] codes that differ, [1] frames with at
+// least one, [2] codes checked.  ~30 G binary64 terms on the bench workload: tens of milliseconds, a debug tool.
+__device__ unsigned long long g_rvq_verify[4];
+__global__ __launch_bounds__(256) void rvq_verify_kernel(const float *__restrict__ x, int64_t x_sb, int64_t x_st, int64_t x_sd,
+                                                         const float *__restrict__ cb, const float *__restrict__ packed, int64_t N,
+                                                         int T, int D, int K, int Q, const int64_t *__restrict__ index) {
+    extern __shared__ __align__(16) float vr[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t f = int64_t(blockIdx.x) * 4 + wave;
+    if (f >= N) return;       // (no workgroup barrier below: a wave only touches its own row)
+    float *r = vr + size_t(wave) * (D + 4);
+    const float *xf = x + (f / T) * x_sb + (f % T) * x_st;
+    for (int d = lane; d < D; d += 64) r[d] = xf[d * x_sd];
+    const int Dp = rvq_dp(D);
+    int bad = 0;
+    for (int q = 0; q < Q; ++q) {
+        const float *cbq = cb + size_t(q) * K * D;
+        const int kq_bits = __float_as_int(packed[q * rvq_stage_floats(K, D) + size_t(Dp) * K + 2 * size_t(K) + 1]);
+        const int Kq = kq_bits > 0 && kq_bits <= K ? kq_bits : K;
+        double best = 1.0 / 0.0;
+        int arg = 0x7fffffff;
+        for (int c0 = 0; c0 < Kq; c0 += 64) {
+            const int c = c0 + lane;
+            const double dc = rvq_dist_lane(r, cbq + size_t(min(c, Kq - 1)) * D, D);
+            if (c < Kq && dc < best) best = dc, arg = c;       // ascending c per lane: a tie keeps the lower index
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ob = __shfl_xor(best, off);
+            const int oa = __shfl_xor(arg, off);
+            if (ob < best || (ob == best && oa < arg)) best = ob, arg = oa;
+        }
+        const int64_t got = index[f * Q + q];
+        if (got != int64_t(arg)) ++bad;
+        const float *cs = cbq + size_t(got >= 0 && got < Kq ? got : 0) * D;
+        for (int d = lane; d < D; d += 64) r[d] = r[d] - cs[d];
+    }
+    if (lane == 0) {
+        if (bad) {
+            atomicAdd(&g_rvq_verify[0], (unsigned long long)bad);
+            atomicAdd(&g_rvq_verify[1], 1ull);
+        }
+        atomicAdd(&g_rvq_verify[2], (unsigned long long)Q);
+    }
 }
 
 static size_t rvq_lds_bytes(int dim, int k, int q, bool *tail_in_lds) {
@@ -1007,12 +1070,36 @@ size_t agx_rvq_workspace_bytes(int32_t batch, int32_t t, int32_t, int32_t, int32
     return size_t(agx::ceil_div64(int64_t(batch) * t, agx::FT)) * q_used * sizeof(double);
 }
 
-// diagnostic: device buffer of (workgroups x 16) 64-bit stamps the next rvq_forward launches fill (NULL switches it off)
+// diagnostic: device buffer of (workgroups x 16) 64-bit stamps the next rvq_forward launches fill (NULL switches it off).
+// PROBE BUILD ONLY (-DAGX_RVQ_PROBE; `tools/rvq_stamps.py build` writes lib/libagx_rvq_probe.so): the product library keeps no
+// raw pointer between calls and refuses.
+#ifdef AGX_RVQ_PROBE
 static unsigned long long *g_rvq_stamps = nullptr;
 static int g_rvq_stamp_q = 0;
 int agx_rvq_debug_stamps(void *device_buffer, int32_t stage) {
     g_rvq_stamps = static_cast<unsigned long long *>(device_buffer);
     g_rvq_stamp_q = stage;
+    return AGX_OK;
+}
+#else
+int agx_rvq_debug_stamps(void *, int32_t) {
+    return agx::fail(AGX_ERR_UNSUPPORTED, "agx_rvq_debug_stamps: probe build only (tools/rvq_stamps.py build)");
+}
+#endif
+
+// Verify mode (knob rvq_verify = 1): the counters of the checker kernel, in the code object (nothing is allocated).
+int agx_rvq_verify_counts(int64_t *out3, int32_t reset) {
+    unsigned long long h[4] = {0, 0, 0, 0};
+    if (out3) {
+        hipError_t e = hipMemcpyFromSymbol(h, HIP_SYMBOL(agx::g_rvq_verify), sizeof(h), 0, hipMemcpyDeviceToHost);   // synchronises
+        if (e != hipSuccess) return agx::fail(AGX_ERR_LAUNCH, "agx_rvq_verify_counts: %s", hipGetErrorString(e));
+        for (int i = 0; i < 3; ++i) out3[i] = int64_t(h[i]);
+    }
+    if (reset) {
+        const unsigned long long z[4] = {0, 0, 0, 0};
+        hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(agx::g_rvq_verify), z, sizeof(z), 0, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return agx::fail(AGX_ERR_LAUNCH, "agx_rvq_verify_counts: %s", hipGetErrorString(e));
+    }
     return AGX_OK;
 }
 
@@ -1040,8 +1127,12 @@ int agx_rvq_forward_ex(const float *x, int64_t x_sb, int64_t x_st, int64_t x_sd,
     const size_t lds = rvq_lds_bytes(dim, k, q_used, &tail_lds);
     if (lds > 160 * 1024) return fail(AGX_ERR_UNSUPPORTED, "rvq_forward: D=%d needs %zu B of LDS", dim, lds);
     RvqArgs a{x, x_sb, x_st, x_sd, codebooks, packed, batch, t, dim, k, q_used, xq, q_sb, q_st, q_sd, index, sq_err,
-              static_cast<double *>(workspace), tuning().b3_dbg == 7 ? 4.f : (tuning().b3_dbg == 8 ? 0.f : (tuning().b3_dbg == 9 ? -1.f : 1.f)),
-              g_rvq_stamps, g_rvq_stamp_q};
+              static_cast<double *>(workspace),
+#ifdef AGX_RVQ_PROBE
+              tuning().b3_dbg == 7 ? 4.f : (tuning().b3_dbg == 8 ? 0.f : (tuning().b3_dbg == 9 ? -1.f : 1.f)), g_rvq_stamps, g_rvq_stamp_q};
+#else
+              1.f, nullptr, 0};
+#endif
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t n = int64_t(batch) * t;
     dim3 grid((unsigned)ceil_div64(n, FT)), block(NT);
@@ -1053,6 +1144,12 @@ int agx_rvq_forward_ex(const float *x, int64_t x_sb, int64_t x_st, int64_t x_sd,
         if (q_used > 0)   // per-stage sums and the commit loss, in a fixed order: deterministic, no atomics, no host arithmetic
             hipLaunchKernelGGL(rvq_sqerr_kernel, dim3(1), dim3(64), 0, st, a.part, int(grid.x), q_used, sq_err, commit_loss,
                                1.0 / (double(batch) * t * dim));
+        if (tuning().rvq_verify && q_used > 0) {   // DEBUG: the full defining search of every (frame, stage) beside the fast path
+            const size_t vlds = size_t(4) * (size_t(dim) + 4) * sizeof(float);
+            if (vlds > 64 * 1024) return fail(AGX_ERR_UNSUPPORTED, "rvq_verify: D=%d too large for the checker", dim);
+            hipLaunchKernelGGL(rvq_verify_kernel, dim3((unsigned)ceil_div64(n, 4)), dim3(256), vlds, st, x, x_sb, x_st, x_sd,
+                               codebooks, packed, n, t, dim, k, q_used, index);
+        }
         return check_launch("rvq_forward");
     };
     // codewords per pass = 8 waves x MT x 32.  MT = 4 (one pass for K = 1024) spills at the 256-VGPR cap

@@ -24,13 +24,36 @@ def env_world() -> Tuple[int, int, int]:
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init(backend: str = "nccl") -> Tuple[int, int, int]:
-    """Join the process group described by RANK / WORLD_SIZE / MASTER_* (no-op for one rank)."""
+# ``force_collective``: run the exchange steps through the backend even when the group has ONE rank (they are identities
+# there).  Off by default -- a single-GPU run pays nothing --; switched on by ``init(..., force=True)`` or
+# ``AGX_FORCE_COLLECTIVE=1`` so that the in-place device path through librccl (flat gradient bucket, EMA statistics) can be
+# executed and checked on a one-GPU box before an 8-GPU node ever sees it (tests/test_gpu_rccl_world1.py).
+_force_collective = os.environ.get("AGX_FORCE_COLLECTIVE", "0") == "1"
+
+
+def force_collective(on: bool = True) -> None:
+    global _force_collective
+    _force_collective = bool(on)
+
+
+def _collective_needed() -> bool:
+    return dist.is_initialized() and (dist.get_world_size() > 1 or _force_collective)
+
+
+def init(backend: str = "nccl", force: bool = False) -> Tuple[int, int, int]:
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_* (no-op for one rank unless ``force``: then a
+    one-rank group is created on 127.0.0.1 and every exchange step really calls the backend)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if force:
+        force_collective(True)
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if backend == "nccl" and torch.cuda.is_available():
+            # bind the communicator to this rank's device up front (no lazy guess from the first tensor; barrier() needs it)
+            kw["device_id"] = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
 
 
@@ -44,7 +67,10 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
 
 def barrier() -> None:
     if dist.is_initialized():
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])     # RCCL: name the device, never let it guess
+        else:
+            dist.barrier()
 
 
 def max_over_ranks(value: float, device="cpu") -> float:
@@ -75,8 +101,8 @@ def sum_over_ranks(value: float, device="cpu") -> float:
 
 
 def allreduce_sum_(t: torch.Tensor) -> None:
-    """In-place sum over ranks (no-op for one rank).  Used for the RVQ's per-code counts and sums."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    """In-place sum over ranks (no-op for one rank unless ``force_collective``).  Used for the RVQ's per-code counts and sums."""
+    if _collective_needed():
         if t.is_cuda and dist.get_backend() == "gloo":
             host = t.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
@@ -87,7 +113,7 @@ def allreduce_sum_(t: torch.Tensor) -> None:
 
 def broadcast_(tensors: Iterable[torch.Tensor], src: int = 0) -> None:
     """In-place broadcast of a list of tensors from ``src`` (no-op for one rank)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _collective_needed():
         return
     for t in tensors:
         if t.is_cuda and dist.get_backend() == "gloo":
@@ -157,7 +183,7 @@ class GradBucket:
         if not self.intact():
             raise RuntimeError("GradBucket: a parameter's .grad no longer aliases the bucket "
                                "(use bucket.zero_() or zero_grad(set_to_none=False))")
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if _collective_needed():
             if self.flat.is_cuda and dist.get_backend() == "gloo":      # CPU rehearsal of the RCCL step
                 host = self.flat.cpu()
                 dist.all_reduce(host, op=dist.ReduceOp.SUM)
@@ -171,11 +197,12 @@ def replica_checksums(module: torch.nn.Module) -> Tuple[float, float]:
     """(min, max) over ranks of a checksum of ALL state -- parameters and buffers (the RVQ's EMA codebooks,
     sums and frequencies are buffers).  Replicas are in sync iff min == max."""
     chk = torch.zeros((), dtype=torch.float64)
-    for t in list(module.parameters()) + list(module.buffers()):
+    state = list(module.parameters()) + list(module.buffers())
+    for t in state:
         chk = chk + t.detach().double().abs().sum().cpu()
     if not dist.is_initialized():
         return float(chk), float(chk)
-    dev = next(module.parameters()).device if dist.get_backend() == "nccl" else "cpu"
+    dev = state[0].device if state and dist.get_backend() == "nccl" else "cpu"
     lo, hi = chk.clone().to(dev).reshape(1), chk.clone().to(dev).reshape(1)
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)

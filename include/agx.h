@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AGX_VERSION 118 /* 118: agx_feature_means(_backward) (the feature-matching pair in one pass); 117: agx_rvq_debug_stamps (diagnostic); 116: agx_multires_backward, agx_layernorm_ct one-pass kernel (same signature); agx_rvq_forward (legacy form) needs the workspace of agx_rvq_workspace_bytes since 114; 115: agx_rvq_ema_stats, agx_conv2d_bwd_data_kernel_name; 114: agx_attention_alibi_backward_ex (any T), agx_rvq_forward_ex; 113: tile images (resblock_p / conv_p), agx_attention_alibi_ex, agx_sizeof_*; 0.1.1: agx_conv_desc gained groups / padding (zero = old behaviour); 111: resample, conv2d column split */
+#define AGX_VERSION 119 /* 119: agx_rvq_verify_counts + knob rvq_verify (debug: the full defining search beside the fast path); agx_rvq_debug_stamps and the b3_dbg 7/8/9 bound knobs exist in the probe build only; 118: agx_feature_means(_backward) (the feature-matching pair in one pass); 117: agx_rvq_debug_stamps (diagnostic); 116: agx_multires_backward, agx_layernorm_ct one-pass kernel (same signature); agx_rvq_forward (legacy form) needs the workspace of agx_rvq_workspace_bytes since 114; 115: agx_rvq_ema_stats, agx_conv2d_bwd_data_kernel_name; 114: agx_attention_alibi_backward_ex (any T), agx_rvq_forward_ex; 113: tile images (resblock_p / conv_p), agx_attention_alibi_ex, agx_sizeof_*; 0.1.1: agx_conv_desc gained groups / padding (zero = old behaviour); 111: resample, conv2d column split */
 
 #define AGX_OK 0
 #define AGX_ERR_BAD_SHAPE (-1)
@@ -66,7 +66,11 @@ int32_t agx_sizeof_conv2d_desc(void);
  *                      padded area x (matrix time + input staging rounds), -1 the least padded area alone, 3..7 forced
  *   "dw2_bf" 0|1       conv2d weight gradient of AGX_IMPL_MFMA_BF16X3 descriptors on the shared kernel: 1 (default) bf16x3
  *                      contraction (both operands split in registers), 0 the fp32 contraction
- *   "dw_xcd" 0|1       conv2d weight gradient: 1 (default) XCD-aware block order -- the tiles of one contraction slice share an L2
+ *   "dw_xcd" 0|1       conv2d weight gradient: 0 (default); 1 = XCD-aware block order -- the tiles of one contraction slice share
+ *                      an L2 (measured SLOWER: 106.6 -> 95.1 TFLOP/s on the 128 -> 128 3 x 3 layer)
+ *   "rvq_verify" 0|1   DEBUG: 1 = every agx_rvq_forward(_ex) launch is followed by a checker kernel that runs the full DEFINING
+ *                      search (binary64, oracle/rvq_exact.c) of every (frame, stage) on the residual the fast path searched and
+ *                      counts the indices that differ (agx_rvq_verify_counts); tens of milliseconds per call at config S
  *   "conv_shape" 0|1   1: 128x128 conv tiles as four row-waves of 1x4 fragments
  *   "rb_impl" 0|1      fused residual block: 1 (default) the persistent ring kernel (csrc/resblock_p.hip) where it applies,
  *                      0 the first kernel (csrc/resblock_mfma.hip) everywhere
@@ -246,10 +250,17 @@ size_t agx_rvq_ema_workspace_bytes(int64_t n_frames, int32_t dim, int32_t q_used
 int agx_rvq_ema_stats(const float *frames, const float *codebooks, const int64_t *index, float *stats, int64_t n_frames,
                       int32_t dim, int32_t k, int32_t q_used, void *workspace, size_t workspace_bytes, void *stream);
 
-/* Diagnostic (not part of the reference surface): the next agx_rvq_forward launches write s_memtime stamps of workgroup w into
+/* Diagnostic (not part of the reference surface), PROBE BUILD ONLY (-DAGX_RVQ_PROBE: `python tools/rvq_stamps.py build` writes
+ * lib/libagx_rvq_probe.so; the product library returns AGX_ERR_UNSUPPORTED and keeps no pointer between calls): the next
+ * agx_rvq_forward launches write s_memtime stamps of workgroup w into
  * device_buffer[w * 16 + slot] (64-bit each; slots 0 / 1 / 15 = kernel start / end of the stage loop / kernel end, 2..13 = the
  * phase boundaries of residual stage `stage`, 14 = the (frame, candidate) pairs that went to the binary64 distance).  NULL = off. */
 int agx_rvq_debug_stamps(void *device_buffer, int32_t stage);
+
+/* Verify mode (knob "rvq_verify" = 1; debug).  out3[0] = codes where the fast path's index differs from the full defining search
+ * run on the same residual, out3[1] = frames with at least one such code, out3[2] = codes checked -- accumulated over every
+ * agx_rvq_forward(_ex) launch since the last reset.  Synchronises the device (a blocking copy).  out3 may be NULL (reset only). */
+int agx_rvq_verify_counts(int64_t *out3, int32_t reset);
 
 /* quantizers[i].dequantize(idx) (vae.py:333): out[n,:] (+)= codebook[idx[n],:].
  * out element (n,d) at n*stride_n + d*stride_d. */

@@ -2,8 +2,12 @@
 """Diagnostic: where one residual stage of rvq_forward spends its cycles (agx_rvq_debug_stamps), on the bench's workload
 (config S, batch 32 x 72 000, `latents` codebooks).  Thread 0 of every workgroup stamps s_memtime at the phase boundaries of
 ONE stage; printed: median [p10 .. p90] over the workgroups, per phase, for every stage in turn.
-usage: rvq_stamps.py [batch | C4] [stage ...]     (C4: BASELINE config 4 -- stereo, 8 x 144 000 samples, wavelet decoder)"""
+The stamps (and the b3_dbg = 7 / 8 / 9 knobs that widen / zero / repurpose the score bound) exist in a PROBE copy of the library
+only: `rvq_stamps.py build` compiles csrc/rvq.hip and csrc/core.hip with -DAGX_RVQ_PROBE (no GPU needed) and links them with the
+product objects into audio_generation_amd/lib/libagx_rvq_probe.so, which the measuring run loads instead of libagx.so.
+usage: rvq_stamps.py build | rvq_stamps.py [batch | C4] [stage ...]     (C4: BASELINE config 4 -- stereo, 8 x 144 000 samples, wavelet decoder)"""
 import os
+import subprocess
 import sys
 
 import numpy as np
@@ -20,7 +24,29 @@ PHASES = [("score GEMM, pass 0", 2, 3), ("bounds + min exchange, pass 0", 3, 4),
           ("whole stage", 2, 13)]
 
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "audio_generation_amd", "lib")
+PROBE = os.path.join(LIBDIR, "libagx_rvq_probe.so")
+
+
+def build():
+    obj, src = os.path.join(LIBDIR, "obj"), os.path.join(ROOT, "audio_generation_amd", "csrc")
+    probe_objs = []
+    for name in ("rvq", "core"):
+        o = os.path.join(LIBDIR, f"{name}_rvq_probe.o")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DAGX_RVQ_PROBE", "-I",
+                               os.path.join(ROOT, "include"), "-I", src, "-Wno-unused-function", "-c",
+                               os.path.join(src, name + ".hip"), "-o", o])
+        probe_objs.append(o)
+    objs = [os.path.join(obj, f) for f in sorted(os.listdir(obj)) if f.endswith(".o") and f not in ("rvq.o", "core.o")]
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", PROBE] + probe_objs + objs)
+    print(PROBE)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "build":
+        return build()
+    _lib.LIB_PATH = PROBE
     c4 = len(sys.argv) > 1 and sys.argv[1] == "C4"
     batch = 8 if c4 else (int(sys.argv[1]) if len(sys.argv) > 1 else 32)
     stages = [int(a) for a in sys.argv[2:]] or list(range(8))
