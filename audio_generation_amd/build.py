@@ -29,6 +29,19 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_hash() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources (csrc/*.hip, csrc/*.hpp, include/*.h, sorted by name): names the
+    BUILD a measurement belongs to where no git history travels (the GPU box gets a snapshot without .git) -- bench.py and
+    tools/pmc_summary.py both record it, so a committed PMC figure says which sources it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp")) +
+                    glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))

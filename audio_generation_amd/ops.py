@@ -26,10 +26,14 @@ def set_observer(obs) -> None:
     _observer = obs
 
 
-def count_macs(kind: str, macs: int) -> None:
+def count_macs(kind: str, macs: int, desc=None) -> None:
     """Report the executed multiply-accumulates of a launch that has no timing hook (backward, 2-D and spectral ops) to the
-    observer's optional ``macs(kind, n)`` method -- bench.py's FLOP account of the training step."""
+    observer's optional ``macs(kind, n)`` method -- bench.py's FLOP account of the training step.  A layer whose descriptor
+    asks for the bf16x3 arithmetic is reported as ``kind + ":bf16x3"`` (its products run on the bf16 matrix pipe at six
+    bf16 flops per fp32-equivalent flop: a different roofline)."""
     if _observer is not None and hasattr(_observer, "macs"):
+        if desc is not None and getattr(desc, "impl", 0) == IMPL_MFMA_BF16X3:
+            kind += ":bf16x3"
         _observer.macs(kind, int(macs))
 
 
@@ -173,7 +177,7 @@ def conv_bwd_data(desc: ConvDesc, dy: Tensor, packed_bwd: Tensor, add: Optional[
             raise AgxError(f"conv_bwd_data: {nm} is {tuple(t.shape)}, dx is {tuple(dx.shape)}")
     add = None if add is None else _f32c(add)
     mask = None if mask is None else _f32c(mask)
-    count_macs("conv_bwd_data", _conv_macs(desc))
+    count_macs("conv_bwd_data", _conv_macs(desc), desc)
     _lib.check(lib.agx_conv_bwd_data(ctypes.byref(desc), _ptr(dy), _ptr(packed_bwd), _ptr(add), _ptr(mask),
                                      float(slope), _ptr(dx), _stream()), "agx_conv_bwd_data")
     return dx
@@ -190,7 +194,7 @@ def conv_bwd_weight(desc: ConvDesc, x: Tensor, dy: Tensor, v: Tensor, g: Optiona
     db = torch.empty(desc.c_out, dtype=torch.float32, device=x.device) if want_bias else None
     ws_bytes = int(lib.agx_conv_bwd_weight_workspace_bytes(ctypes.byref(desc)))
     ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=x.device)
-    count_macs("conv_bwd_weight", _conv_macs(desc))
+    count_macs("conv_bwd_weight", _conv_macs(desc), desc)
     _lib.check(lib.agx_conv_bwd_weight(ctypes.byref(desc), _ptr(x), _ptr(dy), _ptr(v), _ptr(g), _ptr(dv), _ptr(dg),
                                        _ptr(db), _ptr(ws), ws_bytes, _stream()), "agx_conv_bwd_weight")
     return dv, dg, db
@@ -415,7 +419,7 @@ def conv_bwd_data_gelu(desc: ConvDesc, dy: Tensor, packed_bwd: Tensor, pre: Tens
     dy, pre = _f32c(dy), _f32c(pre)
     add = None if add is None else _f32c(add)
     dx = torch.empty(desc.batch, desc.c_in, desc.l_in, dtype=torch.float32, device=dy.device)
-    count_macs("conv_bwd_data", _conv_macs(desc))
+    count_macs("conv_bwd_data", _conv_macs(desc), desc)
     _lib.check(lib.agx_conv_bwd_data_gelu(ctypes.byref(desc), _ptr(dy), _ptr(packed_bwd), _ptr(add), _ptr(pre), _ptr(dx),
                                           _stream()), "agx_conv_bwd_data_gelu")
     return dx
@@ -552,7 +556,7 @@ def conv_grouped_bwd_data(desc: ConvDesc, dz: Tensor, w: Tensor, sigma: Optional
     add = None if add is None else _f32c(add)
     mask = None if mask is None else _f32c(mask)
     dx = torch.empty(desc.batch, desc.c_in, desc.l_in, dtype=torch.float32, device=dz.device)
-    count_macs("conv_bwd_data", _conv_macs(desc))
+    count_macs("conv_bwd_data", _conv_macs(desc), desc)
     _lib.check(lib.agx_conv_grouped_bwd_data(ctypes.byref(desc), _ptr(dz), _ptr(w), _ptr(sigma), _ptr(add), _ptr(mask),
                                              slope, _ptr(dx), _stream()), "agx_conv_grouped_bwd_data")
     return dx
@@ -568,7 +572,7 @@ def conv_grouped_bwd_weight(desc: ConvDesc, x: Tensor, dz: Tensor, want_bias: bo
     db = torch.empty(desc.c_out, dtype=torch.float32, device=x.device) if want_bias else None
     nbytes = int(lib.agx_conv_grouped_bwd_weight_workspace_bytes(ctypes.byref(desc)))
     ws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=x.device)
-    count_macs("conv_bwd_weight", _conv_macs(desc))
+    count_macs("conv_bwd_weight", _conv_macs(desc), desc)
     _lib.check(lib.agx_conv_grouped_bwd_weight(ctypes.byref(desc), _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), _ptr(ws),
                                                nbytes, _stream()), "agx_conv_grouped_bwd_weight")
     return dw, db
@@ -615,7 +619,8 @@ def conv2d_forward(desc, x: Tensor, packed: Tensor, bias: Optional[Tensor]) -> T
     _lib.check(lib.agx_conv2d_out_shape(ctypes.byref(desc), ctypes.byref(ho), ctypes.byref(wo)), "agx_conv2d_out_shape")
     y = torch.empty(desc.batch, desc.c_out, ho.value, wo.value, dtype=torch.float32, device=x.device)
     bias = None if bias is None else _f32c(bias)
-    tok = _observer.begin("other", ("conv2d", 4 * (x.numel() + y.numel()), _conv2d_macs(desc))) if _observer is not None else None
+    tok = _observer.begin("other", ("conv2d:bf16x3" if desc.impl == IMPL_MFMA_BF16X3 else "conv2d", 4 * (x.numel() + y.numel()),
+                                     _conv2d_macs(desc))) if _observer is not None else None
     _lib.check(lib.agx_conv2d_forward(ctypes.byref(desc), _ptr(x), _ptr(packed), _ptr(bias), _ptr(y), _stream()),
                "agx_conv2d_forward")
     if tok is not None:
@@ -646,7 +651,7 @@ def conv2d_bwd_data(desc, dy: Tensor, packed_bwd: Tensor, mask: Optional[Tensor]
     mask = None if mask is None else _f32c(mask)
     add = None if add is None else _f32c(add)
     dx = torch.empty(desc.batch, desc.c_in, desc.h_in, desc.w_in, dtype=torch.float32, device=dy.device)
-    count_macs("conv2d_bwd_data", _conv2d_macs(desc))
+    count_macs("conv2d_bwd_data", _conv2d_macs(desc), desc)
     _lib.check(lib.agx_conv2d_bwd_data(ctypes.byref(desc), _ptr(dy), _ptr(packed_bwd), _ptr(add), _ptr(mask), slope,
                                        _ptr(dx), _stream()), "agx_conv2d_bwd_data")
     return dx
@@ -663,7 +668,7 @@ def conv2d_bwd_weight(desc, x: Tensor, dy: Tensor, w: Optional[Tensor] = None, s
     nbytes = int(lib.agx_conv2d_bwd_weight_workspace_bytes(ctypes.byref(desc)))
     ws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=x.device)
     w = None if w is None else _f32c(w)
-    count_macs("conv2d_bwd_weight", _conv2d_macs(desc))
+    count_macs("conv2d_bwd_weight", _conv2d_macs(desc), desc)
     _lib.check(lib.agx_conv2d_bwd_weight(ctypes.byref(desc), _ptr(x), _ptr(dy), _ptr(w), _ptr(sigma), _ptr(u), _ptr(v),
                                          _ptr(dw), _ptr(db), _ptr(ws), nbytes, _stream()), "agx_conv2d_bwd_weight")
     return dw, db

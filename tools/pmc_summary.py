@@ -73,7 +73,10 @@ def main():
                             "bytes_per_launch": 2 * fk * 1024 + wk * 1024, "launches_averaged": len(dur[k])}
     if json_out:
         import json
-        json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean per dispatch >= "
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from audio_generation_amd.build import source_hash
+        json.dump({"kernel_sources_sha16": source_hash(),      # the build these passes ran on (bench.py compares it with its own)
+                   "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean per dispatch >= "
                              f"{min_us:.0f} us; FETCH_SIZE doubled (gfx950 correction for wide coalesced reads)",
                    "kernels": traffic}, open(json_out, "w"), indent=1)
 

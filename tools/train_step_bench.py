@@ -27,10 +27,12 @@ class FlopCounter:
     """ops observer that only counts: executed MACs of every compute launch of a step (no events, no sync)."""
 
     def __init__(self):
-        self.total, self.by_kind = 0, {}
+        self.total, self.total_bf, self.by_kind = 0, 0, {}
 
     def _add(self, kind, n):
         self.total += n
+        if kind.endswith(":bf16x3"):      # a layer whose descriptor asks for the bf16x3 arithmetic: bf16 matrix pipe
+            self.total_bf += n
         self.by_kind[kind] = self.by_kind.get(kind, 0) + n
 
     def begin(self, kind, info):
@@ -39,13 +41,13 @@ class FlopCounter:
             b, t, d, k, q = info
             self._add("rvq", b * t * q * k * d)
         elif kind == "other":
-            self._add(info[0].split(":")[0], info[2] if len(info) > 2 else 0)
+            self._add(info[0], info[2] if len(info) > 2 else 0)
         elif kind == "resblock":
             e1, _, _ = bench.conv_work(info)
             e2, _, _ = bench.conv_work(ops.conv_desc(info.kind, info.batch, info.c_out, info.c_out, info.l_in, 1))
-            self._add("conv_forward", e1 + e2)
+            self._add("conv_forward" + (":bf16x3" if info.impl == 3 else ""), e1 + e2)
         else:
-            self._add("conv_forward", ops._conv_macs(info))
+            self._add("conv_forward" + (":bf16x3" if info.impl == 3 else ""), ops._conv_macs(info))
         return None
 
     def end(self, tok):
@@ -171,16 +173,30 @@ def main():
     lo, hi = zip(*[agx_dist.replica_checksums(m) for m in [model] + discs])
     same = all(a == b for a, b in zip(lo, hi))
     if rank == 0:
+        # Rooflines.  fp32 launches: the fp32-input MFMA peak (157.3 TFLOP/s).  Launches of bf16x3 descriptors: the dense bf16
+        # MFMA peak at six bf16 flops per fp32-equivalent flop = 2500 / 6 = 416.7 fp32-equivalent TFLOP/s (classified by the
+        # layer's descriptor; the few layers of such a descriptor that fall back to an fp32 kernel are counted on the bf16
+        # pipe too -- that only lowers the fraction).  A step that mixes both is held against the BLENDED floor
+        #   t_floor = flop_bf16x3 / 416.7 T + flop_fp32 / 157.3 T.
+        bf_flop = 2.0 * counter.total_bf
+        fp_flop = step_flop - bf_flop
+        floor_ms = 1e3 * (bf_flop / (2500e12 / 6) + fp_flop / 157.3e12)
+        roof = {"executed_tflop_fp32_pipe": fp_flop * 1e-12, "executed_tflop_bf16_pipe_fp32_equivalent": bf_flop * 1e-12,
+                "blended_floor_ms": floor_ms, "frac_of_blended_roofline": floor_ms / ms,
+                "peaks_tflops": {"fp32_mfma": 157.3, "bf16x3_fp32_equivalent": 2500.0 / 6}}
+        if not bf:
+            roof["frac_of_fp32_mfma_peak"] = step_flop / ms * 1e-9 / 157.3
         print(json.dumps({"what": "train step (fwd + native bwd + grad all-reduce + Adam), config S" +
                           (f" + {len(discs)} discriminators (native forward + backward)" if gan else "") +
                           (" + low-pass, pre-emphasis, 7-window mel loss" if signal else "") +
-                          (" [bf16x3: decoder forward, discriminator Conv2d forward + backward-data" +
-                           (" on the 3 x 3 stride-1 ring layers only]" if bf_mode == "2" else "]") if bf else ""),
+                          (" [bf16x3: decoder forward; discriminator Conv2d forward, backward-data AND the weight-gradient "
+                           "contraction (knob dw2_bf = 1)" +
+                           (", 3 x 3 stride-1 ring layers only]" if bf_mode == "2" else "]") if bf else ""),
                           "backward_order": ("two calls (training.py:374, 380)" if (two_calls or not signal) else "step.training_backward"),
                           "n_gpus": world, "batch_per_gpu": batch, "ms_per_step": ms, "replicas_in_sync": same, "update_codebook": update_cb,
                           "samples_per_s": world * batch * 72000 / ms * 1e3, "losses": losses,
                           "executed_tflop_per_step_per_gpu": step_flop * 1e-12,
-                          "executed_tflops": world * step_flop / ms * 1e-9, "frac_of_fp32_mfma_peak": step_flop / ms * 1e-9 / 157.3,
+                          "executed_tflops": world * step_flop / ms * 1e-9, **roof,
                           "flop_groups_tflop": {k: round(2e-12 * v, 3) for k, v in sorted(counter.by_kind.items())},
                           "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30, **({"ab_ms_per_step": ab} if ab else {})}))
     if torch.distributed.is_initialized():
