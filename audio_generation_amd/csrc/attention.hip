@@ -238,13 +238,8 @@ static int launch_attn(const float *qkv, const float *slopes, float *out, int B,
                        float scale_div, hipStream_t st) {
     const size_t lds = size_t(32 * DVT) * (32 * NJ + 1) * sizeof(float);
     auto kern = attention_alibi_kernel<NJ, DVT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    static DeviceOnce once;
+    if (int rc = prepare_kernel(reinterpret_cast<const void *>(kern), once, 160 * 1024, nullptr, "attention")) return rc;
     dim3 grid(ceil_div(T, 128), H, B), block(256);
     hipLaunchKernelGGL(kern, grid, block, lds, st, qkv, slopes, out, H, Dh, T, scale_div);
     return check_launch("attention_alibi");

@@ -383,12 +383,8 @@ static int launch_bf16_lds(const float *qkv, const float *slopes, float *out, in
                            hipStream_t st) {
     const size_t lds = size_t(2) * Tp * 32 * DVT * 2;
     auto kern = attention_bf16_lds_kernel<DVT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    static DeviceOnce once;
+    if (int rc = prepare_kernel(reinterpret_cast<const void *>(kern), once, 160 * 1024, nullptr, "attention_flash")) return rc;
     hipLaunchKernelGGL(kern, dim3(ceil_div(T, ABL_NT / 2), H, B), dim3(ABL_NT), lds, st, qkv, slopes, out, H, Dh, T, Tp, scale_div);
     return check_launch("attention_bf16_lds");
 }
@@ -398,13 +394,8 @@ static int launch_flash(const float *qkv, const float *slopes, float *out, int B
                         hipStream_t st) {
     const size_t lds = PREC == 0 ? size_t(2) * 32 * DVT * 65 * sizeof(float) : 0;
     auto kern = attention_flash_kernel<DVT, PREC>;
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);   // head_dim 128: 90 KB
-        if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    static DeviceOnce once;
+    if (int rc = prepare_kernel(reinterpret_cast<const void *>(kern), once, lds > 48 * 1024 ? 96 * 1024 : 0, nullptr, "attention_flash")) return rc;
     dim3 grid(ceil_div(T, 128), H, B), block(256);
     hipLaunchKernelGGL(kern, grid, block, lds, st, qkv, slopes, out, H, Dh, T, scale_div);
     return check_launch("attention_flash");
@@ -670,14 +661,12 @@ int launch_attention_flash_backward(const float *qkv, const float *slopes, const
     const size_t l_stats = size_t(Dh * AB_QB + Dh * AB_KB + AB_QB * AB_KB) * sizeof(float);
     const size_t l_dq = size_t(2 * Dh * AB_QB + 2 * Dh * AB_KB + AB_QB * AB_KB) * sizeof(float);
     const size_t l_dkv = size_t(2 * Dh * AB_KB + 2 * Dh * AB_QB + 2 * AB_QB * AB_KB) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        for (const void *k : {reinterpret_cast<const void *>(attn_bwd_stats_kernel), reinterpret_cast<const void *>(attn_bwd_dq_kernel),
-                              reinterpret_cast<const void *>(attn_bwd_dkv_kernel)}) {
-            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);   // head_dim 128: 90 KB
-            if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        }
-        attr_set = true;
+    static DeviceOnce once[3];
+    {
+        const void *ks[3] = {reinterpret_cast<const void *>(attn_bwd_stats_kernel), reinterpret_cast<const void *>(attn_bwd_dq_kernel),
+                             reinterpret_cast<const void *>(attn_bwd_dkv_kernel)};
+        for (int i = 0; i < 3; ++i)
+            if (int rc = prepare_kernel(ks[i], once[i], 96 * 1024, nullptr, "attention_flash_backward")) return rc;   // head_dim 128: 90 KB
     }
     hipLaunchKernelGGL(attn_bwd_stats_kernel, gq, dim3(256), l_stats, st, qkv, slopes, out, dout, lse, delta, H, Dh, T, scale_div);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, gq, dim3(256), l_dq, st, qkv, slopes, dout, lse, delta, dqkv, H, Dh, T, scale_div);

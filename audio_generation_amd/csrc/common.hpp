@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include <cstdarg>
 #include <cstdint>
@@ -57,6 +58,27 @@ inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
     return AGX_OK;
+}
+
+// Per-device launch preparation of one kernel.  The dynamic-LDS attribute (> 64 KB) and the CU count are properties of a
+// DEVICE: round 3 cached them in function-local statics once per PROCESS, so a process that later used a second device never
+// raised the limit there (launches needing > 64 KB of LDS failed) and sized its persistent grid with the first device's CU
+// count; two threads making the first call also raced.  `once` is one static object per kernel instantiation: bit d = done on
+// device d (atomic; devices >= 64 are prepared on every launch).  Returns AGX_OK or a failure code; *n_cu may be NULL.
+struct DeviceOnce {
+    std::atomic<unsigned long long> done{0};
+};
+int device_cu_count(int dev, int *n_cu);     // cached per device (core.hip)
+inline int prepare_kernel(const void *kern, DeviceOnce &once, int lds_limit_bytes, int *n_cu, const char *what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(AGX_ERR_LAUNCH, "%s: cannot query the device", what);
+    const unsigned long long bit = dev >= 0 && dev < 64 ? 1ull << dev : 0ull;
+    if (lds_limit_bytes > 0 && (bit == 0 || !(once.done.load(std::memory_order_acquire) & bit))) {
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_limit_bytes);
+        if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+        once.done.fetch_or(bit, std::memory_order_release);
+    }
+    return n_cu ? device_cu_count(dev, n_cu) : AGX_OK;
 }
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

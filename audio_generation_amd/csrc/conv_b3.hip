@@ -703,19 +703,9 @@ template <int MW, int NW, int WM, int J_, int Q_, int P_>
 static int launch_cb3(const ConvPlan &p, const float *x, const float *wp, const float *bias, float *y, hipStream_t st) {
     using G = Cb3Geom<MW, NW, WM, J_, Q_, P_>;
     auto kern = conv_b3_kernel<MW, NW, WM, J_, Q_, P_>;
-    static bool attr_set = false;
-    static int n_cu = 0;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024);
-        if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-            return fail(AGX_ERR_LAUNCH, "conv_b3: cannot query the device");
-        n_cu = prop.multiProcessorCount;
-        attr_set = true;
-    }
+    static DeviceOnce once;
+    int n_cu = 0;
+    if (int rc = prepare_kernel(reinterpret_cast<const void *>(kern), once, 160 * 1024, &n_cu, "conv_b3")) return rc;
     static_assert(2 * G::LDS_BYTES <= 160 * 1024, "conv_b3: LDS budget of two workgroups per CU");
     const int tb = ceil_div(p.Lt, G::BN), mb = p.M / G::BM;
     const int64_t ntiles64 = int64_t(tb) * mb * p.B;
@@ -882,19 +872,9 @@ static int launch_c2b3(const ConvPlan &p, const float *x, const float *wp, const
                        float *y, hipStream_t st) {
     using G = C2b3Geom<MW, NW, WM, SL, KH, KW>;
     auto kern = conv2d_b3_kernel<MW, NW, WM, SL, KH, KW, Q, QH>;
-    static bool attr_set = false;
-    static int n_cu = 0;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024);
-        if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-            return fail(AGX_ERR_LAUNCH, "conv2d_b3: cannot query the device");
-        n_cu = prop.multiProcessorCount;
-        attr_set = true;
-    }
+    static DeviceOnce once;
+    int n_cu = 0;
+    if (int rc = prepare_kernel(reinterpret_cast<const void *>(kern), once, 160 * 1024, &n_cu, "conv2d_b3")) return rc;
     static_assert(2 * G::LDS_BYTES <= 160 * 1024, "conv2d_b3: LDS budget of two workgroups per CU");
     const int cb = ceil_div(p.Lt, G::WF), rb = ceil_div(p.Tt, G::R), mb = p.M / G::BM;
     const int64_t ntiles64 = int64_t(cb) * rb * mb * p.B;

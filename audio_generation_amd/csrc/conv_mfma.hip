@@ -239,13 +239,8 @@ static int launch_variant(const ConvPlan &p0, const float *x, const float *wp, c
     const size_t lds = size_t(2) * CC * span * sizeof(float);  // double-buffered input tile
     if (lds > 160 * 1024) return fail(AGX_ERR_UNSUPPORTED, "conv_mfma: tile needs %zu B of LDS", lds);
     auto kern = conv_mfma_kernel<MW, NW, WM, WN, CC, MODE, PREC>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    static DeviceOnce once;
+    if (int rc = prepare_kernel(reinterpret_cast<const void *>(kern), once, 160 * 1024, nullptr, "conv_mfma")) return rc;
     dim3 grid(ceil_div(p.Lt, BN), ceil_div(p.M, BM), p.B), block(256);
     if (MODE == 1) grid = dim3(p.B * p.Tout, ceil_div(p.M, BM), ceil_div(p.Lt, BN));
     if (MODE == 2)

@@ -514,19 +514,9 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
 template <class G>
 static int launch_cp(const ConvPlan &p, const float *x, const float *wp, const float *bias, float *y, hipStream_t st) {
     auto kern = conv_p_kernel<G>;
-    static bool attr_set = false;
-    static int n_cu = 0;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-            return fail(AGX_ERR_LAUNCH, "conv_p: cannot query the device");
-        n_cu = prop.multiProcessorCount;
-        attr_set = true;
-    }
+    static DeviceOnce once;
+    int n_cu = 0;
+    if (int rc = prepare_kernel(reinterpret_cast<const void *>(kern), once, 160 * 1024, &n_cu, "conv_p")) return rc;
     static_assert(G::LDS_BYTES <= 160 * 1024, "ring does not fit LDS");
     const int mblocks = p.M / G::BM, nblocks = ceil_div(p.Lt, G::BN);
     const int64_t ntiles64 = int64_t(mblocks) * nblocks * p.B;
@@ -599,19 +589,9 @@ template <class G>
 static int launch_cp2d(const ConvPlan &p, const float *x, const float *wp, const float *bias, const float *add,
                        float *y, hipStream_t st) {
     auto kern = conv_p_kernel<G>;
-    static bool attr_set = false;
-    static int n_cu = 0;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-            return fail(AGX_ERR_LAUNCH, "conv_p: cannot query the device");
-        n_cu = prop.multiProcessorCount;
-        attr_set = true;
-    }
+    static DeviceOnce once;
+    int n_cu = 0;
+    if (int rc = prepare_kernel(reinterpret_cast<const void *>(kern), once, 160 * 1024, &n_cu, "conv_p")) return rc;
     static_assert(G::LDS_BYTES <= 160 * 1024, "ring does not fit LDS");
     const float *mask = (p.epilogue & AGX_EPI_MASK) ? p.mask : nullptr;
     ConvPlan pp = p;

@@ -215,6 +215,21 @@ int lower_conv_bwd_data(const agx_conv_desc *d, ConvPlan *b) {
 
 }  // namespace agx
 
+namespace agx {
+int device_cu_count(int dev, int *n_cu) {
+    static std::atomic<int> cache[64];
+    int v = dev >= 0 && dev < 64 ? cache[dev].load(std::memory_order_relaxed) : 0;
+    if (v <= 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(AGX_ERR_LAUNCH, "cannot query device %d", dev);
+        v = prop.multiProcessorCount;
+        if (dev >= 0 && dev < 64) cache[dev].store(v, std::memory_order_relaxed);
+    }
+    *n_cu = v;
+    return AGX_OK;
+}
+}  // namespace agx
+
 extern "C" {
 
 int agx_version(void) { return AGX_VERSION; }

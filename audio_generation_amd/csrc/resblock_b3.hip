@@ -448,19 +448,9 @@ static int launch_b3(const ConvPlan &p, const float *x, const float *w1, const f
                      float *y, int post_act, hipStream_t st) {
     using G = B3Geom<MW, NW, D, NPB>;
     auto kern = resblock_b3_kernel<MW, NW, D, NPB>;
-    static bool attr_set = false;
-    static int n_cu = 0;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024);
-        if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-            return fail(AGX_ERR_LAUNCH, "resblock_b3: cannot query the device");
-        n_cu = prop.multiProcessorCount;
-        attr_set = true;
-    }
+    static DeviceOnce once;
+    int n_cu = 0;
+    if (int rc = prepare_kernel(reinterpret_cast<const void *>(kern), once, 160 * 1024, &n_cu, "resblock_b3")) return rc;
     static_assert(G::LDS_BYTES * (NPB == 1 ? 2 : 1) <= 160 * 1024, "resblock_b3: LDS budget");
     const int tiles_per_clip = ceil_div(p.Lin, G::BN);
     const int64_t ntiles64 = int64_t(tiles_per_clip) * p.B;

@@ -199,13 +199,8 @@ static int launch_rb(const ConvPlan &p, const float *x, const float *w1, const f
     const int wgs = tuning().rb_wgs;  // diagnostic: cap workgroups per CU by requesting more LDS
     if (wgs >= 1 && wgs <= 3 && lds < size_t(160 * 1024) / wgs) lds = size_t(160 * 1024) / wgs;
     auto kern = resblock_mfma_kernel<MW, NW, CC, SCHED, OCC, PREC>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    static DeviceOnce once;
+    if (int rc = prepare_kernel(reinterpret_cast<const void *>(kern), once, 160 * 1024, nullptr, "resblock_mfma")) return rc;
     dim3 grid(ceil_div(p.Lin, BN), p.B), block(256);
     if (grid.y > 65535) return fail(AGX_ERR_BAD_SHAPE, "resblock: batch too large for one launch");
     hipLaunchKernelGGL(kern, grid, block, lds, st, p, span, post_act, x, w1, b1, w2, b2, y);

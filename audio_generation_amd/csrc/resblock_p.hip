@@ -465,19 +465,9 @@ static int launch_rbp(const ConvPlan &p, const float *x, const float *w1, const 
                       const float *b2, float *y, int post_act, hipStream_t st) {
     using G = RbpGeom<MW, NW, CCH, D, NS>;
     auto kern = resblock_p_kernel<MW, NW, CCH, D, NS>;
-    static bool attr_set = false;
-    static int n_cu = 0;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-            return fail(AGX_ERR_LAUNCH, "resblock_p: cannot query the device");
-        n_cu = prop.multiProcessorCount;
-        attr_set = true;
-    }
+    static DeviceOnce once;
+    int n_cu = 0;
+    if (int rc = prepare_kernel(reinterpret_cast<const void *>(kern), once, 160 * 1024, &n_cu, "resblock_p")) return rc;
     const int tiles_per_clip = ceil_div(p.Lin, G::BN);
     const int64_t ntiles64 = int64_t(tiles_per_clip) * p.B;
     if (ntiles64 > (1 << 30)) return fail(AGX_ERR_BAD_SHAPE, "resblock_p: too many tiles");

@@ -22,9 +22,12 @@ __global__ __launch_bounds__(256) void multires_kernel(const float *__restrict__
     float *lo_a = sm, *lo_b = sm + W;
     float *hk0 = sm + 2 * W, *hk1 = hk0 + K;
     const int tid = threadIdx.x;
-    const int c = blockIdx.y % C;
-    const size_t row = size_t(blockIdx.y) * L;
-    const int t0 = blockIdx.x * MR_TT;
+    // 1-D grid: block = (row, tile) with the tiles of a row adjacent (rows used to sit in gridDim.y: B * C <= 65535)
+    const int n_tx = (L + MR_TT - 1) / MR_TT;
+    const unsigned brow = blockIdx.x / n_tx, btile = blockIdx.x - brow * n_tx;
+    const int c = brow % C;
+    const size_t row = size_t(brow) * L;
+    const int t0 = btile * MR_TT;
     const int g0 = t0 - halo;  // global index of tile position 0
 
     for (int i = tid; i < W; i += 256) {
@@ -118,9 +121,11 @@ __global__ __launch_bounds__(256) void multires_bwd_kernel(const float *__restri
     float *hk0 = gb + W, *hk1 = hk0 + K;
     float *red = hk1 + K;                       // [NP][4]
     const int tid = threadIdx.x;
-    const int c = blockIdx.y % C;
-    const size_t row = size_t(blockIdx.y) * L;
-    const int t0 = blockIdx.x * MRB_TT;
+    const int n_tx = (L + MRB_TT - 1) / MRB_TT;     // 1-D grid: block = (row, tile), as the forward
+    const unsigned brow = blockIdx.x / n_tx, btile = blockIdx.x - brow * n_tx;
+    const int c = brow % C;
+    const size_t row = size_t(brow) * L;
+    const int t0 = btile * MRB_TT;
     const int g0 = t0 - halo;
     const float *wc = w + size_t(c) * (depth + 2);
 
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(256) void multires_bwd_kernel(const float *__restri
     __syncthreads();
     if (tid < NP) {
         const float *r = red + 4 * tid;
-        part[(size_t(blockIdx.y) * gridDim.x + blockIdx.x) * NP + tid] = (r[0] + r[1]) + (r[2] + r[3]);
+        part[size_t(blockIdx.x) * NP + tid] = (r[0] + r[1]) + (r[2] + r[3]);      // (row, tile) order, as before
     }
 }
 
@@ -270,7 +275,9 @@ __global__ __launch_bounds__(256) void wavelet_fold_kernel(const float *__restri
     float *s_lo = sm + P;        // [scale]
     float *s_hi = s_lo + scale;  // [scale]
     const int tid = threadIdx.x;
-    const int c = blockIdx.y % C;
+    const int n_bx = min((L * scale + 255) / 256, 64);     // 1-D grid: block = (row, stripe)
+    const unsigned brow = blockIdx.x / n_bx, bstripe = blockIdx.x - brow * n_bx;
+    const int c = brow % C;
     const float sg = sigma[sigma_len == 1 ? 0 : c];
     if (tid < P) {
         const float t = space[tid];
@@ -286,11 +293,11 @@ __global__ __launch_bounds__(256) void wavelet_fold_kernel(const float *__restri
         s_hi[tid] = hi;
     }
     __syncthreads();
-    const size_t in_row = size_t(blockIdx.y) * L;
+    const size_t in_row = size_t(brow) * L;
     const size_t out_row = in_row * scale;
     const int n_out = L * scale;
     const int n_win = (L - 1) * scale + 1;
-    for (int u = blockIdx.x * 256 + tid; u < n_out; u += gridDim.x * 256) {
+    for (int u = bstripe * 256 + tid; u < n_out; u += n_bx * 256) {
         float v;
         if (u < n_win) {
             const int l0 = u / scale, ph = u - l0 * scale;
@@ -429,12 +436,12 @@ int agx_multires_forward(const float *x, const float *h0, const float *h1, const
     const size_t lds = (2 * (MR_TT + halo) + 2 * kernel) * sizeof(float);
     if (lds > 150 * 1024) return fail(AGX_ERR_UNSUPPORTED, "multires: receptive field %lld too long for LDS", (long long)halo);
     const int64_t rows = int64_t(batch) * channels;
-    if (rows > 65535) return fail(AGX_ERR_BAD_SHAPE, "multires: B*C too large for one launch");
+    if (rows * ceil_div(length, MR_TT) > INT32_MAX) return fail(AGX_ERR_BAD_SHAPE, "multires: too many tiles for one launch");
     auto kern = multires_kernel;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return fail(AGX_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(kern, dim3(ceil_div(length, MR_TT), (unsigned)rows), dim3(256), lds,
+    hipLaunchKernelGGL(kern, dim3((unsigned)(rows * ceil_div(length, MR_TT))), dim3(256), lds,
                        static_cast<hipStream_t>(stream), x, h0, h1, w, y, channels, length, kernel, depth, int(halo));
     return check_launch("multires");
 }
@@ -461,7 +468,7 @@ int agx_multires_backward(const float *x, const float *dout, const float *h0, co
     const size_t lds = (size_t(depth + 4) * (MRB_TT + 2 * halo) + 2 * kernel + 4 * np) * sizeof(float);
     if (lds > 150 * 1024) return fail(AGX_ERR_UNSUPPORTED, "multires_backward: receptive field %lld too long for LDS", (long long)halo);
     const int64_t rows = int64_t(batch) * channels;
-    if (rows > 65535) return fail(AGX_ERR_BAD_SHAPE, "multires_backward: B*C too large for one launch");
+    if (rows * ceil_div(length, MRB_TT) > INT32_MAX) return fail(AGX_ERR_BAD_SHAPE, "multires_backward: too many tiles for one launch");
     auto kern = multires_bwd_kernel;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -469,7 +476,7 @@ int agx_multires_backward(const float *x, const float *dout, const float *h0, co
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int tiles = ceil_div(length, MRB_TT);
     float *part = static_cast<float *>(workspace);
-    hipLaunchKernelGGL(kern, dim3(tiles, (unsigned)rows), dim3(256), lds, st, x, dout, h0, h1, w, dx, part, channels,
+    hipLaunchKernelGGL(kern, dim3((unsigned)(rows * tiles)), dim3(256), lds, st, x, dout, h0, h1, w, dx, part, channels,
                        length, kernel, depth, int(halo));
     hipLaunchKernelGGL(multires_bwd_reduce_kernel, dim3(channels), dim3(64), 0, st, part, batch, channels, tiles, kernel,
                        depth, dh0, dh1, dw);
@@ -495,10 +502,10 @@ int agx_wavelet_fold(const float *h, const float *space, const float *sigma, int
     if (sigma_len != 1 && sigma_len != channels) return fail(AGX_ERR_BAD_SHAPE, "wavelet_fold: sigma_len must be 1 or C");
     if (!h || !space || !sigma || !y) return fail(AGX_ERR_NULL_POINTER, "wavelet_fold: NULL pointer");
     const int64_t rows = int64_t(batch) * channels;
-    if (rows > 65535) return fail(AGX_ERR_BAD_SHAPE, "wavelet_fold: B*C too large for one launch");
-    const int gx = min(ceil_div(length * scale, 256), 64);
+    const int gx = min(ceil_div(length * scale, 256), 64);     // (the kernel derives the same stripe count)
+    if (rows * gx > INT32_MAX) return fail(AGX_ERR_BAD_SHAPE, "wavelet_fold: too many blocks for one launch");
     const size_t lds = (n_points + 2 * scale) * sizeof(float);
-    hipLaunchKernelGGL(wavelet_fold_kernel, dim3(gx, (unsigned)rows), dim3(256), lds,
+    hipLaunchKernelGGL(wavelet_fold_kernel, dim3((unsigned)(rows * gx)), dim3(256), lds,
                        static_cast<hipStream_t>(stream), h, space, sigma, sigma_len, y, channels, length, n_points, scale);
     return check_launch("wavelet_fold");
 }
