@@ -32,7 +32,7 @@ def count_macs(kind: str, macs: int, desc=None) -> None:
     asks for the bf16x3 arithmetic is reported as ``kind + ":bf16x3"`` (its products run on the bf16 matrix pipe at six
     bf16 flops per fp32-equivalent flop: a different roofline)."""
     if _observer is not None and hasattr(_observer, "macs"):
-        if desc is not None and getattr(desc, "impl", 0) == IMPL_MFMA_BF16X3:
+        if desc is not None and getattr(desc, "impl", 0) == _lib.IMPL_MFMA_BF16X3:
             kind += ":bf16x3"
         _observer.macs(kind, int(macs))
 
@@ -619,7 +619,7 @@ def conv2d_forward(desc, x: Tensor, packed: Tensor, bias: Optional[Tensor]) -> T
     _lib.check(lib.agx_conv2d_out_shape(ctypes.byref(desc), ctypes.byref(ho), ctypes.byref(wo)), "agx_conv2d_out_shape")
     y = torch.empty(desc.batch, desc.c_out, ho.value, wo.value, dtype=torch.float32, device=x.device)
     bias = None if bias is None else _f32c(bias)
-    tok = _observer.begin("other", ("conv2d:bf16x3" if desc.impl == IMPL_MFMA_BF16X3 else "conv2d", 4 * (x.numel() + y.numel()),
+    tok = _observer.begin("other", ("conv2d:bf16x3" if desc.impl == _lib.IMPL_MFMA_BF16X3 else "conv2d", 4 * (x.numel() + y.numel()),
                                      _conv2d_macs(desc))) if _observer is not None else None
     _lib.check(lib.agx_conv2d_forward(ctypes.byref(desc), _ptr(x), _ptr(packed), _ptr(bias), _ptr(y), _stream()),
                "agx_conv2d_forward")

@@ -14,14 +14,43 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _oracle_loss_and_grads(x, sd, spec, cbs):
-    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if not k.startswith("quantizer.")}
+def _oracle_loss_and_grads(x, sd, spec, cbs, dt=torch.float32):
+    leaves = {k: v.clone().to(dt).requires_grad_(True) for k, v in sd.items() if not k.startswith("quantizer.")}
+    x = x.to(dt)
     z = codec.encode_latents(x, leaves, spec)
-    zq, index, commit = rvq.residual_quantize_train(z, cbs)
+    zq, index, commit = rvq.residual_quantize_train(z, cbs.to(dt))
     y = codec.decode_latents(zq, leaves, spec)
     loss = ((y - x) ** 2).mean() + commit
     loss.backward()
     return float(loss.detach()), index, {k: v.grad for k, v in leaves.items()}
+
+
+# Gradient tolerance.  The comparator is the oracle's autograd in fp32; the SAME restatement in fp64
+# gives the exact gradient, hence the noise floor of fp32 arithmetic itself (the rule tests/test_gpu_step.py uses).  A
+# parameter passes when the HIP gradient is within TOL = 2e-4 of the exact one (relative to the gradient's largest element),
+# or -- where fp32 arithmetic cannot do better -- no further from it than 3 x the fp32 oracle's own distance.  (Round 3 allowed
+# 2e-3 against the fp32 oracle alone: a dropped O(1e-3) term of the weight-norm chain rule would have passed.)
+TOL = 2e-4
+
+
+def _check_gradients(named_grads, want32, want64, same_indices, skip=lambda name: False):
+    worst, checked = ("", 0.0), 0
+    for name, g in named_grads:
+        if skip(name):
+            continue
+        g = g.detach().cpu().double()
+        w32, w64 = want32[name].double(), want64[name].double()
+        scale = float(w64.abs().max()) + 1e-12
+        if not same_indices:            # the fp64 run chose another code somewhere: only the fp32 comparator applies
+            assert float((g - w32).abs().max()) <= 2e-3 * scale + 1e-9, name
+        else:
+            err = float((g - w64).abs().max())
+            noise = float((w32 - w64).abs().max())
+            assert err <= max(TOL * scale, 3.0 * noise) + 1e-9, (name, err / scale, noise / scale)
+            if err / scale > worst[1]:
+                worst = (name, err / scale)
+        checked += 1
+    return checked, worst
 
 
 @pytest.mark.parametrize("channels,wavelet", [(8, False), (32, False), (8, True)])
@@ -39,6 +68,7 @@ def test_gradients_match_oracle_autograd(channels, wavelet):
     model.quantizer.init_from_latents(z0.transpose(1, 2))
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     want_loss, want_idx, want_g = _oracle_loss_and_grads(x, sd, spec, sd["quantizer.codebooks"])
+    _, idx64, true_g = _oracle_loss_and_grads(x, sd, spec, sd["quantizer.codebooks"], torch.float64)
 
     model = model.to(DEV).train()
     xd = x.to(DEV)
@@ -53,15 +83,10 @@ def test_gradients_match_oracle_autograd(channels, wavelet):
     loss = ((y - xd) ** 2).mean() + commit
     assert abs(float(loss) - want_loss) < 1e-5 * max(1.0, abs(want_loss))
     loss.backward()
-    checked = 0
-    for name, p in model.named_parameters():
-        if name.startswith("quantizer."):
-            continue
-        assert p.grad is not None, name
-        g, w = p.grad.cpu(), want_g[name]
-        scale = float(w.abs().max()) + 1e-12
-        assert float((g - w).abs().max()) <= 2e-3 * scale + 1e-9, (name, float((g - w).abs().max()), scale)
-        checked += 1
+    assert all(p.grad is not None for n, p in model.named_parameters() if not n.startswith("quantizer."))
+    checked, worst = _check_gradients(((n, p.grad) for n, p in model.named_parameters()), want_g, true_g,
+                                      torch.equal(idx64, want_idx), skip=lambda n: n.startswith("quantizer."))
+    print(f"worst gradient error vs the fp64 oracle: {worst[1]:.2e} of max|g| ({worst[0]})")
     ops.conv_bwd_data, ops.conv_bwd_weight = real_bd, real_bw
     n_params = sum(1 for n, _ in model.named_parameters() if not n.startswith("quantizer."))
     assert checked == n_params and checked >= 180
@@ -100,14 +125,16 @@ def test_transformer_bottleneck_gradients():
     leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     xl = x.clone().requires_grad_(True)
     oattn.transformer(xl, leaves, 4).pow(2).mean().backward()
+    leaves64 = {k: v.clone().double().requires_grad_(True) for k, v in sd.items()}
+    oattn.transformer(x.double(), leaves64, 4).pow(2).mean().backward()
     tf = tf.to(DEV).train()
     xg = x.to(DEV).requires_grad_(True)
     y, _, _ = TransformerBottleneck(tf)(xg)
     y.pow(2).mean().backward()
     assert float((xg.grad.cpu() - xl.grad).abs().max()) < 1e-5
-    for name, p in tf.named_parameters():
-        w = leaves[name].grad
-        assert float((p.grad.cpu() - w).abs().max()) <= 2e-3 * float(w.abs().max()) + 1e-9, name
+    checked, worst = _check_gradients(((n, p.grad) for n, p in tf.named_parameters()), {k: v.grad for k, v in leaves.items()},
+                                      {k: v.grad for k, v in leaves64.items()}, True)
+    assert checked == len(leaves)
 
 
 def test_transformer_backward_kernels_against_autograd():
@@ -178,6 +205,7 @@ def test_depthwise_variant_gradients_match_oracle_autograd():
     model.quantizer.init_from_latents(codec.encode_latents(x, sd0, spec).transpose(1, 2))
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     want_loss, want_idx, want_g = _oracle_loss_and_grads(x, sd, spec, sd["quantizer.codebooks"])
+    _, idx64, true_g = _oracle_loss_and_grads(x, sd, spec, sd["quantizer.codebooks"], torch.float64)
     model = model.to(DEV).train()
     xd = x.to(DEV)
     y, commit, index = model(xd)
@@ -185,22 +213,17 @@ def test_depthwise_variant_gradients_match_oracle_autograd():
     loss = ((y - xd) ** 2).mean() + commit
     assert abs(float(loss) - want_loss) < 1e-5 * max(1.0, abs(want_loss))
     loss.backward()
-    checked = 0
-    for name, p in model.named_parameters():
-        if name.startswith("quantizer."):
-            continue
-        assert p.grad is not None, name
-        g, w = p.grad.cpu(), want_g[name]
-        scale = float(w.abs().max()) + 1e-12
-        if name.endswith(".conv1.0.conv.weight_v"):
-            # a 1-element direction: the weight-norm chain rule gives dv = 0 up to rounding on both sides -- compare on
-            # the scale of the gradient of the magnitude g instead
-            scale = float(want_g[name[:-1] + "g"].abs().max()) + 1e-12
-            assert float(g.abs().max()) <= 1e-5 * scale and float(w.abs().max()) <= 1e-5 * scale, name
-        else:
-            assert float((g - w).abs().max()) <= 2e-3 * scale + 1e-9, (name, float((g - w).abs().max()), scale)
-        checked += 1
-    assert checked == sum(1 for n, _ in model.named_parameters() if not n.startswith("quantizer."))
+    one_elem = [n for n, _ in model.named_parameters() if n.endswith(".conv1.0.conv.weight_v")]
+    for name in one_elem:
+        # a 1-element direction: the weight-norm chain rule gives dv = 0 up to rounding on both sides -- compare on
+        # the scale of the gradient of the magnitude g instead
+        g, w = dict(model.named_parameters())[name].grad.cpu(), want_g[name]
+        scale = float(want_g[name[:-1] + "g"].abs().max()) + 1e-12
+        assert float(g.abs().max()) <= 1e-5 * scale and float(w.abs().max()) <= 1e-5 * scale, name
+    checked, _ = _check_gradients(((n, p.grad) for n, p in model.named_parameters()), want_g, true_g,
+                                  torch.equal(idx64, want_idx),
+                                  skip=lambda n: n.startswith("quantizer.") or n in one_elem)
+    assert checked + len(one_elem) == sum(1 for n, _ in model.named_parameters() if not n.startswith("quantizer."))
 
 
 def test_training_step_with_bf16x3_decoder_matches_fp32():
