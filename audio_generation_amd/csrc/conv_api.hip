@@ -24,7 +24,8 @@ const char *resblock_b3_variant(const ConvPlan &p);
 int launch_conv_b3(const ConvPlan &p, const float *x, const float *wp, const float *bias, float *y, hipStream_t st);
 bool conv_b3_supported(const ConvPlan &p);
 const char *conv_b3_variant(const ConvPlan &p);
-int launch_conv_p(const ConvPlan &p, const float *x, const float *wp, const float *bias, float *y, hipStream_t st);
+int launch_conv_p(const ConvPlan &p, const float *x, const float *wp, const float *bias, const float *res, float *y,
+                  hipStream_t st);
 bool conv_p_supported(const ConvPlan &p);
 const char *conv_p_variant(const ConvPlan &p);
 
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void gelu_grad_mul_kernel(float *__restrict__ 
 static int run_conv(const ConvPlan &p, int impl, const float *x, const float *wp, const float *bias,
                     const float *res, float *y, hipStream_t st) {
     if ((impl == AGX_IMPL_AUTO || impl == AGX_IMPL_MFMA) && tuning().conv_impl == 1 && conv_p_supported(p))
-        return launch_conv_p(p, x, wp, bias, y, st);
+        return launch_conv_p(p, x, wp, bias, res, y, st);
     if (impl == AGX_IMPL_MFMA_BF16X3 && tuning().conv_impl == 1 && conv_b3_supported(p)) return launch_conv_b3(p, x, wp, bias, y, st);
     if (impl == AGX_IMPL_AUTO) impl = conv_mfma_supported(p) ? AGX_IMPL_MFMA : AGX_IMPL_DIRECT;
     if (impl == AGX_IMPL_MFMA || impl == AGX_IMPL_MFMA_BF16X3) return launch_conv_mfma(p, x, wp, bias, res, y, st);

@@ -332,6 +332,7 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
     if (PRE3) cp_load_frag<G>(f[0], lds + aLane, lds + bLane, 0, bk);
 
     const bool pre_act = (p.epilogue & AGX_EPI_LEAKY_PRE) != 0;
+    const bool gelu_act = (p.epilogue & AGX_EPI_GELU_PRE) != 0, post_act = (p.epilogue & AGX_EPI_LEAKY_POST) != 0;
     CpTileCur cc = first;
     int qs = 0;   // ring slot of the chunk being consumed
     f32x16 acc[MW][NW];
@@ -447,7 +448,21 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
                             }
                     }
                 } else if (Q == 1) {
+                    // 1-D layers with one output phase also carry the transformer block's epilogues (transformers.py:157-223: exact
+                    // GELU behind FFN-in, the residual add behind W_o / FFN-out) and the unfused residual block's (vae.py:113-117):
+                    // v = post( res + gelu|leaky( acc + bias ) ).  The residual values of a row group are requested before its
+                    // first store (vmcnt counts loads and stores in order: a load between two stores waits for the store).
                     const f32x4 bq = *reinterpret_cast<const f32x4 *>(lds + G::BIAS0 + m4);
+                    float rv[NW][4];
+                    if (add2) {
+#pragma unroll
+                        for (int kk = 0; kk < NW; ++kk) {
+                            const int tc = min(nb * BN + wn * 32 * NW + kk * 32 + li, p.Lt - 1);
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; ++s4)
+                                rv[kk][s4] = *reinterpret_cast<const float *>(ab + unsigned((m4 + s4) * loutv + tc) * 4u);
+                        }
+                    }
 #pragma unroll
                     for (int kk = 0; kk < NW; ++kk) {
                         const int t = nb * BN + wn * 32 * NW + kk * 32 + li;
@@ -455,6 +470,9 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
                         for (int s4 = 0; s4 < 4; ++s4) {
                             float v = acc[i][kk][4 * g + s4] + bq[s4];
                             if (pre_act) v = leaky(v, p.slope);
+                            if (gelu_act) v = gelu_erf(v);
+                            if (add2) v += rv[kk][s4];
+                            if (post_act) v = leaky(v, p.slope);
                             if (t < p.Lt) *reinterpret_cast<float *>(yb + unsigned((m4 + s4) * loutv + t) * 4u) = v;
                         }
                     }
@@ -512,7 +530,8 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
 }
 
 template <class G>
-static int launch_cp(const ConvPlan &p, const float *x, const float *wp, const float *bias, float *y, hipStream_t st) {
+static int launch_cp(const ConvPlan &p, const float *x, const float *wp, const float *bias, const float *res, float *y,
+                     hipStream_t st) {
     auto kern = conv_p_kernel<G>;
     static DeviceOnce once;
     int n_cu = 0;
@@ -529,7 +548,7 @@ static int launch_cp(const ConvPlan &p, const float *x, const float *wp, const f
     const int per_clip = mblocks * nblocks;
     const int sb = grid / per_clip, rem = grid % per_clip;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G::LDS_BYTES, st, p, mblocks, nblocks, ntiles, rem % mblocks,
-                       rem / mblocks, sb, x, wp + p.tile_off, bias, y, static_cast<const float *>(nullptr),
+                       rem / mblocks, sb, x, wp + p.tile_off, bias, y, (p.epilogue & AGX_EPI_RESIDUAL) ? res : nullptr,
                        static_cast<const float *>(nullptr), 0);
     return check_launch("conv_p");
 }
@@ -631,6 +650,11 @@ typedef CpGeom<2, 2, 2, 2, 8, 3, 1, 5, 1, 2> CpUp5;       // upsample x5:       
 typedef CpGeom<2, 2, 2, 2, 8, 3, 1, 4, 1, 2> CpUp4;       // upsample x4:              128 x 128
 typedef CpGeom<2, 2, 1, 4, 8, 3, 1, 3, 1, 2> CpUp3;       // upsample x3 (M = 3 Cout = 192 for 128 -> 64): 64 x 256
 typedef CpGeom<2, 2, 1, 4, 8, 3, 1, 2, 1, 2> CpUp2;       // upsample x2, M = 64:       64 x 256
+// round 4 (configs 3 / 4 off the first-round kernels):
+typedef CpGeom<2, 1, 2, 2, 16, 1, 1, 1, 0, 3> CpK1;       // k = 1 (every Linear of the transformer block, transformers.py:157-223; the
+                                                          // unfused block's second conv): 128 x 64, one phase per chunk -> 3 slots
+typedef CpGeom<2, 2, 2, 2, 4, 11, 1, 1, 5, 2> CpSame11;   // Conv1d(K = 11, padding="same") -- WaveletLayer's first conv at stride 5 (wavelets.py:193-201): 128 x 128
+typedef CpGeom<2, 1, 2, 2, 16, 3, 1, 1, 1, 2> CpSame3;    // Conv1d(K = 3, padding="same") -- WaveletLayer's last conv: 128 x 64
 
 // Conv2d (row-folded; the kernel's row count / row stride / row padding are run-time):
 //                      MW NW WM WN CCH  J  S  Q  P NS  D2
@@ -732,7 +756,8 @@ int launch_conv_p2d(const ConvPlan &p, const float *x, const float *wp, const fl
     }
 }
 
-enum { CP_NONE = 0, CP_DOWN2, CP_DOWN4, CP_DOWN5, CP_DOWN8, CP_K3, CP_K7, CP_UP8, CP_UP5, CP_UP4, CP_UP2, CP_DOWN3, CP_UP3 };
+enum { CP_NONE = 0, CP_DOWN2, CP_DOWN4, CP_DOWN5, CP_DOWN8, CP_K3, CP_K7, CP_UP8, CP_UP5, CP_UP4, CP_UP2, CP_DOWN3, CP_UP3, CP_K1, CP_SAME11,
+       CP_SAME3 };
 
 template <class G>
 static bool cp_fits(const ConvPlan &p) {
@@ -756,13 +781,18 @@ int conv_p_geometry(const ConvPlan &p) {
     if (Q == 4 && J == 3 && S == 1 && P == 1 && cp_fits<CpUp4>(p)) return CP_UP4;
     if (Q == 3 && J == 3 && S == 1 && P == 1 && cp_fits<CpUp3>(p)) return CP_UP3;
     if (Q == 2 && J == 3 && S == 1 && P == 1 && p.M == 64 && cp_fits<CpUp2>(p)) return CP_UP2;
+    if (Q == 1 && J == 1 && S == 1 && P == 0 && cp_fits<CpK1>(p)) return CP_K1;
+    if (Q == 1 && J == 11 && S == 1 && P == 5 && cp_fits<CpSame11>(p)) return CP_SAME11;
+    if (Q == 1 && J == 3 && S == 1 && P == 1 && cp_fits<CpSame3>(p)) return CP_SAME3;
     return CP_NONE;
 }
 
-// can THIS call run on the ring kernel? (epilogue: bias + optional LeakyReLU only)
+// can THIS call run on the ring kernel? (epilogue: bias + optional LeakyReLU; one-phase layers also GELU / residual / the
+// activation behind the residual)
 bool conv_p_supported(const ConvPlan &p) {
     if (p.tile_off < 0 || conv_p_geometry(p) == CP_NONE) return false;
-    if ((p.epilogue & ~AGX_EPI_LEAKY_PRE) != 0 || p.oshift != 0 || p.mask != nullptr) return false;
+    const int epi_ok = p.q == 1 ? (AGX_EPI_LEAKY_PRE | AGX_EPI_RESIDUAL | AGX_EPI_LEAKY_POST | AGX_EPI_GELU_PRE) : AGX_EPI_LEAKY_PRE;
+    if ((p.epilogue & ~epi_ok) != 0 || p.oshift != 0 || p.mask != nullptr) return false;
     if (p.Lvalid != p.Lin || p.Lin < 4 || p.Lout != p.q * p.Lt) return false;   // (ragged L: fix_ragged)
     if (p.q > 1 && p.q % 4 == 0 && (p.Lout % 4 != 0)) return false;
     // 32-bit byte offsets inside a clip (DMA cells: row * Lin + 4 * col; stores: row * Lout + t): very long clips fall back
@@ -786,25 +816,32 @@ const char *conv_p_variant(const ConvPlan &p) {
         case CP_UP2: return "conv_p<up2,64x256>";
         case CP_DOWN3: return "conv_p<down3,128x128>";
         case CP_UP3: return "conv_p<up3,64x256>";
+        case CP_K1: return "conv_p<k1,128x64>";
+        case CP_SAME11: return "conv_p<same11,128x128>";
+        case CP_SAME3: return "conv_p<same3,128x64>";
         default: return "conv_p<unsupported>";
     }
 }
 
-int launch_conv_p(const ConvPlan &p, const float *x, const float *wp, const float *bias, float *y, hipStream_t st) {
+int launch_conv_p(const ConvPlan &p, const float *x, const float *wp, const float *bias, const float *res, float *y,
+                  hipStream_t st) {
     if (!conv_p_supported(p)) return fail(AGX_ERR_UNSUPPORTED, "conv_p: unsupported layer");
     switch (conv_p_geometry(p)) {
-        case CP_DOWN2: return launch_cp<CpDown2>(p, x, wp, bias, y, st);
-        case CP_DOWN4: return launch_cp<CpDown4>(p, x, wp, bias, y, st);
-        case CP_DOWN5: return launch_cp<CpDown5>(p, x, wp, bias, y, st);
-        case CP_DOWN8: return launch_cp<CpDown8>(p, x, wp, bias, y, st);
-        case CP_K3: return launch_cp<CpK3>(p, x, wp, bias, y, st);
-        case CP_K7: return launch_cp<CpK7>(p, x, wp, bias, y, st);
-        case CP_UP8: return launch_cp<CpUp8>(p, x, wp, bias, y, st);
-        case CP_UP5: return launch_cp<CpUp5>(p, x, wp, bias, y, st);
-        case CP_UP4: return launch_cp<CpUp4>(p, x, wp, bias, y, st);
-        case CP_UP2: return launch_cp<CpUp2>(p, x, wp, bias, y, st);
-        case CP_DOWN3: return launch_cp<CpDown3>(p, x, wp, bias, y, st);
-        case CP_UP3: return launch_cp<CpUp3>(p, x, wp, bias, y, st);
+        case CP_DOWN2: return launch_cp<CpDown2>(p, x, wp, bias, res, y, st);
+        case CP_DOWN4: return launch_cp<CpDown4>(p, x, wp, bias, res, y, st);
+        case CP_DOWN5: return launch_cp<CpDown5>(p, x, wp, bias, res, y, st);
+        case CP_DOWN8: return launch_cp<CpDown8>(p, x, wp, bias, res, y, st);
+        case CP_K3: return launch_cp<CpK3>(p, x, wp, bias, res, y, st);
+        case CP_K7: return launch_cp<CpK7>(p, x, wp, bias, res, y, st);
+        case CP_UP8: return launch_cp<CpUp8>(p, x, wp, bias, res, y, st);
+        case CP_UP5: return launch_cp<CpUp5>(p, x, wp, bias, res, y, st);
+        case CP_UP4: return launch_cp<CpUp4>(p, x, wp, bias, res, y, st);
+        case CP_UP2: return launch_cp<CpUp2>(p, x, wp, bias, res, y, st);
+        case CP_DOWN3: return launch_cp<CpDown3>(p, x, wp, bias, res, y, st);
+        case CP_UP3: return launch_cp<CpUp3>(p, x, wp, bias, res, y, st);
+        case CP_K1: return launch_cp<CpK1>(p, x, wp, bias, res, y, st);
+        case CP_SAME11: return launch_cp<CpSame11>(p, x, wp, bias, res, y, st);
+        case CP_SAME3: return launch_cp<CpSame3>(p, x, wp, bias, res, y, st);
         default: return fail(AGX_ERR_UNSUPPORTED, "conv_p: unsupported layer");
     }
 }

@@ -96,6 +96,82 @@ def test_calls_the_ring_kernel_does_not_cover_fall_back():
     desc, packed, bias, x, want = _case("conv", 64, 128, 9, 4, 2, 3, gen)         # shorter than one 16-byte cell
     assert ops.conv_kernel_name(desc).startswith("conv_mfma")
     assert max_abs(ops.conv_forward(desc, x, packed, bias).cpu(), want) < 2e-5 * max(1.0, float(want.abs().max()))
-    # residual epilogue (used by the two-launch residual block and the transformer): first kernel
-    d2 = ops.conv_desc(_lib.CONV_CAUSAL, 2, 512, 512, 64, 3, 1, 1, _lib.EPI_RESIDUAL, 0.1, _lib.IMPL_AUTO)
+    # a second LeakyReLU behind the residual needs a residual; the upsampling (multi-phase) geometries only take bias + LeakyReLU
+    d2 = ops.conv_desc(_lib.CONV_UPSAMPLE, 2, 512, 256, 64, 17, 8, 1, _lib.EPI_RESIDUAL, 0.1, _lib.IMPL_AUTO)
     assert ops.conv_kernel_name(d2).startswith("conv_mfma")
+
+
+# ---- round 4: the one-phase geometries behind configs 3 / 4 (every Linear of the transformer block as a k = 1 conv,
+# transformers.py:157-223; WaveletLayer's two padding="same" convs, wavelets.py:193-201) and their epilogues ----------------
+def _ref_epilogue(pre, epi, res):
+    import torch.nn.functional as F
+    v = pre
+    if epi & _lib.EPI_LEAKY_PRE:
+        v = codec.leaky(v)
+    if epi & _lib.EPI_GELU_PRE:
+        v = F.gelu(v)
+    if epi & _lib.EPI_RESIDUAL:
+        v = v + res
+    if epi & _lib.EPI_LEAKY_POST:
+        v = codec.leaky(v)
+    return v
+
+
+@pytest.mark.parametrize("variant,kind,cin,cout,k", [
+    ("k1", _lib.CONV_CAUSAL, 512, 512, 1), ("k1", _lib.CONV_CAUSAL, 512, 1536, 1), ("k1", _lib.CONV_CAUSAL, 256, 256, 1),
+    ("k1", _lib.CONV_CAUSAL, 128, 128, 1), ("same11", _lib.CONV_SAME, 256, 512, 11), ("same3", _lib.CONV_SAME, 512, 128, 3),
+    ("k3", _lib.CONV_CAUSAL, 512, 512, 3)])
+def test_one_phase_geometries_and_their_epilogues(variant, kind, cin, cout, k):
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(sum(map(ord, variant)) + cin + cout)
+    epis = (0, _lib.EPI_LEAKY_PRE, _lib.EPI_GELU_PRE, _lib.EPI_RESIDUAL, _lib.EPI_RESIDUAL | _lib.EPI_LEAKY_POST,
+            _lib.EPI_LEAKY_PRE | _lib.EPI_RESIDUAL | _lib.EPI_LEAKY_POST)
+    for n, (b, length) in enumerate(((2, 225), (1, 4), (3, 60), (2, 1028), (1, 77), (5, 131), (2, 520))):
+        epi = epis[n % len(epis)]
+        v = torch.randn(cout, cin, k, generator=gen) / (cin * k) ** 0.5
+        g = torch.rand(cout, 1, 1, generator=gen) + 0.5
+        bias = torch.randn(cout, generator=gen) * 0.1
+        x = torch.randn(b, cin, length, generator=gen)
+        res = torch.randn(b, cout, length, generator=gen)
+        w = codec.fold_weight_norm(g, v)
+        pre = codec.causal_conv1d(x, w, bias, stride=1) if kind == _lib.CONV_CAUSAL else F.conv1d(x, w, bias, padding="same")
+        want = _ref_epilogue(pre, epi, res)
+        desc = ops.conv_desc(kind, b, cin, cout, length, k, 1, 1, epi, 0.1, _lib.IMPL_AUTO)
+        packed = ops.conv_pack(desc, v.to(DEV), g.to(DEV))
+        r = res.to(DEV) if epi & _lib.EPI_RESIDUAL else None
+        try:
+            _set("conv_impl", 1)
+            assert ops.conv_kernel_name(desc).startswith(f"conv_p<{variant},"), (ops.conv_kernel_name(desc), variant)
+            y = ops.conv_forward(desc, x.to(DEV), packed, bias.to(DEV), res=r)
+            _set("conv_impl", 0)
+            assert not ops.conv_kernel_name(desc).startswith("conv_p")
+            y_old = ops.conv_forward(desc, x.to(DEV), packed, bias.to(DEV), res=r)
+        finally:
+            _set("conv_impl", 1)
+        tol = 2e-5 * max(1.0, float(want.abs().max()))
+        assert max_abs(y.cpu(), want) < tol, (variant, epi, b, length, max_abs(y.cpu(), want))
+        assert max_abs(y, y_old) < tol
+
+
+@pytest.mark.parametrize("variant,kind,cin,cout,k,b,length,epi", [
+    ("k1", _lib.CONV_CAUSAL, 512, 512, 1, 40, 225, _lib.EPI_RESIDUAL),            # 4 x 4 x 40 = 640 tiles of 128 x 64
+    ("k1", _lib.CONV_CAUSAL, 512, 1536, 1, 32, 225, 0),                           # config 3's QKV projection: 12 x 4 x 32
+    ("k1", _lib.CONV_CAUSAL, 512, 512, 1, 32, 225, _lib.EPI_GELU_PRE),            # ... FFN-in
+    ("same11", _lib.CONV_SAME, 256, 512, 11, 3, 3600, 0),                         # config 4's wavelet block: 4 x 29 x 3
+    ("same3", _lib.CONV_SAME, 512, 128, 3, 3, 18000, 0),                          # 282 x 3 = 846
+    ("k1", _lib.CONV_CAUSAL, 128, 128, 1, 4, 9000, _lib.EPI_RESIDUAL | _lib.EPI_LEAKY_POST),   # the unfused block's second conv
+])
+def test_one_phase_geometries_with_more_tiles_than_workgroups(variant, kind, cin, cout, k, b, length, epi):
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(5)
+    v = torch.randn(cout, cin, k, generator=gen) / (cin * k) ** 0.5
+    bias = torch.randn(cout, generator=gen) * 0.1
+    x = torch.randn(b, cin, length, generator=gen)
+    res = torch.randn(b, cout, length, generator=gen)
+    pre = codec.causal_conv1d(x, v, bias, stride=1) if kind == _lib.CONV_CAUSAL else F.conv1d(x, v, bias, padding="same")
+    want = _ref_epilogue(pre, epi, res)
+    desc = ops.conv_desc(kind, b, cin, cout, length, k, 1, 1, epi, 0.1, _lib.IMPL_AUTO)
+    assert ops.conv_kernel_name(desc).startswith(f"conv_p<{variant},")
+    y = ops.conv_forward(desc, x.to(DEV), ops.conv_pack(desc, v.to(DEV)), bias.to(DEV),
+                         res=res.to(DEV) if epi & _lib.EPI_RESIDUAL else None)
+    assert max_abs(y.cpu(), want) < 2e-5 * max(1.0, float(want.abs().max()))
