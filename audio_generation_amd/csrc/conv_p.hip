@@ -45,7 +45,8 @@ __device__ __forceinline__ void cp_static_for(F &&f) {
 // of a chunk are row i * sh - ph + dh of CCH consecutive feature maps (the page of zeros when that row is padding).
 // QH (D2 only): output-row phases -- backward-data of a strided Conv2d: rows m = (ci * QH + a) * Q + c of the GEMM are
 // the (row, column) phases of input channel ci, written to row QH * t' + a - oshift_h, column Q * f' + c - oshift.
-template <int MW_, int NW_, int WM_, int WN_, int CCH_, int J_, int S_, int Q_, int PL_, int NS_, bool D2_ = false, int QH_ = 1>
+template <int MW_, int NW_, int WM_, int WN_, int CCH_, int J_, int S_, int Q_, int PL_, int NS_, bool D2_ = false, int QH_ = 1,
+          int NB_ = 1024>
 struct CpGeom {
     static constexpr int MW = MW_, NW = NW_, WM = WM_, WN = WN_, CCH = CCH_, J = J_, S = S_, Q = Q_, PL = PL_, NSLOT = NS_;
     static constexpr bool D2 = D2_;
@@ -70,7 +71,7 @@ struct CpGeom {
     static constexpr int RA = (NPA + 3) / 4, RB = (NIB + 3) / 4, NOPS = RA + RB;
     static constexpr int OPP = (NOPS + J - 1) / J;      // DMA instructions per phase
     static constexpr int BIAS0 = NSLOT * SLOT;          // bias[Cout] staged once per kernel (Cout <= 1024)
-    static constexpr int NBIAS = 1024;
+    static constexpr int NBIAS = NB_;                  // most output channels a layer of this geometry may have (bias staged in LDS)
     static constexpr int DUMMY0 = BIAS0 + NBIAS;        // 1 KiB nobody reads: destination of the DMA slots a wave has no piece for
     static constexpr size_t LDS_BYTES = size_t(DUMMY0 + 256) * sizeof(float);
     static constexpr int NDS = MW * (KS == 8 ? 2 : 1) + KS * NW, NMF = KS * MW * NW;   // LDS reads / MFMAs per phase
@@ -651,7 +652,7 @@ typedef CpGeom<2, 2, 2, 2, 8, 3, 1, 4, 1, 2> CpUp4;       // upsample x4:       
 typedef CpGeom<2, 2, 1, 4, 8, 3, 1, 3, 1, 2> CpUp3;       // upsample x3 (M = 3 Cout = 192 for 128 -> 64): 64 x 256
 typedef CpGeom<2, 2, 1, 4, 8, 3, 1, 2, 1, 2> CpUp2;       // upsample x2, M = 64:       64 x 256
 // round 4 (configs 3 / 4 off the first-round kernels):
-typedef CpGeom<2, 1, 2, 2, 16, 1, 1, 1, 0, 3> CpK1;       // k = 1 (every Linear of the transformer block, transformers.py:157-223; the
+typedef CpGeom<2, 1, 2, 2, 16, 1, 1, 1, 0, 3, false, 1, 2048> CpK1;       // k = 1 (every Linear of the transformer block, transformers.py:157-223; the
                                                           // unfused block's second conv): 128 x 64, one phase per chunk -> 3 slots
 typedef CpGeom<2, 2, 2, 2, 4, 11, 1, 1, 5, 2> CpSame11;   // Conv1d(K = 11, padding="same") -- WaveletLayer's first conv at stride 5 (wavelets.py:193-201): 128 x 128
 typedef CpGeom<2, 1, 2, 2, 16, 3, 1, 1, 1, 2> CpSame3;    // Conv1d(K = 3, padding="same") -- WaveletLayer's last conv: 128 x 64

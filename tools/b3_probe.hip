@@ -9,6 +9,7 @@ namespace agx {
 int lower_conv2d(const agx_conv2d_desc *, ConvPlan *) { return AGX_ERR_UNSUPPORTED; }
 int lower_conv2d_bwd_data(const agx_conv2d_desc *, ConvPlan *) { return AGX_ERR_UNSUPPORTED; }
 int conv_p_geometry(const ConvPlan &) { return 0; }
+int conv_b3_geometry(const ConvPlan &) { return 0; }
 }  // namespace agx
 
 #include <algorithm>
