@@ -50,6 +50,10 @@ SIGNATURES = {
     "agx_conv_packed_floats": (c_int64, [_PD]),
     "agx_conv_pack": (c_int, [_PD, c_void_p, c_void_p, c_void_p, c_void_p]),
     "agx_conv_forward": (c_int, [_PD, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "agx_planes_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "agx_planes_split": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "agx_conv_planes_supported": (c_int, [_PD]),
+    "agx_conv_forward_planes": (c_int, [_PD, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "agx_conv_bwd_packed_floats": (c_int64, [_PD]),
     "agx_conv_pack_bwd": (c_int, [_PD, c_void_p, c_void_p, c_void_p, c_void_p]),
     "agx_conv_bwd_data": (c_int, [_PD, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),

@@ -23,6 +23,9 @@ bool resblock_b3_supported(const ConvPlan &p);
 const char *resblock_b3_variant(const ConvPlan &p);
 int launch_conv_b3(const ConvPlan &p, const float *x, const float *wp, const float *bias, float *y, hipStream_t st);
 bool conv_b3_supported(const ConvPlan &p);
+int launch_conv_b3_planes(const ConvPlan &p, const void *x_planes, const float *wp, const float *bias, float *y, void *y_planes,
+                          hipStream_t st);
+int launch_planes_split(const float *x, void *planes, int batch, int channels, int length, hipStream_t st);
 const char *conv_b3_variant(const ConvPlan &p);
 int launch_conv_p(const ConvPlan &p, const float *x, const float *wp, const float *bias, const float *res, float *y,
                   hipStream_t st);
@@ -61,6 +64,39 @@ int agx_conv_forward(const agx_conv_desc *d, const float *x, const float *packed
     if ((p.epilogue & AGX_EPI_RESIDUAL) && !res)
         return fail(AGX_ERR_NULL_POINTER, "agx_conv_forward: residual epilogue without res");
     return run_conv(p, d->impl, x, packed, bias, res, y, static_cast<hipStream_t>(stream));
+}
+
+size_t agx_planes_bytes(int32_t batch, int32_t channels, int32_t length) {
+    if (batch <= 0 || channels <= 0 || length <= 0 || channels % 8 != 0) return 0;
+    return size_t(batch) * (channels / 8) * 3 * size_t(length) * 16;
+}
+
+int agx_planes_split(const float *x, void *planes, int32_t batch, int32_t channels, int32_t length, void *stream) {
+    using namespace agx;
+    if (batch <= 0 || channels <= 0 || length <= 0 || channels % 8 != 0)
+        return fail(AGX_ERR_BAD_SHAPE, "agx_planes_split: bad shape B=%d C=%d L=%d (C must be a multiple of 8)", batch, channels, length);
+    if (!x || !planes) return fail(AGX_ERR_NULL_POINTER, "agx_planes_split: NULL pointer");
+    return launch_planes_split(x, planes, batch, channels, length, static_cast<hipStream_t>(stream));
+}
+
+int agx_conv_forward_planes(const agx_conv_desc *d, const void *x_planes, const float *packed, const float *bias, float *y,
+                            void *y_planes, void *stream) {
+    using namespace agx;
+    ConvPlan p;
+    int rc = lower_conv(d, &p);
+    if (rc != AGX_OK) return rc;
+    if (!x_planes || !packed || (!y && !y_planes)) return fail(AGX_ERR_NULL_POINTER, "agx_conv_forward_planes: NULL pointer");
+    if (d->impl != AGX_IMPL_MFMA_BF16X3 || tuning().conv_impl != 1 || !conv_b3_supported(p))
+        return fail(AGX_ERR_UNSUPPORTED, "agx_conv_forward_planes: the layer has no bf16x3 ring form (ask agx_conv_planes_supported first)");
+    return launch_conv_b3_planes(p, x_planes, packed, bias, y, y_planes, static_cast<hipStream_t>(stream));
+}
+
+int agx_conv_planes_supported(const agx_conv_desc *d) {
+    using namespace agx;
+    ConvPlan p;
+    if (lower_conv(d, &p) != AGX_OK) return 0;
+    if (d->impl != AGX_IMPL_MFMA_BF16X3 || tuning().conv_impl != 1 || !conv_b3_supported(p)) return 0;
+    return (p.q == 1 && p.Cout % 8 == 0) ? 2 : 1;      // 2: the layer can also WRITE planes (one output phase)
 }
 
 int agx_conv_bwd_data(const agx_conv_desc *d, const float *dy, const float *packed_bwd, const float *add,

@@ -31,7 +31,9 @@ __device__ __forceinline__ void cb3_glds_b128(const void *gsrc_lane, void *lds_w
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-template <int MW, int NW, int WM, int J_, int Q_, int P_>
+// XP: the input arrives as ready-made bf16 planes (common.hpp: "activation planes", written by a producer's epilogue or by
+// planes_split_kernel) and is staged by LDS-DMA into TWO plane buffers -- no register staging, no split, no second barrier.
+template <int MW, int NW, int WM, int J_, int Q_, int P_, bool XP = false>
 struct Cb3Geom {
     static constexpr int WN = 4 / WM;                      // waves along the columns
     static constexpr int BM = 32 * MW * WM, BN = 32 * NW * WN, J = J_, Q = Q_, P = P_;
@@ -42,7 +44,9 @@ struct Cb3Geom {
     static constexpr int RW = (NPW + 3) / 4;
     static constexpr int NT = (2 * W + 255) / 256;         // split tasks (time step x 8 channels) per thread and chunk
     static constexpr int NGRP = (J + 1) / 2;               // weight groups per chunk: [0,1] [2,3] .. (the last one single)
-    static constexpr int OFF_W = PLANE_B;
+    static constexpr int NIR = (W + 63) / 64;              // XP: 1 KiB DMA instructions per plane row (the last one partial)
+    static constexpr int RX = (6 * NIR + 3) / 4;           // ... per wave and chunk
+    static constexpr int OFF_W = (XP ? 2 : 1) * PLANE_B;
     static constexpr size_t LDS_BYTES = size_t(OFF_W) + 4 * WSLOT_B;
     static_assert(NGRP % 2 == 0, "an even number of groups per chunk keeps the slot sets alternating");
     static_assert(J % 2 == 1, "taps come in pairs plus one");
@@ -59,11 +63,27 @@ __device__ __forceinline__ void cb3_products(f32x16 (&acc)[N], const cb3x8 (&a)[
         }
 }
 
-template <int MW, int NW, int WM, int J_, int Q_, int P_>
+// four values of one accumulator row group -> three bf16 pieces each (8 bytes per piece: channels 4 lh .. 4 lh + 3 of a cell)
+typedef __bf16 cb3x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void cb3_split4(const float (&v)[4], cb3x4 &h, cb3x4 &m, cb3x4 &l) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 hh = (__bf16)v[e];
+        const float r1 = v[e] - (float)hh;
+        const __bf16 mm = (__bf16)r1;
+        h[e] = hh;
+        m[e] = mm;
+        l[e] = (__bf16)(r1 - (float)mm);
+    }
+}
+
+// XP: x = activation planes (bf16 [B][Cin / 8][3][Lin][8]); YP (Q = 1): y = activation planes of the output instead of fp32
+template <int MW, int NW, int WM, int J_, int Q_, int P_, bool XP = false, bool YP = false>
 __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_clip, int mb_count, int ntiles,
                                                          const float *__restrict__ x, const char *__restrict__ wt,
                                                          const float *__restrict__ bias, float *__restrict__ y) {
-    using G = Cb3Geom<MW, NW, WM, J_, Q_, P_>;
+    using G = Cb3Geom<MW, NW, WM, J_, Q_, P_, XP>;
+    static_assert(!YP || Q_ == 1, "plane output: one output phase");
     constexpr int BM = G::BM, BN = G::BN, W = G::W, J = G::J, Q = G::Q, NT = G::NT;
     constexpr int NSTEP = J * NW;                         // MFMA steps per chunk: (tap, column block); all MW row blocks per step
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -127,9 +147,31 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_
     // chunk is 72 MFMAs per wave -- 2.3 k cycles of matrix pipe, 4.6 k next to the partner workgroup --, less than a global load
     // takes under load, and a request issued ONE chunk ahead was waited for at every chunk boundary.
     int i_k = 0, i_chunk = 0;                             // the next chunk to load: tile index, chunk
-    float st2[2][NT][8];
-    int st_t2[2][NT];
-    auto input_load = [&](float (&st)[NT][8], int (&st_t)[NT]) {
+    // XP: the chunk's six plane rows ((piece, channel half) x W cells of 16 bytes) by LDS-DMA, instruction q = wave + 4 r:
+    // row q / NIR, cells 64 (q % NIR) .. + 63; cells outside the signal come from the page of zeros, lanes past the row's
+    // end are switched off (the only masked DMA: one instruction per row)
+    auto planes_dma = [&](int buf) {
+        const bool live = i_k < my_tiles;
+        int b_, tb_, mb_;
+        decode(min(int(blockIdx.x) + i_k * int(gridDim.x), ntiles - 1), b_, tb_, mb_);
+        const int in0 = tb_ * BN - G::P;
+        const char *xc = reinterpret_cast<const char *>(x) + (size_t(b_) * (p.Cin / 8) + size_t(i_chunk) * 2) * 3 * size_t(Lin) * 16;
+#pragma unroll
+        for (int r = 0; r < G::RX; ++r) {
+            const int q = wave + 4 * r;
+            const int row = q / G::NIR, part = q - row * G::NIR;       // row = piece * 2 + half
+            const int cell = part * 64 + lane;
+            const int pos = in0 + cell;
+            const bool ok = live && pos >= 0 && pos < p.Lvalid;
+            const char *src = ok ? xc + (size_t((row & 1) * 3 + (row >> 1)) * Lin + size_t(pos)) * 16 : zpage;
+            if (q < 6 * G::NIR && cell < W) cb3_glds_b128(src, lds + buf * G::PLANE_B + (row * W + part * 64) * 16);
+        }
+        if (++i_chunk == nch) i_chunk = 0, ++i_k;
+    };
+    float st2[XP ? 1 : 2][XP ? 1 : NT][8];
+    int st_t2[XP ? 1 : 2][XP ? 1 : NT];
+    auto input_load = [&](float (&st)[XP ? 1 : NT][8], int (&st_t)[XP ? 1 : NT]) {
+        if (XP) return;
         const bool live = i_k < my_tiles;
         int b_, tb_, mb_;
         decode(min(int(blockIdx.x) + i_k * int(gridDim.x), ntiles - 1), b_, tb_, mb_);
@@ -138,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_
         unsigned lin4 = unsigned(Lin) * 4u;
         asm volatile("" : "+s"(lin4));
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
+        for (int n = 0; n < (XP ? 1 : NT); ++n) {
             const int u = tid + 256 * n;
             const int uh = u >= W ? 1 : 0;
             const int t = u - uh * W;
@@ -156,9 +198,10 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_
         }
         if (++i_chunk == nch) i_chunk = 0, ++i_k;
     };
-    auto input_store_all = [&](const float (&st)[NT][8], const int (&st_t)[NT]) {
+    auto input_store_all = [&](const float (&st)[XP ? 1 : NT][8], const int (&st_t)[XP ? 1 : NT]) {
+        if (XP) return;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
+        for (int n = 0; n < (XP ? 1 : NT); ++n) {
             cb3x8 h, m, l;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -186,19 +229,22 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_
 #pragma unroll
             for (int i = 0; i < MW; ++i) a[pl][i] = *reinterpret_cast<const cb3x8 *>(ws + (pl * 2 * BM + 32 * i) * 16);
     };
-    auto load_b = [&](cb3x8 (&bf)[3], int j, int kk) {
+    auto load_b = [&](cb3x8 (&bf)[3], int j, int kk, int buf = 0) {     // buf: XP only (two plane buffers, chunk parity)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) bf[pl] = *reinterpret_cast<const cb3x8 *>(lds + bLane + (pl * 2 * W + 32 * kk + j) * 16);
+        for (int pl = 0; pl < 3; ++pl)
+            bf[pl] = *reinterpret_cast<const cb3x8 *>(lds + (XP ? buf * G::PLANE_B : 0) + bLane + (pl * 2 * W + 32 * kk + j) * 16);
     };
 
-    // ---- prologue: chunk 0 -> planes, chunks 1 and 2 on their way ----
+    // ---- prologue: chunk 0 -> planes, chunks 1 and 2 on their way (XP: chunk 0 by DMA, chunk 1 requested) ----
+    if (XP) planes_dma(0);
     input_load(st2[0], st_t2[0]);
     dma_next_group();
     dma_next_group();
     input_store_all(st2[0], st_t2[0]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    input_load(st2[1], st_t2[1]);
+    if (XP) planes_dma(1);
+    input_load(st2[XP ? 0 : 1], st_t2[XP ? 0 : 1]);
     input_load(st2[0], st_t2[0]);
 
     cb3x8 fa[2][3][MW], fb[2][3];
@@ -233,6 +279,10 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_
                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                             __syncthreads();
                             dma_next_group();
+                            // XP, the chunk's LAST group: every wave holds the chunk's last operands, so its plane buffer is free --
+                            // the chunk after next goes there; the NEXT chunk's planes (requested a chunk ago) have landed behind
+                            // this barrier, so the operand prefetch simply runs on across the chunk boundary
+                            if (XP && j == J - 1) planes_dma(cc);
                         }
                         f32x16 part[MW];
 #pragma unroll
@@ -245,13 +295,16 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_
                         if (nj == J) nj = 0;
                         if (!chunk_end) {      // (the next chunk's planes only exist behind the second barrier below)
                             if (nk == 0) load_a(fa[ua ^ 1], nj);
-                            load_b(fb[sb ^ 1], nj, nk);
+                            load_b(fb[sb ^ 1], nj, nk, cc);
+                        } else if (XP && !(c2 + 2 >= nch && cc == 1)) {      // (a tile's first operands are read at its top)
+                            load_a(fa[ua ^ 1], 0);
+                            load_b(fb[sb ^ 1], 0, 0, cc ^ 1);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                         cb3_products<MW>(part, fa[ua], fb[sb], 3, 6);
 #pragma unroll
                         for (int i = 0; i < MW; ++i) acc[i][kk] = part[i];
-                        if (chunk_end) {
+                        if (chunk_end && !XP) {
                             // one plane buffer: every wave is past the chunk's barrier (holds its last operands in registers);
                             // split + write the next chunk (register set of its parity: nch is even, so the parity of a chunk
                             // within its tile is its parity in the stream), barrier, read the next step's operands
@@ -287,7 +340,21 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int mrow = m0 + r0w + 32 * i + 8 * g + 4 * lh;    // + s4; a multiple of 4
-                        if (Q % 4 == 0) {         // the 4 rows are 4 consecutive output samples of one channel: one 16-byte store
+                        if (YP) {                 // activation planes for the next bf16x3 layer: channels mrow .. mrow + 3 = half of a cell
+                            float v4[4];
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; ++s4) {
+                                const float a = acc[i][kk][4 * g + s4] + bq[i][4 * g + s4];
+                                v4[s4] = pre ? leaky(a, p.slope) : a;
+                            }
+                            cb3x4 ph, pm, pl;
+                            cb3_split4(v4, ph, pm, pl);
+                            char *cell = reinterpret_cast<char *>(y) + ((size_t(b) * (p.Cout / 8) + size_t(mrow >> 3)) * 3 * size_t(Lout) + size_t(t)) * 16 +
+                                         (mrow & 4) * 2;
+                            *reinterpret_cast<cb3x4 *>(cell) = ph;
+                            *reinterpret_cast<cb3x4 *>(cell + size_t(Lout) * 16) = pm;
+                            *reinterpret_cast<cb3x4 *>(cell + size_t(Lout) * 32) = pl;
+                        } else if (Q % 4 == 0) {         // the 4 rows are 4 consecutive output samples of one channel: one 16-byte store
                             const int co = mrow / Q, ph = mrow % Q;
                             const float bv = bq[i][4 * g];
                             f32x4 v;
@@ -699,10 +766,10 @@ const char *conv_b3_variant(const ConvPlan &p) {
     }
 }
 
-template <int MW, int NW, int WM, int J_, int Q_, int P_>
+template <int MW, int NW, int WM, int J_, int Q_, int P_, bool XP = false, bool YP = false>
 static int launch_cb3(const ConvPlan &p, const float *x, const float *wp, const float *bias, float *y, hipStream_t st) {
-    using G = Cb3Geom<MW, NW, WM, J_, Q_, P_>;
-    auto kern = conv_b3_kernel<MW, NW, WM, J_, Q_, P_>;
+    using G = Cb3Geom<MW, NW, WM, J_, Q_, P_, XP>;
+    auto kern = conv_b3_kernel<MW, NW, WM, J_, Q_, P_, XP, YP>;
     static DeviceOnce once;
     int n_cu = 0;
     if (int rc = prepare_kernel(reinterpret_cast<const void *>(kern), once, 160 * 1024, &n_cu, "conv_b3")) return rc;
@@ -730,6 +797,60 @@ int launch_conv_b3(const ConvPlan &p, const float *x, const float *wp, const flo
     }
 }
 
+// The same layers fed with activation planes (common.hpp) -- x_planes: bf16 [B][Cin / 8][3][Lin][8]; y_planes (k = 7 layer only, may
+// be NULL): the output as planes [B][Cout / 8][3][Lout][8] instead of fp32.
+int launch_conv_b3_planes(const ConvPlan &p, const void *x_planes, const float *wp, const float *bias, float *y, void *y_planes,
+                          hipStream_t st) {
+    if (!conv_b3_supported(p)) return fail(AGX_ERR_UNSUPPORTED, "conv_b3: unsupported layer");
+    if (int64_t(p.Cin / 8) * 3 * p.Lin * 16 >= (int64_t(1) << 40)) return fail(AGX_ERR_BAD_SHAPE, "conv_b3: clip too long");
+    const float *xp = static_cast<const float *>(x_planes);
+    const int g = conv_b3_geometry(p);
+    if (y_planes && (g != CB3_K7 || p.Cout % 8 != 0)) return fail(AGX_ERR_UNSUPPORTED, "conv_b3: plane output is for the one-phase layer");
+    switch (g) {
+        case CB3_UP2: return launch_cb3<2, 2, 1, 3, 2, 1, true>(p, xp, wp, bias, y, st);
+        case CB3_UP4: return launch_cb3<2, 2, 2, 3, 4, 1, true>(p, xp, wp, bias, y, st);
+        case CB3_UP5: return launch_cb3<2, 2, 2, 3, 5, 1, true>(p, xp, wp, bias, y, st);
+        case CB3_UP8: return launch_cb3<2, 2, 2, 3, 8, 1, true>(p, xp, wp, bias, y, st);
+        case CB3_K7:
+            return y_planes ? launch_cb3<2, 2, 2, 7, 1, 6, true, true>(p, xp, wp, bias, static_cast<float *>(y_planes), st)
+                            : launch_cb3<2, 2, 2, 7, 1, 6, true, false>(p, xp, wp, bias, y, st);
+        default: return fail(AGX_ERR_UNSUPPORTED, "conv_b3: unsupported layer");
+    }
+}
+
+// fp32 (B, C, L) -> activation planes: one thread = one cell (8 channels of one time step), loads coalesced along time
+__global__ __launch_bounds__(256) void planes_split_kernel(const float *__restrict__ x, char *__restrict__ planes, int C8, int L,
+                                                           int64_t ncell) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= ncell) return;
+    const int t = int(i % L);
+    const int64_t bg = i / L;                       // b * C8 + g
+    const float *src = x + bg * 8 * L + t;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = src[size_t(e) * L];
+    cb3x8 h, m, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 hh = (__bf16)v[e];
+        const float r1 = v[e] - (float)hh;
+        const __bf16 mm = (__bf16)r1;
+        h[e] = hh;
+        m[e] = mm;
+        l[e] = (__bf16)(r1 - (float)mm);
+    }
+    char *dst = planes + (bg * 3 * L + t) * 16;
+    *reinterpret_cast<cb3x8 *>(dst) = h;
+    *reinterpret_cast<cb3x8 *>(dst + size_t(L) * 16) = m;
+    *reinterpret_cast<cb3x8 *>(dst + size_t(L) * 32) = l;
+}
+int launch_planes_split(const float *x, void *planes, int batch, int channels, int length, hipStream_t st) {
+    const int64_t ncell = int64_t(batch) * (channels / 8) * length;
+    if (ncell > (int64_t(1) << 38)) return fail(AGX_ERR_BAD_SHAPE, "planes_split: too many cells");
+    hipLaunchKernelGGL(planes_split_kernel, dim3((unsigned)ceil_div64(ncell, 256)), dim3(256), 0, st, x, static_cast<char *>(planes),
+                       channels / 8, length, ncell);
+    return check_launch("planes_split");
+}
 
 // floats of the B3 tile image of a Conv2d plan with the ring form: the plan's own bf16x3 weights, or -- strided forward layers -- the
 // space-to-depth weights (sh sw Cin virtual channels x ceil(kh / sh) ceil(kw / sw) taps: the same count when the strides divide the

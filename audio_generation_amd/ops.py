@@ -147,6 +147,57 @@ def conv_forward(desc: ConvDesc, x: Tensor, packed: Tensor, bias: Optional[Tenso
     return y
 
 
+# ---------------------------------------------------------------- activation planes (bf16x3, include/agx.h)
+def planes_split(x: Tensor) -> Tensor:
+    """fp32 (B, C, L) -> activation planes: bf16 (B, C / 8, 3, L, 8), h + m + l == x exactly."""
+    lib = _lib.load()
+    _need_gpu(x)
+    x = _f32c(x)
+    b, c, length = x.shape
+    if c % 8:
+        raise AgxError(f"planes_split: {c} channels (must be a multiple of 8)")
+    planes = torch.empty((b, c // 8, 3, length, 8), dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.agx_planes_split(_ptr(x), _ptr(planes), b, c, length, _stream()), "agx_planes_split")
+    return planes
+
+
+def planes_join(planes: Tensor) -> Tensor:
+    """The fp32 activation a planes tensor stands for (h + m + l; host-side helper for tests and debugging, torch arithmetic)."""
+    b, g, _, length, _ = planes.shape
+    p = planes.float()
+    return ((p[:, :, 0] + p[:, :, 1]) + p[:, :, 2]).permute(0, 1, 3, 2).reshape(b, g * 8, length).contiguous()
+
+
+def conv_planes_supported(desc: ConvDesc) -> int:
+    """0: no planes path; 1: the layer can read planes; 2: it can also write its output as planes."""
+    return int(_lib.load().agx_conv_planes_supported(ctypes.byref(desc)))
+
+
+def conv_forward_planes(desc: ConvDesc, x_planes: Tensor, packed: Tensor, bias: Optional[Tensor],
+                        out_planes: bool = False) -> Tensor:
+    """``conv_forward`` of a bf16x3 ring layer whose input is given as activation planes; ``out_planes``: the output is
+    returned as planes as well (one-phase layers only)."""
+    lib = _lib.load()
+    _need_gpu(x_planes, packed, bias)
+    if x_planes.dtype != torch.bfloat16 or tuple(x_planes.shape) != (desc.batch, desc.c_in // 8, 3, desc.l_in, 8) \
+            or not x_planes.is_contiguous():
+        raise AgxError(f"conv_forward_planes: planes are {tuple(x_planes.shape)} {x_planes.dtype}, descriptor says "
+                       f"{(desc.batch, desc.c_in // 8, 3, desc.l_in, 8)} bfloat16")
+    l_out = conv_out_len(desc)
+    bias = None if bias is None else _f32c(bias)
+    if out_planes:
+        y = torch.empty((desc.batch, desc.c_out // 8, 3, l_out, 8), dtype=torch.bfloat16, device=x_planes.device)
+    else:
+        y = torch.empty((desc.batch, desc.c_out, l_out), dtype=torch.float32, device=x_planes.device)
+    tok = _observer.begin("conv", desc) if _observer is not None else None
+    _lib.check(lib.agx_conv_forward_planes(ctypes.byref(desc), _ptr(x_planes), _ptr(packed), _ptr(bias),
+                                           None if out_planes else _ptr(y), _ptr(y) if out_planes else None, _stream()),
+               "agx_conv_forward_planes")
+    if tok is not None:
+        _observer.end(tok)
+    return y
+
+
 def conv_pack_bwd(desc: ConvDesc, v: Tensor, g: Optional[Tensor] = None) -> Tensor:
     """Packed image of the layer's backward-data op (``agx_conv_pack_bwd``)."""
     lib = _lib.load()

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define AGX_VERSION 119 /* 119: agx_rvq_verify_counts + knob rvq_verify (debug: the full defining search beside the fast path); agx_rvq_debug_stamps and the b3_dbg 7/8/9 bound knobs exist in the probe build only; 118: agx_feature_means(_backward) (the feature-matching pair in one pass); 117: agx_rvq_debug_stamps (diagnostic); 116: agx_multires_backward, agx_layernorm_ct one-pass kernel (same signature); agx_rvq_forward (legacy form) needs the workspace of agx_rvq_workspace_bytes since 114; 115: agx_rvq_ema_stats, agx_conv2d_bwd_data_kernel_name; 114: agx_attention_alibi_backward_ex (any T), agx_rvq_forward_ex; 113: tile images (resblock_p / conv_p), agx_attention_alibi_ex, agx_sizeof_*; 0.1.1: agx_conv_desc gained groups / padding (zero = old behaviour); 111: resample, conv2d column split */
+#define AGX_VERSION 120 /* 120: activation planes (agx_planes_bytes / agx_planes_split / agx_conv_forward_planes / agx_conv_planes_supported): pre-split bf16x3 input of the decoder's resampling convs; conv_p one-phase geometries (k = 1, "same" k = 11 / 3) with GELU / residual epilogues; 119: agx_rvq_verify_counts + knob rvq_verify (debug: the full defining search beside the fast path); agx_rvq_debug_stamps and the b3_dbg 7/8/9 bound knobs exist in the probe build only; 118: agx_feature_means(_backward) (the feature-matching pair in one pass); 117: agx_rvq_debug_stamps (diagnostic); 116: agx_multires_backward, agx_layernorm_ct one-pass kernel (same signature); agx_rvq_forward (legacy form) needs the workspace of agx_rvq_workspace_bytes since 114; 115: agx_rvq_ema_stats, agx_conv2d_bwd_data_kernel_name; 114: agx_attention_alibi_backward_ex (any T), agx_rvq_forward_ex; 113: tile images (resblock_p / conv_p), agx_attention_alibi_ex, agx_sizeof_*; 0.1.1: agx_conv_desc gained groups / padding (zero = old behaviour); 111: resample, conv2d column split */
 
 #define AGX_OK 0
 #define AGX_ERR_BAD_SHAPE (-1)
@@ -249,6 +249,30 @@ int agx_rvq_forward_ex(const float *x, int64_t x_sb, int64_t x_st, int64_t x_sd,
 size_t agx_rvq_ema_workspace_bytes(int64_t n_frames, int32_t dim, int32_t q_used);
 int agx_rvq_ema_stats(const float *frames, const float *codebooks, const int64_t *index, float *stats, int64_t n_frames,
                       int32_t dim, int32_t k, int32_t q_used, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Activation planes (bf16x3 arithmetic, round 4)                              *
+ * ------------------------------------------------------------------------- *
+ * A bf16x3 layer multiplies three bf16 pieces x = h + m + l of every fp32 operand.  Splitting the INPUT is per-element
+ * vector work that every consumer tile repeats (a polyphase up-conv with M = q Cout rows re-splits the same input tile
+ * M / 128 times).  "Activation planes" are that split done ONCE, by the producer: for an activation (B, C, L), C % 8 == 0,
+ *     planes[b][C / 8][piece 3][L][8]   bf16   (piece 0 = h, 1 = m, 2 = l;  h + m + l == x exactly)
+ * -- 6 bytes per element (1.5 x fp32), a cell of 8 channels x 1 time step = 16 bytes, so a consumer stages a 16-channel
+ * chunk of its input tile as six contiguous row pieces by LDS-DMA: no register staging, no vector work.
+ *   agx_planes_bytes           size of the planes of a (batch, channels, length) activation (0: bad shape)
+ *   agx_planes_split           fp32 (B, C, L) contiguous -> planes (a bandwidth-bound pass; producers with a planes
+ *                              output write them from their epilogue instead)
+ *   agx_conv_planes_supported  0: this descriptor cannot take planes; 1: it can READ planes (AGX_IMPL_MFMA_BF16X3 layers
+ *                              with the ring form: CausalUpsampleConv1d x2 / x4 / x5 / x8, CausalConvT1d k7 s1,
+ *                              vae.py:45-89); 2: it can also WRITE its output as planes (one output phase)
+ *   agx_conv_forward_planes    agx_conv_forward with x given as planes; y_planes != NULL (code 2 layers): the output is
+ *                              written as planes [B][Cout / 8][3][Lout][8] INSTEAD of fp32 (y may then be NULL).
+ *                              Results are bit-identical to agx_conv_forward on the fp32 input (same pieces, same order). */
+size_t agx_planes_bytes(int32_t batch, int32_t channels, int32_t length);
+int agx_planes_split(const float *x, void *planes, int32_t batch, int32_t channels, int32_t length, void *stream);
+int agx_conv_planes_supported(const agx_conv_desc *d);
+int agx_conv_forward_planes(const agx_conv_desc *d, const void *x_planes, const float *packed, const float *bias, float *y,
+                            void *y_planes, void *stream);
 
 /* Diagnostic (not part of the reference surface), PROBE BUILD ONLY (-DAGX_RVQ_PROBE: `python tools/rvq_stamps.py build` writes
  * lib/libagx_rvq_probe.so; the product library returns AGX_ERR_UNSUPPORTED and keeps no pointer between calls): the next

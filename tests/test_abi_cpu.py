@@ -37,7 +37,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/agx.h but not exported by libagx.so"
-    assert lib.agx_version() == 119
+    assert lib.agx_version() == 120
 
 
 def test_out_len_matches_reference_padding_rule(lib):

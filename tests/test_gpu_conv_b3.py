@@ -70,3 +70,44 @@ def test_other_layers_keep_their_kernels():
     assert ops.conv_kernel_name(d).startswith("conv_mfma") and ops.conv_kernel_name(d).endswith(":bf16x3")
     d = ops.conv_desc(_lib.CONV_UPSAMPLE, 2, 48, 32, 400, 5, 2, 1, 0, 0.1, _lib.IMPL_MFMA_BF16X3)   # Cin % 32 != 0
     assert not ops.conv_kernel_name(d).startswith("conv_b3")
+
+
+# ---- round 4: activation planes (include/agx.h) -- the input split once by the producer, staged by LDS-DMA ----------------
+def test_planes_round_trip_is_exact():
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 40, 77, generator=gen) * torch.pow(2.0, 20 * torch.rand(3, 40, 77, generator=gen) - 10)
+    x[0, 0, :5] = torch.tensor([0.0, -0.0, 1.0, 2.0 ** -100, -3.5e20])
+    planes = ops.planes_split(x.to(DEV))
+    assert planes.shape == (3, 5, 3, 77, 8) and planes.dtype == torch.bfloat16
+    assert torch.equal(ops.planes_join(planes).cpu(), x)              # h + m + l == x, bit for bit
+    with pytest.raises(Exception):
+        ops.planes_split(torch.randn(1, 12, 8, device=DEV))           # channels not a multiple of 8
+
+
+@pytest.mark.parametrize("variant,kind,cin,cout,k,s", LAYERS)
+def test_planes_input_is_bit_identical_to_the_fp32_input(variant, kind, cin, cout, k, s):
+    """Same pieces, same products, same order: the plane-fed kernel must reproduce the register-split kernel bit for bit
+    (ragged lengths, clips shorter than a tile, the zero cells of the causal halo, more tiles than workgroups)."""
+    gen = torch.Generator().manual_seed(sum(map(ord, variant)) + cout)
+    for b, length, act in ((1, 3, True), (2, 60, False), (1, 128, True), (3, 129, True), (2, 225, True), (1, 515, False),
+                           (9, 1800 if cin <= 256 else 450, True)):
+        wshape = (cin, cout, k) if kind == "convt" else (cout, cin, k)
+        v = torch.randn(wshape, generator=gen) / (cin * k) ** 0.5
+        bias = torch.randn(cout, generator=gen) * 0.1
+        x = torch.randn(b, cin, length, generator=gen).to(DEV)
+        desc = ops.conv_desc(KIND[kind], b, cin, cout, length, k, s, 1, _lib.EPI_LEAKY_PRE if act else 0, 0.1, _lib.IMPL_MFMA_BF16X3)
+        packed = ops.conv_pack(desc, v.to(DEV))
+        assert ops.conv_planes_supported(desc) == (2 if kind == "convt" else 1)
+        y = ops.conv_forward(desc, x, packed, bias.to(DEV))
+        yp = ops.conv_forward_planes(desc, ops.planes_split(x), packed, bias.to(DEV))
+        assert torch.equal(yp, y), (variant, b, length, float((yp - y).abs().max()))
+        if kind == "convt":       # the one-phase layer also WRITES planes: the same values, split
+            ypp = ops.conv_forward_planes(desc, ops.planes_split(x), packed, bias.to(DEV), out_planes=True)
+            assert torch.equal(ops.planes_join(ypp), y)
+
+
+def test_planes_path_refuses_what_it_cannot_run():
+    d = ops.conv_desc(_lib.CONV_CAUSAL, 2, 64, 128, 4000, 9, 4, 1, 0, 0.1, _lib.IMPL_MFMA_BF16X3)       # strided: no ring form
+    assert ops.conv_planes_supported(d) == 0
+    d = ops.conv_desc(_lib.CONV_UPSAMPLE, 2, 512, 256, 64, 17, 8, 1, 0, 0.1, _lib.IMPL_AUTO)            # fp32 descriptor
+    assert ops.conv_planes_supported(d) == 0
