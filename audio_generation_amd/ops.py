@@ -83,7 +83,7 @@ def _need_gpu(*tensors: Optional[Tensor]) -> None:
         if not t.is_cuda:
             raise AgxError("audio_generation_amd runs on the MI355X only: got a tensor on "
                            f"'{t.device}'.  There is no CPU / eager fallback.")
-        if t.dtype not in (torch.float32, torch.int64, torch.float64, torch.uint8):
+        if t.dtype not in (torch.float32, torch.int64, torch.float64, torch.uint8, torch.bfloat16):   # bfloat16: activation planes
             raise AgxError(f"unsupported dtype {t.dtype}")
 
 
