@@ -164,7 +164,14 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_
             const int pos = in0 + cell;
             const bool ok = live && pos >= 0 && pos < p.Lvalid;
             const char *src = ok ? xc + (size_t((row & 1) * 3 + (row >> 1)) * Lin + size_t(pos)) * 16 : zpage;
-            if (q < 6 * G::NIR && cell < W) cb3_glds_b128(src, lds + buf * G::PLANE_B + (row * W + part * 64) * 16);
+            // exactly RX instructions per wave (the counted waits rely on it): slots past the last row re-write this wave's last
+            // real piece (same bytes, same wave: in order)
+            const bool real = q < 6 * G::NIR;
+            const int rowd = real ? row : 5, partd = real ? part : G::NIR - 1;
+            const int celld = partd * 64 + lane;
+            const int posd = in0 + celld;
+            const char *srcd = real ? src : ((live && posd >= 0 && posd < p.Lvalid) ? xc + (size_t((rowd & 1) * 3 + (rowd >> 1)) * Lin + size_t(posd)) * 16 : zpage);
+            if (celld < W) cb3_glds_b128(srcd, lds + buf * G::PLANE_B + (rowd * W + partd * 64) * 16);
         }
         if (++i_chunk == nch) i_chunk = 0, ++i_k;
     };
@@ -276,13 +283,25 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_
                         const bool group_end = last_of_phase && ((j & 1) == 1 || j == J - 1);
                         const bool chunk_end = last_of_phase && j == J - 1;
                         if (group_end) {      // early barrier: this group's last operands are in registers
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            // COUNTED wait (round 4; vmcnt counts loads and LDS-DMA in issue order).  A group-end barrier needs the
+                            // weight group issued at the previous one.  Behind the chunk's LAST barrier the next input went out as
+                            // well -- the plane DMA of the chunk after next (XP: RX instructions per wave) or the register loads
+                            // (8 NT) --, needed a whole chunk later: at the chunk's FIRST group end they stay in flight (round 3
+                            // drained them with vmcnt(0) two taps after their issue, every chunk).  Later group ends of the chunk
+                            // wait for everything (their weights are younger than that input).
+                            if (j == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XP ? G::RX : 8 * NT) : "memory");
+                            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                             __syncthreads();
                             dma_next_group();
                             // XP, the chunk's LAST group: every wave holds the chunk's last operands, so its plane buffer is free --
                             // the chunk after next goes there; the NEXT chunk's planes (requested a chunk ago) have landed behind
                             // this barrier, so the operand prefetch simply runs on across the chunk boundary
-                            if (XP && j == J - 1) planes_dma(cc);
+                            if (XP && j == J - 1) {
+                                asm volatile("" ::: "memory");
+                                __builtin_amdgcn_sched_barrier(0);
+                                planes_dma(cc);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
                         }
                         f32x16 part[MW];
 #pragma unroll

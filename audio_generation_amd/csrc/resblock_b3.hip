@@ -262,9 +262,22 @@ __global__ __launch_bounds__(256, NPB == 1 ? 2 : 1) void resblock_b3_kernel(Conv
                             // EARLY barrier: this group's last operands are in registers already, so its slots (and, at the
                             // chunk's end, nothing of the plane buffer) are needed no more.  The next group's weights -- and
                             // the next chunk's planes -- have landed once every wave has waited for its own part.
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            // COUNTED wait (round 4).  vmcnt counts loads and LDS-DMA together, in issue order.  What this barrier
+                            // needs is the weight DMA issued at the previous one; the next chunk's 8 NT input loads (HBM latency)
+                            // were issued behind phases 4 / 5 at the j == 1 barrier and are only needed at the chunk's end: at the
+                            // j == 3 barrier they may stay in flight (the vmcnt(0) of round 3 drained them two phases after their
+                            // issue, every chunk).  The j == 5 barrier needs phase 6 (younger than the loads): vmcnt(0).
+                            if (j == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * NT) : "memory");
+                            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                             __syncthreads();
-                            if (j == 1) { dma_phase(4); dma_phase(5); input_load(); }
+                            if (j == 1) {
+                                dma_phase(4);
+                                dma_phase(5);
+                                asm volatile("" ::: "memory");          // the loads stay BEHIND the two DMA phases in issue order
+                                __builtin_amdgcn_sched_barrier(0);
+                                input_load();
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
                             else if (j == 3) { dma_phase(6); dma_advance_chunk(); }
                             else if (j == 5) { dma_phase(0); dma_phase(1); }
                             else { dma_phase(2); dma_phase(3); }
