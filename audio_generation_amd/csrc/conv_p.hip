@@ -652,8 +652,9 @@ typedef CpGeom<2, 2, 2, 2, 8, 3, 1, 4, 1, 2> CpUp4;       // upsample x4:       
 typedef CpGeom<2, 2, 1, 4, 8, 3, 1, 3, 1, 2> CpUp3;       // upsample x3 (M = 3 Cout = 192 for 128 -> 64): 64 x 256
 typedef CpGeom<2, 2, 1, 4, 8, 3, 1, 2, 1, 2> CpUp2;       // upsample x2, M = 64:       64 x 256
 // round 4 (configs 3 / 4 off the first-round kernels):
-typedef CpGeom<2, 1, 2, 2, 16, 1, 1, 1, 0, 3, false, 1, 2048> CpK1;       // k = 1 (every Linear of the transformer block, transformers.py:157-223; the
-                                                          // unfused block's second conv): 128 x 64, one phase per chunk -> 3 slots
+typedef CpGeom<2, 2, 2, 2, 16, 1, 1, 1, 0, 3, false, 1, 2048> CpK1;       // k = 1 (every Linear of the transformer block, transformers.py:157-223; the
+                                                          // unfused block's second conv): 128 x 128 (12 KB of operands per 16-MFMA phase on 128 x 64 tiles ran
+                                                          // into the CU's LDS-DMA rate: 75 TFLOP/s), one phase per chunk -> 3 slots
 typedef CpGeom<2, 2, 2, 2, 4, 11, 1, 1, 5, 2> CpSame11;   // Conv1d(K = 11, padding="same") -- WaveletLayer's first conv at stride 5 (wavelets.py:193-201): 128 x 128
 typedef CpGeom<2, 1, 2, 2, 16, 3, 1, 1, 1, 2> CpSame3;    // Conv1d(K = 3, padding="same") -- WaveletLayer's last conv: 128 x 64
 
@@ -817,7 +818,7 @@ const char *conv_p_variant(const ConvPlan &p) {
         case CP_UP2: return "conv_p<up2,64x256>";
         case CP_DOWN3: return "conv_p<down3,128x128>";
         case CP_UP3: return "conv_p<up3,64x256>";
-        case CP_K1: return "conv_p<k1,128x64>";
+        case CP_K1: return "conv_p<k1,128x128>";
         case CP_SAME11: return "conv_p<same11,128x128>";
         case CP_SAME3: return "conv_p<same3,128x64>";
         default: return "conv_p<unsupported>";
