@@ -158,7 +158,12 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
                                                         const float *__restrict__ mask2, int wfs) {
     constexpr int MW = G::MW, NW = G::NW, KS = G::KS, J = G::J, S = G::S, Q = G::Q, BM = G::BM, BN = G::BN;
     constexpr int SLOT = G::SLOT, AFL = G::AFL, CCH = G::CCH;
-    constexpr bool PRE3 = G::NSLOT == 3;
+    // NSLOT >= 3: the next chunk is complete one interval early and its first operands are read before the barrier.  NSLOT > 3
+    // (round 4, the one-phase k = 1 layers whose interval is only 16 / 32 MFMAs): DEPTH = NSLOT - 3 further chunks stay IN FLIGHT
+    // across the interval's barrier -- the wait at the end of an interval is counted (vmcnt(DEPTH * NOPS): every wave issues
+    // exactly NOPS DMA instructions per chunk, in order), so a chunk has DEPTH + 1 intervals to arrive instead of one.
+    constexpr bool PRE3 = G::NSLOT >= 3;
+    constexpr int DEPTH = G::NSLOT > 3 ? G::NSLOT - 3 : 0, QN = DEPTH + 2;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -292,16 +297,27 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
     // after this wave's DMA has landed: cells that straddle the end of a ragged row hold x[L-4 .. L-1]; shift them to
     // x[pos .. L-1] followed by zeros.  Only the last time block of a clip, and only when L % 4 != 0.
     const bool ragged = (p.Lvalid & 3) != 0;
-    auto fix_ragged = [&]() {
-        if (!ragged || !d_live || d_in0a + segf <= p.Lvalid) return;
+    // states of the chunks whose DMA may still be in flight (newest last): what fix_ragged needs once a chunk has landed
+    bool q_live[QN];
+    int q_in0a[QN], q_irow[QN];
+    float *q_slot[QN];
+#pragma unroll
+    for (int i = 0; i < QN; ++i) q_live[i] = false, q_in0a[i] = 0, q_irow[i] = 0, q_slot[i] = lds;
+    auto push_state = [&]() {
+#pragma unroll
+        for (int i = 0; i + 1 < QN; ++i) q_live[i] = q_live[i + 1], q_in0a[i] = q_in0a[i + 1], q_irow[i] = q_irow[i + 1], q_slot[i] = q_slot[i + 1];
+        q_live[QN - 1] = d_live, q_in0a[QN - 1] = d_in0a, q_irow[QN - 1] = d_irow, q_slot[QN - 1] = d_slot;
+    };
+    auto fix_ragged = [&](int qi) {
+        if (!ragged || !q_live[qi] || q_in0a[qi] + segf <= p.Lvalid) return;
 #pragma unroll
         for (int r = 0; r < G::RB; ++r) {
             const int n = wave + 4 * r;
-            const int pos = d_in0a + colB[r];
+            const int pos = q_in0a[qi] + colB[r];
             const int over = pos + 4 - p.Lvalid;
-            const bool rowok = !D2 || unsigned(d_irow + rowB[D2 ? r : 0]) < unsigned(p.Tin);
+            const bool rowok = !D2 || unsigned(q_irow[qi] + rowB[D2 ? r : 0]) < unsigned(p.Tin);
             if (n < G::NIB && rowok && pos >= 0 && pos < p.Lvalid && over > 0) {
-                f32x4 *cell = reinterpret_cast<f32x4 *>(d_slot + AFL + n * 256 + lane * 4);
+                f32x4 *cell = reinterpret_cast<f32x4 *>(q_slot[qi] + AFL + n * 256 + lane * 4);
                 const f32x4 v = *cell;
                 f32x4 o;
                 o[0] = over == 1 ? v[1] : (over == 2 ? v[2] : v[3]);
@@ -319,14 +335,19 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
     };
 
     for (int i = tid; i < G::NBIAS; i += 256) lds[G::BIAS0 + i] = (bias && i < p.Cout) ? bias[i] : 0.f;
+    // prologue: NSLOT - 1 chunks requested; chunk 0 (and 1: its first operands are read below) must have landed
     issue_all();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    fix_ragged();
+    push_state();
     if (PRE3) {
-        issue_all();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        fix_ragged();
+#pragma unroll
+        for (int c = 1; c < G::NSLOT - 1; ++c) {
+            issue_all();
+            push_state();
+        }
     }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH * G::NOPS) : "memory");
+    if (PRE3) fix_ragged(QN - 2 - DEPTH);
+    fix_ragged(QN - 1 - DEPTH);
     __syncthreads();
 
     CpFrag<MW, NW, KS> f[2];
@@ -356,8 +377,9 @@ __global__ __launch_bounds__(256, 2) void conv_p_kernel(ConvPlan p, int mblocks,
             if (j + 1 < J || PRE3) cp_interleave<G>();
             else __builtin_amdgcn_sched_barrier(0);
         });
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the requested chunk has landed
-        fix_ragged();
+        push_state();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH * G::NOPS) : "memory");   // this wave's part of the chunk requested DEPTH intervals ago has landed
+        fix_ragged(QN - 1 - DEPTH);
         __syncthreads();                                   // everyone's has; the consumed slot is free
         if (!PRE3 && !tail_chunk) cp_load_frag<G>(f[(PAR + J) & 1], An, Bn, 0, bk);
         qs = qsn;
@@ -652,9 +674,9 @@ typedef CpGeom<2, 2, 2, 2, 8, 3, 1, 4, 1, 2> CpUp4;       // upsample x4:       
 typedef CpGeom<2, 2, 1, 4, 8, 3, 1, 3, 1, 2> CpUp3;       // upsample x3 (M = 3 Cout = 192 for 128 -> 64): 64 x 256
 typedef CpGeom<2, 2, 1, 4, 8, 3, 1, 2, 1, 2> CpUp2;       // upsample x2, M = 64:       64 x 256
 // round 4 (configs 3 / 4 off the first-round kernels):
-typedef CpGeom<2, 2, 2, 2, 16, 1, 1, 1, 0, 3, false, 1, 2048> CpK1;       // k = 1 (every Linear of the transformer block, transformers.py:157-223; the
+typedef CpGeom<2, 2, 2, 2, 16, 1, 1, 1, 0, 4, false, 1, 2048> CpK1;       // k = 1 (every Linear of the transformer block, transformers.py:157-223; the
                                                           // unfused block's second conv): 128 x 128 (12 KB of operands per 16-MFMA phase on 128 x 64 tiles ran
-                                                          // into the CU's LDS-DMA rate: 75 TFLOP/s), one phase per chunk -> 3 slots
+                                                          // no faster than 128 x 64: 75 TFLOP/s either way), one phase per chunk -> 4 slots, one chunk in flight across the barrier
 typedef CpGeom<2, 2, 2, 2, 4, 11, 1, 1, 5, 2> CpSame11;   // Conv1d(K = 11, padding="same") -- WaveletLayer's first conv at stride 5 (wavelets.py:193-201): 128 x 128
 typedef CpGeom<2, 1, 2, 2, 16, 3, 1, 1, 1, 2> CpSame3;    // Conv1d(K = 3, padding="same") -- WaveletLayer's last conv: 128 x 64
 
