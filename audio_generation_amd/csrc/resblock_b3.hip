@@ -426,29 +426,42 @@ __global__ __launch_bounds__(256, NPB == 1 ? 2 : 1) void resblock_b3_kernel(Conv
             }
             if (pass == 0) B3_TSTAMP(10);
             static_assert((C / 16 * NW) % 2 == 0, "the split register sets must line up across passes");
-            // residual + trailing activation + store (accumulator layout: 128-byte row segments per half wave)
+            // residual + trailing activation + store (accumulator layout: 128-byte row segments per half wave).  Round 4: ALL of the
+            // pass's residual loads are issued before the first use (the GEMM1 accumulators are dead: their registers hold the
+            // pass's x) -- one exposed memory round trip per pass instead of one per (row block, column block); round 3 loaded 16
+            // values, waited, stored, and the next block's loads queued behind those stores (vmcnt counts both in order).
+            // (C = 128 / 256 keep one block at a time: a whole pass of x in registers spilled 132 / 204 bytes per lane there.)
+            constexpr int XB = MW <= 2 ? HS * NW : 1;      // (row block, column block) pairs whose residual is in flight together (C >= 128: register budget)
+            static_assert((HS * NW) % XB == 0, "residual batches");
 #pragma unroll
-            for (int io = 0; io < HS; ++io)
+            for (int g0 = 0; g0 < HS * NW; g0 += XB) {
+                float xr[XB][16];
 #pragma unroll
-                for (int kk = 0; kk < NW; ++kk) {
-                    const int col = t0 + n0 + 32 * kk + li;
-                    const int colc = min(col, Lin - 1);
-                    float xr[16];
+                for (int gi = 0; gi < XB; ++gi) {
+                    const int io = (g0 + gi) / NW, kk = (g0 + gi) % NW;
+                    const int colc = min(t0 + n0 + 32 * kk + li, Lin - 1);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = 32 * (pass * HS + io) + 8 * (r >> 2) + 4 * lh + (r & 3);
-                        xr[r] = *reinterpret_cast<const float *>(xb + (unsigned(row) * linv + unsigned(colc)) * 4u);
+                        xr[gi][r] = *reinterpret_cast<const float *>(xb + (unsigned(row) * linv + unsigned(colc)) * 4u);
                     }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int gi = 0; gi < XB; ++gi) {
+                    const int io = (g0 + gi) / NW, kk = (g0 + gi) % NW;
+                    const int col = t0 + n0 + 32 * kk + li;
                     if (col < Lin) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int row = 32 * (pass * HS + io) + 8 * (r >> 2) + 4 * lh + (r & 3);
-                            float v = out[io][kk][r] + xr[r];
+                            float v = out[io][kk][r] + xr[gi][r];
                             if (post_act) v = leaky(v, p.slope);
                             *reinterpret_cast<float *>(yb + (unsigned(row) * linv + unsigned(col)) * 4u) = v;
                         }
                     }
                 }
+            }
             if (pass == 0) B3_TSTAMP(11);
         }
         B3_TSTAMP(12);
