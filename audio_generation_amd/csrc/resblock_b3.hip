@@ -42,9 +42,15 @@ typedef __bf16 b3x8 __attribute__((ext_vector_type(8)));
     do {                                                                                                               \
         if (lane == 0) g_stamps[(blockIdx.x * 4 + wave) * 16 + (slot)] = __builtin_amdgcn_s_memrealtime();             \
     } while (0)
+// shader-clock stamp next to a realtime (100 MHz) one: the clock the chip holds over the kernel = d memtime / d memrealtime x 100 MHz
+#define B3_CSTAMP(slot)                                                                                                \
+    do {                                                                                                               \
+        if (lane == 0) g_stamps[(blockIdx.x * 4 + wave) * 16 + (slot)] = __builtin_amdgcn_s_memtime();                 \
+    } while (0)
 #else
 #define B3_TSTAMP(slot) ((void)0)
 #define B3_RSTAMP(slot) ((void)0)
+#define B3_CSTAMP(slot) ((void)0)
 #endif
 
 __device__ __attribute__((aligned(1024))) float g_b3_zero_page[256] = {0.f};
@@ -119,6 +125,7 @@ __global__ __launch_bounds__(256, NPB == 1 ? 2 : 1) void resblock_b3_kernel(Conv
     const int first_b = int(blockIdx.x) / tiles_per_clip, first_t = int(blockIdx.x) - first_b * tiles_per_clip;
 
     B3_RSTAMP(14);
+    if (NCH <= 4) B3_CSTAMP(5);      // (slots 5 .. 8 are chunk stamps only for C = 128: 8 chunks)
     float *bias_s = reinterpret_cast<float *>(lds + G::OFF_BIAS);
     for (int i = tid; i < 2 * C; i += 256) bias_s[i] = i < C ? (b1 ? b1[i] : 0.f) : (b2 ? b2[i - C] : 0.f);
 
@@ -466,6 +473,7 @@ __global__ __launch_bounds__(256, NPB == 1 ? 2 : 1) void resblock_b3_kernel(Conv
         }
         B3_TSTAMP(12);
     }
+    if (NCH <= 4) B3_CSTAMP(6);
     B3_RSTAMP(15);
 }
 

@@ -82,6 +82,18 @@ int main(int argc, char **argv) {
         if (!t[14] || !t[15]) continue;
         st.push_back((t[14] - tmin) * 0.01); en.push_back((t[15] - tmin) * 0.01); life.push_back((t[15] - t[14]) * 0.01);
     }
+    // in-kernel clock (C <= 64: slots 5 / 6 hold s_memtime at the kernel's start / end, next to the 100 MHz stamps 14 / 15)
+    std::vector<double> ghz;
+    for (int w = 0; w < 4096 && nch <= 4; ++w) {
+        unsigned long long *t = &z[w * 16];
+        if (!t[5] || !t[6] || !t[14] || !t[15] || t[15] <= t[14]) continue;
+        ghz.push_back(double(t[6] - t[5]) / double(t[15] - t[14]) * 0.1);
+    }
+    if (!ghz.empty()) {
+        std::sort(ghz.begin(), ghz.end());
+        printf("  shader clock over the kernel (d s_memtime / d s_memrealtime): median %.3f GHz [p10 %.3f .. p90 %.3f]\n", ghz[ghz.size() / 2],
+               ghz[ghz.size() / 10], ghz[ghz.size() * 9 / 10]);
+    }
     std::sort(st.begin(), st.end()); std::sort(en.begin(), en.end()); std::sort(life.begin(), life.end());
     if (!st.empty())
         printf("  waves: %zu; start us: median %.1f p90 %.1f max %.1f; end us: p10 %.1f median %.1f max %.1f; lifetime us: p10 %.1f median %.1f\n",
