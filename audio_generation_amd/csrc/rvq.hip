@@ -11,7 +11,7 @@
 //      per operand; rows = codewords streamed from the stage image in L2 -- the phase is bound by the CU's L2 port: 2 MB per
 //      stage and workgroup --, columns = the 32 frames read from the planes), per-frame minimum by in-lane min over the
 //      accumulator registers + one lane shuffle + an 8-entry LDS exchange;
-//   B. every codeword whose score is within a rigorous error margin of the minimum is a candidate; a frame with one
+//   B. every codeword whose score is within the error margin of the minimum (kernel header of the error unit: what is proved, what is modelled) is a candidate; a frame with one
 //      candidate is decided, the rest are decided by the defining binary64 distance (sequential, unfused): squares by all
 //      lanes, the d-ordered sums of up to 16 pairs side by side, one lane each;
 //   C. r -= c, index written, squared residual accumulated, and the next stage's r' = fl(r - mu) split into the planes.
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(NT) void rvq_forward_kernel(RvqArgs a) {
             // (x = h + m + O(2^-16 x)); a 16-deep block of d is three v_mfma_f32_32x32x16_bf16 per subtile -- m.h, h.m, h.h
             // (small terms first; m.m is below 2^-16 of the product and goes into the error bound) -- 96 cycles against 512
             // for the same block on the fp32-input MFMA.  The scores only SELECT candidates: every decision is still made
-            // on the rigorous bound below and, among several candidates, by the defining binary64 distance, so the indices
+            // on the bound below and, among several candidates, by the defining binary64 distance, so the indices
             // do not depend on this arithmetic.  Lane (code, half) holds dims 16 kq + 8 half + (0..7): the codeword pieces
             // are two 16-byte loads of the CbH image straight from L2, requested NB - 1 blocks ahead into a ring of register
             // sets (statically addressed: the loop is unrolled by NB); the residual pieces are two conflict-free

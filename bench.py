@@ -195,13 +195,18 @@ def build_model(dev):
     return model.to(dev)
 
 
-def calibrate_codebooks(model, x_small, recipe):
+def calibrate_codebooks(model, x_small, recipe, n_clips=None):
     """Synthetic codebooks.  ``survey``: the letter of 8(d) -- ``randn(Q,K,D) * sigma``, seed 7, sigma =
     std of the encoder output measured in the same run.  ``latents``: stage 0 = latent frames of the first clips +
     noise, later stages shrinking randn (what a k-means-initialised quantiser looks like: the arg-min is spread
     over hundreds of codes instead of the few nearest to the latents' common offset)."""
     with torch.no_grad():
+        # n_clips: x_small is the WHOLE batch and the first n_clips clips' latents are used -- bit-identical to encoding those clips
+        # alone (batch items are independent, tests/test_gpu_fullsize.py) but every launch of the run then has the measured batch
+        # size, so a rocprofv3 --stats average of a kernel is not polluted by small calibration launches
         z = model._run_encoders(x_small)
+        if n_clips is not None:
+            z = z[:n_clips].contiguous()
         if recipe == "survey":
             sigma = float(z.std())
             model.quantizer.init_randn(sigma, seed=7)
@@ -382,7 +387,7 @@ def main():
     model = build_model(dev)
     x_cpu = make_inputs(bsz, rank)
     x = x_cpu.to(dev)                       # inputs resident in HBM before the timed region
-    sigma = calibrate_codebooks(model, x[:8], args.codebooks)
+    sigma = calibrate_codebooks(model, x, args.codebooks, n_clips=8)
     if world > 1:
         # weights + codebooks replicated.  Every rank calibrated on its own shard (inputs are seeded per rank):
         # rank 0's codebooks win, so all ranks search the same codebooks (the RVQ's candidate count is data dependent).
@@ -516,7 +521,7 @@ def main():
         from oracle import codec as _codec, rvq as _rvq
         other = "latents" if args.codebooks == "survey" else "survey"
         keep = {k: v.clone() for k, v in model.quantizer.state_dict().items()}
-        calibrate_codebooks(model, x[:8], other)
+        calibrate_codebooks(model, x, other, n_clips=8)
         with torch.no_grad():
             y_o, _, idx_o = model(x[:n_cpu])
             cbs_o = model.quantizer.codebooks.detach().cpu()
@@ -594,7 +599,7 @@ def main():
         # the other synthetic-codebook recipe, same arithmetic as the measured run (eager)
         other = "latents" if args.codebooks == "survey" else "survey"
         keep = {k: v.clone() for k, v in model.quantizer.state_dict().items()}
-        calibrate_codebooks(model, x[:8], other)
+        calibrate_codebooks(model, x, other, n_clips=8)
         r = measure("bf16x3" if args.arith == "mixed" else "fp32", "fp32")
         r.pop("index_agreement_with_measured_run"), r.pop("waveform_rms_vs_measured_run")
         with torch.no_grad():
