@@ -12,45 +12,58 @@
 
 namespace agx {
 
-// Thread-local last-error message (the only mutable global state of the library besides the diagnostics: Tuning, the RVQ stamp buffer).
+// Thread-local last-error message (the only mutable global state of the library besides the measurement knobs below -- relaxed atomics --
+// and, in the PROBE build only, the RVQ stamp buffer).
 void set_error(const char *fmt, ...);
 int fail(int code, const char *fmt, ...);
 const char *last_error();
 
+// A measurement knob: a process-wide int read at launch time and written by agx_set_tuning.  Relaxed atomic (round 4): a host
+// thread changing a knob while another thread launches is a defined -- if pointless -- thing to do; no ordering is implied.
+struct Knob {
+    std::atomic<int> v;
+    explicit Knob(int x) : v(x) {}
+    operator int() const { return v.load(std::memory_order_relaxed); }
+    Knob &operator=(int x) {
+        v.store(x, std::memory_order_relaxed);
+        return *this;
+    }
+};
+
 // diagnostic knobs (agx_set_tuning)
 struct Tuning {
-    int rb_cc = 16;   // channels per LDS chunk of the fused residual block (16 or 32)
-    int rb_wgs = 0;   // 1..3: cap resident workgroups per CU of the fused residual block (0 = natural)
-    int patch_tie = 1;  // 2-D patch tiles: 1 = among the R x WF splits with the same padded area take the one that stages the fewest
+    Knob rb_cc{16};   // channels per LDS chunk of the fused residual block (16 or 32)
+    Knob rb_wgs{0};   // 1..3: cap resident workgroups per CU of the fused residual block (0 = natural)
+    Knob patch_tie{1};  // 2-D patch tiles: 1 = among the R x WF splits with the same padded area take the one that stages the fewest
                         // input elements (tall tiles share the row halo), 0 = always the widest
-    int bf_sched = -1;  // (-1 = per-shape table) schedule of the bf16x3 main loop in the fused residual block: 0 split after the MFMAs,
+    Knob bf_sched{-1};  // (-1 = per-shape table) schedule of the bf16x3 main loop in the fused residual block: 0 split after the MFMAs,
                         // 1 the same with MFMA / VALU interleave hints, 2 split before the MFMAs
-    int dw2_shared = 2; // conv2d weight gradient: workgroup-shared operand slots + one barrier per item for 1 = the 128-row tiles, 2 = also the
+    Knob dw2_shared{2}; // conv2d weight gradient: workgroup-shared operand slots + one barrier per item for 1 = the 128-row tiles, 2 = also the
                         // 64- / 32-row tiles (64 -> 64 3 x 3: 81 -> 90 TFLOP/s since the DMA issue is cheap), 0 = wave-private buffers
-    int c2b3_sl = 0;    // conv2d_b3 tile split R x 2^SL: 0 = cost model (padded area x (matrix time + staging rounds)), -1 = least padded area
+    Knob c2b3_sl{0};    // conv2d_b3 tile split R x 2^SL: 0 = cost model (padded area x (matrix time + staging rounds)), -1 = least padded area
                         // with ties to the widest rows (the first rule), 3..7 = forced where the tile has it
-    int dw2_prepad = 1; // conv2d weight gradient of maps narrower than 32 columns: 1 = the shared kernel on zero-padded flattened copies, 0 = staged kernel
-    int dw2_bf = 1;     // conv2d weight gradient of bf16x3 descriptors on the shared kernel: 1 = bf16x3 contraction, 0 = fp32 (exact)
-    int dw2_direct = 2; // conv2d weight gradient on the barrier-free LDS-DMA kernel: 1 = stride-1 "same" layers, 2 = also the column-strided
+    Knob dw2_prepad{1}; // conv2d weight gradient of maps narrower than 32 columns: 1 = the shared kernel on zero-padded flattened copies, 0 = staged kernel
+    Knob dw2_bf{1};     // conv2d weight gradient of bf16x3 descriptors on the shared kernel: 1 = bf16x3 contraction, 0 = fp32 (exact)
+    Knob dw2_direct{2}; // conv2d weight gradient on the barrier-free LDS-DMA kernel: 1 = stride-1 "same" layers, 2 = also the column-strided
                         // layers (x read through its column-phase planes), 0 = the staged kernel everywhere
-    int dw_direct = 3;  // 1-D weight gradient on the barrier-free kernel: 3 = every dense layer (strided / transposed ones through a
+    Knob dw_direct{3};  // 1-D weight gradient on the barrier-free kernel: 3 = every dense layer (strided / transposed ones through a
                         // phase-split copy of x / dy), 2 = the stride-1 layers, 1 = the k = 1 layers only, 0 = none
-    int dw1_wgs = 768;  // workgroups the 1-D LDS-free weight-gradient kernel aims for
-    int dw_wgs = 1536;  // workgroups the conv2d weight-gradient kernel aims for (slices = dw_wgs / tiles)
-    int dw_xcd = 0;     // conv2d weight gradient: 1 = XCD-aware block order (all tiles of a contraction slice on one XCD's L2); measured
+    Knob dw1_wgs{768};  // workgroups the 1-D LDS-free weight-gradient kernel aims for
+    Knob dw_wgs{1536};  // workgroups the conv2d weight-gradient kernel aims for (slices = dw_wgs / tiles)
+    Knob dw_xcd{0};     // conv2d weight gradient: 1 = XCD-aware block order (all tiles of a contraction slice on one XCD's L2); measured
                         // WORSE (128 -> 128 3 x 3: 106.6 -> 95.1 TFLOP/s): the slice's operands are better spread over the eight L2s
-    int conv_cc = 0;    // diagnostic: force the LDS chunk (8/16/32 channels) of the MFMA conv; 0 = table
-    int conv_shape = 0; // diagnostic: 1 = 128x128 conv tiles as 4 row-waves x (1x4) fragments
-    int conv_short = 1; // 1: 128x64 conv tiles when the 128x128 grid is under two workgroups per CU
-    int rb_occ = 2;    // 3: build of the fused residual block capped at 168 VGPRs (3 waves/SIMD)
-    int conv_impl = 1;  // resampling / stride-1 1-D layers: 1 = persistent ring kernel (conv_p.hip) where it applies, 0 = conv_mfma.hip
-    int rb_impl = 1;    // fused residual block: 1 = persistent ring kernel (resblock_p.hip) where it applies, 0 = resblock_mfma.hip
-    int b3_dbg = 0;    // DIAGNOSTIC switchboard of round 3 (default 0 everywhere): 1 = resblock_b3 alternates (C = 64 as one 64 x 512 workgroup
+    Knob conv_cc{0};    // diagnostic: force the LDS chunk (8/16/32 channels) of the MFMA conv; 0 = table
+    Knob conv_shape{0}; // diagnostic: 1 = 128x128 conv tiles as 4 row-waves x (1x4) fragments
+    Knob conv_short{1}; // 1: 128x64 conv tiles when the 128x128 grid is under two workgroups per CU
+    Knob rb_occ{2};    // 3: build of the fused residual block capped at 168 VGPRs (3 waves/SIMD)
+    Knob conv_impl{1};  // resampling / stride-1 1-D layers: 1 = persistent ring kernel (conv_p.hip) where it applies, 0 = conv_mfma.hip
+    Knob rb_impl{1};    // fused residual block: 1 = persistent ring kernel (resblock_p.hip) where it applies, 0 = resblock_mfma.hip
+    Knob b3_dbg{0};    // DIAGNOSTIC switchboard of round 3 (default 0 everywhere): 1 = resblock_b3 alternates (C = 64 as one 64 x 512 workgroup
                        // per CU, C = 128 as 128 x 256 with double-buffered planes), 2 = resblock_b3 without the GEMM1 priority.  Values
                        // 7 / 8 / 9 (RVQ score bound: accumulation term x 4 / x 0 / candidate counts in the squared-error output) act in
                        // the PROBE build of rvq.hip only (-DAGX_RVQ_PROBE); agx_set_tuning refuses them otherwise
-    int rvq_verify = 0; // DEBUG: 1 = rvq_forward is followed by the checker kernel (full defining search of every (frame, stage), agx_rvq_verify_counts)
-    int rb_sched = -1; // phase scheduling of the fused residual block (mfma_tile.hpp: 0 / 1 / 2; -1 = per-shape table)
+    Knob rvq_verify{0}; // DEBUG: 1 = rvq_forward is followed by the checker kernel (full defining search of every (frame, stage), agx_rvq_verify_counts)
+    Knob rb_sched{-1}; // phase scheduling of the fused residual block (mfma_tile.hpp: 0 / 1 / 2; -1 = per-shape table)
 };
 Tuning &tuning();
 
