@@ -157,6 +157,24 @@ def test_large_common_offset_with_tiny_spread_d560():
     assert want_i[..., 0].unique().numel() > 30
 
 
+def test_mfma_rounding_model_at_instruction_level():
+    """The model the accumulation term rests on, measured on THIS device: tools/mfma_bf16_err.hip (built by
+    ``__graft_entry__.build()``) runs ``v_mfma_f32_32x32x16_bf16`` on nine operand families -- the five of round 3 plus one
+    product 2^20 above fifteen same-signed ones, a huge +/- pair that cancels, products at the bottom of the fp32 range,
+    exponents spread over 2^40 against an accumulator of the other sign -- and compares every result with the exact sum: the
+    worst error must stay inside the 35 x 2^-24 (|c| + sum |a b|) the kernel allows (measured: 7.05)."""
+    import os
+    import re
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "mfma_bf16_err_bin")
+    assert os.path.exists(exe), "tools/mfma_bf16_err_bin is missing: run __graft_entry__.build()"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    m = re.search(r"WORST_UNITS ([0-9.]+) ALLOWED 35 (\w+)", out.stdout)
+    assert m, out.stdout[-500:] + out.stderr[-500:]
+    print(out.stdout)
+    assert out.returncode == 0 and m.group(2) == "OK" and float(m.group(1)) <= 35.0, out.stdout
+
+
 def test_verify_mode_catches_a_wrong_index():
     """The checker itself: feed agx_rvq_forward's verify pass a codebook tensor that differs from the packed search
     image in ONE codeword (the fast path searches the stale image): the counters must report the frames that moved."""
