@@ -86,8 +86,8 @@ int agx_conv_forward_planes(const agx_conv_desc *d, const void *x_planes, const 
     int rc = lower_conv(d, &p);
     if (rc != AGX_OK) return rc;
     if (!x_planes || !packed || (!y && !y_planes)) return fail(AGX_ERR_NULL_POINTER, "agx_conv_forward_planes: NULL pointer");
-    if (d->impl != AGX_IMPL_MFMA_BF16X3 || tuning().conv_impl != 1 || !conv_b3_supported(p))
-        return fail(AGX_ERR_UNSUPPORTED, "agx_conv_forward_planes: the layer has no bf16x3 ring form (ask agx_conv_planes_supported first)");
+    if (d->impl != AGX_IMPL_MFMA_BF16X3 || tuning().conv_impl != 1 || !conv_b3_supported(p) || p.s != 1 || (p.q == 1 && p.J != 7))
+        return fail(AGX_ERR_UNSUPPORTED, "agx_conv_forward_planes: the layer has no plane-fed bf16x3 ring form (ask agx_conv_planes_supported first)");
     return launch_conv_b3_planes(p, x_planes, packed, bias, y, y_planes, static_cast<hipStream_t>(stream));
 }
 
@@ -96,6 +96,7 @@ int agx_conv_planes_supported(const agx_conv_desc *d) {
     ConvPlan p;
     if (lower_conv(d, &p) != AGX_OK) return 0;
     if (d->impl != AGX_IMPL_MFMA_BF16X3 || tuning().conv_impl != 1 || !conv_b3_supported(p)) return 0;
+    if (p.s != 1 || (p.q == 1 && p.J != 7)) return 0;   // the strided down-convs and the causal k = 3 layer take fp32 input only
     return (p.q == 1 && p.Cout % 8 == 0) ? 2 : 1;      // 2: the layer can also WRITE planes (one output phase)
 }
 

@@ -33,23 +33,28 @@ __device__ __forceinline__ void cb3_glds_b128(const void *gsrc_lane, void *lds_w
 
 // XP: the input arrives as ready-made bf16 planes (common.hpp: "activation planes", written by a producer's epilogue or by
 // planes_split_kernel) and is staged by LDS-DMA into TWO plane buffers -- no register staging, no split, no second barrier.
-template <int MW, int NW, int WM, int J_, int Q_, int P_, bool XP = false>
+// S (round 4): input step per output position -- the encoder's strided down-convs (CausalConv1d(K = 2 s + 1, stride s), vae.py:136-139).
+// The planes of a chunk are PHASE-SPLIT: position w of the tile's input window sits in row w % S at cell w / S, so tap j of output t
+// (w = S t + j) reads row j % S at cell t + j / S -- unit lane stride, conflict-free, an immediate offset per tap as for S = 1.
+template <int MW, int NW, int WM, int J_, int Q_, int P_, bool XP = false, int S_ = 1>
 struct Cb3Geom {
     static constexpr int WN = 4 / WM;                      // waves along the columns
-    static constexpr int BM = 32 * MW * WM, BN = 32 * NW * WN, J = J_, Q = Q_, P = P_;
-    static constexpr int W = BN + J - 1;                   // time steps per plane row (tile + halo)
-    static constexpr int PLANE_B = 6 * W * 16;             // one chunk: [piece 3][lane half 2][W][8 bf16]
+    static constexpr int BM = 32 * MW * WM, BN = 32 * NW * WN, J = J_, Q = Q_, P = P_, S = S_;
+    static constexpr int WP = BN - 1 + (J + S - 1) / S;    // cells per phase row (S = 1: tile + halo = BN + J - 1)
+    static constexpr int W = S * WP;                       // cells per (piece, lane half): S phase rows
+    static constexpr int PLANE_B = 6 * W * 16;             // one chunk: [piece 3][lane half 2][phase S][WP][8 bf16]
     static constexpr int WSLOT_B = 96 * BM;                // one phase of weights: [piece 3][lane half 2][BM][8 bf16]
     static constexpr int NPW = WSLOT_B / 1024;             // 1 KiB DMA pieces per phase (BM / 64 per (piece, half))
     static constexpr int RW = (NPW + 3) / 4;
     static constexpr int NT = (2 * W + 255) / 256;         // split tasks (time step x 8 channels) per thread and chunk
-    static constexpr int NGRP = (J + 1) / 2;               // weight groups per chunk: [0,1] [2,3] .. (the last one single)
+    static constexpr int NGRP = (J + 1) / 2;               // weight groups per chunk: [0,1] [2,3] .. (the last one single); an odd count
+                                                           // swaps the two slot sets from chunk to chunk (running group parity)
     static constexpr int NIR = (W + 63) / 64;              // XP: 1 KiB DMA instructions per plane row (the last one partial)
     static constexpr int RX = (6 * NIR + 3) / 4;           // ... per wave and chunk
     static constexpr int OFF_W = (XP ? 2 : 1) * PLANE_B;
     static constexpr size_t LDS_BYTES = size_t(OFF_W) + 4 * WSLOT_B;
-    static_assert(NGRP % 2 == 0, "an even number of groups per chunk keeps the slot sets alternating");
     static_assert(J % 2 == 1, "taps come in pairs plus one");
+    static_assert(!(XP && S > 1), "plane input: stride-1 layers");
 };
 
 template <int N>
@@ -78,13 +83,13 @@ __device__ __forceinline__ void cb3_split4(const float (&v)[4], cb3x4 &h, cb3x4 
 }
 
 // XP: x = activation planes (bf16 [B][Cin / 8][3][Lin][8]); YP (Q = 1): y = activation planes of the output instead of fp32
-template <int MW, int NW, int WM, int J_, int Q_, int P_, bool XP = false, bool YP = false>
+template <int MW, int NW, int WM, int J_, int Q_, int P_, bool XP = false, bool YP = false, int S_ = 1>
 __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_clip, int mb_count, int ntiles,
                                                          const float *__restrict__ x, const char *__restrict__ wt,
                                                          const float *__restrict__ bias, float *__restrict__ y) {
-    using G = Cb3Geom<MW, NW, WM, J_, Q_, P_, XP>;
+    using G = Cb3Geom<MW, NW, WM, J_, Q_, P_, XP, S_>;
     static_assert(!YP || Q_ == 1, "plane output: one output phase");
-    constexpr int BM = G::BM, BN = G::BN, W = G::W, J = G::J, Q = G::Q, NT = G::NT;
+    constexpr int BM = G::BM, BN = G::BN, W = G::W, J = G::J, Q = G::Q, NT = G::NT, S = G::S, WP = G::WP;
     constexpr int NSTEP = J * NW;                         // MFMA steps per chunk: (tap, column block); all MW row blocks per step
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_
     auto dma_next_group = [&]() {
         const bool live = w_k < my_tiles;
         const int chunk = w_g / G::NGRP, which = w_g % G::NGRP;
-        const int set2 = (which & 1) * 2;
+        const int set2 = (w_g & 1) * 2;          // running group parity (a tile has an even number of groups: nch is even)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int j = 2 * which + i;
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_
         const bool live = i_k < my_tiles;
         int b_, tb_, mb_;
         decode(min(int(blockIdx.x) + i_k * int(gridDim.x), ntiles - 1), b_, tb_, mb_);
-        const int in0 = tb_ * BN - G::P;
+        const int in0 = tb_ * BN * S - G::P;
         const char *xc = reinterpret_cast<const char *>(x + (size_t(b_) * p.Cin + i_chunk * 16) * Lin);
         unsigned lin4 = unsigned(Lin) * 4u;
         asm volatile("" : "+s"(lin4));
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_
             const bool ok = live && task && pos >= 0 && pos < p.Lvalid;
             const int posc = min(max(pos, 0), Lin - 1);
             const unsigned off = unsigned(8 * uh) * lin4 + unsigned(posc) * 4u;
-            st_t[n] = task ? (uh * W + t) : -1;
+            st_t[n] = task ? (uh * W + (S == 1 ? t : (t % S) * WP + t / S)) : -1;      // phase-split cell of window position t
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float v = *reinterpret_cast<const float *>(xc + (off + unsigned(e) * lin4));
@@ -229,8 +234,8 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_
 
     const int aLane = (lh * BM + r0w + li) * 16;          // + (piece * 2 BM + 32 i) * 16
     const int bLane = (lh * W + n0 + li) * 16;            // + (piece * 2 W + 32 k + j) * 16
-    auto load_a = [&](cb3x8 (&a)[3][MW], int j) {
-        const char *ws = lds + G::OFF_W + (((j >> 1) & 1) * 2 + (j & 1)) * G::WSLOT_B + aLane;
+    auto load_a = [&](cb3x8 (&a)[3][MW], int j, int gpar) {      // gpar: parity of the group's running index (cc NGRP + j / 2)
+        const char *ws = lds + G::OFF_W + ((gpar & 1) * 2 + (j & 1)) * G::WSLOT_B + aLane;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
@@ -239,7 +244,8 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_
     auto load_b = [&](cb3x8 (&bf)[3], int j, int kk, int buf = 0) {     // buf: XP only (two plane buffers, chunk parity)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
-            bf[pl] = *reinterpret_cast<const cb3x8 *>(lds + (XP ? buf * G::PLANE_B : 0) + bLane + (pl * 2 * W + 32 * kk + j) * 16);
+            bf[pl] = *reinterpret_cast<const cb3x8 *>(lds + (XP ? buf * G::PLANE_B : 0) + bLane +
+                                                      (pl * 2 * W + (j % S) * WP + 32 * kk + j / S) * 16);
     };
 
     // ---- prologue: chunk 0 -> planes, chunks 1 and 2 on their way (XP: chunk 0 by DMA, chunk 1 requested) ----
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_
             for (int kk = 0; kk < NW; ++kk)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][kk][r] = 0.f;
-        load_a(fa[0], 0);
+        load_a(fa[0], 0, 0);
         load_b(fb[0], 0, 0);
 
         for (int c2 = 0; c2 < nch; c2 += 2) {
@@ -312,11 +318,12 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_
                         int nj = j, nk = kk + 1;
                         if (nk == NW) nk = 0, ++nj;
                         if (nj == J) nj = 0;
+                        const int ngp0 = (cc ^ 1) * G::NGRP;      // group parity base of the NEXT chunk (a tile starts at 0: nch is even)
                         if (!chunk_end) {      // (the next chunk's planes only exist behind the second barrier below)
-                            if (nk == 0) load_a(fa[ua ^ 1], nj);
+                            if (nk == 0) load_a(fa[ua ^ 1], nj, cc * G::NGRP + (nj >> 1));
                             load_b(fb[sb ^ 1], nj, nk, cc);
                         } else if (XP && !(c2 + 2 >= nch && cc == 1)) {      // (a tile's first operands are read at its top)
-                            load_a(fa[ua ^ 1], 0);
+                            load_a(fa[ua ^ 1], 0, ngp0);
                             load_b(fb[sb ^ 1], 0, 0, cc ^ 1);
                         }
                         __builtin_amdgcn_sched_barrier(0);
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvPlan p, int tb_per_
                             input_store_all(st2[cc ^ 1], st_t2[cc ^ 1]);
                             __builtin_amdgcn_sched_barrier(0);
                             __syncthreads();
-                            load_a(fa[ua ^ 1], 0);
+                            load_a(fa[ua ^ 1], 0, ngp0);
                             load_b(fb[sb ^ 1], 0, 0);
                             input_load(st2[cc ^ 1], st_t2[cc ^ 1]);   // the chunk THREE ahead: two chunks of flight time
                         }
@@ -752,24 +759,34 @@ __global__ __launch_bounds__(256, 2) void conv2d_b3_kernel(ConvPlan p, int cb_co
     C2S_WRITE();
 }
 
-enum { CB3_NONE = 0, CB3_UP2, CB3_UP4, CB3_UP5, CB3_UP8, CB3_K7 };
+enum { CB3_NONE = 0, CB3_UP2, CB3_UP4, CB3_UP5, CB3_UP8, CB3_K7, CB3_K3, CB3_DOWN2, CB3_DOWN4, CB3_DOWN5, CB3_DOWN8 };
 
 // shape-only test (also decides whether agx_conv_pack of a bf16x3 descriptor appends the B3 tile image: common.hpp)
 int conv_b3_geometry(const ConvPlan &p) {
-    if (p.prec != 1 || p.G != 1 || p.d != 1 || p.s != 1 || p.kh != 1 || p.Tout != 1 || p.pm_R != 0) return CB3_NONE;
+    if (p.prec != 1 || p.G != 1 || p.d != 1 || p.kh != 1 || p.Tout != 1 || p.pm_R != 0) return CB3_NONE;
     if (p.Cin % 32 != 0) return CB3_NONE;                      // whole 16-channel chunks, an even number of them
-    if (p.q == 2 && p.J == 3 && p.P == 1 && p.M == 64) return CB3_UP2;
-    if (p.q == 4 && p.J == 3 && p.P == 1 && p.M % 128 == 0) return CB3_UP4;
-    if (p.q == 5 && p.J == 3 && p.P == 1 && p.M % 128 == 0) return CB3_UP5;
-    if (p.q == 8 && p.J == 3 && p.P == 1 && p.M % 128 == 0) return CB3_UP8;
-    if (p.q == 1 && p.J == 7 && p.P == 6 && p.M % 128 == 0) return CB3_K7;
+    if (p.s == 1) {
+        if (p.q == 2 && p.J == 3 && p.P == 1 && p.M == 64) return CB3_UP2;
+        if (p.q == 4 && p.J == 3 && p.P == 1 && p.M % 128 == 0) return CB3_UP4;
+        if (p.q == 5 && p.J == 3 && p.P == 1 && p.M % 128 == 0) return CB3_UP5;
+        if (p.q == 8 && p.J == 3 && p.P == 1 && p.M % 128 == 0) return CB3_UP8;
+        if (p.q == 1 && p.J == 7 && p.P == 6 && p.M % 128 == 0) return CB3_K7;
+        if (p.q == 1 && p.J == 3 && p.P == 2 && p.M % 128 == 0) return CB3_K3;      // causal k = 3 (the encoder's last conv, vae.py:266)
+        return CB3_NONE;
+    }
+    // round 4: the encoder's strided down-convs CausalConv1d(K = 2 s + 1, stride s) (vae.py:136-139), P = K - s
+    if (p.q != 1) return CB3_NONE;
+    if (p.s == 2 && p.J == 5 && p.P == 3 && p.M == 64) return CB3_DOWN2;
+    if (p.s == 4 && p.J == 9 && p.P == 5 && p.M % 128 == 0) return CB3_DOWN4;
+    if (p.s == 5 && p.J == 11 && p.P == 6 && p.M % 128 == 0) return CB3_DOWN5;
+    if (p.s == 8 && p.J == 17 && p.P == 9 && p.M % 128 == 0) return CB3_DOWN8;
     return CB3_NONE;
 }
 
 bool conv_b3_supported(const ConvPlan &p) {
     if (p.tile_off < 0 || conv_b3_geometry(p) == CB3_NONE) return false;
     if ((p.epilogue & ~AGX_EPI_LEAKY_PRE) != 0 || p.oshift != 0 || p.mask != nullptr) return false;
-    if (p.Lvalid != p.Lin || p.Lin < 1 || p.Lout != p.q * p.Lt || p.Lt != p.Lin) return false;
+    if (p.Lvalid != p.Lin || p.Lin < 1 || p.Lout != p.q * p.Lt || (p.s == 1 && p.Lt != p.Lin)) return false;
     if (int64_t(p.Cin) * p.Lin * 4 >= (int64_t(1) << 32)) return false;     // 32-bit byte offsets of the input loads
     return true;
 }
@@ -781,14 +798,19 @@ const char *conv_b3_variant(const ConvPlan &p) {
         case CB3_UP5: return "conv_b3<up5,128x128>";
         case CB3_UP8: return "conv_b3<up8,128x128>";
         case CB3_K7: return "conv_b3<k7,128x128>";
+        case CB3_K3: return "conv_b3<k3,128x128>";
+        case CB3_DOWN2: return "conv_b3<down2,64x128>";
+        case CB3_DOWN4: return "conv_b3<down4,128x64>";
+        case CB3_DOWN5: return "conv_b3<down5,128x64>";
+        case CB3_DOWN8: return "conv_b3<down8,128x32>";
         default: return "conv_b3<unsupported>";
     }
 }
 
-template <int MW, int NW, int WM, int J_, int Q_, int P_, bool XP = false, bool YP = false>
+template <int MW, int NW, int WM, int J_, int Q_, int P_, bool XP = false, bool YP = false, int S_ = 1>
 static int launch_cb3(const ConvPlan &p, const float *x, const float *wp, const float *bias, float *y, hipStream_t st) {
-    using G = Cb3Geom<MW, NW, WM, J_, Q_, P_, XP>;
-    auto kern = conv_b3_kernel<MW, NW, WM, J_, Q_, P_, XP, YP>;
+    using G = Cb3Geom<MW, NW, WM, J_, Q_, P_, XP, S_>;
+    auto kern = conv_b3_kernel<MW, NW, WM, J_, Q_, P_, XP, YP, S_>;
     static DeviceOnce once;
     int n_cu = 0;
     if (int rc = prepare_kernel(reinterpret_cast<const void *>(kern), once, 160 * 1024, &n_cu, "conv_b3")) return rc;
@@ -812,6 +834,12 @@ int launch_conv_b3(const ConvPlan &p, const float *x, const float *wp, const flo
         case CB3_UP5: return launch_cb3<2, 2, 2, 3, 5, 1>(p, x, wp, bias, y, st);
         case CB3_UP8: return launch_cb3<2, 2, 2, 3, 8, 1>(p, x, wp, bias, y, st);
         case CB3_K7: return launch_cb3<2, 2, 2, 7, 1, 6>(p, x, wp, bias, y, st);
+        case CB3_K3: return launch_cb3<2, 2, 2, 3, 1, 2>(p, x, wp, bias, y, st);
+        //                          MW NW WM  J  Q  P  XP     YP     S      tile (rows x output columns)
+        case CB3_DOWN2: return launch_cb3<2, 1, 1, 5, 1, 3, false, false, 2>(p, x, wp, bias, y, st);     //  64 x 128
+        case CB3_DOWN4: return launch_cb3<2, 1, 2, 9, 1, 5, false, false, 4>(p, x, wp, bias, y, st);     // 128 x 64
+        case CB3_DOWN5: return launch_cb3<2, 1, 2, 11, 1, 6, false, false, 5>(p, x, wp, bias, y, st);    // 128 x 64
+        case CB3_DOWN8: return launch_cb3<1, 1, 4, 17, 1, 9, false, false, 8>(p, x, wp, bias, y, st);    // 128 x 32
         default: return fail(AGX_ERR_UNSUPPORTED, "conv_b3: unsupported layer");
     }
 }
@@ -824,6 +852,7 @@ int launch_conv_b3_planes(const ConvPlan &p, const void *x_planes, const float *
     if (int64_t(p.Cin / 8) * 3 * p.Lin * 16 >= (int64_t(1) << 40)) return fail(AGX_ERR_BAD_SHAPE, "conv_b3: clip too long");
     const float *xp = static_cast<const float *>(x_planes);
     const int g = conv_b3_geometry(p);
+    if (p.s != 1 || g == CB3_K3) return fail(AGX_ERR_UNSUPPORTED, "conv_b3: plane input is for the decoder's stride-1 layers");
     if (y_planes && (g != CB3_K7 || p.Cout % 8 != 0)) return fail(AGX_ERR_UNSUPPORTED, "conv_b3: plane output is for the one-phase layer");
     switch (g) {
         case CB3_UP2: return launch_cb3<2, 2, 1, 3, 2, 1, true>(p, xp, wp, bias, y, st);

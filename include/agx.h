@@ -45,7 +45,8 @@ int32_t agx_sizeof_conv_desc(void);
 int32_t agx_sizeof_conv2d_desc(void);
 
 /* Diagnostic tuning knobs (A/B experiments from one process; defaults are the
- * shipped configuration).  Unknown names return AGX_ERR_BAD_SHAPE.
+ * shipped configuration).  Unknown names return AGX_ERR_BAD_SHAPE.  Process-wide relaxed atomics read at launch
+ * time: changing one while another thread launches is defined but pointless -- set them before the first launch.
  *   "rb_cc"  16 | 32   channels per LDS chunk of the fused residual block
  *   "rb_wgs" 0 | 1..3  cap on resident workgroups per CU of the fused residual block (0 = natural)
  *   "rb_sched" 0|1|2   phase scheduling of the fused residual block (csrc/mfma_tile.hpp)

@@ -66,7 +66,7 @@ def test_more_tiles_than_workgroups(variant, kind, cin, cout, k, s, b, length):
 
 
 def test_other_layers_keep_their_kernels():
-    d = ops.conv_desc(_lib.CONV_CAUSAL, 2, 64, 128, 4000, 9, 4, 1, _lib.EPI_LEAKY_PRE, 0.1, _lib.IMPL_MFMA_BF16X3)
+    d = ops.conv_desc(_lib.CONV_CAUSAL, 2, 64, 128, 4000, 9, 3, 1, _lib.EPI_LEAKY_PRE, 0.1, _lib.IMPL_MFMA_BF16X3)   # k9 s3: no ring form
     assert ops.conv_kernel_name(d).startswith("conv_mfma") and ops.conv_kernel_name(d).endswith(":bf16x3")
     d = ops.conv_desc(_lib.CONV_UPSAMPLE, 2, 48, 32, 400, 5, 2, 1, 0, 0.1, _lib.IMPL_MFMA_BF16X3)   # Cin % 32 != 0
     assert not ops.conv_kernel_name(d).startswith("conv_b3")
@@ -107,7 +107,65 @@ def test_planes_input_is_bit_identical_to_the_fp32_input(variant, kind, cin, cou
 
 
 def test_planes_path_refuses_what_it_cannot_run():
-    d = ops.conv_desc(_lib.CONV_CAUSAL, 2, 64, 128, 4000, 9, 4, 1, 0, 0.1, _lib.IMPL_MFMA_BF16X3)       # strided: no ring form
+    d = ops.conv_desc(_lib.CONV_CAUSAL, 2, 64, 128, 4000, 9, 4, 1, 0, 0.1, _lib.IMPL_MFMA_BF16X3)       # strided: fp32 input only
     assert ops.conv_planes_supported(d) == 0
     d = ops.conv_desc(_lib.CONV_UPSAMPLE, 2, 512, 256, 64, 17, 8, 1, 0, 0.1, _lib.IMPL_AUTO)            # fp32 descriptor
     assert ops.conv_planes_supported(d) == 0
+
+
+# ---- round 4: the encoder's strided down-convs (phase-split planes) and its causal k = 3 layer on the bf16x3 ring --------
+STRIDED = [("down2", 32, 64, 5, 2), ("down4", 64, 128, 9, 4), ("down5", 128, 256, 11, 5), ("down8", 256, 512, 17, 8),
+           ("k3", 512, 512, 3, 1), ("down4", 256, 512, 9, 4)]
+
+
+def _strided_case(cin, cout, k, s, b, length, gen, act):
+    v = torch.randn(cout, cin, k, generator=gen) / (cin * k) ** 0.5
+    g = torch.rand(cout, 1, 1, generator=gen) + 0.5
+    bias = torch.randn(cout, generator=gen) * 0.1
+    x = torch.randn(b, cin, length, generator=gen)
+    want = codec.causal_conv1d(x, codec.fold_weight_norm(g, v), bias, stride=s)
+    if act:
+        want = codec.leaky(want)
+    out = {}
+    for impl in (_lib.IMPL_MFMA_BF16X3, _lib.IMPL_AUTO):
+        desc = ops.conv_desc(_lib.CONV_CAUSAL, b, cin, cout, length, k, s, 1, _lib.EPI_LEAKY_PRE if act else 0, 0.1, impl)
+        packed = ops.conv_pack(desc, v.to(DEV), g.to(DEV))
+        out[impl] = (ops.conv_kernel_name(desc), ops.conv_forward(desc, x.to(DEV), packed, bias.to(DEV)), desc)
+    return out, want
+
+
+@pytest.mark.parametrize("variant,cin,cout,k,s", STRIDED)
+def test_strided_down_convs_against_the_oracle_and_the_fp32_ring(variant, cin, cout, k, s):
+    """CausalConv1d(K = 2 s + 1, stride s) (vae.py:136-139) incl. ``_calc_extra_pad`` (vae.py:39-43: lengths that are not a
+    multiple of the stride), clips shorter than a tile, ragged tiles."""
+    gen = torch.Generator().manual_seed(sum(map(ord, variant)) + cout)
+    for b, length, act in ((1, 8, True), (2, 64, False), (1, 130, True), (3, 521, True), (2, 1027, False), (2, 1800, True),
+                           (1, 4096 + 3, True)):
+        out, want = _strided_case(cin, cout, k, s, b, length, gen, act)
+        name, y, desc = out[_lib.IMPL_MFMA_BF16X3]
+        if name.startswith("conv_b3"):
+            assert name.startswith(f"conv_b3<{variant},") and name.endswith(":bf16x3"), name
+        else:      # a cropped right pad (negative extra pad) keeps the first kernels: allowed, but then say so
+            assert name.startswith("conv_mfma"), name
+        tol = TOL * max(1.0, float(want.abs().max()))
+        assert tuple(y.shape) == tuple(want.shape)
+        assert max_abs(y.cpu(), want) < tol, (variant, b, length, name, max_abs(y.cpu(), want))
+        assert max_abs(y, out[_lib.IMPL_AUTO][1]) < tol
+        assert ops.conv_planes_supported(desc) == 0
+
+
+@pytest.mark.parametrize("variant,cin,cout,k,s,b,length", [
+    ("down2", 32, 64, 5, 2, 5, 72000),       # 282 x 5 = 1410 tiles of 64 x 128
+    ("down4", 64, 128, 9, 4, 6, 36000),      # 141 x 6 = 846 tiles of 128 x 64
+    ("down5", 128, 256, 11, 5, 12, 9000),    # 2 x 29 x 12 = 696
+    ("down8", 256, 512, 17, 8, 24, 1800),    # 4 x 8 x 24 = 768 tiles of 128 x 32
+    ("k3", 512, 512, 3, 1, 36, 225),
+])
+def test_strided_more_tiles_than_workgroups_and_run_to_run(variant, cin, cout, k, s, b, length):
+    gen = torch.Generator().manual_seed(13 + cin)
+    out, want = _strided_case(cin, cout, k, s, b, length, gen, True)
+    name, y, _ = out[_lib.IMPL_MFMA_BF16X3]
+    assert name.startswith(f"conv_b3<{variant},"), name
+    assert max_abs(y.cpu(), want) < TOL * max(1.0, float(want.abs().max()))
+    out2, _ = _strided_case(cin, cout, k, s, b, length, torch.Generator().manual_seed(13 + cin), True)
+    assert torch.equal(y, out2[_lib.IMPL_MFMA_BF16X3][1])
