@@ -300,3 +300,45 @@ def test_quantizer_says_what_it_ignores():
         qz.ops, rq._packed_codebooks = real_ops, real_pack
     assert len(msgs) == 2 and "SOM" in msgs[0] and "prioritize_early" in msgs[1], msgs
     assert all("som_quantizer" in m and "parity unpinned" in m for m in msgs)
+
+
+def _force_worker(port, out):
+    """One rank, gloo, ``force=True``: the exchange steps call the backend although the group has a single member."""
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    assert agx_dist.init("gloo", force=True) == (0, 0, 1) and dist.is_initialized()
+    calls = {"n": 0}
+    real = dist.all_reduce
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+
+    dist.all_reduce = counting
+    params = [torch.nn.Parameter(torch.randn(n)) for n in (5, 64, 3)]
+    bucket = agx_dist.GradBucket(params)
+    for p in params:
+        p.grad.copy_(torch.arange(p.numel(), dtype=torch.float32))
+    before = bucket.flat.clone()
+    bucket.allreduce_mean_()
+    stats = torch.arange(12, dtype=torch.float32).reshape(3, 4)
+    agx_dist.allreduce_sum_(stats)
+    forced = calls["n"]
+    agx_dist.force_collective(False)
+    bucket.allreduce_mean_()          # world 1, not forced: no collective
+    dist.all_reduce = real
+    agx_dist.barrier()
+    out.put((forced, calls["n"], bool(torch.equal(bucket.flat, before)), bucket.intact(),
+             bool(torch.equal(stats, torch.arange(12, dtype=torch.float32).reshape(3, 4)))))
+    dist.destroy_process_group()
+
+
+def test_force_collective_runs_the_exchange_steps_at_world_size_one():
+    """The switch tests/test_gpu_rccl_world1.py uses to execute the RCCL branch on one GPU, rehearsed on gloo."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    p = ctx.Process(target=_force_worker, args=(_free_port(), out))
+    p.start()
+    forced, total, same, intact, stats_same = out.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert forced == 2 and total == 2 and same and intact and stats_same
