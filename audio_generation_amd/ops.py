@@ -157,7 +157,10 @@ def planes_split(x: Tensor) -> Tensor:
     if c % 8:
         raise AgxError(f"planes_split: {c} channels (must be a multiple of 8)")
     planes = torch.empty((b, c // 8, 3, length, 8), dtype=torch.bfloat16, device=x.device)
+    tok = _observer.begin("other", ("planes_split", 10 * x.numel())) if _observer is not None else None
     _lib.check(lib.agx_planes_split(_ptr(x), _ptr(planes), b, c, length, _stream()), "agx_planes_split")
+    if tok is not None:
+        _observer.end(tok)
     return planes
 
 

@@ -430,9 +430,44 @@ class CausalVQAE(nn.Module):
         return x
 
     def _decoders_hip(self, x: Tensor) -> Tensor:
-        for dec in self.decoders:
+        decs = list(self.decoders)
+        x, decs = self._decoder_head_on_planes(x, decs)
+        for dec in decs:
             x = dec(x)
         return x
+
+    def _decoder_head_on_planes(self, x: Tensor, decs):
+        """bf16x3 decoders, inference: the k = 7 transposed conv (vae.py:269) writes its output as ACTIVATION PLANES
+        (include/agx.h: the three bf16 pieces of every element, split once in the producer's epilogue) and the first
+        block's polyphase up-conv (vae.py:176-179; M = 8 x 256 rows = 16 row blocks that each re-split the same input
+        tile otherwise) stages them by LDS-DMA.  Bit-identical to the fp32-activation path (same pieces, same products,
+        same order: tests/test_gpu_conv_b3.py, test_gpu_fullsize.py); any other configuration takes the plain path."""
+        if torch.is_grad_enabled() or len(decs) < 2 or x.dim() != 3:
+            return x, decs
+        head, blk = decs[0], decs[1]
+        if not (isinstance(head, CausalConvT1d) and head.impl == IMPL_MFMA_BF16X3 and isinstance(blk, CausalDecoderBlock)
+                and not blk.wavelet and not hasattr(blk, "multires")):
+            return x, decs
+        up, act = blk.in_conv[0], blk.in_conv[1]
+        slope = _leaky_slope(act)
+        if not (isinstance(up, CausalUpsampleConv1d) and up.impl == IMPL_MFMA_BF16X3 and x.shape[1] % 8 == 0):
+            return x, decs
+        hc, uc = head.conv, up.conv
+        d0 = ops.conv_desc(head.kind, x.shape[0], hc.in_channels, hc.out_channels, x.shape[2], hc.kernel_size[0], hc.stride[0],
+                           hc.dilation[0], 0, 0.1, head.impl)
+        if hc.stride[0] != 1 or ops.conv_planes_supported(d0) != 2:
+            return x, decs
+        d1 = ops.conv_desc(up.kind, x.shape[0], uc.in_channels, uc.out_channels, ops.conv_out_len(d0), uc.kernel_size[0], uc.stride[0],
+                           uc.dilation[0], EPI_LEAKY_PRE if slope is not None else 0, slope or 0.0, up.impl)
+        if ops.conv_planes_supported(d1) < 1:
+            return x, decs
+        xp = ops.planes_split(x)                                             # the RVQ's output: 15 MB at config S
+        yp = ops.conv_forward_planes(d0, xp, hc.packed(head.kind, head.impl), None if hc.bias is None else hc.bias.detach(),
+                                     out_planes=True)
+        h = ops.conv_forward_planes(d1, yp, uc.packed(up.kind, up.impl), None if uc.bias is None else uc.bias.detach())
+        for seq in blk.layers:
+            h = _run_fused_pair(seq[0], seq[1], h)
+        return h, decs[2:]
 
     def _run_encoders(self, x: Tensor) -> Tensor:
         """Encoder stack; when a gradient is needed, forward + backward on the HIP kernels (native_backward.py)."""

@@ -135,3 +135,38 @@ def test_bf16x3_decoder_matches_fp32_and_oracle(setup):
     scale = float(y.abs().max())
     assert float((y2 - y).abs().max()) <= 2e-5 * scale
     assert float((y2 - y).pow(2).mean().sqrt()) <= 1e-6 * max(scale, 1.0)
+
+
+def test_bf16x3_decoder_head_on_activation_planes_is_bit_identical(setup):
+    """Round 4: with the decoder on the bf16x3 kernels the k = 7 transposed conv writes ACTIVATION PLANES and the first
+    up-conv stages them by LDS-DMA (CausalVQAE._decoder_head_on_planes).  Same pieces, same products, same order: the
+    waveform must equal the fp32-activation path bit for bit -- at the full size of config S and on a ragged short clip."""
+    model, x, z, y, commit, index = setup
+    model.set_conv_arithmetic(decoders="bf16x3")
+    calls = {"n": 0}
+    real = ops.conv_forward_planes
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+
+    try:
+        ops.conv_forward_planes = counting
+        with torch.no_grad():
+            y_planes, _, idx_planes = model(x)
+            y_short, _, _ = model(x[:3, :, :320 * 37])
+        ops.conv_forward_planes = real
+        assert calls["n"] == 4                                  # (k7 + up8) x two forwards went through the planes path
+        head = type(model)._decoder_head_on_planes
+        type(model)._decoder_head_on_planes = lambda self, h, decs: (h, decs)     # the plain path
+        try:
+            with torch.no_grad():
+                y_plain, _, idx_plain = model(x)
+                y_short_plain, _, _ = model(x[:3, :, :320 * 37])
+        finally:
+            type(model)._decoder_head_on_planes = head
+    finally:
+        ops.conv_forward_planes = real
+        model.set_conv_arithmetic()
+    assert torch.equal(idx_planes, idx_plain) and torch.equal(idx_planes, index)
+    assert torch.equal(y_planes, y_plain) and torch.equal(y_short, y_short_plain)
