@@ -271,3 +271,44 @@ def test_multires_placement_is_off_by_default_and_adds_only_its_own_keys():
                            multires_encoders=[True, False], multires_decoders=True, multires_kernel_size=3, multires_depth=2)
     sd = codec.init_state_dict(spec)
     assert extra <= set(sd) and sd["decoders.2.multires.w"].shape == (4, 4) and sd["encoders.1.multires.h0"].shape == (8, 1, 3)
+
+
+def test_round4_entry_points_and_knobs_on_the_host(lib):
+    """Activation planes, verify mode and the probe-only diagnostics: what can be checked without a GPU."""
+    import ctypes
+    assert lib.agx_planes_bytes(32, 512, 225) == 32 * 64 * 3 * 225 * 16      # 6 bytes per element
+    assert lib.agx_planes_bytes(1, 12, 8) == 0                               # channels not a multiple of 8
+    assert lib.agx_planes_split(None, None, 1, 12, 8, None) == -1            # AGX_ERR_BAD_SHAPE before anything is touched
+    d = _lib.ConvDesc(_lib.CONV_UPSAMPLE, 2, 512, 256, 225, 17, 8, 1, 0, 0.1, _lib.IMPL_MFMA_BF16X3, 1, 0)
+    assert lib.agx_conv_planes_supported(ctypes.byref(d)) == 1               # reads planes
+    d = _lib.ConvDesc(_lib.CONV_TRANSPOSED, 2, 512, 512, 225, 7, 1, 1, 0, 0.1, _lib.IMPL_MFMA_BF16X3, 1, 0)
+    assert lib.agx_conv_planes_supported(ctypes.byref(d)) == 2               # ... and writes them
+    d = _lib.ConvDesc(_lib.CONV_CAUSAL, 2, 64, 128, 4000, 9, 4, 1, 0, 0.1, _lib.IMPL_MFMA_BF16X3, 1, 0)
+    assert lib.agx_conv_planes_supported(ctypes.byref(d)) == 0               # strided: fp32 input (its own ring form)
+    buf = ctypes.create_string_buffer(96)
+    assert lib.agx_conv_kernel_name(ctypes.byref(d), buf, 96) == 0 and buf.value.decode().startswith("conv_b3<down4,")
+    d = _lib.ConvDesc(_lib.CONV_UPSAMPLE, 2, 512, 256, 225, 17, 8, 1, 0, 0.1, _lib.IMPL_AUTO, 1, 0)
+    assert lib.agx_conv_planes_supported(ctypes.byref(d)) == 0               # fp32 descriptor
+    d = _lib.ConvDesc(_lib.CONV_CAUSAL, 32, 512, 1536, 225, 1, 1, 1, 0, 0.1, _lib.IMPL_AUTO, 1, 0)
+    assert lib.agx_conv_kernel_name(ctypes.byref(d), buf, 96) == 0 and buf.value.decode().startswith("conv_p<k1,")
+    # knobs: the verify mode is a product knob; the ones that weaken the RVQ bound exist in the probe build only
+    assert lib.agx_set_tuning(b"rvq_verify", 1) == 0 and lib.agx_get_tuning(b"rvq_verify") == 1
+    assert lib.agx_set_tuning(b"rvq_verify", 0) == 0
+    for v in (7, 8, 9):
+        assert lib.agx_set_tuning(b"b3_dbg", v) == -5                        # AGX_ERR_UNSUPPORTED
+    assert lib.agx_get_tuning(b"b3_dbg") == 0
+    assert lib.agx_rvq_debug_stamps(None, 0) == -5
+
+
+def test_bench_roofline_of_a_forward_that_mixes_the_two_matrix_pipes():
+    """bench.arithmetic_roofline: bf16x3 kernels against 2500 / 6, the step against the blended floor (never a bf16x3 figure over the fp32 peak)."""
+    import bench
+    per = {"resblock_b3<2,2,x2>:bf16x3": dict(ms=2.0, launches=2, macs=2 * 100e9, ref_macs=0, bytes=0, avg_us=1000.0, tflops=200.0, gbps=0.0,
+                                              launches_per_step=1.0, ms_per_step=1.0),
+           "resblock_p<2,2,8>": dict(ms=4.0, launches=2, macs=2 * 125e9, ref_macs=0, bytes=0, avg_us=2000.0, tflops=125.0, gbps=0.0,
+                                     launches_per_step=1.0, ms_per_step=2.0)}
+    r = bench.arithmetic_roofline(per, 3.2)
+    assert r["kernel"].endswith(":bf16x3") and abs(r["peak"] - 2500.0 / 6) < 1e-9 and abs(r["frac"] - 200.0 / (2500.0 / 6)) < 1e-12
+    floor = 1e3 * (200e9 / (2500e12 / 6) + 250e9 / 157.3e12)
+    assert abs(r["blended_floor_ms"] - floor) < 1e-9 and abs(r["frac_of_blended_roofline"] - floor / 3.2) < 1e-12
+    assert "frac_of_fp32_mfma_peak" not in r
