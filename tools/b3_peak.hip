@@ -131,12 +131,65 @@ __global__ __launch_bounds__(256, 2) void step_loop16(const float *in, float *ou
     if (tid == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
+// Composition (e) of DESIGN 4.13: K = 32 = TWO piece products of one 16-channel phase (lane quarter q >> 1 selects the piece through a per-lane
+// plane offset, q & 1 the channel half) -- today's LDS images stay, but every piece is re-read per product pair: per 64 x 32 block and phase
+// 3 pairs x (4 A + 2 B) = 18 ds_read_b128 for 24 MFMAs of 16 cycles (0.75 per MFMA against 0.25 in the chunk-pair composition above).
+// Operands of the next pair are requested while the current pair's 8 MFMAs run (two register sets).
+__global__ __launch_bounds__(256, 2) void step_loop16_pairs(const float *in, float *out, unsigned long long *clk, int iters) {
+    __shared__ __attribute__((aligned(16))) char lds[48 * 1024];
+    const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4;
+    for (int i = tid; i < 12 * 1024; i += 256) reinterpret_cast<float *>(lds)[i] = in[(blockIdx.x * 4096 + i) & 0xffff] * 1e-3f;
+    __syncthreads();
+    f32x4 acc[8];
+    for (int a = 0; a < 8; ++a)
+        for (int r = 0; r < 4; ++r) acc[a][r] = 0.f;
+    // planes of 2 KB: A image [plane 3][half 2][64 rows][16 B] = 6 planes, B image behind it; lane offsets: piece by q >> 1, half by q & 1
+    const int PAa[3] = {1, 2, 1}, PAb[3] = {0, 0, 0}, PBa[3] = {1, 0, 0}, PBb[3] = {2, 1, 0};     // (m,h)(m,l) | (l,h)(h,m) | (m,h)(h,h)
+    int offA[3], offB[3];
+    for (int p = 0; p < 3; ++p) {
+        offA[p] = (((q >> 1) ? PAb[p] : PAa[p]) * 2 + (q & 1)) * 1024 + (lane & 15) * 16;
+        offB[p] = 24 * 1024 + (((q >> 1) ? PBb[p] : PBa[p]) * 2 + (q & 1)) * 512 + (lane & 15) * 16;
+    }
+    b3x8 fa[2][4], fb[2][2];
+    auto load_pair = [&](int set, int p, int it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[set][i] = *reinterpret_cast<const b3x8 *>(lds + offA[p] + i * 256 + (it & 1) * 6144);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[set][j] = *reinterpret_cast<const b3x8 *>(lds + offB[p] + j * 256 + ((it & 7) * 3072));
+    };
+    load_pair(0, 0, 0);
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {          // four 16-channel phases = the FLOPs of the four K = 16 steps of step_loop
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const int set = (s * 3 + p) & 1;
+                load_pair(set ^ 1, (p + 1) % 3, it * 4 + s);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[set][i], fb[set][j], acc[i * 2 + j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float sum = 0.f;
+    for (int a = 0; a < 8; ++a)
+        for (int r = 0; r < 4; ++r) sum += acc[a][r];
+    out[blockIdx.x * 256 + tid] = sum;
+    if (tid == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
 template <int MODE, bool S16 = false>
 void run(const char *name, int wg_per_cu, const float *din, float *dout, unsigned long long *dclk) {
     const int grid = 256 * wg_per_cu, iters = 4000;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    auto kern = S16 ? step_loop16<MODE> : step_loop<MODE>;
+    auto kern = MODE == 3 ? step_loop16_pairs : (S16 ? step_loop16<MODE < 3 ? MODE : 2> : step_loop<MODE < 3 ? MODE : 2>);
     for (int warm = 0; warm < 2; ++warm) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, din, dout, dclk, iters);
     hipDeviceSynchronize();
     float best = 1e30f;
@@ -177,5 +230,7 @@ int main() {
     run<1, true>("B fragments from LDS, one step ahead", 2, din, dout, dclk);
     run<2, true>("B every step + A every 2 steps from LDS", 1, din, dout, dclk);
     run<2, true>("B every step + A every 2 steps from LDS", 2, din, dout, dclk);
+    run<3, true>("product pairs: 18 ds_read_b128 per 24 MFMAs", 1, din, dout, dclk);
+    run<3, true>("product pairs: 18 ds_read_b128 per 24 MFMAs", 2, din, dout, dclk);
     return 0;
 }
